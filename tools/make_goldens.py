@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference) on CPU.
+
+Runs only in the build container (the reference does not travel to the GPU box).  Nothing of the reference is
+copied: this script imports its modules, feeds them deterministic synthetic weights/batches from
+upnerf_amd.synth, and stores inputs + outputs + gradients as data.
+
+Import shims: utils/camera.py imports easydict (used only in procrustes_analysis, camera.py:364-382) and
+utils/ray.py imports kornia (used only in get_ray_directions, ray.py:5-27); neither is installed, neither is on
+the hot path, so empty stand-in modules are registered for the import only.
+
+The orchestration files (models/nerf_system.py) need pytorch_lightning (absent), so the ~40 lines of glue of
+NeRFSystem.training_step/forward (nerf_system.py:93-186) are re-stated below with the reference's own leaf
+functions: se3_to_SE3, compose, get_rays, render_rays, TransientNet, UPNeRFLoss.
+
+RNG: torch.rand / torch.rand_like are wrapped while render_rays runs so that the uniform draws are recorded
+(in call order) and stored in the fixture; checkers inject them instead of re-drawing.
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+_ed = types.ModuleType("easydict"); _ed.EasyDict = dict; sys.modules["easydict"] = _ed
+_ko = types.ModuleType("kornia"); _ko.create_meshgrid = None; sys.modules["kornia"] = _ko
+sys.path.insert(0, REF)
+
+import models.rendering as ref_rendering  # noqa: E402
+import models.nerf as ref_nerf  # noqa: E402
+import models.transient_net as ref_tnet  # noqa: E402
+import losses as ref_losses  # noqa: E402
+import utils.camera as ref_camera  # noqa: E402
+import utils.ray as ref_ray  # noqa: E402
+
+from upnerf_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+MAX_GRAD_ELEMS = 384
+
+
+class RecordRand:
+    """Record every uniform draw the reference makes inside render_rays."""
+
+    def __enter__(self):
+        self.draws = []
+        self._rand, self._rand_like = torch.rand, torch.rand_like
+
+        def rand(*a, **k):
+            t = self._rand(*a, **k); self.draws.append(t.clone()); return t
+
+        def rand_like(x, **k):
+            t = self._rand_like(x, **k); self.draws.append(t.clone()); return t
+
+        torch.rand, torch.rand_like = rand, rand_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.rand_like = self._rand, self._rand_like
+
+
+def schedule_mult(progress, sched):  # nerf_system.py:452-461 (cannot import: needs pytorch_lightning)
+    s, e = sched
+    if progress < s:
+        return 0
+    if progress > e:
+        return 1
+    return (1 - math.cos(math.pi * (progress - s) / (e - s))) / 2
+
+
+def build(case):
+    n_img = case["n_img"]
+    kw = dict(D=case["D"], W=case["W"], feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    models, sds = {}, {}
+    for typ in ("coarse", "fine") if case["Nf"] > 0 else ("coarse",):
+        m = ref_nerf.NeRF(typ, c2f=case["c2f"], **kw)
+        sd = synth.nerf_state(typ, seed=case["seed"], progress=case["progress"], sigma_bias=case.get("sigma_bias", 0.0), **kw)
+        m.load_state_dict(sd)
+        if case.get("encode_candidate") is False:
+            m.encode_candidate = False
+        models[f"nerf_{typ}"] = m
+    tn = ref_tnet.TransientNet(n_img, beta_min=0.1, trasient_dim=128, feat_dim=384)
+    tn.load_state_dict(synth.transient_state(n_img, seed=case["seed"]))
+    tabs = synth.tables(n_img, seed=case["seed"], fine=case["Nf"] > 0)
+    emb = {k: torch.nn.Embedding.from_pretrained(v.clone(), freeze=False) for k, v in tabs.items()}
+    return models, tn, emb
+
+
+def run_case(name, case):
+    torch.manual_seed(case["seed"])
+    models, tn, emb = build(case)
+    b = synth.batch(case["R"], case["n_img"], seed=case["seed"] + 1, identity_c2w=case.get("identity_c2w", True))
+    idx = b["img_idx"]
+    fine = case["Nf"] > 0
+    # --- glue restated from NeRFSystem.training_step (nerf_system.py:150-186) ---
+    if case["pose_opt"]:
+        refine = ref_camera.lie.se3_to_SE3(emb["se3_refine"](idx))
+        pose = ref_camera.pose.compose([refine, b["c2w"]])
+    else:
+        pose = b["c2w"]
+    rays_o, rays_d = ref_ray.get_rays(b["directions"], pose)
+    rays = torch.cat([rays_o, rays_d, b["ray_infos"]], 1)
+    near, far = 0.1, 5.0
+    scale, shift = torch.unbind(emb["depth_scale"](idx), 1)
+    pred_inv = b["inv_depths"] * torch.exp(scale) + shift
+    pred_inv[pred_inv < 1 / far] = 1 / far
+    depth = 1.0 / pred_inv
+    depth[depth < near] = near
+    m = case["sched"] if "sched" in case else schedule_mult(case["progress"], (0.1, 0.5))
+    embeddings = {k[len("embedding_"):]: v for k, v in emb.items() if k.startswith("embedding_")}
+    with RecordRand() as rec:
+        res = ref_rendering.render_rays(models=models, embeddings=embeddings, rays=rays, img_idx=idx, sched_mult=m,
+                                        sched_phase=0, N_samples=case["Nc"], use_disp=case.get("use_disp", False),
+                                        perturb=case["perturb"], N_importance=case["Nf"], white_back=False,
+                                        encode_feat=True, validation=False)
+    # NeRFSystem.forward transient blend (nerf_system.py:128-146)
+    if m > 0:
+        t = tn(b["feats"], idx)
+        res["rgb_coarse"] = res["s_rgb_coarse"] * (1 - t["alpha"].detach()) + t["rgb"].detach() * t["alpha"].detach()
+        if fine:
+            res["rgb_fine"] = res["s_rgb_fine"] * (1 - t["alpha"]) + t["rgb"] * t["alpha"]
+        res["t_beta"], res["t_alpha"] = t["beta"], t["alpha"]
+    loss_fn = ref_losses.UPNeRFLoss(depth_mult=1e-3, alpha_reg=1.0, encode_feat=True, fine=fine)
+    loss_d = loss_fn(res, b["rgbs"], b["feats"], depth, m)
+    loss = sum(l for l in loss_d.values())
+    if rays.requires_grad:
+        rays.retain_grad()
+    loss.backward()
+
+    out = {"meta_sched": np.float64(m)}
+    for k, v in case.items():
+        if k == "c2f":
+            out["cfg_c2f"] = np.array(v if v is not None else (-1.0, -1.0), dtype=np.float64)
+        elif isinstance(v, (int, float, bool)):
+            out["cfg_" + k] = np.float64(v)
+    for i, u in enumerate(rec.draws):
+        out[f"u_{i}"] = u.numpy()
+    out["n_draws"] = np.int64(len(rec.draws))
+    out["in_rays"] = rays.detach().numpy()
+    out["in_depth"] = depth.detach().numpy()
+    for k, v in res.items():
+        out["res_" + k] = v.detach().numpy()
+    for k, v in loss_d.items():
+        out["loss_" + k] = v.detach().numpy()
+    out["loss_total"] = loss.detach().numpy()
+    out["grad_rays"] = rays.grad.numpy() if rays.grad is not None else np.zeros_like(out["in_rays"])
+
+    def put_grad(key, g):
+        if g is None:
+            out["gradnone_" + key] = np.int64(1)
+            return
+        g = g.detach().reshape(-1)
+        out["gsum_" + key] = np.array([g.double().sum().item(), g.double().abs().sum().item()])
+        if g.numel() > MAX_GRAD_ELEMS:
+            stride = g.numel() // MAX_GRAD_ELEMS
+            out["gstride_" + key] = np.int64(stride)
+            g = g[::stride]
+        out["grad_" + key] = g.numpy().copy()
+
+    for k, e_ in emb.items():
+        put_grad(k + ".weight", e_.weight.grad)
+    for mk, mod in models.items():
+        for pn, p in mod.named_parameters():
+            put_grad(f"{mk}.{pn}", p.grad)
+    for pn, p in tn.named_parameters():
+        put_grad(f"transient_net.{pn}", p.grad)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: sched={m:.4f} draws={[tuple(u.shape) for u in rec.draws]} loss={loss.item():.6f} "
+          f"keys={sorted(res.keys())} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+BASE = dict(n_img=12, seed=3, sigma_bias=2.0)
+CASES = {
+    # BASELINE.json configs[0] shape (4-layer x 64 MLP, coarse only, poses frozen, sched 0)
+    "cfg1_small": dict(BASE, R=24, D=4, W=64, Nc=64, Nf=0, c2f=None, progress=0.0, perturb=1.0, pose_opt=False),
+    "cfg1_small_fine": dict(BASE, R=10, D=4, W=64, Nc=32, Nf=32, c2f=(0.1, 0.5), progress=0.3, perturb=1.0, pose_opt=True),
+    # BASELINE.json configs[1] shape at a handful of rays, the three schedule phases
+    "cfg2_phase0": dict(BASE, R=6, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.05, perturb=1.0, pose_opt=True),
+    "cfg2_phase1": dict(BASE, R=6, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.3, perturb=1.0, pose_opt=True),
+    "cfg2_phase2": dict(BASE, R=6, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.8, perturb=1.0, pose_opt=True),
+    # deterministic resampling (validation path: perturb=0 -> det=True), non-identity c2w
+    "cfg2_det_phase1": dict(BASE, R=5, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.25, perturb=0.0,
+                            pose_opt=True, identity_c2w=False),
+    # banker's rounding of n_s: 0.33203125*128 = 42.5 -> 42
+    "small_round_half": dict(BASE, R=7, D=4, W=64, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.3, sched=0.33203125,
+                             perturb=1.0, pose_opt=True),
+    # disparity sampling
+    "small_disp": dict(BASE, R=7, D=4, W=64, Nc=48, Nf=16, c2f=None, progress=0.0, sched=0.5, perturb=1.0,
+                       pose_opt=True, use_disp=True),
+    # TTO shape: sched 1, candidate head disabled (nerf_system_optmize.py:265-266)
+    "small_tto": dict(BASE, R=9, D=4, W=64, Nc=32, Nf=64, c2f=(0.1, 0.5), progress=0.9, sched=1.0, perturb=0.0,
+                      pose_opt=True, encode_candidate=False),
+    # non-candidate branch with sched<1 (rendering.py:134-150)
+    "small_nocand": dict(BASE, R=9, D=4, W=64, Nc=32, Nf=32, c2f=(0.1, 0.5), progress=0.3, sched=0.5, perturb=1.0,
+                         pose_opt=True, encode_candidate=False),
+    # all PE bands masked (progress < c2f start), zero se3 is covered by test_pose (separate fixture)
+    "small_allmasked": dict(BASE, R=8, D=4, W=64, Nc=32, Nf=32, c2f=(0.1, 0.5), progress=0.02, perturb=1.0, pose_opt=True),
+}
+
+
+def leaf_fixtures():
+    """Leaf-function vectors: se3 exp (incl. w = 0), PE layout, sample_pdf edge cases."""
+    out = {}
+    wu = synth.uniform("leaf_se3", (9, 6), 5) * 0.5
+    wu[0] = 0.0
+    wu[1, :3] = 0.0
+    wu = wu.clone().requires_grad_(True)
+    Rt = ref_camera.lie.se3_to_SE3(wu)
+    probe = synth.uniform("leaf_probe", (9, 3, 4), 5)
+    (Rt * probe).sum().backward()
+    out["se3_in"], out["se3_out"], out["se3_probe"], out["se3_grad"] = wu.detach().numpy(), Rt.detach().numpy(), probe.numpy(), wu.grad.numpy()
+    x = synth.uniform("leaf_pe", (11, 3), 5) * 4.0
+    for tag, c2f, prog in (("none", None, 0.0), ("mid", (0.1, 0.5), 0.3), ("frac", (0.1, 0.5), 0.27)):
+        m = ref_nerf.NeRF("coarse", D=2, W=8, c2f=c2f)
+        m.progress.data.fill_(prog)
+        out[f"pe_{tag}"] = m.positional_encoding(x, 10).detach().numpy()
+        out[f"pedir_{tag}"] = m.positional_encoding(x, 4).detach().numpy()
+    out["pe_x"] = x.numpy()
+    # sample_pdf: searchsorted(right=True) edges, zero-weight bins, det and explicit u
+    bins = torch.tensor([[0.0, 1.0, 2.0, 4.0]]).repeat(2, 1)
+    w = torch.tensor([[0.25, 0.25, 0.5], [0.0, 1.0, 0.0]]) - 1e-5
+    u = torch.tensor([[0.0, 0.25, 0.5, 0.999, 1.0], [0.0, 1e-6, 0.5, 0.99999, 1.0]])
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: u.clone()
+    try:
+        out["pdf_edge_out"] = ref_rendering.sample_pdf(bins, w, 5, det=False).numpy()
+    finally:
+        torch.rand = real_rand
+    out["pdf_edge_bins"], out["pdf_edge_w"], out["pdf_edge_u"] = bins.numpy(), w.numpy(), u.numpy()
+    bins2 = torch.sort(synth.uniform("leaf_bins", (6, 63), 5, 0.1, 5.0), -1)[0]
+    w2 = synth.uniform("leaf_w", (6, 62), 5, 0.0, 1.0) ** 4
+    w2[2] = 0.0
+    out["pdf_det_out"] = ref_rendering.sample_pdf(bins2, w2, 128, det=True).numpy()
+    out["pdf_det_bins"], out["pdf_det_w"] = bins2.numpy(), w2.numpy()
+    np.savez_compressed(os.path.join(OUT, "leaf.npz"), **out)
+    print("leaf fixtures written")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    only = sys.argv[1:]
+    os.makedirs(OUT, exist_ok=True)
+    if not only or "leaf" in only:
+        leaf_fixtures()
+    for n, c in CASES.items():
+        if not only or n in only:
+            run_case(n, c)
