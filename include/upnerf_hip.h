@@ -1,0 +1,233 @@
+/*
+ * upnerf_hip.h -- C ABI of libupnerf_hip.so, the MI355X (gfx950) implementation of the UP-NeRF
+ * render_rays training hot path.
+ *
+ * The reference (mlvlab/UP-NeRF) is pure Python on PyTorch: it has no native boundary of its own
+ * (SURVEY.md 2.2).  The entry points below are therefore the leaf operations its Python hot path
+ * performs, one per group of ATen launches, and each cites the reference lines it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add to call them from models/rendering.py.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a hipError_t (>0) on a HIP failure, or a negative
+ *    UPNERF_E* code on an argument error; nothing is printed, nothing throws.
+ *  - all pointers are DEVICE pointers to fp32 (or int64 where said), row-major, contiguous; they
+ *    are borrowed for the duration of the call (stream-ordered) -- the library allocates nothing
+ *    and keeps no global state.  `stream` is a hipStream_t passed as void*.
+ *  - "rows" M = R * S (rays x samples per ray), sample i of ray r is row r*S + i.
+ */
+#ifndef UPNERF_HIP_H
+#define UPNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UPNERF_ABI_VERSION 1
+#define UPNERF_EINVAL (-1)   /* bad size / null pointer */
+#define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
+
+#define UPNERF_TILE_ROWS 128 /* rows of samples per workgroup in the fused MLP kernels */
+#define UPNERF_X0 64         /* positional encoding 3+6*10 = 63 padded to 64 floats per row */
+#define UPNERF_AUXK 80       /* per-ray rgb-head side input [dirPE(27) | appearance(48) | 0 x5] */
+#define UPNERF_CK 16         /* candidate embedding width */
+#define UPNERF_MAX_D 8
+
+int upnerf_abi_version(void);
+
+/* ---- a2-a4: pose refinement + ray generation (utils/camera.py:87-98,113-152 se3_to_SE3;
+ *      camera.py:51-58 compose_pair; utils/ray.py:44-56 get_rays batched branch) -------------------
+ * se3 [R][6] (already gathered rows of se3_refine, or NULL = identity refinement), c2w [R][3][4],
+ * dirs [R][3] camera-space directions -> rays_o [R][3], rays_d [R][3] (unit norm).
+ * bwd: g_o, g_d [R][3] -> g_se3 [R][6] (per ray; the caller scatter-adds rows by img_idx). */
+int upnerf_pose_rays_fwd(int R, const float* se3, const float* c2w, const float* dirs,
+                         float* rays_o, float* rays_d, void* stream);
+int upnerf_pose_rays_bwd(int R, const float* se3, const float* c2w, const float* dirs,
+                         const float* g_o, const float* g_d, float* g_se3, void* stream);
+
+/* ---- a5: stratified coarse depths (models/rendering.py:232-249) ---------------------------------
+ * near_far [R][2]; steps [S] = linspace(0,1,S); u [R][S] uniform draws or NULL (perturb == 0);
+ * z_out [R][S]. */
+int upnerf_sample_coarse(int R, int S, const float* near_far, const float* steps, const float* u,
+                         float perturb, int use_disp, float* z_out, void* stream);
+
+/* ---- a11: inverse-CDF resampling (models/rendering.py:7-50 sample_pdf) ---------------------------
+ * z [R][S] coarse depths (bins = midpoints, computed inside), weights [R][S] (only [1:S-1] used),
+ * u [u_rows][n] with u_rows == R, or u_rows == 1 for the deterministic linspace; writes n values per
+ * ray to out + r*out_stride. */
+int upnerf_sample_pdf(int R, int S, const float* z, const float* weights, const float* u, int u_rows,
+                      int n, float* out, int out_stride, void* stream);
+
+/* ---- a12: ascending sort of each row (models/rendering.py:275,290,298,307 torch.sort values) ----- */
+int upnerf_sort_rows(int R, int S, float* z, void* stream);
+
+/* ---- per-ray rgb-head side input: [PE(rays_d, L=4, masked) | appearance row | 0]  (nerf.py:102-107;
+ *      the reference repeats it per sample, rendering.py:104-109) ---------------------------------- */
+int upnerf_ray_aux(int R, const float* rays_d, const float* a_rows /*[R][48] or NULL*/,
+                   const float* wk_dir /*[4]*/, float* aux /*[R][UPNERF_AUXK]*/, void* stream);
+
+/* ---- a6-a9: fused NeRF field, forward (models/nerf.py:80-124 + 126-147) --------------------------
+ * Layout of the packed parameter buffer `P` (floats): offsets below, every matrix row-major [N][Kp]
+ * with Kp a multiple of 8 (zero padded).  See upnerf_amd/packing.py for the packing from the
+ * reference's state_dict names. */
+typedef struct {
+  int32_t W, D, skip;            /* width (64 or 256), depth (<= 8), index of the skip layer or -1 */
+  int32_t w[UPNERF_MAX_D];       /* trunk layer l: [W][Kp_l], Kp_0 = 64, Kp_skip = 64 + W, else W */
+  int32_t b[UPNERF_MAX_D];       /* trunk biases [W] */
+  int32_t we, be;                /* xyz_encoding_final [W][W], [W] */
+  int32_t wsig, bsig;            /* share_sigma.0 [W], [1] */
+  int32_t wc1, bc1;              /* candidate_encoding.0 [W/2][W + 16], [W/2] */
+  int32_t wc2, bc2;              /* candidate_encoding.2 [W/2][W/2], [W/2] */
+  int32_t wcsig, bcsig;          /* candidate_sigma.0 [W/2], [1] */
+  int32_t wr1, br1;              /* folded rgb_share_layer.0 [W/2][W + 80], [W/2] */
+  int32_t wr2, br2;              /* rgb_share_layer.2 [3][W/2], [3] (padded to 4) */
+  int32_t total;                 /* floats in P */
+  /* transposed copies for the backward data-gradient chain, in buffer PT */
+  int32_t t_w[UPNERF_MAX_D];     /* layer l: [Kin_l][W] with Kin_0 = 64; skip: h part [W][W] */
+  int32_t t_skipx;               /* skip layer, encoding part [64][W] */
+  int32_t t_we;                  /* [W][W] */
+  int32_t t_head;                /* [W][W]: cols [0,W/2) = wr1[:, :W]^T, cols [W/2,W) = wc1[:, :W]^T */
+  int32_t t_wc2;                 /* [W/2][W/2] */
+  int32_t t_total;
+} upnerf_layout;
+
+typedef struct {
+  int32_t R, S;                  /* rays, samples per ray */
+  int32_t use_cand, use_rgb;     /* sched_mult < 1 && encode_candidate ; sched_mult > 0 */
+  const float* rays_o;           /* [R][3] */
+  const float* rays_d;           /* [R][3] */
+  const float* z;                /* [R][S] */
+  const float* c_rows;           /* [R][16] candidate embedding rows (use_cand) */
+  const float* aux;              /* [R][80] from upnerf_ray_aux (use_rgb) */
+  float wk_xyz[10];              /* BARF band weights for the xyz encoding */
+  const float* P;                /* packed parameters */
+  /* per-sample outputs */
+  float* sigma_s;                /* [M] softplus output */
+  float* sigma_c;                /* [M] (use_cand) */
+  float* rgb;                    /* [M][3] sigmoid output (use_rgb) */
+  /* activations kept for compositing and for the backward pass */
+  float* x0;                     /* [M][64] */
+  float* h;                      /* [D][M][W] post-ReLU trunk activations */
+  float* e;                      /* [M][W]   xyz_encoding_final output */
+  float* g1;                     /* [M][W/2] (use_cand) */
+  float* g2;                     /* [M][W/2] (use_cand) */
+  float* r1;                     /* [M][W/2] (use_rgb) */
+} upnerf_field_fwd_args;
+
+int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
+
+/* ---- a10: alpha compositing, forward (models/rendering.py:125-218) -------------------------------
+ * Features are composited in the W-wide space of xyz_encoding_final / candidate_encoding and projected
+ * once per ray by the caller (exact algebra: feat = W_f (sum w e) + b_f sum w). */
+typedef struct {
+  int32_t R, S, W;
+  int32_t mode;                  /* 0: candidate+shared (sched==0), 1: both + rgb (0<sched<1),
+                                    2: shared only (sched==1), 3: shared only, feature map (no candidate, sched<1) */
+  const float* z;                /* [R][S] */
+  const float* sigma_s;          /* [M] */
+  const float* sigma_c;          /* [M] modes 0,1 */
+  const float* rgb;              /* [M][3] modes 1,2,3 when sched>0 */
+  int32_t has_rgb;
+  const float* e;                /* [M][W] */
+  const float* g2;               /* [M][W/2] modes 0,1 */
+  /* per-sample outputs (also the saved state of the backward) */
+  float* w_all;                  /* [M] alpha*T       -> c_weights      (modes 0,1) */
+  float* w_sj;                   /* [M] alpha_s*T     (joint transmittance, modes 0,1) */
+  float* w_cj;                   /* [M] alpha_c*T     (modes 0,1) */
+  float* w_s;                    /* [M] alpha_s*T_s   -> s_weights */
+  /* per-ray outputs */
+  float* E_s;                    /* [R][W]   sum_i ws_feat_i e_i   (ws_feat = w_sj in modes 0,1; w_s in mode 3) */
+  float* G_c;                    /* [R][W/2] sum_i w_cj g2_i       (modes 0,1) */
+  float* sum_sfeat;              /* [R] sum_i ws_feat_i */
+  float* t_weight;               /* [R] sum_i w_cj */
+  float* c_depth;                /* [R] sum_i w_all z */
+  float* s_depth;                /* [R] sum_i w_s z */
+  float* rgb_map;                /* [R][3] sum_i w_s rgb_i */
+} upnerf_composite_fwd_args;
+
+int upnerf_composite_fwd(const upnerf_composite_fwd_args* a, void* stream);
+
+/* ---- a10 backward (division-free reverse scan) ------------------------------ */
+typedef struct {
+  int32_t R, S, W, mode, has_rgb;
+  const float* z; const float* sigma_s; const float* sigma_c; const float* rgb;
+  const float* e; const float* g2;
+  const float* w_all; const float* w_sj; const float* w_cj; const float* w_s;
+  /* upstream gradients (any may be NULL = zero) */
+  const float* g_E_s;            /* [R][W] */
+  const float* g_G_c;            /* [R][W/2] */
+  const float* g_sum_sfeat;      /* [R] */
+  const float* g_t_weight;       /* [R] */
+  const float* g_c_depth;        /* [R] */
+  const float* g_s_depth;        /* [R] */
+  const float* g_rgb_map;        /* [R][3] */
+  const float* g_w_all;          /* [M] */
+  const float* g_w_s;            /* [M] */
+  /* outputs */
+  float* d_sigma_s;              /* [M] */
+  float* d_sigma_c;              /* [M] modes 0,1 */
+  float* d_rgb;                  /* [M][3] has_rgb */
+} upnerf_composite_bwd_args;
+
+int upnerf_composite_bwd(const upnerf_composite_bwd_args* a, void* stream);
+
+/* ---- a7-a9 backward: data-gradient chain through the fused field (autograd of nerf.py:80-124) ----
+ * Consumes the per-sample gradients from upnerf_composite_bwd plus the rank-1 feature terms
+ * (w_feat_s[m] * g_E_s[ray], w_cj[m] * g_G_c[ray]) and writes the pre-activation gradient of every layer
+ * (inputs of upnerf_wgrad) and d(xyz). */
+typedef struct {
+  int32_t R, S, use_cand, use_rgb, need_dxyz;
+  const float* PT;               /* transposed parameter copies (layout t_*) */
+  const float* P;                /* forward parameters (vectors wsig, wcsig, wr2) */
+  const float* d_sigma_s; const float* d_sigma_c; const float* d_rgb;
+  const float* sigma_s; const float* sigma_c; const float* rgb;
+  const float* w_feat_s;         /* [M] weight multiplying e_i in the feature map (w_sj or w_s), or NULL */
+  const float* w_cj;             /* [M] */
+  const float* g_E_s;            /* [R][W] or NULL */
+  const float* g_G_c;            /* [R][W/2] or NULL */
+  const float* x0; const float* h; const float* g1; const float* g2; const float* r1;
+  /* outputs */
+  float* gz_h;                   /* [D][M][W] */
+  float* gz_e;                   /* [M][W] */
+  float* gz_g1; float* gz_g2;    /* [M][W/2] */
+  float* gz_r1;                  /* [M][W/2] */
+  float* dpre_sig_s;             /* [M] */
+  float* dpre_sig_c;             /* [M] */
+  float* dpre_rgb;               /* [M][4] (3 used) */
+  float* dxyz;                   /* [M][3] (need_dxyz) */
+} upnerf_field_bwd_args;
+
+int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream);
+
+/* ---- weight gradients: dW[N][ldo] (+)= sum_m A[m][n] * B[m][k], db[n] = sum_m A[m][n] ------------
+ * A [M][lda] (N columns used), B [M][ldb] (K columns used); K, N multiples of 32 (N <= 256, K <= 256).
+ * `slabs` is scratch for nsplit partial results (nsplit * N * K floats); reduced in fixed order, so the
+ * result is bitwise reproducible.  db may be NULL. */
+int upnerf_wgrad(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
+                 float* dW, int ldo, float* db, float* slabs, int nsplit, void* stream);
+
+/* dw[c][k] = sum_m v[m*ldv + c] * X[m][k], c < nvec <= 4; dbv[c] = sum_m v[m*ldv + c]   (N=1/3 heads) */
+int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const float* X, int ldx, int K,
+                     float* dw /*[nvec][K]*/, float* dbv /*[nvec]*/, float* scratch, int nsplit, void* stream);
+
+/* out[r][c] = sum_{i<S} X[(r*S+i)][c]  (per-ray sums of a per-sample tensor; embedding-row gradients) */
+int upnerf_ray_sum(int R, int S, const float* X, int C, float* out, void* stream);
+/* (d_o, d_d)[r] = (sum_i dxyz_i, sum_i z_i dxyz_i)    */
+int upnerf_ray_geom_bwd(int R, int S, const float* dxyz, const float* z, float* d_o, float* d_d, void* stream);
+
+/* ---- generic fp32 MFMA linear layer: C[M][N] = act(A[M][K] . B[N][K]^T + bias) --------------------
+ * (TransientNet, models/transient_net.py:27-38, and the per-ray feature projection.)  K multiple of 8,
+ * act: 0 none, 1 relu.  N arbitrary (ldb/ldc are row strides). */
+int upnerf_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                  const float* bias, float* C, int ldc, int act, void* stream);
+
+/* ---- a18: fused Adam on a flat fp32 buffer (torch.optim.Adam semantics, utils/optim.py:20-33) ---- */
+int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                float eps, float bias_corr1, float bias_corr2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPNERF_HIP_H */

@@ -237,6 +237,24 @@ def py_round(x: float) -> int:
     return int(round(x))
 
 
+# a5: stratified coarse depths  (models/rendering.py:232-249)
+def coarse_depths(near: Tensor, far: Tensor, N_samples: int, use_disp: bool, perturb: float,
+                  u: Optional[Tensor]) -> Tensor:
+    """near, far [R,1] -> z [R,N_samples]; `u` [R,N_samples] are the uniform draws used when perturb > 0."""
+    s = torch.linspace(0, 1, N_samples, dtype=near.dtype)
+    if not use_disp:
+        z = near * (1 - s) + far * s
+    else:
+        z = 1 / (1 / near * (1 - s) + 1 / far * s)
+    z = z.expand(near.shape[0], N_samples)
+    if perturb > 0:  # rendering.py:240-249
+        mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        upper = torch.cat([mid, z[:, -1:]], -1)
+        lower = torch.cat([z[:, :1], mid], -1)
+        z = lower + (upper - lower) * (perturb * u)
+    return z
+
+
 # --------------------------------------------------------------------------------------
 # a5, a12: render_rays  (models/rendering.py:53-314)
 # --------------------------------------------------------------------------------------
@@ -259,18 +277,8 @@ def render_rays(models: Dict[str, Params], cfgs: Dict[str, NerfCfg], embeddings:
 
     R = rays.shape[0]
     o, d = rays[:, 0:3], rays[:, 3:6]
-    near, far = rays[:, 6:7], rays[:, 7:8]
-    s = torch.linspace(0, 1, N_samples, dtype=rays.dtype)
-    if not use_disp:
-        z = near * (1 - s) + far * s
-    else:
-        z = 1 / (1 / near * (1 - s) + 1 / far * s)
-    z = z.expand(R, N_samples)
-    if perturb > 0:  # rendering.py:240-249
-        mid = 0.5 * (z[:, :-1] + z[:, 1:])
-        upper = torch.cat([mid, z[:, -1:]], -1)
-        lower = torch.cat([z[:, :1], mid], -1)
-        z = lower + (upper - lower) * (perturb * draw((R, N_samples)))
+    z = coarse_depths(rays[:, 6:7], rays[:, 7:8], N_samples, use_disp, perturb,
+                      draw((R, N_samples)) if perturb > 0 else None)
 
     res: Dict[str, Tensor] = {}
 

@@ -1,0 +1,319 @@
+"""GPU parity tests, kernel by kernel: every C-ABI entry point of libupnerf_hip.so against the CPU oracle
+(oracle/upnerf_oracle.py) or, for the fused kernels' internals, against the torch restatement of the kernels'
+arithmetic (tests/kernel_space.py, itself pinned to the oracle by tests/test_packing_cpu.py).
+
+Tolerances (max-normalised error, golden_util.rel_err): fp32 MFMA vs fp32 CPU BLAS differ only in summation order:
+1e-5 on activations and per-ray maps, 1e-4 on gradients (the bar BASELINE.json states is 1e-4)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import kernel_space as ks
+from golden_util import GOLDEN, Case, orc, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACT = 1e-5
+TOL_GRAD = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from upnerf_amd import _lib, camera, ops, rendering
+    return dict(lib=_lib, camera=camera, ops=ops, rendering=rendering)
+
+
+def cpu(t):
+    return t.detach().cpu()
+
+
+def gen(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+# ------------------------------------------------------------------------------------------ a2-a4
+@pytest.mark.parametrize("identity", [True, False])
+def test_pose_rays_fwd_bwd(hip, identity):
+    R = 67
+    se3 = gen((R, 6), 1) * 0.3
+    se3[0] = 0.0          # zero-initialised table entry (nerf_system.py:407)
+    se3[1, :3] = 0.0
+    se3[2] *= 5.0         # large rotation, exercises the high Taylor terms
+    if identity:
+        c2w = torch.eye(3, 4).repeat(R, 1, 1)
+    else:
+        q, _ = torch.linalg.qr(gen((R, 3, 3), 2))
+        c2w = torch.cat([q, gen((R, 3, 1), 3)], -1)
+    dirs = gen((R, 3), 4)
+    dirs[:, 2] = -1.0
+    go, gd = gen((R, 3), 5), gen((R, 3), 6)
+    s_ref = se3.clone().requires_grad_(True)
+    o_ref, d_ref = orc.get_rays(dirs, orc.compose_pair(orc.se3_exp(s_ref), c2w))
+    ((o_ref * go).sum() + (d_ref * gd).sum()).backward()
+    s_gpu = se3.cuda().requires_grad_(True)
+    o, d = hip["camera"].refine_and_get_rays(s_gpu, c2w.cuda(), dirs.cuda())
+    ((o * go.cuda()).sum() + (d * gd.cuda()).sum()).backward()
+    assert rel_err(cpu(o), o_ref.detach()) < 1e-6 and rel_err(cpu(d), d_ref.detach()) < 1e-6
+    assert torch.isfinite(s_gpu.grad).all()
+    assert rel_err(cpu(s_gpu.grad), s_ref.grad) < 2e-5
+    # no refinement = plain get_rays, both calling conventions of utils/ray.py:30-67
+    o2, d2 = hip["camera"].get_rays(dirs.cuda(), c2w.cuda())
+    o2r, d2r = orc.get_rays(dirs, c2w)
+    assert rel_err(cpu(o2), o2r) < 1e-6 and rel_err(cpu(d2), d2r) < 1e-6
+    o3, d3 = hip["camera"].get_rays(dirs.cuda(), c2w[0].cuda())
+    o3r, d3r = orc.get_rays(dirs, c2w[0])
+    assert rel_err(cpu(o3), o3r) < 1e-6 and rel_err(cpu(d3), d3r) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ a5
+@pytest.mark.parametrize("S,perturb,disp", [(64, 0.0, False), (64, 1.0, False), (48, 0.5, True), (128, 1.0, False)])
+def test_sample_coarse(hip, S, perturb, disp):
+    L = hip["lib"]
+    R = 33
+    nf = torch.stack([gen((R,), 7, 0.05, 0.3), gen((R,), 8, 3.0, 6.0)], 1)
+    u = gen((R, S), 9, 0.0, 1.0)
+    ref = orc.coarse_depths(nf[:, :1], nf[:, 1:], S, disp, perturb, u if perturb > 0 else None)
+    z = torch.empty(R, S, device="cuda")
+    steps = torch.linspace(0, 1, S).cuda()
+    ud = u.cuda()
+    L.check(L.lib.upnerf_sample_coarse(R, S, L.ptr(nf.cuda()), L.ptr(steps), L.ptr(ud) if perturb > 0 else None,
+                                       perturb, int(disp), L.ptr(z), L.stream()), "sample_coarse")
+    assert np.array_equal(cpu(z).numpy(), ref.numpy())  # same op order, no contraction: bit exact
+
+
+# ------------------------------------------------------------------------------------------ a11, a12
+def _run_pdf(hip, z, w_full, n, det, u):
+    R, S = z.shape
+    out = torch.zeros(R, n + 3, device="cuda")
+    hip["rendering"].sample_pdf(z.cuda(), w_full.cuda(), n, det, out, 3, None if det else u.cuda())
+    return cpu(out)[:, 3:]
+
+
+def test_sample_pdf_matches_oracle(hip):
+    R, S, n = 29, 64, 128
+    z = torch.sort(gen((R, S), 10, 0.1, 5.0), -1)[0]
+    w = gen((R, S), 11, 0.0, 1.0) ** 6
+    w[3] = 0.0                       # all-zero weights: uniform pdf from the eps
+    w[4, 10:50] = 0.0                # empty bins inside
+    mid = 0.5 * (z[:, :-1] + z[:, 1:])
+    u = gen((R, n), 12, 0.0, 1.0)
+    u[5, 0], u[5, 1] = 0.0, 1.0 - 1e-7
+    ref = orc.sample_pdf(mid, w[:, 1:-1], n, False, u)
+    got = _run_pdf(hip, z, w, n, False, u)
+    assert float((got - ref).abs().max()) < 2e-6
+    ref = orc.sample_pdf(mid, w[:, 1:-1], n, True)
+    got = _run_pdf(hip, z, w, n, True, None)
+    assert float((got - ref).abs().max()) < 2e-6
+
+
+def test_sample_pdf_reference_edge_fixture(hip):
+    """searchsorted(right=True) knots, u == 1, zero-weight bins: vectors produced by the reference itself."""
+    g = np.load(f"{GOLDEN}/leaf.npz")
+    bins, w, u = (torch.from_numpy(g[k]) for k in ("pdf_edge_bins", "pdf_edge_w", "pdf_edge_u"))
+    # rebuild a z whose mid-points are the fixture's bins: z_{j+1} = 2 b_j - z_j
+    z = torch.zeros(bins.shape[0], bins.shape[1] + 1)
+    z[:, 0] = bins[:, 0] - 0.5
+    for j in range(bins.shape[1]):
+        z[:, j + 1] = 2 * bins[:, j] - z[:, j]
+    wf = torch.cat([torch.zeros(2, 1), w, torch.zeros(2, 1)], 1)
+    got = _run_pdf(hip, z, wf, u.shape[1], False, u)
+    assert float((got - torch.from_numpy(g["pdf_edge_out"])).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("S", [64, 192, 256, 7])
+def test_sort_rows(hip, S):
+    L = hip["lib"]
+    R = 41
+    z = gen((R, S), 13)
+    z[0, : S // 2] = z[0, S // 2: 2 * (S // 2)]  # duplicates
+    zd = z.cuda().contiguous()
+    L.check(L.lib.upnerf_sort_rows(R, S, L.ptr(zd), L.stream()), "sort_rows")
+    assert np.array_equal(cpu(zd).numpy(), torch.sort(z, -1)[0].numpy())
+
+
+# ------------------------------------------------------------------------------------------ generic GEMMs
+@pytest.mark.parametrize("M,N,K,relu", [(300, 256, 384, True), (129, 384, 256, False), (64, 1, 256, False),
+                                        (500, 3, 128, False), (77, 128, 384, True), (4096, 16, 128, False)])
+def test_linear_fwd_bwd(hip, M, N, K, relu):
+    x, w, b = gen((M, K), 20), gen((N, K), 21) / K ** 0.5, gen((N,), 22)
+    gy = gen((M, N), 23)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y_ref = torch.nn.functional.linear(xr, wr, br)
+    y_ref = torch.relu(y_ref) if relu else y_ref
+    (y_ref * gy).sum().backward()
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = hip["ops"].hip_linear(xg, wg, bg, relu)
+    (y * gy.cuda()).sum().backward()
+    assert rel_err(cpu(y), y_ref.detach()) < TOL_ACT
+    assert rel_err(cpu(xg.grad), xr.grad) < TOL_GRAD
+    assert rel_err(cpu(wg.grad), wr.grad) < TOL_GRAD
+    assert rel_err(cpu(bg.grad), br.grad) < TOL_GRAD
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (333, 128, 256), (5000, 256, 64), (64, 32, 16), (777, 64, 80),
+                                   (40000, 256, 256)])
+def test_wgrad_and_bias(hip, M, N, K):
+    a, b = gen((M, N), 30), gen((M, K), 31)
+    dW = torch.empty(N, K, device="cuda")
+    db = torch.empty(N, device="cuda")
+    hip["ops"].wgrad_into(M, a.cuda(), N, N, b.cuda(), K, K, dW.data_ptr(), K, db.data_ptr(), torch.device("cuda", 0))
+    ref = a.double().t() @ b.double()
+    assert rel_err(cpu(dW), ref) < TOL_ACT
+    assert rel_err(cpu(db), a.double().sum(0)) < TOL_ACT
+    # bitwise reproducible (fixed-order slab reduction, no atomics)
+    dW2 = torch.empty(N, K, device="cuda")
+    hip["ops"].wgrad_into(M, a.cuda(), N, N, b.cuda(), K, K, dW2.data_ptr(), K, None, torch.device("cuda", 0))
+    assert torch.equal(dW, dW2)
+
+
+def test_vec_wgrad(hip):
+    M, K = 3001, 128
+    v, x = gen((M, 4), 32), gen((M, K), 33)
+    dw = torch.empty(3, K, device="cuda")
+    dbv = torch.empty(3, device="cuda")
+    hip["ops"].vec_wgrad_into(M, v.cuda(), 4, 3, x.cuda(), K, K, dw.data_ptr(), dbv.data_ptr(), torch.device("cuda", 0))
+    assert rel_err(cpu(dw), v[:, :3].double().t() @ x.double()) < TOL_ACT
+    assert rel_err(cpu(dbv), v[:, :3].double().sum(0)) < TOL_ACT
+
+
+def test_adam_matches_torch_optim(hip):
+    n = 10007
+    p0 = gen((n,), 40)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=5e-4, eps=1e-8)
+    p, m, v = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        g = gen((n,), 40 + step) * (0.0 if step == 3 else 1.0)
+        ref.grad = g.clone()
+        opt.step()
+        hip["ops"].adam_flat_(p, g.cuda(), m, v, step, 5e-4)
+        assert rel_err(cpu(p), ref.detach()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ fused field + composite
+def _setup_pass(c, typ, hip):
+    """Inputs of one field pass of golden case `c` (CPU tensors) + the packer."""
+    from test_packing_cpu import build_model
+    st = c.state(requires_grad=False)
+    b = c.batch()
+    idx = b["img_idx"]
+    pose = orc.compose_pair(orc.se3_exp(st["se3_refine"][idx]), b["c2w"]) if c.pose_opt else b["c2w"]
+    o, d = orc.get_rays(b["directions"], pose)
+    model = build_model(c, typ, st)
+    keep = {}
+    real = orc.schedule_mult
+    orc.schedule_mult = lambda p, s: c.sched
+    try:
+        with torch.no_grad():
+            orc.training_forward(st, c.cfgs(), b, c.hparams(), c.progress, u_list=c.u_list, keep=keep)
+    finally:
+        orc.schedule_mult = real
+    z = keep["z_coarse" if typ == "coarse" else "z_fine"].contiguous()
+    use_cand = bool(c.sched < 1 and model.encode_candidate)
+    use_rgb = bool(c.sched > 0)
+    mode = (1 if use_rgb else 0) if use_cand else (3 if c.sched < 1 else 2)
+    return dict(model=model, o=o.contiguous(), d=d.contiguous(), z=z, a_rows=st[f"embedding_{typ}_a"][idx],
+                c_rows=st[f"embedding_{typ}_c"][idx], use_cand=use_cand, use_rgb=use_rgb, mode=mode,
+                wk_xyz=hip["rendering"].band_weights(10, c.progress, c.c2f),
+                wk_dir=hip["rendering"].band_weights(4, c.progress, c.c2f))
+
+
+STAGE_CASES = [("cfg1_small", "coarse"), ("cfg2_phase0", "coarse"), ("cfg2_phase1", "fine"), ("cfg2_phase2", "fine"),
+               ("small_nocand", "fine"), ("small_round_half", "fine"), ("small_allmasked", "coarse")]
+
+
+@pytest.mark.parametrize("name,typ", STAGE_CASES)
+def test_field_pass_stage_by_stage(hip, name, typ):
+    c = Case(name)
+    s = _setup_pass(c, typ, hip)
+    rd = hip["rendering"]
+    model, pk = s["model"], s["model"].packer
+    R, S = s["z"].shape
+    # ---- CPU: kernel-space forward with every pre-activation kept, random upstream gradients
+    P_ref = model.packed().detach().clone().requires_grad_(True)
+    o_ref, d_ref = s["o"].clone().requires_grad_(True), s["d"].clone().requires_grad_(True)
+    c_ref, a_ref = s["c_rows"].clone().requires_grad_(True), s["a_rows"].clone().requires_grad_(True)
+    aux_ref = ks.ray_aux(d_ref.detach(), a_ref, s["wk_dir"])
+    f = ks.field(P_ref, pk, o_ref, d_ref, s["z"], c_ref, aux_ref, s["wk_xyz"], s["use_cand"], s["use_rgb"], keep_pre=True)
+    out_ref = ks.composite(f, s["z"], s["mode"], s["use_rgb"], pk.W)
+    names = ["E_s", "G_c", "sum_sfeat", "t_weight", "c_depth", "s_depth", "rgb_map", "w_all", "w_s"]
+    ups = {n: gen(tuple(out_ref[n].shape), 50 + i) for i, n in enumerate(names) if n in out_ref}
+    sum((out_ref[n] * ups[n]).sum() for n in ups).backward()
+
+    # ---- GPU
+    model_g = model.cuda()
+    P_g = model_g.packed().detach().clone().requires_grad_(True)
+    assert rel_err(cpu(P_g), P_ref.detach()) < 1e-6
+    o_g, d_g = s["o"].cuda().requires_grad_(True), s["d"].cuda().requires_grad_(True)
+    c_g, a_g = s["c_rows"].cuda().requires_grad_(True), s["a_rows"].cuda().requires_grad_(True)
+    cfg = rd._PassCfg(pk, s["mode"], s["use_cand"], s["use_rgb"], s["wk_xyz"], s["wk_dir"])
+    outs = rd._FieldPass.apply(o_g, d_g, s["z"].cuda(), c_g, a_g, P_g, cfg)
+    node = next(t.grad_fn for t in outs if t.grad_fn is not None)
+    sv = node.saved
+    M = R * S
+    errs = {}
+
+    def cmp(tag, got, ref, tol):
+        e = rel_err(cpu(got).reshape(-1), ref.detach().reshape(-1))
+        errs[tag] = e
+        return e < tol
+
+    ok = True
+    ok &= cmp("x0", sv["x0"], f["x0"], 2e-6)
+    for l in range(pk.D):
+        ok &= cmp(f"h{l}", sv["h"][l], f["h"][l], TOL_ACT)
+    ok &= cmp("sigma_s", sv["sigma_s"], f["sigma_s"], TOL_ACT)
+    ok &= cmp("e", sv["e"], f["e"], TOL_ACT)
+    if s["use_cand"]:
+        for k in ("g1", "g2", "sigma_c"):
+            ok &= cmp(k, sv[k], f[k], TOL_ACT)
+    if s["use_rgb"]:
+        ok &= cmp("aux", sv["aux"], aux_ref, 2e-6)
+        for k in ("r1", "rgb"):
+            ok &= cmp(k, sv[k], f[k], TOL_ACT)
+    for i, n in enumerate(names):
+        if n in out_ref:
+            ok &= cmp("out_" + n, outs[i], out_ref[n], TOL_ACT)
+    assert ok, {k: v for k, v in errs.items() if v > 1e-6}
+
+    # ---- backward
+    sink = {}
+    rd._DEBUG_SINK = sink
+    try:
+        sum((outs[i] * ups[n].cuda()).sum() for i, n in enumerate(names) if n in ups).backward()
+    finally:
+        rd._DEBUG_SINK = None
+    ok = True
+    ok &= cmp("dpre_s", sink["dpre_s"], f["pre_sig_s"].grad, TOL_GRAD)
+    for l in range(pk.D):
+        ok &= cmp(f"gz_h{l}", sink["gz_h"][l], f["pre_h"][l].grad, TOL_GRAD)
+    ok &= cmp("gz_e", sink["gz_e"], f["e"].grad, TOL_GRAD)
+    if s["use_cand"]:
+        ok &= cmp("dpre_c", sink["dpre_c"], f["pre_sig_c"].grad, TOL_GRAD)
+        ok &= cmp("gz_g2", sink["gz_g2"], f["pre_g2"].grad, TOL_GRAD)
+        ok &= cmp("gz_g1", sink["gz_g1"], f["pre_g1"].grad, TOL_GRAD)
+        ok &= cmp("d_c_rows", c_g.grad, c_ref.grad, TOL_GRAD)
+    if s["use_rgb"]:
+        ok &= cmp("dpre_rgb", sink["dpre_rgb"][:, :3], f["pre_rgb"].grad, TOL_GRAD)
+        ok &= cmp("gz_r1", sink["gz_r1"], f["pre_r1"].grad, TOL_GRAD)
+        ok &= cmp("d_a_rows", a_g.grad, a_ref.grad, TOL_GRAD)
+    ok &= cmp("d_o", o_g.grad, o_ref.grad, TOL_GRAD)
+    ok &= cmp("d_d", d_g.grad, d_ref.grad, TOL_GRAD)
+    L = pk.L
+    W, W2 = pk.W, pk.W2
+    pieces = {"w0": (L.w[0], W * 64), "b0": (L.b[0], W), "we": (L.we, W * W), "be": (L.be, W), "wsig": (L.wsig, W),
+              "bsig": (L.bsig, 1)}
+    for l in range(1, pk.D):
+        pieces[f"w{l}"] = (L.w[l], W * (64 + W if l == pk.skip else W))
+        pieces[f"b{l}"] = (L.b[l], W)
+    if s["use_cand"]:
+        pieces.update(wc1=(L.wc1, W2 * (W + 16)), bc1=(L.bc1, W2), wc2=(L.wc2, W2 * W2), bc2=(L.bc2, W2),
+                      wcsig=(L.wcsig, W2), bcsig=(L.bcsig, 1))
+    if s["use_rgb"]:
+        pieces.update(wr1=(L.wr1, W2 * (W + 80)), br1=(L.br1, W2), wr2=(L.wr2, 3 * W2), br2=(L.br2, 3))
+    for k, (off, n) in pieces.items():
+        ok &= cmp("dP_" + k, P_g.grad[off:off + n], P_ref.grad[off:off + n], TOL_GRAD)
+    assert ok, {k: v for k, v in errs.items() if v > 1e-5}

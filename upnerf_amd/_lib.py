@@ -1,0 +1,129 @@
+"""ctypes binding of libupnerf_hip.so (C ABI: include/upnerf_hip.h).
+
+The product path has no CPU or PyTorch fallback: if the shared library is missing or does not export every
+entry point, importing this module raises, loudly.  Build it with `python __graft_entry__.py` (or
+`make -C upnerf_amd/csrc`)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libupnerf_hip.so")
+MAX_D = 8
+TILE_ROWS, X0, AUXK, CK = 128, 64, 80, 16
+
+_fp = C.c_void_p
+
+
+class Layout(C.Structure):
+    _fields_ = [("W", C.c_int32), ("D", C.c_int32), ("skip", C.c_int32),
+                ("w", C.c_int32 * MAX_D), ("b", C.c_int32 * MAX_D),
+                ("we", C.c_int32), ("be", C.c_int32), ("wsig", C.c_int32), ("bsig", C.c_int32),
+                ("wc1", C.c_int32), ("bc1", C.c_int32), ("wc2", C.c_int32), ("bc2", C.c_int32),
+                ("wcsig", C.c_int32), ("bcsig", C.c_int32), ("wr1", C.c_int32), ("br1", C.c_int32),
+                ("wr2", C.c_int32), ("br2", C.c_int32), ("total", C.c_int32),
+                ("t_w", C.c_int32 * MAX_D), ("t_skipx", C.c_int32), ("t_we", C.c_int32), ("t_head", C.c_int32),
+                ("t_wc2", C.c_int32), ("t_total", C.c_int32)]
+
+
+class FieldFwdArgs(C.Structure):
+    _fields_ = [("R", C.c_int32), ("S", C.c_int32), ("use_cand", C.c_int32), ("use_rgb", C.c_int32),
+                ("rays_o", _fp), ("rays_d", _fp), ("z", _fp), ("c_rows", _fp), ("aux", _fp),
+                ("wk_xyz", C.c_float * 10), ("P", _fp),
+                ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
+                ("x0", _fp), ("h", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp)]
+
+
+class CompositeFwdArgs(C.Structure):
+    _fields_ = [("R", C.c_int32), ("S", C.c_int32), ("W", C.c_int32), ("mode", C.c_int32),
+                ("z", _fp), ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp), ("has_rgb", C.c_int32),
+                ("e", _fp), ("g2", _fp),
+                ("w_all", _fp), ("w_sj", _fp), ("w_cj", _fp), ("w_s", _fp),
+                ("E_s", _fp), ("G_c", _fp), ("sum_sfeat", _fp), ("t_weight", _fp), ("c_depth", _fp),
+                ("s_depth", _fp), ("rgb_map", _fp)]
+
+
+class CompositeBwdArgs(C.Structure):
+    _fields_ = [("R", C.c_int32), ("S", C.c_int32), ("W", C.c_int32), ("mode", C.c_int32), ("has_rgb", C.c_int32),
+                ("z", _fp), ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp), ("e", _fp), ("g2", _fp),
+                ("w_all", _fp), ("w_sj", _fp), ("w_cj", _fp), ("w_s", _fp),
+                ("g_E_s", _fp), ("g_G_c", _fp), ("g_sum_sfeat", _fp), ("g_t_weight", _fp), ("g_c_depth", _fp),
+                ("g_s_depth", _fp), ("g_rgb_map", _fp), ("g_w_all", _fp), ("g_w_s", _fp),
+                ("d_sigma_s", _fp), ("d_sigma_c", _fp), ("d_rgb", _fp)]
+
+
+class FieldBwdArgs(C.Structure):
+    _fields_ = [("R", C.c_int32), ("S", C.c_int32), ("use_cand", C.c_int32), ("use_rgb", C.c_int32),
+                ("need_dxyz", C.c_int32),
+                ("PT", _fp), ("P", _fp),
+                ("d_sigma_s", _fp), ("d_sigma_c", _fp), ("d_rgb", _fp),
+                ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
+                ("w_feat_s", _fp), ("w_cj", _fp), ("g_E_s", _fp), ("g_G_c", _fp),
+                ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp),
+                ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
+                ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp)]
+
+
+_i, _f, _p = C.c_int, C.c_float, C.c_void_p
+_SIGNATURES = {
+    "upnerf_abi_version": [],
+    "upnerf_pose_rays_fwd": [_i, _p, _p, _p, _p, _p, _p],
+    "upnerf_pose_rays_bwd": [_i, _p, _p, _p, _p, _p, _p, _p],
+    "upnerf_sample_coarse": [_i, _i, _p, _p, _p, _f, _i, _p, _p],
+    "upnerf_sample_pdf": [_i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
+    "upnerf_sort_rows": [_i, _i, _p, _p],
+    "upnerf_ray_aux": [_i, _p, _p, C.POINTER(C.c_float), _p, _p],
+    "upnerf_field_fwd": [C.POINTER(Layout), C.POINTER(FieldFwdArgs), _p],
+    "upnerf_composite_fwd": [C.POINTER(CompositeFwdArgs), _p],
+    "upnerf_composite_bwd": [C.POINTER(CompositeBwdArgs), _p],
+    "upnerf_field_bwd": [C.POINTER(Layout), C.POINTER(FieldBwdArgs), _p],
+    "upnerf_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
+    "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
+    "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
+    "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],
+    "upnerf_linear": [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p],
+    "upnerf_adam": [C.c_int64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p],
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            "(there is no CPU/PyTorch fallback for the render_rays hot path).")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it")
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    return lib
+
+
+lib = _load()
+if lib.upnerf_abi_version() != 1:
+    raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int64 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda, "libupnerf_hip operates on device memory only"
+    assert t.is_contiguous(), "non-contiguous tensor handed to the HIP path"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported shape"}.get(rc, f"hipError_t {rc}")
+        raise RuntimeError(f"{what} failed: {kind}")

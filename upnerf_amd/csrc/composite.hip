@@ -1,0 +1,303 @@
+// Alpha compositing along rays for gfx950 (models/rendering.py:125-218), forward and backward.
+//
+// One 64-lane wavefront owns one ray.  Samples are processed in chunks of 64 (one sample per lane): the
+// exclusive transmittance product T_i = prod_{j<i} (1 - alpha_j) is a wave-level scan built from __shfl_up
+// with a running carry between chunks, so any S works (64 coarse, 192 or 256 fine).  Feature maps are
+// accumulated in the W-wide space of xyz_encoding_final (e) and W/2-wide candidate encoding (g2): for each
+// sample the wave reads one contiguous row (16 bytes per lane) and scales it by the broadcast weight; the
+// 384-wide projection happens once per ray on the host side of the boundary.
+//
+// Backward: division-free reverse scan of SURVEY Appendix A.3 -- with X_j = sum of (weight_j * upstream_j)
+//   d sigma_s,i = delta_i [ e_s,i T_i Gs_i + e_a,i T_i Gw_i - sum_{j>i} X_j ]  (+ the shared-only field's term)
+// where e_* = exp(-delta sigma) so that no (1 - alpha) ever appears in a denominator.
+#include "common.cuh"
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float excl_prod_scan(float x, int lane, float& total) {
+  // inclusive Hillis-Steele product over the wave, then shift by one lane
+  float v = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(v, d);
+    if (lane >= d) v *= t;
+  }
+  total = __shfl(v, 63);
+  const float e = __shfl_up(v, 1);
+  return lane == 0 ? 1.0f : e;
+}
+
+__device__ __forceinline__ float excl_suffix_sum(float x, int lane, float& total) {
+  float v = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_down(v, d);
+    if (lane + d < 64) v += t;
+  }
+  total = __shfl(v, 0);
+  const float e = __shfl_down(v, 1);
+  return lane == 63 ? 0.0f : e;
+}
+
+struct Alphas {
+  float delta, es, ec, ea;  // exp(-delta*sigma_s), exp(-delta*sigma_c), exp(-delta*(sigma_s+sigma_c))
+  float a_s, a_c, a_all;    // 1 - exp(...)
+};
+
+__device__ __forceinline__ Alphas alphas_at(const float* __restrict__ z, const float* __restrict__ sig_s,
+                                            const float* __restrict__ sig_c, size_t base, int i, int S, bool joint) {
+  Alphas A;
+  A.delta = (i == S - 1) ? 1e2f : z[base + i + 1] - z[base + i];  // rendering.py:125-129
+  const float ss = sig_s[base + i];
+  A.es = expf(-A.delta * ss);
+  A.a_s = 1.0f - A.es;
+  A.ec = 1.0f; A.ea = A.es; A.a_c = 0.0f; A.a_all = A.a_s;
+  if (joint) {
+    const float sc = sig_c[base + i];
+    A.ec = expf(-A.delta * sc);
+    A.a_c = 1.0f - A.ec;
+    A.ea = expf(-A.delta * (ss + sc));
+    A.a_all = 1.0f - A.ea;
+  }
+  return A;
+}
+
+template <int W>
+__global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composite_fwd_args a) {
+  constexpr int W2 = W / 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.R) return;
+  const int S = a.S;
+  const size_t base = (size_t)r * S;
+  const bool joint = a.mode <= 1;
+  const bool feat_from_ws = a.mode == 3;       // feature map weighted by the shared-only weights
+  const bool want_feat = a.mode != 2;
+  float carryT = 1.0f, carryTs = 1.0f;
+  float acc_cd = 0.f, acc_sd = 0.f, acc_tw = 0.f, acc_sf = 0.f, acc_rgb[3] = {0.f, 0.f, 0.f};
+  f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accG = {0.f, 0.f, 0.f, 0.f};
+  const bool laneE = lane < W / 4, laneG = lane < W2 / 4;
+  for (int c0 = 0; c0 < S; c0 += 64) {
+    const int i = c0 + lane;
+    const bool valid = i < S;
+    float zi = 0.f, w_all = 0.f, w_sj = 0.f, w_cj = 0.f, w_s = 0.f;
+    Alphas A;
+    A.a_s = A.a_c = A.a_all = 0.f;
+    if (valid) {
+      A = alphas_at(a.z, a.sigma_s, a.sigma_c, base, i, S, joint);
+      zi = a.z[base + i];
+    }
+    float tot;
+    if (joint) {
+      // 1 - alpha is formed from alpha (not from the exponential) like the reference (rendering.py:156-161)
+      const float T = carryT * excl_prod_scan(valid ? 1.0f - A.a_all : 1.0f, lane, tot);
+      carryT *= tot;
+      w_all = A.a_all * T; w_sj = A.a_s * T; w_cj = A.a_c * T;
+      if (valid) {
+        a.w_all[base + i] = w_all; a.w_sj[base + i] = w_sj; a.w_cj[base + i] = w_cj;
+      }
+      acc_cd += w_all * zi;
+      acc_tw += w_cj;
+    }
+    const float Ts = carryTs * excl_prod_scan(valid ? 1.0f - A.a_s : 1.0f, lane, tot);
+    carryTs *= tot;
+    w_s = A.a_s * Ts;
+    if (valid) a.w_s[base + i] = w_s;
+    acc_sd += w_s * zi;
+    if (a.has_rgb && valid) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc_rgb[c] += w_s * a.rgb[(base + i) * 3 + c];
+    }
+    if (want_feat) {
+      const float wf = feat_from_ws ? w_s : w_sj;
+      acc_sf += wf;
+      const int nv = (S - c0) < 64 ? (S - c0) : 64;
+      for (int j = 0; j < nv; ++j) {
+        const float wj = __shfl(wf, j);
+        const size_t m = base + c0 + j;
+        if (laneE) {
+          const f32x4 ev = *(const f32x4*)&a.e[m * W + 4 * lane];
+          accE.x += wj * ev.x; accE.y += wj * ev.y; accE.z += wj * ev.z; accE.w += wj * ev.w;
+        }
+        if (joint) {
+          const float cj = __shfl(w_cj, j);
+          if (laneG) {
+            const f32x4 gv = *(const f32x4*)&a.g2[m * W2 + 4 * lane];
+            accG.x += cj * gv.x; accG.y += cj * gv.y; accG.z += cj * gv.z; accG.w += cj * gv.w;
+          }
+        }
+      }
+    }
+  }
+  const float cd = wave_sum(acc_cd), sd = wave_sum(acc_sd), tw = wave_sum(acc_tw), sf = wave_sum(acc_sf);
+  float rg[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rg[c] = wave_sum(acc_rgb[c]);
+  if (lane == 0) {
+    a.s_depth[r] = sd;
+    if (joint) { a.c_depth[r] = cd; a.t_weight[r] = tw; }
+    if (want_feat) a.sum_sfeat[r] = sf;
+    if (a.has_rgb) { a.rgb_map[r * 3] = rg[0]; a.rgb_map[r * 3 + 1] = rg[1]; a.rgb_map[r * 3 + 2] = rg[2]; }
+  }
+  if (want_feat) {
+    if (laneE) *(f32x4*)&a.E_s[(size_t)r * W + 4 * lane] = accE;
+    if (joint && laneG) *(f32x4*)&a.G_c[(size_t)r * W2 + 4 * lane] = accG;
+  }
+}
+
+#define MAX_CHUNKS 16
+template <int W>
+__global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composite_bwd_args a) {
+  constexpr int W2 = W / 2;
+  __shared__ float carry_s[4][2][MAX_CHUNKS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.R) return;
+  const int S = a.S;
+  const size_t base = (size_t)r * S;
+  const bool joint = a.mode <= 1;
+  const bool feat_from_ws = a.mode == 3;
+  const bool want_feat = a.mode != 2;
+  const bool laneE = lane < W / 4, laneG = lane < W2 / 4;
+  const int nchunk = (S + 63) >> 6;
+  // forward pre-pass: transmittance at the start of every chunk
+  {
+    float cT = 1.0f, cTs = 1.0f;
+    for (int c = 0; c < nchunk; ++c) {
+      if (lane == 0) { carry_s[wave][0][c] = cT; carry_s[wave][1][c] = cTs; }
+      const int i = c * 64 + lane;
+      float om = 1.0f, oms = 1.0f;
+      if (i < S) {
+        const Alphas A = alphas_at(a.z, a.sigma_s, a.sigma_c, base, i, S, joint);
+        om = 1.0f - A.a_all; oms = 1.0f - A.a_s;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { om *= __shfl_xor(om, d); oms *= __shfl_xor(oms, d); }
+      cT *= om; cTs *= oms;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  f32x4 gE = {0.f, 0.f, 0.f, 0.f}, gG = {0.f, 0.f, 0.f, 0.f};
+  if (want_feat && a.g_E_s && laneE) gE = *(const f32x4*)&a.g_E_s[(size_t)r * W + 4 * lane];
+  if (joint && a.g_G_c && laneG) gG = *(const f32x4*)&a.g_G_c[(size_t)r * W2 + 4 * lane];
+  const float g_sf = (want_feat && a.g_sum_sfeat) ? a.g_sum_sfeat[r] : 0.f;
+  const float g_tw = (joint && a.g_t_weight) ? a.g_t_weight[r] : 0.f;
+  const float g_cd = (joint && a.g_c_depth) ? a.g_c_depth[r] : 0.f;
+  const float g_sd = a.g_s_depth ? a.g_s_depth[r] : 0.f;
+  float g_rm[3] = {0.f, 0.f, 0.f};
+  if (a.has_rgb && a.g_rgb_map) { g_rm[0] = a.g_rgb_map[r * 3]; g_rm[1] = a.g_rgb_map[r * 3 + 1]; g_rm[2] = a.g_rgb_map[r * 3 + 2]; }
+  const bool need_dots = want_feat && (a.g_E_s || (joint && a.g_G_c));
+
+  float sufX = 0.f, sufY = 0.f;  // suffix sums over later chunks
+  for (int c = nchunk - 1; c >= 0; --c) {
+    const int c0 = c * 64, i = c0 + lane;
+    const bool valid = i < S;
+    // <g_E_s, e_i> and <g_G_c, g2_i> for the 64 samples of the chunk: lane j keeps sample j's result
+    float dotE = 0.f, dotG = 0.f;
+    if (need_dots) {
+      const int nv = (S - c0) < 64 ? (S - c0) : 64;
+      for (int j = 0; j < nv; ++j) {
+        const size_t m = base + c0 + j;
+        float pe = 0.f, pg = 0.f;
+        if (laneE) {
+          const f32x4 ev = *(const f32x4*)&a.e[m * W + 4 * lane];
+          pe = gE.x * ev.x + gE.y * ev.y + gE.z * ev.z + gE.w * ev.w;
+        }
+        if (joint && laneG) {
+          const f32x4 gv = *(const f32x4*)&a.g2[m * W2 + 4 * lane];
+          pg = gG.x * gv.x + gG.y * gv.y + gG.z * gv.z + gG.w * gv.w;
+        }
+        pe = wave_sum(pe);
+        if (joint) pg = wave_sum(pg);
+        if (lane == j) { dotE = pe; dotG = pg; }
+      }
+    }
+    Alphas A;
+    A.delta = 0.f; A.es = A.ec = A.ea = 1.f; A.a_s = A.a_c = A.a_all = 0.f;
+    float zi = 0.f;
+    if (valid) {
+      A = alphas_at(a.z, a.sigma_s, a.sigma_c, base, i, S, joint);
+      zi = a.z[base + i];
+    }
+    float tot, ds = 0.f, dc = 0.f;
+    if (joint) {
+      const float T = carry_s[wave][0][c] * excl_prod_scan(valid ? 1.0f - A.a_all : 1.0f, lane, tot);
+      const float Gs = dotE + g_sf, Gc = dotG + g_tw;
+      const float Gw = g_cd * zi + ((a.g_w_all && valid) ? a.g_w_all[base + i] : 0.f);
+      const float X = valid ? (A.a_s * T) * Gs + (A.a_c * T) * Gc + (A.a_all * T) * Gw : 0.f;
+      const float suf = excl_suffix_sum(X, lane, tot) + sufX;
+      sufX += tot;
+      ds = A.delta * (A.es * T * Gs + A.ea * T * Gw - suf);
+      dc = A.delta * (A.ec * T * Gc + A.ea * T * Gw - suf);
+    }
+    {
+      const float Ts = carry_s[wave][1][c] * excl_prod_scan(valid ? 1.0f - A.a_s : 1.0f, lane, tot);
+      const float w_s = A.a_s * Ts;
+      float Gws = g_sd * zi + ((a.g_w_s && valid) ? a.g_w_s[base + i] : 0.f);
+      if (a.has_rgb && valid) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) Gws += g_rm[ch] * a.rgb[(base + i) * 3 + ch];
+      }
+      if (feat_from_ws) Gws += dotE + g_sf;
+      const float Y = valid ? w_s * Gws : 0.f;
+      const float suf = excl_suffix_sum(Y, lane, tot) + sufY;
+      sufY += tot;
+      ds += A.delta * (A.es * Ts * Gws - suf);
+      if (a.has_rgb && valid) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) a.d_rgb[(base + i) * 3 + ch] = w_s * g_rm[ch];
+      }
+    }
+    if (valid) {
+      a.d_sigma_s[base + i] = ds;
+      if (joint) a.d_sigma_c[base + i] = dc;
+    }
+  }
+}
+
+int check_common(int R, int S, int W, int mode) {
+  if (R <= 0 || S <= 0 || S > 64 * MAX_CHUNKS) return UPNERF_EINVAL;
+  if (W != 64 && W != 256) return UPNERF_EUNSUP;
+  if (mode < 0 || mode > 3) return UPNERF_EINVAL;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int upnerf_composite_fwd(const upnerf_composite_fwd_args* a, void* stream) {
+  if (!a) return UPNERF_EINVAL;
+  int rc = check_common(a->R, a->S, a->W, a->mode);
+  if (rc) return rc;
+  const bool joint = a->mode <= 1, want_feat = a->mode != 2;
+  if (!a->z || !a->sigma_s || !a->w_s || !a->s_depth) return UPNERF_EINVAL;
+  if (joint && (!a->sigma_c || !a->w_all || !a->w_sj || !a->w_cj || !a->c_depth || !a->t_weight || !a->g2 || !a->G_c))
+    return UPNERF_EINVAL;
+  if (want_feat && (!a->e || !a->E_s || !a->sum_sfeat)) return UPNERF_EINVAL;
+  if (a->has_rgb && (!a->rgb || !a->rgb_map)) return UPNERF_EINVAL;
+  const dim3 grid((a->R + 3) / 4), block(NTHREADS);
+  if (a->W == 256)
+    hipLaunchKernelGGL(composite_fwd_kernel<256>, grid, block, 0, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(composite_fwd_kernel<64>, grid, block, 0, (hipStream_t)stream, *a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_composite_bwd(const upnerf_composite_bwd_args* a, void* stream) {
+  if (!a) return UPNERF_EINVAL;
+  int rc = check_common(a->R, a->S, a->W, a->mode);
+  if (rc) return rc;
+  const bool joint = a->mode <= 1, want_feat = a->mode != 2;
+  if (!a->z || !a->sigma_s || !a->d_sigma_s) return UPNERF_EINVAL;
+  if (joint && (!a->sigma_c || !a->d_sigma_c)) return UPNERF_EINVAL;
+  if (want_feat && a->g_E_s && !a->e) return UPNERF_EINVAL;
+  if (joint && a->g_G_c && !a->g2) return UPNERF_EINVAL;
+  if (a->has_rgb && (!a->rgb || !a->d_rgb)) return UPNERF_EINVAL;
+  const dim3 grid((a->R + 3) / 4), block(NTHREADS);
+  if (a->W == 256)
+    hipLaunchKernelGGL(composite_bwd_kernel<256>, grid, block, 0, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(composite_bwd_kernel<64>, grid, block, 0, (hipStream_t)stream, *a);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,325 @@
+// Weight-gradient contraction, the generic fp32 MFMA linear layer, the vector-head weight gradients and the
+// fused Adam step for gfx950.
+//
+// upnerf_wgrad: dW[n][k] = sum_m A[m][n] B[m][k]  (autograd of nn.Linear weights, models/nerf.py:39-78).
+//   The reduction runs over ALL samples (M = rays x samples, ~786k), the output is at most 256x256, so the
+//   grid splits M: each workgroup keeps a full [TN x TK] output block in accumulator registers (up to
+//   16 tiles of 32x32 per wave = 256 AGPRs; one wave per SIMD gets the whole 512-entry register file on CDNA4),
+//   streams its slice of A and B through double-buffered LDS in 32-row chunks, and writes one partial slab.
+//   A second tiny kernel sums the slabs in a fixed order -> bitwise reproducible, no float atomics.
+//   MFMA orientation: lane (i, h) feeds A-operand A[m+h][n0+i] and B-operand B[m+h][k0+i]; both are plain
+//   ds_read_b32 of 32 consecutive floats per half-wave (bank-conflict free without padding).
+#include "common.cuh"
+
+namespace {
+
+#define WG_CHUNK 32
+
+template <int MTW, int NTW>
+__global__ __launch_bounds__(NTHREADS, 1) void wgrad_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                            const float* __restrict__ B, int ldb,
+                                                            float* __restrict__ slabs, float* __restrict__ bslabs,
+                                                            int rows_per_split) {
+  constexpr int TN = 64 * MTW, TK = 64 * NTW;
+  constexpr int A4 = WG_CHUNK * TN / 4 / NTHREADS, B4 = WG_CHUNK * TK / 4 / NTHREADS;  // float4 per thread per chunk
+  __shared__ __attribute__((aligned(16))) float As[2][WG_CHUNK * TN];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WG_CHUNK * TK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int n0 = (wave >> 1) * 32 * MTW, k0 = (wave & 1) * 32 * NTW;
+  const int split = blockIdx.x;
+  const int nblk = blockIdx.y * TN, kblk = blockIdx.z * TK;  // output block origin (N, K larger than one block)
+  const int mbeg = split * rows_per_split;
+  const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  f32x16 acc[MTW][NTW];
+  acc_zero(acc);
+  float bsum[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) bsum[mt] = 0.f;
+
+  f32x4 ra[A4 > 0 ? A4 : 1], rb[B4 > 0 ? B4 : 1];
+  auto gload = [&](int mc) {
+#pragma unroll
+    for (int q = 0; q < A4; ++q) {
+      const int idx = tid + q * NTHREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
+      const int m = mc + row;
+      ra[q] = (m < mend && nblk + 4 * c4 < N) ? *(const f32x4*)&A[(size_t)m * lda + nblk + 4 * c4]
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < B4; ++q) {
+      const int idx = tid + q * NTHREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
+      const int m = mc + row;
+      rb[q] = (m < mend && kblk + 4 * c4 < K) ? *(const f32x4*)&B[(size_t)m * ldb + kblk + 4 * c4]
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < A4; ++q) *(f32x4*)&As[buf][(tid + q * NTHREADS) * 4] = ra[q];
+#pragma unroll
+    for (int q = 0; q < B4; ++q) *(f32x4*)&Bs[buf][(tid + q * NTHREADS) * 4] = rb[q];
+  };
+
+  int buf = 0;
+  if (mbeg < mend) gload(mbeg);
+  for (int mc = mbeg; mc < mend; mc += WG_CHUNK) {
+    lstore(buf);
+    __syncthreads();
+    if (mc + WG_CHUNK < mend) gload(mc + WG_CHUNK);
+    const float* as = As[buf];
+    const float* bs = Bs[buf];
+#pragma unroll 4
+    for (int mm = 0; mm < WG_CHUNK; mm += 2) {
+      float av[MTW], bv[NTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) av[mt] = as[(mm + hh) * TN + n0 + 32 * mt + li];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) bv[nt] = bs[(mm + hh) * TK + k0 + 32 * nt + li];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        bsum[mt] += av[mt];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    buf ^= 1;
+  }
+  // partial slab [split][by][bz][TN][TK]
+  const size_t blk = ((size_t)split * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+  float* slab = slabs + blk * TN * TK;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        slab[n * TK + k0 + 32 * nt + li] = acc[mt][nt][r];
+      }
+  if (bslabs && blockIdx.z == 0 && (wave & 1) == 0) {
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const float s = bsum[mt] + __shfl_xor(bsum[mt], 32);
+      if (hh == 0) bslabs[((size_t)split * gridDim.y + blockIdx.y) * TN + n0 + 32 * mt + li] = s;
+    }
+  }
+}
+
+// dW[n][k] = sum_split slab[split][by][bz][n%TN][k%TK]   (fixed order)
+__global__ void wgrad_reduce_kernel(int N, int K, int TN, int TK, int nsplit, const float* __restrict__ slabs,
+                                    const float* __restrict__ bslabs, float* __restrict__ dW, int ldo,
+                                    float* __restrict__ db) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
+  if (idx < N * K) {
+    const int n = idx / K, k = idx - n * K;
+    const int by = n / TN, bz = k / TK;
+    const size_t off = ((size_t)by * gz + bz) * TN * TK + (size_t)(n - by * TN) * TK + (k - bz * TK);
+    const size_t stride = (size_t)gy * gz * TN * TK;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += slabs[off + sp * stride];
+    dW[(size_t)n * ldo + k] = s;
+  }
+  if (db && idx < N) {
+    const int by = idx / TN;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += bslabs[((size_t)sp * gy + by) * TN + (idx - by * TN)];
+    db[idx] = s;
+  }
+}
+
+// ---- N = 1 / 3 heads: dw[c][k] = sum_m v[m][c] X[m][k]
+__global__ __launch_bounds__(NTHREADS) void vec_wgrad_kernel(int M, const float* __restrict__ v, int ldv, int nvec,
+                                                            const float* __restrict__ X, int ldx, int K,
+                                                            float* __restrict__ part, int rows_per_split) {
+  const int k = threadIdx.x, split = blockIdx.x;
+  const int mbeg = split * rows_per_split;
+  const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bacc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int m = mbeg; m < mend; ++m) {
+    const float x = k < K ? X[(size_t)m * ldx + k] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < nvec) {
+        const float vv = v[(size_t)m * ldv + c];
+        acc[c] += vv * x;
+        bacc[c] += vv;
+      }
+    }
+  }
+  // part layout [split][4][K+1]: last column = sum of v
+  for (int c = 0; c < nvec; ++c) {
+    if (k < K) part[((size_t)split * 4 + c) * (K + 1) + k] = acc[c];
+    if (k == 0) part[((size_t)split * 4 + c) * (K + 1) + K] = bacc[c];
+  }
+}
+
+__global__ void vec_wgrad_reduce_kernel(int nvec, int K, int nsplit, const float* __restrict__ part,
+                                        float* __restrict__ dw, float* __restrict__ dbv) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nvec * (K + 1)) return;
+  const int c = idx / (K + 1), k = idx - c * (K + 1);
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)sp * 4 + c) * (K + 1) + k];
+  if (k < K) dw[(size_t)c * K + k] = s;
+  else if (dbv) dbv[c] = s;
+}
+
+// ---- generic linear: C = act(A B^T + bias); A tile staged in LDS in K-chunks of 128
+#define LIN_KC 128
+__global__ __launch_bounds__(NTHREADS, 1) void linear_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                             const float* __restrict__ B, int ldb,
+                                                             const float* __restrict__ bias, float* __restrict__ C,
+                                                             int ldc, int act) {
+  __shared__ __attribute__((aligned(16))) float As[TILE * LIN_KC];
+  using TW = WaveTile<256>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * TILE, nb = blockIdx.y * 256;
+  const int n0 = TW::n0(wave), row0 = TW::row0(wave);
+  f32x16 acc[TW::MT][TW::NT];
+  acc_zero(acc);
+  // B rows beyond N are clamped (their columns are never stored)
+  const int li = lane & 31, hh = lane >> 5;
+  for (int kc = 0; kc < K; kc += LIN_KC) {
+    const int kk = (K - kc) < LIN_KC ? (K - kc) : LIN_KC;
+    const int gpr = kk >> 2;
+    __syncthreads();
+    for (int idx = tid; idx < TILE * gpr; idx += NTHREADS) {
+      const int row = idx / gpr, g = idx - row * gpr;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m0 + row < M) v = *(const f32x4*)&A[(size_t)(m0 + row) * lda + kc + 4 * g];
+      *(f32x4*)&As[swz4(row, 4 * g, LIN_KC)] = v;
+    }
+    __syncthreads();
+    const int T = kk >> 3;
+    for (int t = 0; t < T; ++t) {
+      f32x4 a[TW::MT], b[TW::NT];
+#pragma unroll
+      for (int nt = 0; nt < TW::NT; ++nt) {
+        int n = nb + n0 + 32 * nt + li;
+        n = n < N ? n : N - 1;
+        b[nt] = *(const f32x4*)&B[(size_t)n * ldb + kc + 8 * t + 4 * hh];
+      }
+#pragma unroll
+      for (int mt = 0; mt < TW::MT; ++mt) {
+        const int row = row0 + 32 * mt + li;
+        a[mt] = *(const f32x4*)&As[swz4(row, 8 * t + 4 * hh, LIN_KC)];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < TW::MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < TW::NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < TW::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < TW::NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int col = nb + n0 + 32 * nt + li;
+        if (row < M && col < N) {
+          float v = acc[mt][nt][r] + (bias ? bias[col] : 0.f);
+          if (act == 1) v = fmaxf(v, 0.f);
+          C[(size_t)row * ldc + col] = v;
+        }
+      }
+}
+
+// ---- Adam (torch.optim.Adam, no weight decay / amsgrad): same op order as torch's single-tensor path
+__global__ void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = m[i] + (gi - m[i]) * (1.f - b1);       // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = v[i] * b2 + (1.f - b2) * gi * gi;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+template <int MTW, int NTW>
+int launch_wgrad(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* slabs, float* bslabs,
+                 int nsplit, int rows_per_split, hipStream_t st) {
+  constexpr int TN = 64 * MTW, TK = 64 * NTW;
+  dim3 grid(nsplit, (N + TN - 1) / TN, (K + TK - 1) / TK);
+  hipLaunchKernelGGL((wgrad_kernel<MTW, NTW>), grid, dim3(NTHREADS), 0, st, M, N, K, A, lda, B, ldb, slabs, bslabs,
+                     rows_per_split);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// Scratch needed by upnerf_wgrad for (N, K, nsplit): nsplit * (roundup(N) * roundup(K) + roundup(N)) floats,
+// where roundup() is to the block shape chosen below (<= 256).
+static void wgrad_shape(int N, int K, int* TN, int* TK) {
+  *TN = N >= 256 ? 256 : (N > 64 ? 128 : 64);
+  *TK = K >= 256 ? 256 : (K > 64 ? 128 : 64);
+}
+
+extern "C" int upnerf_wgrad(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
+                            float* db, float* slabs, int nsplit, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !dW || !slabs || nsplit <= 0) return UPNERF_EINVAL;
+  if ((N & 3) || (K & 3) || (lda & 3) || (ldb & 3)) return UPNERF_EINVAL;
+  int TN, TK;
+  wgrad_shape(N, K, &TN, &TK);
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = (((M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
+  float* bslabs = slabs + (size_t)nsplit * gy * gz * TN * TK;
+  int rc;
+  if (TN == 256 && TK == 256) rc = launch_wgrad<4, 4>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
+  else if (TN == 256 && TK == 128) rc = launch_wgrad<4, 2>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
+  else if (TN == 256 && TK == 64) rc = launch_wgrad<4, 1>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
+  else if (TN == 128 && TK == 256) rc = launch_wgrad<2, 4>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
+  else if (TN == 128 && TK == 128) rc = launch_wgrad<2, 2>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
+  else if (TN == 128 && TK == 64) rc = launch_wgrad<2, 1>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
+  else if (TN == 64 && TK == 256) rc = launch_wgrad<1, 4>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
+  else if (TN == 64 && TK == 128) rc = launch_wgrad<1, 2>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
+  else rc = launch_wgrad<1, 1>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
+  if (rc) return rc;
+  const int total = N * K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, N, K, TN, TK, nsplit, slabs,
+                     bslabs, dW, ldo, db);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const float* X, int ldx, int K, float* dw,
+                                float* dbv, float* scratch, int nsplit, void* stream) {
+  if (M <= 0 || nvec <= 0 || nvec > 4 || K <= 0 || K > 256 || !v || !X || !dw || !scratch || nsplit <= 0)
+    return UPNERF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = (M + nsplit - 1) / nsplit;
+  hipLaunchKernelGGL(vec_wgrad_kernel, dim3(nsplit), dim3(NTHREADS), 0, st, M, v, ldv, nvec, X, ldx, K, scratch, rows);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  const int total = nvec * (K + 1);
+  hipLaunchKernelGGL(vec_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, nvec, K, nsplit, scratch, dw,
+                     dbv);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
+                             float* C, int ldc, int act, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 3) || (ldb & 3) || !A || !B || !C) return UPNERF_EINVAL;
+  dim3 grid((M + TILE - 1) / TILE, (N + 255) / 256);
+  hipLaunchKernelGGL(linear_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, M, N, K, A, lda, B, ldb, bias, C, ldc,
+                     act);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                           float eps, float bias_corr1, float bias_corr2, void* stream) {
+  if (n <= 0 || !p || !g || !m || !v) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n, p,
+                     g, m, v, lr, beta1, beta2, eps, bias_corr1, sqrtf(bias_corr2));
+  return (int)hipGetLastError();
+}

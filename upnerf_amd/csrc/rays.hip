@@ -1,0 +1,439 @@
+// Per-ray kernels of the UP-NeRF hot path on gfx950: SE(3) pose refinement + ray generation (forward and
+// analytic backward), stratified coarse depths, inverse-CDF resampling, per-row sort, per-ray side inputs and
+// the per-ray reductions of the backward pass.  All of them are HBM/latency bound and tiny next to the MLP;
+// they exist so that the path has no eager ATen launches and no host round trips.
+//
+// Floating-point contraction is disabled in this file: the reference evaluates these expressions as separate
+// fp32 ATen ops (one rounding per op), and the sampled depths feed sin(2^9 pi x), so a fused multiply-add here
+// would show up as ~1e-4 differences in the highest encoding band.
+#include "common.cuh"
+#pragma clang fp contract(off)
+
+namespace {
+
+// ---- a2: Taylor coefficients of sin(x)/x, (1-cos x)/x^2, (x-sin x)/x^3 as polynomials in q = |w|^2
+//      (utils/camera.py:126-152, nth=10).  c_i = (-1)^i / (2i+1)!, / (2i+2)!, / (2i+3)!
+struct Taylor {
+  float A, B, C, dA, dB, dC;  // values and derivatives with respect to q
+};
+
+__device__ __forceinline__ Taylor taylor_abc(float q) {
+  double fa = 1.0, fb = 2.0, fc = 6.0;  // (2i+1)!, (2i+2)!, (2i+3)! at i = 0
+  float ca[11], cb[11], cc[11];
+#pragma unroll
+  for (int i = 0; i <= 10; ++i) {
+    if (i > 0) {
+      fa *= (double)(2 * i) * (2 * i + 1);
+      fb *= (double)(2 * i + 1) * (2 * i + 2);
+      fc *= (double)(2 * i + 2) * (2 * i + 3);
+    }
+    const double sgn = (i & 1) ? -1.0 : 1.0;
+    ca[i] = (float)(sgn / fa);
+    cb[i] = (float)(sgn / fb);
+    cc[i] = (float)(sgn / fc);
+  }
+  Taylor t;
+  t.A = ca[10]; t.B = cb[10]; t.C = cc[10];
+  t.dA = 10.f * ca[10]; t.dB = 10.f * cb[10]; t.dC = 10.f * cc[10];
+#pragma unroll
+  for (int i = 9; i >= 0; --i) {
+    t.A = t.A * q + ca[i];
+    t.B = t.B * q + cb[i];
+    t.C = t.C * q + cc[i];
+    if (i >= 1) {
+      t.dA = t.dA * q + (float)i * ca[i];
+      t.dB = t.dB * q + (float)i * cb[i];
+      t.dC = t.dC * q + (float)i * cc[i];
+    }
+  }
+  return t;
+}
+
+__device__ __forceinline__ void hat3(const float w[3], float K[3][3]) {
+  K[0][0] = 0.f;   K[0][1] = -w[2]; K[0][2] = w[1];
+  K[1][0] = w[2];  K[1][1] = 0.f;   K[1][2] = -w[0];
+  K[2][0] = -w[1]; K[2][1] = w[0];  K[2][2] = 0.f;
+}
+
+__device__ __forceinline__ void mat3mul(const float a[3][3], const float b[3][3], float c[3][3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[i][j] = a[i][0] * b[0][j] + a[i][1] * b[1][j] + a[i][2] * b[2][j];
+}
+
+// refinement pose [R | V u] from one se(3) row (camera.py:87-98)
+__device__ __forceinline__ void se3_exp_dev(const float* wu, float Rm[3][3], float Vm[3][3], float t[3], float K[3][3],
+                                            float K2[3][3], Taylor& ty) {
+  const float w[3] = {wu[0], wu[1], wu[2]};
+  const float q = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  ty = taylor_abc(q);
+  hat3(w, K);
+  mat3mul(K, K, K2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float id = (i == j) ? 1.f : 0.f;
+      Rm[i][j] = id + ty.A * K[i][j] + ty.B * K2[i][j];
+      Vm[i][j] = id + ty.B * K[i][j] + ty.C * K2[i][j];
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = Vm[i][0] * wu[3] + Vm[i][1] * wu[4] + Vm[i][2] * wu[5];
+}
+
+__global__ void pose_rays_fwd_kernel(int R, const float* __restrict__ se3, const float* __restrict__ c2w,
+                                     const float* __restrict__ dirs, float* __restrict__ rays_o,
+                                     float* __restrict__ rays_d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float Rc[3][3], tc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rc[i][j] = c2w[r * 12 + i * 4 + j];
+    tc[i] = c2w[r * 12 + i * 4 + 3];
+  }
+  float Rn[3][3], tn[3];
+  if (se3) {
+    float Rm[3][3], Vm[3][3], t[3], K[3][3], K2[3][3];
+    Taylor ty;
+    se3_exp_dev(se3 + r * 6, Rm, Vm, t, K, K2, ty);
+    mat3mul(Rc, Rm, Rn);  // compose([refine, c2w]) = c2w o refine (camera.py:51-58, nerf_system.py:160)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tn[i] = (Rc[i][0] * t[0] + Rc[i][1] * t[1] + Rc[i][2] * t[2]) + tc[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rn[i][j] = Rc[i][j];
+      tn[i] = tc[i];
+    }
+  }
+  // get_rays (ray.py:44-56): d = R dir / |R dir|, o = t
+  const float dx = dirs[r * 3], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
+  float v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = dx * Rn[i][0] + dy * Rn[i][1] + dz * Rn[i][2];
+  const float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    rays_d[r * 3 + i] = v[i] / nrm;
+    rays_o[r * 3 + i] = tn[i];
+  }
+}
+
+__global__ void pose_rays_bwd_kernel(int R, const float* __restrict__ se3, const float* __restrict__ c2w,
+                                     const float* __restrict__ dirs, const float* __restrict__ g_o,
+                                     const float* __restrict__ g_d, float* __restrict__ g_se3) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float Rc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rc[i][j] = c2w[r * 12 + i * 4 + j];
+  float Rm[3][3], Vm[3][3], t[3], K[3][3], K2[3][3];
+  Taylor ty;
+  const float* wu = se3 + r * 6;
+  se3_exp_dev(wu, Rm, Vm, t, K, K2, ty);
+  float Rn[3][3];
+  mat3mul(Rc, Rm, Rn);
+  const float dir[3] = {dirs[r * 3], dirs[r * 3 + 1], dirs[r * 3 + 2]};
+  float v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = dir[0] * Rn[i][0] + dir[1] * Rn[i][1] + dir[2] * Rn[i][2];
+  const float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const float d[3] = {v[0] / nrm, v[1] / nrm, v[2] / nrm};
+  const float gd[3] = {g_d[r * 3], g_d[r * 3 + 1], g_d[r * 3 + 2]};
+  const float go[3] = {g_o[r * 3], g_o[r * 3 + 1], g_o[r * 3 + 2]};
+  const float dg = d[0] * gd[0] + d[1] * gd[1] + d[2] * gd[2];
+  float gv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) gv[i] = (gd[i] - d[i] * dg) / nrm;
+  // Rn = Rc Rm, v = Rn dir:  g_Rm = Rc^T (gv dir^T);  tn = Rc t + tc: g_t = Rc^T go
+  float gR[3][3], gt[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float rg = Rc[0][i] * gv[0] + Rc[1][i] * gv[1] + Rc[2][i] * gv[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gR[i][j] = rg * dir[j];
+    gt[i] = Rc[0][i] * go[0] + Rc[1][i] * go[1] + Rc[2][i] * go[2];
+  }
+  // t = V u
+  const float u[3] = {wu[3], wu[4], wu[5]};
+  float gu[3], gV[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    gu[i] = Vm[0][i] * gt[0] + Vm[1][i] * gt[1] + Vm[2][i] * gt[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gV[i][j] = gt[i] * u[j];
+  }
+  // R = I + A K + B K2, V = I + B K + C K2
+  float gA = 0.f, gB = 0.f, gC = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      gA += gR[i][j] * K[i][j];
+      gB += gR[i][j] * K2[i][j] + gV[i][j] * K[i][j];
+      gC += gV[i][j] * K2[i][j];
+    }
+  // gradient reaching K directly and through K2 = K K:  g_K += G K^T + K^T G with G = B gR + C gV
+  float G[3][3], gK[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G[i][j] = ty.B * gR[i][j] + ty.C * gV[i][j];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float s = ty.A * gR[i][j] + ty.B * gV[i][j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s += G[i][k] * K[j][k] + K[k][i] * G[k][j];
+      gK[i][j] = s;
+    }
+  const float w[3] = {wu[0], wu[1], wu[2]};
+  const float gq = 2.f * (gA * ty.dA + gB * ty.dB + gC * ty.dC);
+  g_se3[r * 6 + 0] = (gK[2][1] - gK[1][2]) + gq * w[0];
+  g_se3[r * 6 + 1] = (gK[0][2] - gK[2][0]) + gq * w[1];
+  g_se3[r * 6 + 2] = (gK[1][0] - gK[0][1]) + gq * w[2];
+  g_se3[r * 6 + 3] = gu[0];
+  g_se3[r * 6 + 4] = gu[1];
+  g_se3[r * 6 + 5] = gu[2];
+}
+
+// ---- a5: stratified depths (rendering.py:232-249)
+__device__ __forceinline__ float base_z(float near, float far, float s, int use_disp) {
+  if (!use_disp) return near * (1.f - s) + far * s;
+  return 1.f / (1.f / near * (1.f - s) + 1.f / far * s);
+}
+
+__global__ void sample_coarse_kernel(int R, int S, const float* __restrict__ near_far, const float* __restrict__ steps,
+                                     const float* __restrict__ u, float perturb, int use_disp, float* __restrict__ z) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * S) return;
+  const int r = idx / S, i = idx - r * S;
+  const float near = near_far[2 * r], far = near_far[2 * r + 1];
+  const float zi = base_z(near, far, steps[i], use_disp);
+  if (perturb > 0.f && u) {
+    const float zl = i > 0 ? base_z(near, far, steps[i - 1], use_disp) : zi;
+    const float zr = i < S - 1 ? base_z(near, far, steps[i + 1], use_disp) : zi;
+    const float upper = i < S - 1 ? 0.5f * (zi + zr) : zi;
+    const float lower = i > 0 ? 0.5f * (zl + zi) : zi;
+    z[idx] = lower + (upper - lower) * (perturb * u[idx]);
+  } else {
+    z[idx] = zi;
+  }
+}
+
+// ---- a11: sample_pdf (rendering.py:7-50); one wave per ray, cdf kept in LDS.
+#define PDF_MAXS 1024
+__global__ __launch_bounds__(NTHREADS) void sample_pdf_kernel(int R, int S, const float* __restrict__ z,
+                                                             const float* __restrict__ weights,
+                                                             const float* __restrict__ u, int u_rows, int n,
+                                                             float* __restrict__ out, int out_stride) {
+  __shared__ float cdf_s[4][PDF_MAXS];
+  __shared__ float bins_s[4][PDF_MAXS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  float* cdf = cdf_s[wave];
+  float* bins = bins_s[wave];
+  const int B = S - 2;  // number of weights; cdf and bins have B+1 entries
+  const float eps = 1e-5f;
+  float part = 0.f;
+  for (int j = lane; j < B; j += 64) {
+    const float w = weights[(size_t)r * S + 1 + j] + eps;
+    cdf[j + 1] = w;  // staged; turned into the running sum below
+    part += w;
+  }
+  for (int j = lane; j <= B; j += 64) bins[j] = 0.5f * (z[(size_t)r * S + j] + z[(size_t)r * S + j + 1]);
+  const float total = wave_sum(part);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    // torch.cumsum on CPU accumulates float rows in double and rounds each prefix to float
+    double run = 0.0;
+    cdf[0] = 0.f;
+    for (int j = 0; j < B; ++j) {
+      run += (double)(cdf[j + 1] / total);
+      cdf[j + 1] = (float)run;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  for (int k = lane; k < n; k += 64) {
+    const float uk = u[(size_t)(u_rows == 1 ? 0 : r) * n + k];
+    // searchsorted(cdf, u, right=True): number of entries <= u
+    int lo = 0, hi = B + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= uk) lo = mid + 1; else hi = mid;
+    }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < B ? lo : B;
+    const float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
+    float den = c1 - c0;
+    if (den < eps) den = 1.f;
+    out[(size_t)r * out_stride + k] = b0 + (uk - c0) / den * (b1 - b0);
+  }
+}
+
+// ---- a12: per-row ascending sort (values only) by rank counting in LDS; stable for ties.
+__global__ __launch_bounds__(NTHREADS) void sort_rows_kernel(int R, int S, float* __restrict__ z) {
+  __shared__ float v_s[4][PDF_MAXS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  float* v = v_s[wave];
+  for (int j = lane; j < S; j += 64) v[j] = z[(size_t)r * S + j];
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  for (int e = lane; e < S; e += 64) {
+    const float x = v[e];
+    int rank = 0;
+    for (int j = 0; j < S; ++j) {
+      const float y = v[j];
+      rank += (y < x || (y == x && j < e)) ? 1 : 0;
+    }
+    z[(size_t)r * S + rank] = x;
+  }
+}
+
+// ---- per-ray side input of the colour head: [PE(dir, L=4) | a | 0]
+__global__ void ray_aux_kernel(int R, const float* __restrict__ rays_d, const float* __restrict__ a_rows,
+                               float w0, float w1, float w2, float w3, float* __restrict__ aux) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float* o = aux + (size_t)r * UPNERF_AUXK;
+  const float wk[4] = {w0, w1, w2, w3};
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const float x = rays_d[r * 3 + n];
+    o[n] = x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float arg = x * ldexpf(3.14159274101257324f, k);
+      float sv, cv;
+      sincosf(arg, &sv, &cv);
+      o[3 + 8 * n + k] = sv * wk[k];
+      o[3 + 8 * n + 4 + k] = cv * wk[k];
+    }
+  }
+  for (int j = 0; j < 48; ++j) o[27 + j] = a_rows ? a_rows[(size_t)r * 48 + j] : 0.f;
+  for (int j = 75; j < UPNERF_AUXK; ++j) o[j] = 0.f;
+}
+
+// ---- out[r][c] = sum_i X[r*S+i][c]; one block per ray, one thread per column (C <= 256)
+__global__ void ray_sum_kernel(int S, const float* __restrict__ X, int C, float* __restrict__ out) {
+  const int r = blockIdx.x, c = threadIdx.x;
+  if (c >= C) return;
+  const float* p = X + (size_t)r * S * C + c;
+  float s0 = 0.f, s1 = 0.f;
+  int i = 0;
+  for (; i + 1 < S; i += 2) {
+    s0 += p[(size_t)i * C];
+    s1 += p[(size_t)(i + 1) * C];
+  }
+  if (i < S) s0 += p[(size_t)i * C];
+  out[(size_t)r * C + c] = s0 + s1;
+}
+
+// ---- (d_o, d_d) = (sum_i dxyz_i, sum_i z_i dxyz_i); one wave per ray
+__global__ __launch_bounds__(NTHREADS) void ray_geom_bwd_kernel(int R, int S, const float* __restrict__ dxyz,
+                                                               const float* __restrict__ z, float* __restrict__ d_o,
+                                                               float* __restrict__ d_d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+  for (int i = lane; i < S; i += 64) {
+    const size_t m = (size_t)r * S + i;
+    const float zz = z[m];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const float g = dxyz[m * 3 + n];
+      so[n] += g;
+      sd[n] += zz * g;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const float a = wave_sum(so[n]), b = wave_sum(sd[n]);
+    if (lane == 0) {
+      d_o[r * 3 + n] = a;
+      d_d[r * 3 + n] = b;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int upnerf_abi_version(void) { return UPNERF_ABI_VERSION; }
+
+extern "C" int upnerf_pose_rays_fwd(int R, const float* se3, const float* c2w, const float* dirs, float* rays_o,
+                                    float* rays_d, void* stream) {
+  if (R <= 0 || !c2w || !dirs || !rays_o || !rays_d) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(pose_rays_fwd_kernel, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, R, se3, c2w, dirs,
+                     rays_o, rays_d);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_pose_rays_bwd(int R, const float* se3, const float* c2w, const float* dirs, const float* g_o,
+                                    const float* g_d, float* g_se3, void* stream) {
+  if (R <= 0 || !se3 || !c2w || !dirs || !g_o || !g_d || !g_se3) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(pose_rays_bwd_kernel, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, R, se3, c2w, dirs,
+                     g_o, g_d, g_se3);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_sample_coarse(int R, int S, const float* near_far, const float* steps, const float* u,
+                                    float perturb, int use_disp, float* z_out, void* stream) {
+  if (R <= 0 || S <= 0 || !near_far || !steps || !z_out) return UPNERF_EINVAL;
+  if (perturb > 0.f && !u) return UPNERF_EINVAL;
+  const long long n = (long long)R * S;
+  hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R, S,
+                     near_far, steps, u, perturb, use_disp, z_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_sample_pdf(int R, int S, const float* z, const float* weights, const float* u, int u_rows, int n,
+                                 float* out, int out_stride, void* stream) {
+  if (R <= 0 || S < 3 || S > PDF_MAXS || n < 0 || !z || !weights || !out) return UPNERF_EINVAL;
+  if (n == 0) return 0;
+  if (!u || (u_rows != 1 && u_rows != R) || out_stride < n) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(sample_pdf_kernel, dim3((R + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, S, z, weights, u,
+                     u_rows, n, out, out_stride);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_sort_rows(int R, int S, float* z, void* stream) {
+  if (R <= 0 || S <= 0 || S > PDF_MAXS || !z) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(sort_rows_kernel, dim3((R + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, S, z);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_ray_aux(int R, const float* rays_d, const float* a_rows, const float* wk_dir, float* aux,
+                              void* stream) {
+  if (R <= 0 || !rays_d || !wk_dir || !aux) return UPNERF_EINVAL;
+  // wk_dir is a HOST pointer to 4 floats (band weights are host scalars derived from the step counter)
+  hipLaunchKernelGGL(ray_aux_kernel, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, R, rays_d, a_rows,
+                     wk_dir[0], wk_dir[1], wk_dir[2], wk_dir[3], aux);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_ray_sum(int R, int S, const float* X, int C, float* out, void* stream) {
+  if (R <= 0 || S <= 0 || C <= 0 || C > 256 || !X || !out) return UPNERF_EINVAL;
+  const int threads = ((C + 63) / 64) * 64;
+  hipLaunchKernelGGL(ray_sum_kernel, dim3(R), dim3(threads), 0, (hipStream_t)stream, S, X, C, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_ray_geom_bwd(int R, int S, const float* dxyz, const float* z, float* d_o, float* d_d,
+                                   void* stream) {
+  if (R <= 0 || S <= 0 || !dxyz || !z || !d_o || !d_d) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(ray_geom_bwd_kernel, dim3((R + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, S, dxyz, z, d_o,
+                     d_d);
+  return (int)hipGetLastError();
+}

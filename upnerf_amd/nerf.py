@@ -1,0 +1,90 @@
+"""NeRF field module with the reference's parameter names, shapes and attributes (models/nerf.py:5-78), so
+state_dicts interchange with the reference and Lightning checkpoints load unchanged.
+
+When called through upnerf_amd.render_rays the module is evaluated by the fused HIP kernels from its packed
+parameter buffer (`packed()`); `forward()` keeps the reference's per-sample calling convention
+(nerf.py:80-124) and runs layer by layer on the HIP linear kernel."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .ops import hip_linear
+from .packing import NerfPacker
+
+
+class NeRF(nn.Module):
+    def __init__(self, typ, D=8, W=256, skips=[4], encode_feat=True, feat_dim=384, xyz_L=10, dir_L=8,
+                 appearance_dim=48, candidate_dim=16, c2f=None):
+        super().__init__()
+        self.typ, self.D, self.W, self.skips = typ, D, W, list(skips)
+        self.xyz_L, self.dir_L = xyz_L, dir_L
+        self.in_channels_xyz, self.in_channels_dir = 6 * xyz_L + 3, 6 * dir_L + 3
+        self.feat_dim, self.appearance_dim, self.candidate_dim = feat_dim, appearance_dim, candidate_dim
+        self.encode_feat = encode_feat
+        self.encode_appearance = appearance_dim > 0
+        self.encode_candidate = candidate_dim > 0
+        self.c2f = c2f
+        self.progress = nn.Parameter(torch.tensor(0.0))  # written through .data only
+        if not encode_feat:
+            raise NotImplementedError("nerf.feat_dim = 0 is not implemented on the HIP path")
+        for i in range(D):
+            k = self.in_channels_xyz if i == 0 else (W + self.in_channels_xyz if i in self.skips else W)
+            setattr(self, f"xyz_encoding_{i + 1}", nn.Sequential(nn.Linear(k, W), nn.ReLU(True)))
+        self.xyz_encoding_final = nn.Linear(W, W)
+        self.share_sigma = nn.Sequential(nn.Linear(W, 1), nn.Softplus())
+        self.feat_share_layer = nn.Linear(W, feat_dim)
+        in_rgb = feat_dim + self.in_channels_dir + (appearance_dim if self.encode_appearance else 0)
+        self.rgb_share_layer = nn.Sequential(nn.Linear(in_rgb, W // 2), nn.ReLU(True), nn.Linear(W // 2, 3),
+                                             nn.Sigmoid())
+        if self.encode_candidate:
+            self.candidate_encoding = nn.Sequential(nn.Linear(W + candidate_dim, W // 2), nn.ReLU(True),
+                                                    nn.Linear(W // 2, W // 2), nn.ReLU(True))
+            self.candidate_sigma = nn.Sequential(nn.Linear(W // 2, 1), nn.Softplus())
+            self.feat_candidate_layer = nn.Linear(W // 2, feat_dim)
+        self.packer = NerfPacker(W, D, self.skips, self.in_channels_xyz, self.in_channels_dir, feat_dim,
+                                 appearance_dim, candidate_dim)
+
+    def packed(self) -> torch.Tensor:
+        """Flat kernel-layout parameter buffer, differentiable w.r.t. the parameters."""
+        p = dict(self.named_parameters())
+        return self.packer.pack(p)
+
+    # ---- reference-compatible per-sample call (nerf.py:80-124); not used by render_rays
+    def positional_encoding(self, x, L):
+        freq = (2 ** torch.arange(L, dtype=torch.float32, device=x.device)) * torch.pi
+        arg = x[..., None] * freq
+        enc = torch.stack([arg.sin(), arg.cos()], dim=-2)
+        if self.c2f is not None:
+            start, end = self.c2f
+            alpha = (self.progress.data - start) / (end - start) * L
+            k = torch.arange(L, dtype=torch.float32, device=x.device)
+            enc = enc * ((1 - ((alpha - k).clamp(min=0, max=1) * torch.pi).cos()) / 2)
+        return torch.cat([x, enc.reshape(*x.shape[:-1], -1)], -1)
+
+    def forward(self, inputs, sched_mult, sigma_only=False):
+        lin = lambda m, x, relu=False: hip_linear(x, m.weight, m.bias, relu)
+        ret = {}
+        x0 = self.positional_encoding(inputs["input_xyz"], self.xyz_L)
+        h = x0
+        for i in range(self.D):
+            if i in self.skips:
+                h = torch.cat([x0, h], 1)
+            h = lin(getattr(self, f"xyz_encoding_{i + 1}")[0], h, True)
+        ret["s_sigma"] = torch.nn.functional.softplus(lin(self.share_sigma[0], h))
+        if sigma_only:
+            return ret
+        e = lin(self.xyz_encoding_final, h)
+        ret["s_feat"] = lin(self.feat_share_layer, e)
+        if sched_mult < 1 and self.encode_candidate:
+            g = lin(self.candidate_encoding[0], torch.cat([e, inputs["input_c"]], 1), True)
+            g = lin(self.candidate_encoding[2], g, True)
+            ret["c_sigma"] = torch.nn.functional.softplus(lin(self.candidate_sigma[0], g))
+            ret["c_feat"] = lin(self.feat_candidate_layer, g)
+        if sched_mult > 0:
+            parts = [ret["s_feat"], self.positional_encoding(inputs["input_dir"], self.dir_L)]
+            if self.encode_appearance:
+                parts.append(inputs["input_a"])
+            r = lin(self.rgb_share_layer[0], torch.cat(parts, 1), True)
+            ret["s_rgb"] = torch.sigmoid(lin(self.rgb_share_layer[2], r))
+        return ret

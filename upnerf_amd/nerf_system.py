@@ -1,0 +1,254 @@
+"""NeRFSystem: host-side orchestration of one UP-NeRF training step with the reference's module surface
+(models/nerf_system.py:22-461): same constructor (flat dotted hparams), attribute names, state_dict keys, hook
+names and schedule semantics, so train.py / tto.py style drivers and Lightning checkpoints carry over.
+
+pytorch_lightning is optional (it is not installed in this image): when importable, NeRFSystem subclasses
+LightningModule; otherwise a minimal base provides the few members the hooks use (optimizers(), lr_schedulers(),
+manual_backward, log, global_step) and `fit_steps()` drives training.
+
+Differences by design: poses/rays, rendering, transient net run on the HIP path; the per-step host sync of the
+reference (progress.item(), nerf_system.py:180) is replaced by a host-side step counter; with world_size > 1 the
+gradient all-reduce is explicit (upnerf_amd.parallel.GradSync) instead of DDP hooks."""
+from __future__ import annotations
+
+import math
+from collections import defaultdict
+
+import torch
+from torch import nn
+
+from .camera import refine_and_get_rays
+from .losses import UPNeRFLoss
+from .nerf import NeRF
+from .optim import get_learning_rate, get_optimizer, get_scheduler
+from .parallel import GradSync
+from .rendering import render_rays
+from .transient_net import TransientNet
+
+try:  # pragma: no cover - Lightning is absent in the build image
+    from pytorch_lightning import LightningModule as _Base
+    _HAVE_PL = True
+except Exception:
+    _HAVE_PL = False
+
+    class _Base(nn.Module):
+        """The members of LightningModule that NeRFSystem's hooks touch."""
+
+        def __init__(self):
+            super().__init__()
+            self.global_step = 0
+            self._opts, self._scheds, self.logged = None, None, {}
+            self.automatic_optimization = True
+
+        def save_hyperparameters(self, hp):
+            self.hparams = dict(hp)
+
+        def log(self, name, value, **kw):
+            self.logged[name] = value
+
+        def _ensure_optim(self):
+            if self._opts is None:
+                opts, scheds = self.configure_optimizers()
+                self._opts, self._scheds = list(opts), [s["scheduler"] for s in scheds]
+
+        def optimizers(self):
+            self._ensure_optim()
+            return self._opts if len(self._opts) > 1 else self._opts[0]
+
+        def lr_schedulers(self):
+            self._ensure_optim()
+            return self._scheds if len(self._scheds) > 1 else self._scheds[0]
+
+        def manual_backward(self, loss):
+            loss.backward()
+
+
+class NeRFSystem(_Base):
+    def __init__(self, hparams, train_dataset=None, val_dataset=None):
+        super().__init__()
+        self.save_hyperparameters(hparams)
+        self.automatic_optimization = False
+        self.candidate_schedule = self.hparams["candidate_schedule"]
+        self.fine = self.hparams["nerf.N_importance"] > 0
+        self.loss = UPNeRFLoss(depth_mult=self.hparams["loss.depth_mult"], alpha_reg=self.hparams["loss.alpha_reg"],
+                               encode_feat=self.hparams["nerf.feat_dim"] > 0, fine=self.fine)
+        self.val_log_N = 0
+        self.train_dataset, self.val_dataset = train_dataset, val_dataset
+        self._host_progress = 0.0
+        self.grad_sync = None
+
+    # ---- hooks -----------------------------------------------------------------------------------
+    def setup(self, stage=None):
+        if self.train_dataset is None:
+            self.dataset_setup()
+        self.model_setup()
+
+    def dataset_setup(self):
+        raise NotImplementedError(
+            "dataset construction (datasets/phototourism.py) is outside the accelerated path; pass train_dataset / "
+            "val_dataset objects (anything with N_images_train and white_back) to NeRFSystem(...)")
+
+    def configure_optimizers(self):
+        hp = self.hparams
+        self.optimizer = get_optimizer(hp["optimizer.type"], hp["optimizer.lr"], self.models_to_train)
+        sched = get_scheduler(hp["optimizer.scheduler.type"], hp["optimizer.lr"], hp["optimizer.scheduler.lr_end"],
+                              hp["max_steps"], self.optimizer)
+        optimizer, scheduler = [self.optimizer], [{"scheduler": sched, "interval": "step"}]
+        if hp["pose.optimize"]:
+            self.optimizer_pose = get_optimizer(hp["optimizer_pose.type"], hp["optimizer_pose.lr"],
+                                                [self.depth_scale, self.se3_refine])
+            sched_p = get_scheduler(hp["optimizer_pose.scheduler.type"], hp["optimizer_pose.lr"],
+                                    hp["optimizer_pose.scheduler.lr_end"], hp["max_steps"], self.optimizer_pose)
+            optimizer += [self.optimizer_pose]
+            scheduler += [{"scheduler": sched_p, "interval": "step"}]
+        return optimizer, scheduler
+
+    def model_setup(self):
+        hp = self.hparams
+        N_images = self.train_dataset.N_images_train
+        self.embeddings, self.models_to_train = {}, []
+        for kind, dim in (("a", hp["nerf.appearance_dim"]), ("c", hp["nerf.candidate_dim"])):
+            if dim > 0:
+                for typ in ("coarse", "fine") if self.fine else ("coarse",):
+                    emb = nn.Embedding(N_images, dim)
+                    setattr(self, f"embedding_{typ}_{kind}", emb)
+                    self.embeddings[f"{typ}_{kind}"] = emb
+                    self.models_to_train += [emb]
+        kw = dict(encode_feat=hp["nerf.feat_dim"] > 0, feat_dim=hp["nerf.feat_dim"], xyz_L=hp["nerf.N_emb_xyz"],
+                  dir_L=hp["nerf.N_emb_dir"], appearance_dim=hp["nerf.appearance_dim"],
+                  candidate_dim=hp["nerf.candidate_dim"], c2f=hp["pose.c2f"],
+                  D=hp.get("nerf.D", 8), W=hp.get("nerf.W", 256))  # D/W: build extension
+        self.nerf_coarse = NeRF("coarse", **kw)
+        self.models = {"nerf_coarse": self.nerf_coarse}
+        if self.fine:
+            self.nerf_fine = NeRF("fine", **kw)
+            self.models["nerf_fine"] = self.nerf_fine
+        self.transient_net = TransientNet(N_images=N_images, beta_min=hp["t_net.beta_min"],
+                                          trasient_dim=hp["t_net.transient_dim"], feat_dim=hp["t_net.feat_dim"])
+        self.models["transient_network"] = self.transient_net
+        self.models_to_train += [self.models]
+        self.se3_refine = nn.Embedding(N_images, 6)
+        nn.init.zeros_(self.se3_refine.weight)
+        self.depth_scale = nn.Embedding(N_images, 2)
+        nn.init.zeros_(self.depth_scale.weight)
+
+    # ---- forward (nerf_system.py:93-148) -------------------------------------------------------------
+    def forward(self, rays, feats, img_idx, sched_mult, train=True, u_list=None):
+        hp = self.hparams
+        sched_phase = 0 if sched_mult == 0 else (2 if sched_mult == 1 else 1)
+        B = rays.shape[0]
+        results = defaultdict(list)
+        chunk = B if train else hp["val.chunk_size"]
+        for i in range(0, B, chunk):
+            out = render_rays(models=self.models, embeddings=self.embeddings, rays=rays[i:i + chunk],
+                              img_idx=img_idx[i:i + chunk], sched_mult=sched_mult, sched_phase=sched_phase,
+                              N_samples=hp["nerf.N_samples"], use_disp=hp["nerf.use_disp"],
+                              perturb=hp["nerf.perturb"] if train else 0, N_importance=hp["nerf.N_importance"],
+                              white_back=getattr(self.train_dataset, "white_back", False),
+                              encode_feat=hp["nerf.feat_dim"] > 0, validation=not train, u_list=u_list)
+            for k, v in out.items():
+                results[k] += [v]
+        results = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in results.items()}
+        if sched_mult > 0:
+            if self.transient_net is not None:
+                t = self.transient_net(feats, img_idx)
+                t_rgbs, t_alphas, t_betas = t["rgb"], t["alpha"], t["beta"]
+                results["rgb_coarse"] = results["s_rgb_coarse"] * (1 - t_alphas.detach()) \
+                    + t_rgbs.detach() * t_alphas.detach()
+                if "s_rgb_fine" in results:
+                    results["rgb_fine"] = results["s_rgb_fine"] * (1 - t_alphas) + t_rgbs * t_alphas
+                results["t_beta"], results["t_alpha"] = t_betas, t_alphas
+            else:
+                results["rgb_coarse"] = results["s_rgb_coarse"]
+        return results
+
+    # ---- pieces of training_step, exposed for tests and the benchmark ------------------------------------
+    def rays_from_batch(self, batch):
+        idx = batch["img_idx"]
+        se3 = self.se3_refine(idx) if self.hparams["pose.optimize"] else None
+        rays_o, rays_d = refine_and_get_rays(se3, batch["c2w"], batch["directions"])
+        return torch.cat([rays_o, rays_d, batch["ray_infos"]], 1)
+
+    def depth_targets(self, batch):
+        """Affine-corrected mono-depth prior (nerf_system.py:169-177)."""
+        near, far = self.hparams["nerf.near"], self.hparams["nerf.far"]
+        scale, shift = torch.unbind(self.depth_scale(batch["img_idx"]), 1)
+        p = batch["inv_depths"] * torch.exp(scale) + shift
+        p = torch.where(p < 1 / far, torch.full_like(p, 1 / far), p)
+        d = 1.0 / p
+        return torch.where(d < near, torch.full_like(d, near), d)
+
+    def compute_loss(self, batch, u_list=None):
+        rays = self.rays_from_batch(batch)
+        depth = self.depth_targets(batch)
+        sched_mult = self.get_schedule_mult(self._host_progress)
+        results = self(rays, batch["feats"], batch["img_idx"], sched_mult, u_list=u_list)
+        loss_d = self.loss(results, batch["rgbs"], batch["feats"], depth, sched_mult)
+        return sum(l for l in loss_d.values()), loss_d, results
+
+    def set_progress(self, progress: float):
+        """Host-side copy of NeRF.progress (avoids the reference's per-step .item() sync)."""
+        self._host_progress = float(progress)
+        self.nerf_coarse.progress.data.fill_(progress)
+        if self.fine:
+            self.nerf_fine.progress.data.fill_(progress)
+
+    def training_step(self, batch, batch_nb=0, u_list=None):
+        hp = self.hparams
+        loss, loss_d, results = self.compute_loss(batch, u_list=u_list)
+        opts = self.optimizers()
+        scheds = self.lr_schedulers()
+        opts = opts if isinstance(opts, (list, tuple)) else [opts]
+        scheds = scheds if isinstance(scheds, (list, tuple)) else [scheds]
+        for o in opts:
+            o.zero_grad()
+        self.manual_backward(loss)
+        if self.grad_sync is not None:
+            self.grad_sync()
+        for o, s in zip(opts, scheds):
+            o.step()
+            s.step()
+        if not _HAVE_PL:
+            self.global_step += len(opts)  # Lightning 1.9 counts one global step per optimizer.step
+        self.log("lr", get_learning_rate(opts[0]))
+        self.log("train/loss", loss.detach())
+        for k, v in loss_d.items():
+            self.log(f"train/{k}", v.detach(), prog_bar=True)
+        if hp["pose.optimize"]:  # progress only advances with pose optimisation
+            self.set_progress(self.global_step / (hp["max_steps"] * 2))
+        return loss
+
+    def enable_data_parallel(self, check=False):
+        """Average gradients over torch.distributed ranks after every backward (one flat all-reduce)."""
+        self.grad_sync = GradSync([p for p in self.parameters()], check=check)
+
+    def get_schedule_mult(self, progress):
+        s, e = self.candidate_schedule
+        if progress < s:
+            return 0
+        if progress > e:
+            return 1
+        return (1 - math.cos(math.pi * (progress - s) / (e - s))) / 2
+
+
+class SyntheticDataset:
+    """Stand-in for datasets/phototourism.py in benchmarks and tests: only the members the system reads."""
+
+    def __init__(self, N_images_train: int, white_back: bool = False):
+        self.N_images_train, self.white_back = N_images_train, white_back
+
+
+def default_hparams(**over):
+    """configs/default.yaml as the flat dotted dict configs/config.py:12-31 produces."""
+    hp = {"seed": 42, "num_gpus": 1, "debug": False, "nerf.N_samples": 128, "nerf.N_importance": 128,
+          "nerf.N_emb_xyz": 10, "nerf.N_emb_dir": 4, "nerf.near": 0.1, "nerf.far": 5.0, "nerf.appearance_dim": 48,
+          "nerf.candidate_dim": 16, "nerf.feat_dim": 384, "nerf.use_disp": False, "nerf.perturb": 1.0,
+          "t_net.beta_min": 0.1, "t_net.transient_dim": 128, "t_net.feat_dim": 384, "loss.depth_mult": 1e-3,
+          "loss.alpha_reg": 1.0, "optimizer.type": "adam", "optimizer.lr": 5e-4,
+          "optimizer.scheduler.type": "ExponentialLR", "optimizer.scheduler.lr_end": 5e-5,
+          "optimizer_pose.type": "adam", "optimizer_pose.lr": 2e-3, "optimizer_pose.scheduler.type": "ExponentialLR",
+          "optimizer_pose.scheduler.lr_end": 1e-5, "max_steps": 600000, "train.batch_size": 2048,
+          "val.chunk_size": 4096, "pose.optimize": True, "pose.c2f": (0.1, 0.5), "pose.noise": -1,
+          "candidate_schedule": (0.1, 0.5)}
+    hp.update(over)
+    return hp

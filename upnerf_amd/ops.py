@@ -1,0 +1,127 @@
+"""Thin torch.autograd wrappers over single C-ABI entry points (linear layer, weight gradients, Adam).
+
+PyTorch is used here for device memory, streams and autograd bookkeeping only; the arithmetic is in
+libupnerf_hip.so.  Nothing in this file falls back to ATen matmuls."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+_WS: Dict[Tuple[str, int], torch.Tensor] = {}
+
+
+def workspace(tag: str, numel: int, device) -> torch.Tensor:
+    """Grow-only fp32 scratch, one per (tag, device); stream-ordered reuse."""
+    key = (tag, device.index if device.index is not None else torch.cuda.current_device())
+    t = _WS.get(key)
+    if t is None or t.numel() < numel:
+        t = torch.empty(max(numel, 1), device=device, dtype=torch.float32)
+        _WS[key] = t
+    return t
+
+
+def nsplit_for(M: int) -> int:
+    return max(1, min(256, M // 256))
+
+
+def wgrad_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor, ldb: int, K: int, dW_ptr: int, ldo: int,
+               db_ptr: Optional[int], device, a_off: int = 0, b_off: int = 0):
+    """dW[N][ldo] = sum_m A[m][a_off + n] B[m][b_off + k];  db[n] = sum_m A[m][a_off+n]  (pointers may be offsets
+    into a larger gradient buffer)."""
+    ns = nsplit_for(M)
+    ws = workspace("wgrad", ns * (256 * 256 + 256), device)
+    rc = lib.upnerf_wgrad(M, A.data_ptr() + 4 * a_off, lda, N, B.data_ptr() + 4 * b_off, ldb, K, dW_ptr, ldo,
+                          db_ptr, ptr(ws), ns, stream())
+    check(rc, "upnerf_wgrad")
+
+
+def vec_wgrad_into(M: int, v: torch.Tensor, ldv: int, nvec: int, X: torch.Tensor, ldx: int, K: int, dw_ptr: int,
+                   dbv_ptr: Optional[int], device):
+    ns = nsplit_for(M)
+    ws = workspace("vec_wgrad", ns * 4 * (K + 1), device)
+    check(lib.upnerf_vec_wgrad(M, ptr(v), ldv, nvec, ptr(X), ldx, K, dw_ptr, dbv_ptr, ptr(ws), ns, stream()),
+          "upnerf_vec_wgrad")
+
+
+def linear_raw(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int) -> torch.Tensor:
+    """y = act(x w^T + b) with x [M][K], w [N][K]; K is padded to a multiple of 8 when needed."""
+    M, K = x.shape
+    N = w.shape[0]
+    if K % 8:
+        pad = 8 - K % 8
+        x, w = F.pad(x, (0, pad)), F.pad(w, (0, pad))
+        K += pad
+    x, w = x.contiguous(), w.contiguous()
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    check(lib.upnerf_linear(M, N, K, ptr(x), K, ptr(w), K, ptr(b.contiguous()) if b is not None else None, ptr(y), N,
+                            act, stream()), "upnerf_linear")
+    return y
+
+
+class HipLinear(torch.autograd.Function):
+    """y = act(x W^T + b) on the fp32 MFMA kernel (nn.Linear [+ ReLU] of models/transient_net.py:11-25 and the
+    per-ray feature projection)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act: int):
+        y = linear_raw(x.detach(), w.detach(), None if b is None else b.detach(), act)
+        ctx.save_for_backward(x, w, y if act == 1 else None)
+        ctx.has_bias, ctx.act = b is not None, act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        if ctx.act == 1:
+            gy = gy * (y > 0)
+        M, K = x.shape
+        N = w.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = linear_raw(gy, w.t(), None, 0)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            xc = x.contiguous()
+            gw = torch.empty(N, K, device=x.device, dtype=torch.float32)
+            gb = torch.empty(N, device=x.device, dtype=torch.float32)
+            if N <= 4:
+                vec_wgrad_into(M, gy, N, N, xc, K, K, gw.data_ptr(), gb.data_ptr(), x.device) if K <= 256 else \
+                    _vec_wgrad_wide(M, gy, N, xc, K, gw, gb)
+            else:
+                Kp, Np = (K + 3) // 4 * 4, (N + 3) // 4 * 4
+                assert Kp == K and Np == N, "HipLinear needs in/out features that are multiples of 4 (or out <= 4)"
+                for n0 in range(0, N, 256):
+                    nn_ = min(256, N - n0)
+                    for k0 in range(0, K, 256):
+                        kk = min(256, K - k0)
+                        wgrad_into(M, gy, N, nn_, xc, K, kk, gw.data_ptr() + 4 * (n0 * K + k0), K,
+                                   gb.data_ptr() + 4 * n0 if k0 == 0 else None, x.device, a_off=n0, b_off=k0)
+            if not ctx.has_bias:
+                gb = None
+        return gx, gw, gb, None
+
+
+def _vec_wgrad_wide(M, gy, N, xc, K, gw, gb):
+    for k0 in range(0, K, 256):
+        kk = min(256, K - k0)
+        part = torch.empty(N, kk, device=xc.device, dtype=torch.float32)
+        xs = xc[:, k0:k0 + kk].contiguous()
+        vec_wgrad_into(M, gy, N, N, xs, kk, kk, part.data_ptr(), gb.data_ptr(), xc.device)
+        gw[:, k0:k0 + kk] = part
+
+
+def hip_linear(x, w, b=None, relu: bool = False):
+    return HipLinear.apply(x, w, b, 1 if relu else 0)
+
+
+def adam_flat_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
+               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
+    """In-place Adam update of a flat fp32 buffer (utils/optim.py:20-33 -> torch.optim.Adam semantics)."""
+    check(lib.upnerf_adam(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), lr, beta1, beta2, eps, 1 - beta1 ** step,
+                          1 - beta2 ** step, stream()), "upnerf_adam")

@@ -1,0 +1,158 @@
+"""Parameter packing for the fused field kernels.
+
+The HIP kernels read every matrix of one NeRF from ONE flat fp32 buffer `P` (row-major [N][Kp], K padded to a
+multiple of 8, see include/upnerf_hip.h:upnerf_layout) and the backward chain reads transposed copies from `PT`.
+`pack()` builds P from the module's parameters with differentiable torch ops (pad / cat / one small matmul for the
+folded colour layer), so the gradient the kernels write in P's layout flows back to parameters that keep the
+reference's names and shapes (models/nerf.py:39-78) -- state_dicts stay interchangeable with the reference.
+
+Folding: rgb_share_layer.0 consumes cat[s_feat, PE(dir), a] with s_feat = W_f e + b_f, so
+  W_r1[:, :F] s_feat = (W_r1[:, :F] W_f) e + W_r1[:, :F] b_f
+and the kernels only ever see the [W/2][W] product; autograd differentiates the product."""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from ._lib import AUXK, CK, MAX_D, X0, Layout
+
+
+def _align(n, a=4):
+    return (n + a - 1) // a * a
+
+
+class NerfPacker:
+    def __init__(self, W: int, D: int, skips, in_xyz: int, in_dir: int, feat_dim: int, appearance_dim: int,
+                 candidate_dim: int):
+        if W not in (64, 256):
+            raise ValueError(f"HIP field kernels support W in (64, 256), got {W}")
+        if not 1 <= D <= MAX_D:
+            raise ValueError(f"HIP field kernels support 1 <= D <= {MAX_D}, got {D}")
+        if in_xyz != 63:
+            raise ValueError("HIP field kernels are specialised for N_emb_xyz = 10 (63-wide encoding)")
+        if in_dir != 27:
+            raise ValueError("HIP field kernels are specialised for N_emb_dir = 4 (27-wide encoding)")
+        if appearance_dim not in (0, 48) or candidate_dim not in (0, CK):
+            raise ValueError("HIP field kernels support appearance_dim in (0, 48) and candidate_dim in (0, 16)")
+        active = [s for s in skips if 0 < s < D]
+        if len(active) > 1:
+            raise ValueError("at most one active skip connection is supported")
+        self.W, self.D, self.W2 = W, D, W // 2
+        self.skip = active[0] if active else -1
+        self.feat_dim, self.A, self.C, self.in_dir = feat_dim, appearance_dim, candidate_dim, in_dir
+        self.has_cand = candidate_dim > 0
+        L = Layout()
+        L.W, L.D, L.skip = W, D, self.skip
+        off = 0
+
+        def take(n):
+            nonlocal off
+            o = off
+            off += _align(n)
+            return o
+
+        W2 = self.W2
+        for l in range(D):
+            k = X0 if l == 0 else (X0 + W if l == self.skip else W)
+            L.w[l] = take(W * k)
+        for l in range(D):
+            L.b[l] = take(W)
+        L.we, L.be = take(W * W), take(W)
+        L.wsig, L.bsig = take(W), take(4)
+        L.wc1, L.bc1 = take(W2 * (W + CK)), take(W2)
+        L.wc2, L.bc2 = take(W2 * W2), take(W2)
+        L.wcsig, L.bcsig = take(W2), take(4)
+        L.wr1, L.br1 = take(W2 * (W + AUXK)), take(W2)
+        L.wr2, L.br2 = take(4 * W2), take(4)
+        L.total = off
+        off = 0
+        for l in range(D):
+            L.t_w[l] = take((X0 if l == 0 else W) * W)
+        L.t_skipx = take(X0 * W)
+        L.t_we = take(W * W)
+        L.t_head = take(W * W)
+        L.t_wc2 = take(W2 * W2)
+        L.t_total = off
+        self.L = L
+
+    # ------------------------------------------------------------------ forward-form buffer
+    def pack(self, p: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """p: name -> parameter (reference names, e.g. 'xyz_encoding_1.0.weight').  Returns P [L.total]."""
+        W, W2, D, L = self.W, self.W2, self.D, self.L
+        dev, dt = p["xyz_encoding_1.0.weight"].device, torch.float32
+        pieces = []
+
+        def put(t, n):
+            t = t.reshape(-1)
+            pad = _align(n) - t.numel()
+            assert t.numel() == n and pad >= 0
+            pieces.append(F.pad(t, (0, pad)) if pad else t)
+
+        for l in range(D):
+            w = p[f"xyz_encoding_{l + 1}.0.weight"]
+            if l == 0:
+                put(F.pad(w, (0, 1)), W * X0)
+            elif l == self.skip:
+                put(torch.cat([F.pad(w[:, :63], (0, 1)), w[:, 63:]], 1), W * (X0 + W))
+            else:
+                put(w, W * W)
+        for l in range(D):
+            put(p[f"xyz_encoding_{l + 1}.0.bias"], W)
+        put(p["xyz_encoding_final.weight"], W * W)
+        put(p["xyz_encoding_final.bias"], W)
+        put(p["share_sigma.0.weight"], W)
+        put(F.pad(p["share_sigma.0.bias"], (0, 3)), 4)
+        if self.has_cand:
+            put(p["candidate_encoding.0.weight"], W2 * (W + CK))
+            put(p["candidate_encoding.0.bias"], W2)
+            put(p["candidate_encoding.2.weight"], W2 * W2)
+            put(p["candidate_encoding.2.bias"], W2)
+            put(p["candidate_sigma.0.weight"], W2)
+            put(F.pad(p["candidate_sigma.0.bias"], (0, 3)), 4)
+        else:
+            for n in (W2 * (W + CK), W2, W2 * W2, W2, W2, 4):
+                put(torch.zeros(n, device=dev, dtype=dt), n)
+        Fd = self.feat_dim
+        wr = p["rgb_share_layer.0.weight"]  # [W2][F + 27 + A]
+        fold = wr[:, :Fd] @ p["feat_share_layer.weight"]  # [W2][W]
+        aux_w = F.pad(wr[:, Fd:], (0, AUXK - (self.in_dir + self.A))) if self.A else \
+            F.pad(wr[:, Fd:], (0, AUXK - self.in_dir))
+        put(torch.cat([fold, aux_w], 1), W2 * (W + AUXK))
+        put(wr[:, :Fd] @ p["feat_share_layer.bias"] + p["rgb_share_layer.0.bias"], W2)
+        put(F.pad(p["rgb_share_layer.2.weight"], (0, 0, 0, 1)), 4 * W2)
+        put(F.pad(p["rgb_share_layer.2.bias"], (0, 1)), 4)
+        P = torch.cat(pieces)
+        assert P.numel() == L.total
+        return P
+
+    # ------------------------------------------------------------------ transposed copies (no grad)
+    @torch.no_grad()
+    def pack_t(self, P: torch.Tensor) -> torch.Tensor:
+        W, W2, D, L = self.W, self.W2, self.D, self.L
+        PT = torch.empty(L.t_total, device=P.device, dtype=P.dtype)
+
+        def mat(o, n, k):
+            return P[o:o + n * k].view(n, k)
+
+        def putT(o, m):  # m: [rows][cols] written row-major at PT[o:]
+            PT[o:o + m.numel()] = m.reshape(-1)
+
+        for l in range(D):
+            if l == 0:
+                putT(L.t_w[0], mat(L.w[0], W, X0).t())
+            elif l == self.skip:
+                w = mat(L.w[l], W, X0 + W)
+                putT(L.t_skipx, w[:, :X0].t())
+                putT(L.t_w[l], w[:, X0:].t())
+            else:
+                putT(L.t_w[l], mat(L.w[l], W, W).t())
+        if self.skip < 0:
+            PT[L.t_skipx:L.t_skipx + X0 * W] = 0
+        putT(L.t_we, mat(L.we, W, W).t())
+        wr1 = mat(L.wr1, W2, W + AUXK)[:, :W]
+        wc1 = mat(L.wc1, W2, W + CK)[:, :W]
+        putT(L.t_head, torch.cat([wr1.t(), wc1.t()], 1))
+        putT(L.t_wc2, mat(L.wc2, W2, W2).t())
+        return PT

@@ -1,0 +1,345 @@
+"""render_rays on MI355X: same signature, result keys and schedule semantics as the reference's
+models/rendering.py:53-314, executed by the hand-written HIP kernels of libupnerf_hip.so.
+
+Call graph of one pass (coarse or fine), all on the caller's current HIP stream:
+    upnerf_ray_aux -> upnerf_field_fwd -> upnerf_composite_fwd -> (per-ray feature projection, upnerf_linear)
+and of its backward:
+    upnerf_composite_bwd -> upnerf_field_bwd -> upnerf_wgrad x layers (+ upnerf_vec_wgrad for the 1/3-wide heads)
+    -> upnerf_ray_sum / upnerf_ray_geom_bwd for the per-ray inputs.
+Between the passes: upnerf_sample_pdf + upnerf_sort_rows (no gradient: the reference detaches the weights,
+rendering.py:271-303, and z is a constant w.r.t. every trainable).
+
+There is no fallback: unsupported configurations raise."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, X0, check, lib, ptr,
+                   stream)
+from .ops import hip_linear, linear_raw, nsplit_for, vec_wgrad_into, wgrad_into
+
+__all__ = ["render_rays", "sample_pdf", "band_weights"]
+
+_LINSPACE: Dict[tuple, torch.Tensor] = {}
+_DEBUG_SINK: Optional[dict] = None  # tests set this to a dict to receive the backward's intermediate buffers
+
+
+def _linspace01(n: int, device) -> torch.Tensor:
+    """torch.linspace(0, 1, n) evaluated on the host (the reference's values on its CPU path) and cached."""
+    key = (n, str(device))
+    t = _LINSPACE.get(key)
+    if t is None:
+        t = torch.linspace(0, 1, n, dtype=torch.float32).to(device)
+        _LINSPACE[key] = t
+    return t
+
+
+def band_weights(L: int, progress: float, c2f) -> List[float]:
+    """BARF coarse-to-fine weights w_k of the positional encoding (models/nerf.py:137-143), evaluated in fp32 on
+    the host exactly as the reference evaluates them on its tensors."""
+    if c2f is None:
+        return [1.0] * L
+    start, end = c2f
+    alpha = (torch.tensor(float(progress), dtype=torch.float32) - start) / (end - start) * L
+    k = torch.arange(L, dtype=torch.float32)
+    w = (1 - ((alpha - k).clamp(min=0, max=1) * torch.pi).cos()) / 2
+    return [float(x) for x in w]
+
+
+def _empty(*shape, device):
+    return torch.empty(*shape, device=device, dtype=torch.float32)
+
+
+class _PassCfg:
+    """Static (non-tensor) description of one field pass."""
+
+    def __init__(self, packer, mode: int, use_cand: bool, use_rgb: bool, wk_xyz, wk_dir):
+        self.packer, self.mode, self.use_cand, self.use_rgb = packer, mode, use_cand, use_rgb
+        self.wk_xyz, self.wk_dir = wk_xyz, wk_dir
+
+
+class _FieldPass(torch.autograd.Function):
+    """Field evaluation + compositing of all samples of a ray batch.
+
+    Returns per-ray sums in the trunk-width space (projected to the 384-d feature map by the caller) and the
+    per-sample weights; see include/upnerf_hip.h:upnerf_composite_fwd_args for the meaning of every output."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, z, c_rows, a_rows, P, cfg: _PassCfg):
+        ctx.set_materialize_grads(False)
+        pk, L = cfg.packer, cfg.packer.L
+        W, W2, D = pk.W, pk.W2, pk.D
+        R, S = z.shape
+        M = R * S
+        dev = z.device
+        st = stream()
+        rays_o, rays_d, z = rays_o.detach().contiguous(), rays_d.detach().contiguous(), z.detach().contiguous()
+        P = P.detach().contiguous()
+        c_rows = c_rows.detach().contiguous() if (c_rows is not None and cfg.use_cand) else None
+        a_rows_c = a_rows.detach().contiguous() if a_rows is not None else None
+        joint, want_feat = cfg.mode <= 1, cfg.mode != 2
+
+        aux = None
+        if cfg.use_rgb:
+            aux = _empty(R, AUXK, device=dev)
+            wk = (C.c_float * 4)(*cfg.wk_dir)
+            check(lib.upnerf_ray_aux(R, ptr(rays_d), ptr(a_rows_c), wk, ptr(aux), st), "upnerf_ray_aux")
+
+        sigma_s = _empty(M, device=dev)
+        sigma_c = _empty(M, device=dev) if cfg.use_cand else None
+        rgb = _empty(M, 3, device=dev) if cfg.use_rgb else None
+        x0, h, e = _empty(M, X0, device=dev), _empty(D, M, W, device=dev), _empty(M, W, device=dev)
+        g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
+        g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
+        r1 = _empty(M, W2, device=dev) if cfg.use_rgb else None
+        fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
+                          rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
+                          wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(P), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
+                          rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1))
+        check(lib.upnerf_field_fwd(C.byref(L), C.byref(fa), st), "upnerf_field_fwd")
+
+        w_all = _empty(R, S, device=dev) if joint else None
+        w_sj = _empty(R, S, device=dev) if joint else None
+        w_cj = _empty(R, S, device=dev) if joint else None
+        w_s = _empty(R, S, device=dev)
+        E_s = _empty(R, W, device=dev) if want_feat else None
+        G_c = _empty(R, W2, device=dev) if joint else None
+        sum_sfeat = _empty(R, device=dev) if want_feat else None
+        t_weight = _empty(R, device=dev) if joint else None
+        c_depth = _empty(R, device=dev) if joint else None
+        s_depth = _empty(R, device=dev)
+        rgb_map = _empty(R, 3, device=dev) if cfg.use_rgb else None
+        ca = CompositeFwdArgs(R=R, S=S, W=W, mode=cfg.mode, z=ptr(z), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
+                              rgb=ptr(rgb), has_rgb=int(cfg.use_rgb), e=ptr(e), g2=ptr(g2), w_all=ptr(w_all),
+                              w_sj=ptr(w_sj), w_cj=ptr(w_cj), w_s=ptr(w_s), E_s=ptr(E_s), G_c=ptr(G_c),
+                              sum_sfeat=ptr(sum_sfeat), t_weight=ptr(t_weight), c_depth=ptr(c_depth),
+                              s_depth=ptr(s_depth), rgb_map=ptr(rgb_map))
+        check(lib.upnerf_composite_fwd(C.byref(ca), st), "upnerf_composite_fwd")
+
+        ctx.cfg, ctx.dims = cfg, (R, S)
+        ctx.has_a = a_rows is not None
+        ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, e=e, g1=g1, g2=g2, r1=r1, w_all=w_all, w_sj=w_sj,
+                         w_cj=w_cj, w_s=w_s)
+        z0 = torch.zeros(0, device=dev)
+        outs = (E_s, G_c, sum_sfeat, t_weight, c_depth, s_depth, rgb_map, w_all, w_s)
+        return tuple(o if o is not None else z0 for o in outs)
+
+    @staticmethod
+    def backward(ctx, gE, gG, gsf, gtw, gcd, gsd, grm, gwall, gws):
+        cfg, (R, S), sv = ctx.cfg, ctx.dims, ctx.saved
+        pk, L = cfg.packer, cfg.packer.L
+        W, W2, D = pk.W, pk.W2, pk.D
+        M = R * S
+        dev = sv["z"].device
+        st = stream()
+        joint, want_feat = cfg.mode <= 1, cfg.mode != 2
+
+        def g(t, ok=True):
+            return t.contiguous() if (ok and t is not None and t.numel() > 0) else None
+
+        gE, gsf = g(gE, want_feat), g(gsf, want_feat)
+        gG, gtw, gcd, gwall = g(gG, joint), g(gtw, joint), g(gcd, joint), g(gwall, joint)
+        gsd, gws, grm = g(gsd), g(gws), g(grm, cfg.use_rgb)
+
+        d_sigma_s = _empty(M, device=dev)
+        d_sigma_c = _empty(M, device=dev) if joint else None
+        d_rgb = _empty(M, 3, device=dev) if cfg.use_rgb else None
+        cb = CompositeBwdArgs(R=R, S=S, W=W, mode=cfg.mode, has_rgb=int(cfg.use_rgb), z=ptr(sv["z"]),
+                              sigma_s=ptr(sv["sigma_s"]), sigma_c=ptr(sv["sigma_c"]), rgb=ptr(sv["rgb"]),
+                              e=ptr(sv["e"]), g2=ptr(sv["g2"]), w_all=ptr(sv["w_all"]), w_sj=ptr(sv["w_sj"]),
+                              w_cj=ptr(sv["w_cj"]), w_s=ptr(sv["w_s"]), g_E_s=ptr(gE), g_G_c=ptr(gG),
+                              g_sum_sfeat=ptr(gsf), g_t_weight=ptr(gtw), g_c_depth=ptr(gcd), g_s_depth=ptr(gsd),
+                              g_rgb_map=ptr(grm), g_w_all=ptr(gwall), g_w_s=ptr(gws), d_sigma_s=ptr(d_sigma_s),
+                              d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb))
+        check(lib.upnerf_composite_bwd(C.byref(cb), st), "upnerf_composite_bwd")
+
+        need_dxyz = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        P = sv["P"]
+        PT = pk.pack_t(P)
+        gz_h, gz_e = _empty(D, M, W, device=dev), _empty(M, W, device=dev)
+        gz_g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
+        gz_g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
+        gz_r1 = _empty(M, W2, device=dev) if cfg.use_rgb else None
+        dpre_s = _empty(M, device=dev)
+        dpre_c = _empty(M, device=dev) if cfg.use_cand else None
+        dpre_rgb = _empty(M, 4, device=dev) if cfg.use_rgb else None
+        dxyz = _empty(M, 3, device=dev) if need_dxyz else None
+        w_feat = (sv["w_sj"] if joint else sv["w_s"]) if gE is not None else None
+        fb = FieldBwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), need_dxyz=int(need_dxyz),
+                          PT=ptr(PT), P=ptr(P), d_sigma_s=ptr(d_sigma_s), d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb),
+                          sigma_s=ptr(sv["sigma_s"]), sigma_c=ptr(sv["sigma_c"]), rgb=ptr(sv["rgb"]),
+                          w_feat_s=ptr(w_feat), w_cj=ptr(sv["w_cj"]) if gG is not None else None, g_E_s=ptr(gE),
+                          g_G_c=ptr(gG), x0=ptr(sv["x0"]), h=ptr(sv["h"]), g1=ptr(sv["g1"]), g2=ptr(sv["g2"]),
+                          r1=ptr(sv["r1"]), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
+                          gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
+                          dxyz=ptr(dxyz))
+        check(lib.upnerf_field_bwd(C.byref(L), C.byref(fb), st), "upnerf_field_bwd")
+
+        if _DEBUG_SINK is not None:
+            _DEBUG_SINK.update(d_sigma_s=d_sigma_s, d_sigma_c=d_sigma_c, d_rgb=d_rgb, gz_h=gz_h, gz_e=gz_e, gz_g1=gz_g1,
+                               gz_g2=gz_g2, gz_r1=gz_r1, dpre_s=dpre_s, dpre_c=dpre_c, dpre_rgb=dpre_rgb, dxyz=dxyz)
+        # ---- weight gradients, written straight into a buffer with P's layout
+        dP = torch.zeros(L.total, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
+        d_c_rows = d_a_rows = None
+        if dP is not None:
+            base = dP.data_ptr()
+            at = lambda off: base + 4 * off
+            h, x0 = sv["h"], sv["x0"]
+            for l in range(D):
+                gz = gz_h[l]
+                if l == 0:
+                    wgrad_into(M, gz, W, W, x0, X0, X0, at(L.w[0]), X0, at(L.b[0]), dev)
+                elif l == pk.skip:
+                    wgrad_into(M, gz, W, W, x0, X0, X0, at(L.w[l]), X0 + W, at(L.b[l]), dev)
+                    wgrad_into(M, gz, W, W, h[l - 1], W, W, at(L.w[l] + X0), X0 + W, None, dev)
+                else:
+                    wgrad_into(M, gz, W, W, h[l - 1], W, W, at(L.w[l]), W, at(L.b[l]), dev)
+            wgrad_into(M, gz_e, W, W, h[D - 1], W, W, at(L.we), W, at(L.be), dev)
+            vec_wgrad_into(M, dpre_s, 1, 1, h[D - 1], W, W, at(L.wsig), at(L.bsig), dev)
+        if cfg.use_cand:
+            rs = _empty(R, W2, device=dev)
+            check(lib.upnerf_ray_sum(R, S, ptr(gz_g1), W2, ptr(rs), st), "upnerf_ray_sum")
+            if dP is not None:
+                wgrad_into(M, gz_g1, W2, W2, sv["e"], W, W, at(L.wc1), W + CK, at(L.bc1), dev)
+                wgrad_into(R, rs, W2, W2, sv["c_rows"], CK, CK, at(L.wc1 + W), W + CK, None, dev)
+                wgrad_into(M, gz_g2, W2, W2, sv["g1"], W2, W2, at(L.wc2), W2, at(L.bc2), dev)
+                vec_wgrad_into(M, dpre_c, 1, 1, sv["g2"], W2, W2, at(L.wcsig), at(L.bcsig), dev)
+            if ctx.needs_input_grad[3]:
+                wc = P[L.wc1:L.wc1 + W2 * (W + CK)].view(W2, W + CK)[:, W:]
+                d_c_rows = linear_raw(rs, wc.t(), None, 0)
+        if cfg.use_rgb:
+            rs = _empty(R, W2, device=dev)
+            check(lib.upnerf_ray_sum(R, S, ptr(gz_r1), W2, ptr(rs), st), "upnerf_ray_sum")
+            if dP is not None:
+                wgrad_into(M, gz_r1, W2, W2, sv["e"], W, W, at(L.wr1), W + AUXK, at(L.br1), dev)
+                wgrad_into(R, rs, W2, W2, sv["aux"], AUXK, AUXK, at(L.wr1 + W), W + AUXK, None, dev)
+                vec_wgrad_into(M, dpre_rgb, 4, 3, sv["r1"], W2, W2, at(L.wr2), at(L.br2), dev)
+            if ctx.has_a and ctx.needs_input_grad[4]:
+                wa = P[L.wr1:L.wr1 + W2 * (W + AUXK)].view(W2, W + AUXK)[:, W + 27:W + 75]
+                d_a_rows = linear_raw(rs, wa.t(), None, 0)
+        d_o = d_d = None
+        if need_dxyz:
+            d_o, d_d = _empty(R, 3, device=dev), _empty(R, 3, device=dev)
+            check(lib.upnerf_ray_geom_bwd(R, S, ptr(dxyz), ptr(sv["z"]), ptr(d_o), ptr(d_d), st), "upnerf_ray_geom_bwd")
+        ctx.saved = None
+        return d_o, d_d, None, d_c_rows, d_a_rows, dP, None
+
+
+def sample_pdf(z_coarse: torch.Tensor, weights: torch.Tensor, n: int, det: bool, out: torch.Tensor, col0: int,
+               u: Optional[torch.Tensor] = None):
+    """Inverse-CDF resampling of one weight set (models/rendering.py:7-50) into out[:, col0:col0+n].
+
+    z_coarse [R][S] (bins = interval mid-points), weights [R][S] (entries 1..S-2 are used, as the reference
+    passes weights[:, 1:-1]).  det=True uses u = linspace(0,1,n); otherwise `u` ([R][n]) or fresh torch.rand."""
+    R, S = z_coarse.shape
+    if n == 0:
+        return
+    if det:
+        uu, rows = _linspace01(n, z_coarse.device), 1
+    else:
+        uu = u if u is not None else torch.rand(R, n, device=z_coarse.device)
+        uu, rows = uu.contiguous(), R
+        assert tuple(uu.shape) == (R, n)
+    stride = out.shape[1]
+    check(lib.upnerf_sample_pdf(R, S, ptr(z_coarse), ptr(weights), ptr(uu), rows, n, out.data_ptr() + 4 * col0, stride,
+                                stream()), "upnerf_sample_pdf")
+
+
+def _project_feat(model, E_s, sum_sfeat, G_c=None, t_weight=None):
+    """feat map = W_f (sum w e) + b_f sum w  [+ W_cf (sum w_c g) + b_cf sum w_c]  (nerf.py:95,100 composited by
+    rendering.py:166-177)."""
+    feat = hip_linear(E_s, model.feat_share_layer.weight) + sum_sfeat[:, None] * model.feat_share_layer.bias
+    if G_c is not None:
+        feat = feat + hip_linear(G_c, model.feat_candidate_layer.weight) \
+            + t_weight[:, None] * model.feat_candidate_layer.bias
+    return feat
+
+
+def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use_disp=False, perturb=0,
+                N_importance=0, test_time=False, encode_feat=True, **kwargs):
+    """Drop-in for the reference's render_rays (models/rendering.py:53-66): same positional/keyword arguments,
+    unknown kwargs (sched_phase, white_back, validation) accepted and ignored, same result keys
+    per schedule phase.  `test_time` is dead in the reference (Q1) and is ignored here too.
+
+    Extension used by the parity tests: kwargs["u_list"] = explicit uniform draws consumed in the reference's RNG
+    call order (coarse jitter [R,Nc], then the sample_pdf draws)."""
+    if not rays.is_cuda:
+        raise RuntimeError("upnerf_amd.render_rays runs on the GPU only (no CPU fallback)")
+    if not encode_feat:
+        raise NotImplementedError("nerf.feat_dim = 0 (rgb-only candidate head) is not implemented on the HIP path")
+    draws = list(kwargs["u_list"]) if kwargs.get("u_list") is not None else None
+    dev = rays.device
+    R = rays.shape[0]
+    st = stream()
+
+    def draw(n):
+        if draws is not None:
+            t = draws.pop(0).to(dev, torch.float32).contiguous()
+            assert tuple(t.shape) == (R, n), (tuple(t.shape), (R, n))
+            return t
+        return torch.rand(R, n, device=dev)
+
+    rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
+    near_far = rays[:, 6:8].detach().contiguous()
+    z = _empty(R, N_samples, device=dev)
+    u0 = draw(N_samples) if perturb > 0 else None
+    check(lib.upnerf_sample_coarse(R, N_samples, ptr(near_far), ptr(_linspace01(N_samples, dev)), ptr(u0),
+                                   float(perturb), int(bool(use_disp)), ptr(z), st), "upnerf_sample_coarse")
+    results = {}
+
+    def inference(model, zz):
+        typ = model.typ
+        a_rows = embeddings[f"{typ}_a"](img_idx) if model.encode_appearance else None
+        c_rows = embeddings[f"{typ}_c"](img_idx) if model.encode_candidate else None
+        progress = float(model.progress.data)
+        use_cand = bool(sched_mult < 1 and model.encode_candidate)
+        use_rgb = bool(sched_mult > 0)
+        mode = (1 if use_rgb else 0) if use_cand else (3 if sched_mult < 1 else 2)
+        cfg = _PassCfg(model.packer, mode, use_cand, use_rgb, band_weights(model.xyz_L, progress, model.c2f),
+                       band_weights(model.dir_L, progress, model.c2f))
+        E_s, G_c, sum_sf, t_w, c_dep, s_dep, rgb_map, w_all, w_s = _FieldPass.apply(
+            rays_o, rays_d, zz, c_rows, a_rows, model.packed(), cfg)
+        if sched_mult < 1:
+            if not model.encode_candidate:  # rendering.py:134-150
+                results[f"s_weights_{typ}"] = w_s
+                results[f"feat_{typ}"] = _project_feat(model, E_s, sum_sf)
+            else:  # rendering.py:151-182
+                results[f"c_weights_{typ}"] = w_all
+                results[f"c_depth_{typ}"] = c_dep
+                results[f"feat_{typ}"] = _project_feat(model, E_s, sum_sf, G_c, t_w)
+                results[f"t_weight_{typ}"] = t_w
+        if sched_mult > 0:  # rendering.py:195-209
+            results[f"s_weights_{typ}"] = w_s
+            results[f"s_rgb_{typ}"] = rgb_map
+        results[f"s_depth_{typ}"] = s_dep  # rendering.py:211-218
+
+    inference(models["nerf_coarse"], z)
+    if N_importance > 0:
+        model = models["nerf_fine"]
+        det = perturb == 0
+        S = N_samples + N_importance
+        zf = _empty(R, S, device=dev)
+        zf[:, :N_samples] = z
+
+        def resample(key, n, col0):
+            sample_pdf(z, results[key].detach().contiguous(), n, det, zf, col0, None if det else draw(n))
+
+        if model.encode_candidate:  # rendering.py:267-300
+            if sched_mult == 0:
+                resample("c_weights_coarse", N_importance, N_samples)
+            elif 0 < sched_mult < 1:
+                n_s = round(sched_mult * N_importance)  # Python banker's rounding, like the reference (Q6)
+                resample("c_weights_coarse", N_importance - n_s, N_samples + n_s)
+                resample("s_weights_coarse", n_s, N_samples)
+            elif sched_mult == 1:
+                resample("s_weights_coarse", N_importance, N_samples)
+        else:  # rendering.py:300-307
+            resample("s_weights_coarse", N_importance, N_samples)
+        check(lib.upnerf_sort_rows(R, S, ptr(zf), st), "upnerf_sort_rows")
+        inference(model, zf)
+    return results
