@@ -262,10 +262,12 @@ def render_rays(models: Dict[str, Params], cfgs: Dict[str, NerfCfg], embeddings:
                 rays: Tensor, img_idx: Tensor, sched_mult: float, N_samples: int = 64,
                 use_disp: bool = False, perturb: float = 0, N_importance: int = 0,
                 progress: float = 0.0, u_list: Optional[Sequence[Tensor]] = None,
-                keep: Optional[dict] = None) -> Dict[str, Tensor]:
+                keep: Optional[dict] = None, z_fine_override: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """models: {"nerf_coarse": params, "nerf_fine": params}; embeddings: {"coarse_a": weight[N_img,48], ...}.
     u_list (optional): explicit uniform draws consumed in the reference's RNG call order:
-    [coarse jitter [R,Nc]] then the sample_pdf draws.  `keep` (optional dict) receives z_coarse/z_fine."""
+    [coarse jitter [R,Nc]] then the sample_pdf draws.  `keep` (optional dict) receives z_coarse/z_fine.
+    z_fine_override (tests only): evaluate the fine pass at these depths instead of the resampled ones -- the
+    resampling has no gradient, so this isolates everything else from the (ill-conditioned) inverse-CDF step."""
     draws = list(u_list) if u_list is not None else None
 
     def draw(shape):
@@ -320,6 +322,8 @@ def render_rays(models: Dict[str, Params], cfgs: Dict[str, NerfCfg], embeddings:
                 z = torch.sort(torch.cat([z, resample("s_weights_coarse", N_importance)], -1), -1)[0]
         else:  # rendering.py:300-307
             z = torch.sort(torch.cat([z, resample("s_weights_coarse", N_importance)], -1), -1)[0]
+        if z_fine_override is not None:
+            z = z_fine_override
         if keep is not None:
             keep["z_fine"] = z
         run("nerf_fine", z)
@@ -397,7 +401,8 @@ def upnerf_loss(res: Dict[str, Tensor], rgb: Tensor, feat: Tensor, depth: Tensor
 # One training-step forward = the glue of NeRFSystem.training_step  (nerf_system.py:150-186)
 # --------------------------------------------------------------------------------------
 def training_forward(state: Dict[str, Params], cfgs: Dict[str, NerfCfg], batch: Dict[str, Tensor], hp: dict,
-                     progress: float, u_list: Optional[Sequence[Tensor]] = None, keep: Optional[dict] = None):
+                     progress: float, u_list: Optional[Sequence[Tensor]] = None, keep: Optional[dict] = None,
+                     z_fine_override: Optional[Tensor] = None):
     """state: {"nerf_coarse","nerf_fine","transient_net": params, "embedding_coarse_a": weight, ...,
     "se3_refine": weight, "depth_scale": weight}.  Returns (loss_dict, results)."""
     idx = batch["img_idx"]
@@ -415,7 +420,7 @@ def training_forward(state: Dict[str, Params], cfgs: Dict[str, NerfCfg], batch: 
     res = render_rays({k: state[k] for k in ("nerf_coarse", "nerf_fine") if k in state}, cfgs, emb, rays, idx, m,
                       N_samples=hp["nerf.N_samples"], use_disp=hp.get("nerf.use_disp", False),
                       perturb=hp.get("nerf.perturb", 1.0), N_importance=hp["nerf.N_importance"],
-                      progress=progress, u_list=u_list, keep=keep)
+                      progress=progress, u_list=u_list, keep=keep, z_fine_override=z_fine_override)
     if m > 0:
         t = transient_net(state["transient_net"], batch["feats"], idx, hp.get("t_net.beta_min", 0.1))
         blend_transient(res, t, fine)

@@ -17,6 +17,38 @@ pytestmark = pytest.mark.gpu
 TOL_MAP, TOL_W, TOL_GRAD = 1e-4, 2e-4, 1e-3
 
 
+def oracle_grads(c, dtype, z_fine=None):
+    from golden_util import named_grads, orc
+    st = c.state(dtype=dtype)
+    real = orc.schedule_mult
+    orc.schedule_mult = lambda p, s: c.sched
+    keep = {}
+    try:
+        losses, _ = orc.training_forward(st, c.cfgs(), c.batch(dtype), c.hparams(), c.progress,
+                                         u_list=[u.to(dtype) for u in c.u_list], keep=keep,
+                                         z_fine_override=None if z_fine is None else z_fine.to(dtype))
+    finally:
+        orc.schedule_mult = real
+    sum(losses.values()).backward()
+    return named_grads(st), keep
+
+
+def reference_fp32_noise(c):
+    """Per-tensor gradient noise of the reference's OWN arithmetic: oracle in fp32 vs the same oracle in fp64
+    (max-normalised).  With all encoding bands active (2^9 pi x) a 1e-7 shift of a resampled depth changes
+    sin/cos by 1e-3, so the reference's fp32 gradients are themselves only good to ~4e-3 in those phases
+    (cfg2_phase2, small_tto); where the arithmetic is well conditioned the noise is ~1e-6 and the flat gate applies.
+    The gradient gate below is max(TOL_GRAD, 4 x this noise)."""
+    g32, keep = oracle_grads(c, torch.float32)
+    g64, _ = oracle_grads(c, torch.float64)
+    noise = {}
+    for k, a in g32.items():
+        b = g64[k]
+        if a is not None and b is not None:
+            noise[k] = float((a.double() - b).abs().max() / max(float(b.abs().max()), 1e-30))
+    return noise, keep
+
+
 def build_system(c):
     from upnerf_amd.nerf_system import NeRFSystem, SyntheticDataset, default_hparams
     hp = default_hparams(**{"nerf.N_samples": c.Nc, "nerf.N_importance": c.Nf, "nerf.use_disp": c.use_disp,
@@ -52,7 +84,8 @@ def test_training_step_matches_reference_golden(name):
     c = Case(name)
     sysm = build_system(c)
     batch = {k: v.cuda() for k, v in c.batch().items()}
-    loss, loss_d, res = sysm.compute_loss(batch, u_list=[u.clone() for u in c.u_list])
+    keep = {}
+    loss, loss_d, res = sysm.compute_loss(batch, u_list=[u.clone() for u in c.u_list], keep=keep)
     exp = c.expected_results()
     assert set(res.keys()) == set(exp.keys()), (sorted(res.keys()), sorted(exp.keys()))
     errs = {}
@@ -66,9 +99,33 @@ def test_training_step_matches_reference_golden(name):
     for k, v in loss_d.items():
         assert abs(float(v) - float(el[k])) <= TOL_MAP * max(abs(float(el[k])), 1e-2), (k, float(v), float(el[k]))
     assert abs(float(loss) - float(el["total"])) <= TOL_MAP * max(abs(float(el["total"])), 1e-2)
+    if sysm._last_rays.requires_grad:
+        sysm._last_rays.retain_grad()
     loss.backward()
     got = {n: p.grad for n, p in sysm.named_parameters()}
+    noise, okeep = reference_fp32_noise(c)
+    worst_noise = max(noise.values()) if noise else 0.0
+
+    # The reference's inverse-CDF rule `denom < eps -> 1` (rendering.py:44-46) makes the resampled depth of a draw
+    # that lands in a bin of mass ~eps jump by a bin width under 1e-7 perturbations of the coarse weights.  When that
+    # happened (GPU depths != reference depths for some sample) the golden gradients are compared loosely and the
+    # strict comparison is made against the oracle evaluated at the GPU's own fine depths.
+    flipped = False
+    if c.fine:
+        dz = (keep["z_fine"].cpu() - okeep["z_fine"]).abs()
+        assert float((dz < 1e-5).float().mean()) > 0.99, "resampled depths disagree beyond isolated eps-bin flips"
+        flipped = bool(dz.max() > 1e-5)
     bad = {}
+
+    def gate(n):
+        return max(TOL_GRAD, 4 * noise.get(n, worst_noise)) if not flipped else 5e-2
+
+    if sysm._last_rays.requires_grad:
+        gr, er = sysm._last_rays.grad.cpu().numpy(), c.g["grad_rays"]
+        for tag, sl in (("rays_o", slice(0, 3)), ("rays_d", slice(3, 6))):
+            e = rel_err(gr[:, sl], er[:, sl])
+            if e >= (max(TOL_GRAD, 4 * worst_noise) if not flipped else 5e-2):
+                bad["grad_" + tag] = e
     for n, e in c.expected_grads().items():
         if n.endswith(".progress"):
             continue
@@ -86,9 +143,19 @@ def test_training_step_matches_reference_golden(name):
         sub = (flat[::stride] if stride else flat).numpy()[: len(vals)]
         scale = max(float(np.abs(vals).max()), sums[1] / flat.numel(), 1e-12)
         err = float(np.abs(sub - vals).max()) / scale
-        if err >= TOL_GRAD:
-            bad[n] = err
-    assert not bad, bad
+        if err >= gate(n):
+            bad[n] = (err, noise.get(n, 0.0))
+    assert not bad, ("vs reference golden", flipped, bad)
+    if flipped:
+        ref, _ = oracle_grads(c, torch.float32, z_fine=keep["z_fine"].cpu())
+        for n, r in ref.items():
+            if r is None or n.endswith(".progress"):
+                continue
+            g = got[n.replace("embedding_", "embedding_") if n in got else n]
+            err = rel_err(g.detach().cpu().numpy(), r.numpy())
+            if err >= max(TOL_GRAD, 4 * noise.get(n, worst_noise)):
+                bad[n] = (err, noise.get(n, 0.0))
+        assert not bad, ("vs oracle at the GPU's fine depths", bad)
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

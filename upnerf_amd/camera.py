@@ -29,9 +29,12 @@ class _PoseRays(torch.autograd.Function):
             return None, None, None
         R = directions.shape[0]
         z = lambda g: torch.zeros(R, 3, device=directions.device) if g is None else g.contiguous()
+        # keep the contiguous copies alive until the launch has been enqueued (a temporary would be returned to the
+        # caching allocator, and re-used by the next copy, before the kernel reads it)
+        g_o, g_d = z(g_o), z(g_d)
         g = torch.empty(R, 6, device=directions.device, dtype=torch.float32)
-        check(lib.upnerf_pose_rays_bwd(R, ptr(se3), ptr(c2w), ptr(directions), ptr(z(g_o)), ptr(z(g_d)), ptr(g),
-                                       stream()), "upnerf_pose_rays_bwd")
+        check(lib.upnerf_pose_rays_bwd(R, ptr(se3), ptr(c2w), ptr(directions), ptr(g_o), ptr(g_d), ptr(g), stream()),
+              "upnerf_pose_rays_bwd")
         return g, None, None
 
 

@@ -40,6 +40,30 @@ __device__ __forceinline__ float excl_suffix_sum(float x, int lane, float& total
   return lane == 63 ? 0.0f : e;
 }
 
+__device__ __forceinline__ double excl_prod_scan_d(double x, int lane, double& total) {
+  double v = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double t = __shfl_up(v, d);
+    if (lane >= d) v *= t;
+  }
+  total = __shfl(v, 63);
+  const double e = __shfl_up(v, 1);
+  return lane == 0 ? 1.0 : e;
+}
+
+__device__ __forceinline__ double excl_suffix_sum_d(double x, int lane, double& total) {
+  double v = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double t = __shfl_down(v, d);
+    if (lane + d < 64) v += t;
+  }
+  total = __shfl(v, 0);
+  const double e = __shfl_down(v, 1);
+  return lane == 63 ? 0.0 : e;
+}
+
 struct Alphas {
   float delta, es, ec, ea;  // exp(-delta*sigma_s), exp(-delta*sigma_c), exp(-delta*(sigma_s+sigma_c))
   float a_s, a_c, a_all;    // 1 - exp(...)
@@ -150,7 +174,7 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
 template <int W>
 __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composite_bwd_args a) {
   constexpr int W2 = W / 2;
-  __shared__ float carry_s[4][2][MAX_CHUNKS];
+  __shared__ double carry_s[4][2][MAX_CHUNKS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
   if (r >= a.R) return;
@@ -161,16 +185,19 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
   const bool want_feat = a.mode != 2;
   const bool laneE = lane < W / 4, laneG = lane < W2 / 4;
   const int nchunk = (S + 63) >> 6;
-  // forward pre-pass: transmittance at the start of every chunk
+  // The bracket  (1-alpha_i) T_i G_i - sum_{j>i} w_j G_j  is a small residual of two nearly equal terms (it
+  // telescopes to T_end G when G is constant along the ray), so transmittances and suffix sums of the backward are
+  // carried in fp64: the result is then the exact gradient of the fp32 forward values, like the reference's CPU
+  // autograd whose cumsum accumulates in double.  (This kernel is latency bound; the fp64 scans cost nothing.)
   {
-    float cT = 1.0f, cTs = 1.0f;
+    double cT = 1.0, cTs = 1.0;
     for (int c = 0; c < nchunk; ++c) {
       if (lane == 0) { carry_s[wave][0][c] = cT; carry_s[wave][1][c] = cTs; }
       const int i = c * 64 + lane;
-      float om = 1.0f, oms = 1.0f;
+      double om = 1.0, oms = 1.0;
       if (i < S) {
         const Alphas A = alphas_at(a.z, a.sigma_s, a.sigma_c, base, i, S, joint);
-        om = 1.0f - A.a_all; oms = 1.0f - A.a_s;
+        om = (double)(1.0f - A.a_all); oms = (double)(1.0f - A.a_s);
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) { om *= __shfl_xor(om, d); oms *= __shfl_xor(oms, d); }
@@ -190,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
   if (a.has_rgb && a.g_rgb_map) { g_rm[0] = a.g_rgb_map[r * 3]; g_rm[1] = a.g_rgb_map[r * 3 + 1]; g_rm[2] = a.g_rgb_map[r * 3 + 2]; }
   const bool need_dots = want_feat && (a.g_E_s || (joint && a.g_G_c));
 
-  float sufX = 0.f, sufY = 0.f;  // suffix sums over later chunks
+  double sufX = 0.0, sufY = 0.0;  // suffix sums over later chunks
   for (int c = nchunk - 1; c >= 0; --c) {
     const int c0 = c * 64, i = c0 + lane;
     const bool valid = i < S;
@@ -221,38 +248,42 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
       A = alphas_at(a.z, a.sigma_s, a.sigma_c, base, i, S, joint);
       zi = a.z[base + i];
     }
-    float tot, ds = 0.f, dc = 0.f;
+    double tot, ds = 0.0, dc = 0.0;
     if (joint) {
-      const float T = carry_s[wave][0][c] * excl_prod_scan(valid ? 1.0f - A.a_all : 1.0f, lane, tot);
-      const float Gs = dotE + g_sf, Gc = dotG + g_tw;
-      const float Gw = g_cd * zi + ((a.g_w_all && valid) ? a.g_w_all[base + i] : 0.f);
-      const float X = valid ? (A.a_s * T) * Gs + (A.a_c * T) * Gc + (A.a_all * T) * Gw : 0.f;
-      const float suf = excl_suffix_sum(X, lane, tot) + sufX;
+      const double om = valid ? (double)(1.0f - A.a_all) : 1.0;
+      const double T = carry_s[wave][0][c] * excl_prod_scan_d(om, lane, tot);
+      const double Gs = (double)dotE + g_sf, Gc = (double)dotG + g_tw;
+      const double Gw = (double)g_cd * zi + ((a.g_w_all && valid) ? (double)a.g_w_all[base + i] : 0.0);
+      const double X = valid ? ((double)A.a_s * Gs + (double)A.a_c * Gc + (double)A.a_all * Gw) * T : 0.0;
+      const double suf = excl_suffix_sum_d(X, lane, tot) + sufX;
       sufX += tot;
-      ds = A.delta * (A.es * T * Gs + A.ea * T * Gw - suf);
-      dc = A.delta * (A.ec * T * Gc + A.ea * T * Gw - suf);
+      // d alpha_s / d sigma_s = delta e_s etc.; the Gw term uses (1 - alpha) = the factor T_{i+1} is built from,
+      // so it telescopes against the suffix sum
+      ds = (double)A.delta * ((double)A.es * T * Gs + om * T * Gw - suf);
+      dc = (double)A.delta * ((double)A.ec * T * Gc + om * T * Gw - suf);
     }
     {
-      const float Ts = carry_s[wave][1][c] * excl_prod_scan(valid ? 1.0f - A.a_s : 1.0f, lane, tot);
-      const float w_s = A.a_s * Ts;
-      float Gws = g_sd * zi + ((a.g_w_s && valid) ? a.g_w_s[base + i] : 0.f);
+      const double oms = valid ? (double)(1.0f - A.a_s) : 1.0;
+      const double Ts = carry_s[wave][1][c] * excl_prod_scan_d(oms, lane, tot);
+      const double w_s = (double)A.a_s * Ts;
+      double Gws = (double)g_sd * zi + ((a.g_w_s && valid) ? (double)a.g_w_s[base + i] : 0.0);
       if (a.has_rgb && valid) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) Gws += g_rm[ch] * a.rgb[(base + i) * 3 + ch];
+        for (int ch = 0; ch < 3; ++ch) Gws += (double)g_rm[ch] * (double)a.rgb[(base + i) * 3 + ch];
       }
-      if (feat_from_ws) Gws += dotE + g_sf;
-      const float Y = valid ? w_s * Gws : 0.f;
-      const float suf = excl_suffix_sum(Y, lane, tot) + sufY;
+      if (feat_from_ws) Gws += (double)dotE + g_sf;
+      const double Y = valid ? w_s * Gws : 0.0;
+      const double suf = excl_suffix_sum_d(Y, lane, tot) + sufY;
       sufY += tot;
-      ds += A.delta * (A.es * Ts * Gws - suf);
+      ds += (double)A.delta * (oms * Ts * Gws - suf);
       if (a.has_rgb && valid) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) a.d_rgb[(base + i) * 3 + ch] = w_s * g_rm[ch];
+        for (int ch = 0; ch < 3; ++ch) a.d_rgb[(base + i) * 3 + ch] = (float)w_s * g_rm[ch];
       }
     }
     if (valid) {
-      a.d_sigma_s[base + i] = ds;
-      if (joint) a.d_sigma_c[base + i] = dc;
+      a.d_sigma_s[base + i] = (float)ds;
+      if (joint) a.d_sigma_c[base + i] = (float)dc;
     }
   }
 }

@@ -16,6 +16,14 @@
 
 namespace {
 
+// o + d*z with two roundings (the reference's `rays_o + rays_d * z` is two ATen ops, rendering.py:251); the
+// __f*_rn intrinsics are plain operators in HIP and would be contracted into one fma.
+__device__ __forceinline__ float mul_then_add(float o, float d, float z) {
+#pragma clang fp contract(off)
+  const float p = d * z;
+  return o + p;
+}
+
 // dot of LDS row segment [c0, c0+K) with w[0..K), split over the two threads of a row pair
 __device__ __forceinline__ float rowdot(const float* Hs, int ldw, int row, int half, int c0, int K, const float* __restrict__ w) {
   float s = 0.0f;
@@ -48,9 +56,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L,
     if (m < M) {
       const int r = m / S;
       const float zz = a.z[m];
-      x = __fadd_rn(a.rays_o[3 * r + 0], __fmul_rn(a.rays_d[3 * r + 0], zz));
-      y = __fadd_rn(a.rays_o[3 * r + 1], __fmul_rn(a.rays_d[3 * r + 1], zz));
-      zc = __fadd_rn(a.rays_o[3 * r + 2], __fmul_rn(a.rays_d[3 * r + 2], zz));
+      x = mul_then_add(a.rays_o[3 * r + 0], a.rays_d[3 * r + 0], zz);
+      y = mul_then_add(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], zz);
+      zc = mul_then_add(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], zz);
     }
     Hs[swz(tid, 0, W)] = x;
     Hs[swz(tid, 1, W)] = y;
@@ -64,11 +72,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L,
     const float xv = Hs[swz(row, n, W)];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-      const float arg = __fmul_rn(xv, ldexpf(PI_F, k));
+      const float arg = xv * ldexpf(PI_F, k);
       float sv, cv;
       sincosf(arg, &sv, &cv);
-      Hs[swz(row, 3 + 20 * n + k, W)] = __fmul_rn(sv, a.wk_xyz[k]);
-      Hs[swz(row, 3 + 20 * n + 10 + k, W)] = __fmul_rn(cv, a.wk_xyz[k]);
+      Hs[swz(row, 3 + 20 * n + k, W)] = sv * a.wk_xyz[k];
+      Hs[swz(row, 3 + 20 * n + 10 + k, W)] = cv * a.wk_xyz[k];
     }
   }
   __syncthreads();

@@ -243,14 +243,16 @@ __global__ __launch_bounds__(NTHREADS) void sample_pdf_kernel(int R, int S, cons
   float* bins = bins_s[wave];
   const int B = S - 2;  // number of weights; cdf and bins have B+1 entries
   const float eps = 1e-5f;
-  float part = 0.f;
+  double part = 0.0;
   for (int j = lane; j < B; j += 64) {
     const float w = weights[(size_t)r * S + 1 + j] + eps;
     cdf[j + 1] = w;  // staged; turned into the running sum below
-    part += w;
+    part += (double)w;
   }
   for (int j = lane; j <= B; j += 64) bins[j] = 0.5f * (z[(size_t)r * S + j] + z[(size_t)r * S + j + 1]);
-  const float total = wave_sum(part);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+  const float total = (float)part;  // correctly rounded sum of the row
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) {
     // torch.cumsum on CPU accumulates float rows in double and rounds each prefix to float

@@ -133,7 +133,7 @@ class NeRFSystem(_Base):
         nn.init.zeros_(self.depth_scale.weight)
 
     # ---- forward (nerf_system.py:93-148) -------------------------------------------------------------
-    def forward(self, rays, feats, img_idx, sched_mult, train=True, u_list=None):
+    def forward(self, rays, feats, img_idx, sched_mult, train=True, u_list=None, keep=None):
         hp = self.hparams
         sched_phase = 0 if sched_mult == 0 else (2 if sched_mult == 1 else 1)
         B = rays.shape[0]
@@ -145,7 +145,7 @@ class NeRFSystem(_Base):
                               N_samples=hp["nerf.N_samples"], use_disp=hp["nerf.use_disp"],
                               perturb=hp["nerf.perturb"] if train else 0, N_importance=hp["nerf.N_importance"],
                               white_back=getattr(self.train_dataset, "white_back", False),
-                              encode_feat=hp["nerf.feat_dim"] > 0, validation=not train, u_list=u_list)
+                              encode_feat=hp["nerf.feat_dim"] > 0, validation=not train, u_list=u_list, keep=keep)
             for k, v in out.items():
                 results[k] += [v]
         results = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in results.items()}
@@ -178,11 +178,12 @@ class NeRFSystem(_Base):
         d = 1.0 / p
         return torch.where(d < near, torch.full_like(d, near), d)
 
-    def compute_loss(self, batch, u_list=None):
+    def compute_loss(self, batch, u_list=None, keep=None):
         rays = self.rays_from_batch(batch)
+        self._last_rays = rays  # kept for tests (gradient w.r.t. the rays)
         depth = self.depth_targets(batch)
         sched_mult = self.get_schedule_mult(self._host_progress)
-        results = self(rays, batch["feats"], batch["img_idx"], sched_mult, u_list=u_list)
+        results = self(rays, batch["feats"], batch["img_idx"], sched_mult, u_list=u_list, keep=keep)
         loss_d = self.loss(results, batch["rgbs"], batch["feats"], depth, sched_mult)
         return sum(l for l in loss_d.values()), loss_d, results
 

@@ -58,9 +58,9 @@ def linear_raw(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act:
         x, w = F.pad(x, (0, pad)), F.pad(w, (0, pad))
         K += pad
     x, w = x.contiguous(), w.contiguous()
+    b = b.contiguous() if b is not None else None  # (named: must outlive the launch call)
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    check(lib.upnerf_linear(M, N, K, ptr(x), K, ptr(w), K, ptr(b.contiguous()) if b is not None else None, ptr(y), N,
-                            act, stream()), "upnerf_linear")
+    check(lib.upnerf_linear(M, N, K, ptr(x), K, ptr(w), K, ptr(b), ptr(y), N, act, stream()), "upnerf_linear")
     return y
 
 

@@ -266,8 +266,9 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
     unknown kwargs (sched_phase, white_back, validation) accepted and ignored, same result keys
     per schedule phase.  `test_time` is dead in the reference (Q1) and is ignored here too.
 
-    Extension used by the parity tests: kwargs["u_list"] = explicit uniform draws consumed in the reference's RNG
-    call order (coarse jitter [R,Nc], then the sample_pdf draws)."""
+    Extensions used by the parity tests: kwargs["u_list"] = explicit uniform draws consumed in the reference's RNG
+    call order (coarse jitter [R,Nc], then the sample_pdf draws); kwargs["keep"] = dict that receives the sampled
+    depths (z_coarse, z_fine)."""
     if not rays.is_cuda:
         raise RuntimeError("upnerf_amd.render_rays runs on the GPU only (no CPU fallback)")
     if not encode_feat:
@@ -318,6 +319,9 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
             results[f"s_rgb_{typ}"] = rgb_map
         results[f"s_depth_{typ}"] = s_dep  # rendering.py:211-218
 
+    keep = kwargs.get("keep")
+    if keep is not None:
+        keep["z_coarse"] = z
     inference(models["nerf_coarse"], z)
     if N_importance > 0:
         model = models["nerf_fine"]
@@ -341,5 +345,7 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
         else:  # rendering.py:300-307
             resample("s_weights_coarse", N_importance, N_samples)
         check(lib.upnerf_sort_rows(R, S, ptr(zf), st), "upnerf_sort_rows")
+        if keep is not None:
+            keep["z_fine"] = zf
         inference(model, zf)
     return results
