@@ -16,6 +16,42 @@ from ._lib import check, lib, ptr, stream
 _WS: Dict[Tuple[str, int], torch.Tensor] = {}
 
 
+class KernelTimer:
+    """Per-kernel device timing with HIP events recorded on the stream the kernels are enqueued on (torch's current
+    stream).  Disabled by default (zero overhead); bench.py enables it over the timed region to obtain the average
+    launch duration of each hot kernel for the roofline figures."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def run(self, name: str, fn, units: int = 0):
+        if not self.enabled:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.records.setdefault(name, []).append((e0, e1, units))
+        return out
+
+    def reset(self):
+        self.records = {}
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_ms, units_per_launch); synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            out[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
+                             units_per_launch=sum(u for _, _, u in evs) / len(evs))
+        return out
+
+
+TIMER = KernelTimer()
+
+
 def workspace(tag: str, numel: int, device) -> torch.Tensor:
     """Grow-only fp32 scratch, one per (tag, device); stream-ordered reuse."""
     key = (tag, device.index if device.index is not None else torch.cuda.current_device())
@@ -36,8 +72,9 @@ def wgrad_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor, ldb: 
     into a larger gradient buffer)."""
     ns = nsplit_for(M)
     ws = workspace("wgrad", ns * (256 * 256 + 256), device)
-    rc = lib.upnerf_wgrad(M, A.data_ptr() + 4 * a_off, lda, N, B.data_ptr() + 4 * b_off, ldb, K, dW_ptr, ldo,
-                          db_ptr, ptr(ws), ns, stream())
+    rc = TIMER.run(f"wgrad_{N}x{K}", lambda: lib.upnerf_wgrad(M, A.data_ptr() + 4 * a_off, lda, N,
+                                                              B.data_ptr() + 4 * b_off, ldb, K, dW_ptr, ldo, db_ptr,
+                                                              ptr(ws), ns, stream()), units=M)
     check(rc, "upnerf_wgrad")
 
 

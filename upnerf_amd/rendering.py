@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, X0, check, lib, ptr,
                    stream)
-from .ops import hip_linear, linear_raw, nsplit_for, vec_wgrad_into, wgrad_into
+from .ops import TIMER, hip_linear, linear_raw, nsplit_for, vec_wgrad_into, wgrad_into
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
@@ -100,7 +100,8 @@ class _FieldPass(torch.autograd.Function):
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(P), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
                           rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1))
-        check(lib.upnerf_field_fwd(C.byref(L), C.byref(fa), st), "upnerf_field_fwd")
+        check(TIMER.run("field_fwd", lambda: lib.upnerf_field_fwd(C.byref(L), C.byref(fa), st), units=M),
+              "upnerf_field_fwd")
 
         w_all = _empty(R, S, device=dev) if joint else None
         w_sj = _empty(R, S, device=dev) if joint else None
@@ -118,7 +119,8 @@ class _FieldPass(torch.autograd.Function):
                               w_sj=ptr(w_sj), w_cj=ptr(w_cj), w_s=ptr(w_s), E_s=ptr(E_s), G_c=ptr(G_c),
                               sum_sfeat=ptr(sum_sfeat), t_weight=ptr(t_weight), c_depth=ptr(c_depth),
                               s_depth=ptr(s_depth), rgb_map=ptr(rgb_map))
-        check(lib.upnerf_composite_fwd(C.byref(ca), st), "upnerf_composite_fwd")
+        check(TIMER.run("composite_fwd", lambda: lib.upnerf_composite_fwd(C.byref(ca), st), units=M),
+              "upnerf_composite_fwd")
 
         ctx.cfg, ctx.dims = cfg, (R, S)
         ctx.has_a = a_rows is not None
@@ -156,7 +158,8 @@ class _FieldPass(torch.autograd.Function):
                               g_sum_sfeat=ptr(gsf), g_t_weight=ptr(gtw), g_c_depth=ptr(gcd), g_s_depth=ptr(gsd),
                               g_rgb_map=ptr(grm), g_w_all=ptr(gwall), g_w_s=ptr(gws), d_sigma_s=ptr(d_sigma_s),
                               d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb))
-        check(lib.upnerf_composite_bwd(C.byref(cb), st), "upnerf_composite_bwd")
+        check(TIMER.run("composite_bwd", lambda: lib.upnerf_composite_bwd(C.byref(cb), st), units=M),
+              "upnerf_composite_bwd")
 
         need_dxyz = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         P = sv["P"]
@@ -178,7 +181,8 @@ class _FieldPass(torch.autograd.Function):
                           r1=ptr(sv["r1"]), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz))
-        check(lib.upnerf_field_bwd(C.byref(L), C.byref(fb), st), "upnerf_field_bwd")
+        check(TIMER.run("field_bwd", lambda: lib.upnerf_field_bwd(C.byref(L), C.byref(fb), st), units=M),
+              "upnerf_field_bwd")
 
         if _DEBUG_SINK is not None:
             _DEBUG_SINK.update(d_sigma_s=d_sigma_s, d_sigma_c=d_sigma_c, d_rgb=d_rgb, gz_h=gz_h, gz_e=gz_e, gz_g1=gz_g1,
