@@ -29,7 +29,7 @@ extern "C" {
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
-#define UPNERF_TILE_ROWS 128 /* rows of samples per workgroup in the fused MLP kernels */
+#define UPNERF_TILE_ROWS 64  /* rows of samples per workgroup in the fused field kernels */
 #define UPNERF_X0 64         /* positional encoding 3+6*10 = 63 padded to 64 floats per row */
 #define UPNERF_AUXK 80       /* per-ray rgb-head side input [dirPE(27) | appearance(48) | 0 x5] */
 #define UPNERF_CK 16         /* candidate embedding width */
@@ -69,9 +69,15 @@ int upnerf_ray_aux(int R, const float* rays_d, const float* a_rows /*[R][48] or 
                    const float* wk_dir /*[4]*/, float* aux /*[R][UPNERF_AUXK]*/, void* stream);
 
 /* ---- a6-a9: fused NeRF field, forward (models/nerf.py:80-124 + 126-147) --------------------------
- * Layout of the packed parameter buffer `P` (floats): offsets below, every matrix row-major [N][Kp]
- * with Kp a multiple of 8 (zero padded).  See upnerf_amd/packing.py for the packing from the
- * reference's state_dict names. */
+ * Layout of the packed parameter buffers (floats): offsets below; a matrix is [N][Kp] with Kp a multiple
+ * of 8 (zero padded), N a multiple of 32.  Two orderings of the SAME offsets are used:
+ *   row-major      W[n][k] at off + n*Kp + k           -- gradients (upnerf_wgrad output) and host code
+ *   fragment order W[n][k] at off + ((n/32)*(Kp/8) + k/8)*256 + (((k/4)%2)*32 + n%32)*4 + k%4
+ *                                                        -- what upnerf_field_fwd/bwd READ (one 1 KiB block =
+ *                                                           one wave-wide MFMA B-operand load)
+ * Vectors (biases, the 1- and 3-wide heads wsig/wcsig/wr2) are stored plainly in both.
+ * See upnerf_amd/packing.py (pack / frag / pack_t / frag_t) for the packing from the reference's
+ * state_dict names. */
 typedef struct {
   int32_t W, D, skip;            /* width (64 or 256), depth (<= 8), index of the skip layer or -1 */
   int32_t w[UPNERF_MAX_D];       /* trunk layer l: [W][Kp_l], Kp_0 = 64, Kp_skip = 64 + W, else W */
@@ -102,7 +108,7 @@ typedef struct {
   const float* c_rows;           /* [R][16] candidate embedding rows (use_cand) */
   const float* aux;              /* [R][80] from upnerf_ray_aux (use_rgb) */
   float wk_xyz[10];              /* BARF band weights for the xyz encoding */
-  const float* P;                /* packed parameters */
+  const float* P;                /* packed parameters, matrices in fragment order */
   /* per-sample outputs */
   float* sigma_s;                /* [M] softplus output */
   float* sigma_c;                /* [M] (use_cand) */
@@ -179,7 +185,7 @@ int upnerf_composite_bwd(const upnerf_composite_bwd_args* a, void* stream);
  * (inputs of upnerf_wgrad) and d(xyz). */
 typedef struct {
   int32_t R, S, use_cand, use_rgb, need_dxyz;
-  const float* PT;               /* transposed parameter copies (layout t_*) */
+  const float* PT;               /* transposed parameter copies (layout t_*), fragment order */
   const float* P;                /* forward parameters (vectors wsig, wcsig, wr2) */
   const float* d_sigma_s; const float* d_sigma_c; const float* d_rgb;
   const float* sigma_s; const float* sigma_c; const float* rgb;
@@ -208,7 +214,8 @@ int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_args* a, voi
 int upnerf_wgrad(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
                  float* dW, int ldo, float* db, float* slabs, int nsplit, void* stream);
 
-/* dw[c][k] = sum_m v[m*ldv + c] * X[m][k], c < nvec <= 4; dbv[c] = sum_m v[m*ldv + c]   (N=1/3 heads) */
+/* dw[c][k] = sum_m v[m*ldv + c] * X[m][k], c < nvec <= 3; dbv[c] = sum_m v[m*ldv + c]   (N=1/3 heads);
+ * K in {32, 64, 128, 256}; scratch: nsplit * 4 * (K+1) floats */
 int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const float* X, int ldx, int K,
                      float* dw /*[nvec][K]*/, float* dbv /*[nvec]*/, float* scratch, int nsplit, void* stream);
 

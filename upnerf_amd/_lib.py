@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libupnerf_hip.so")
 MAX_D = 8
-TILE_ROWS, X0, AUXK, CK = 128, 64, 80, 16
+TILE_ROWS, X0, AUXK, CK = 64, 64, 80, 16
 
 _fp = C.c_void_p
 

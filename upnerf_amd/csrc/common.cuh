@@ -9,9 +9,9 @@
 //     [128][W] fp32 with a 16-byte-granule XOR swizzle (granule ^= row & 15), which makes both the
 //     ds_read_b128 operand reads (16 distinct rows per lane group) and the ds_write_b32 accumulator
 //     write-back (32 consecutive columns of one row) bank-conflict free;
-//   * weights are streamed from L2 straight into registers in fragment order ([N][K] row-major, each lane
-//     reading 4 consecutive k of its own output column): they are private to a wave, so an LDS round trip
-//     would only add traffic.
+//   * weights are streamed from L2 straight into registers, pre-packed per step in MFMA fragment order so that
+//     each operand load is one contiguous 1 KiB wave-wide access; they are private to a wave, so an LDS round
+//     trip would only add traffic.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,7 +20,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define TILE UPNERF_TILE_ROWS
 #define NTHREADS 256
 
 #define HIP_TRY(expr)                        \
@@ -38,15 +37,19 @@ __device__ __forceinline__ int swz4(int row, int k, int ldw) { return row * ldw 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// How the four waves of a workgroup share a [128 x N] output tile (32x32 MFMA tiles).
-template <int N>
+// How the four waves of a workgroup share a [TILE x N] output tile (32x32 MFMA tiles).  When there are fewer
+// than four wave-sized pieces (narrow layers of the 64-wide model) the surplus waves recompute a piece another
+// wave owns and store identical values -- harmless, and it keeps every wave on the same barrier sequence.
+template <int N, int TILE>
 struct WaveTile {
-  static constexpr int NT = (N >= 256) ? 2 : 1;                 // 32-column tiles per wave
-  static constexpr int WN = (N / 32 / NT) >= 4 ? 4 : (N / 32 / NT);  // waves along N
-  static constexpr int WM = 4 / WN;                             // waves along M
-  static constexpr int MT = 4 / WM;                             // 32-row tiles per wave
+  static constexpr int NT = (N >= 256) ? 2 : 1;                        // 32-column tiles per wave
+  static constexpr int NG = N / 32 / NT;                               // column groups
+  static constexpr int MG = TILE / 32;                                 // 32-row groups in the tile
+  static constexpr int WN = NG >= 4 ? 4 : NG;                          // waves along N
+  static constexpr int WM = (4 / WN) < MG ? (4 / WN) : MG;             // waves along M
+  static constexpr int MT = MG / WM;                                   // 32-row tiles per wave
   __device__ static __forceinline__ int n0(int wave) { return (wave % WN) * 32 * NT; }
-  __device__ static __forceinline__ int row0(int wave) { return (wave / WN) * 32 * MT; }
+  __device__ static __forceinline__ int row0(int wave) { return ((wave / WN) % WM) * 32 * MT; }
 };
 
 template <int MT, int NT>
@@ -59,39 +62,69 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT][NT]) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 }
 
-// acc[128-row tile][n0 .. n0+32*NT) += Hs[:, kA0 .. kA0+K) . Wp[n][kB0 .. kB0+K)^T
-//   Hs: swizzled LDS activations, row stride ldw;  Wp: global [N][ldb] row-major;  K % 8 == 0.
+// Weight matrices are read in FRAGMENT ORDER (packing.py:NerfPacker.frag): for a row-major [N][Kp] matrix,
+//   frag[((n/32) * (Kp/8) + k/8) * 256 + ((k/4)%2 * 32 + n%32) * 4 + k%4] = W[n][k]
+// i.e. the 64 x 16 bytes one wave needs for one 32-column tile and 8 consecutive k form one contiguous 1 KiB block:
+// every B-operand load is a fully coalesced global_load_dwordx4 and each byte is fetched exactly once per workgroup
+// (row-major weights made every load touch 32 different 128-byte lines and thrashed the 32 KiB L1).
+//
+// acc[TILE rows][n0 .. n0+32*NT) += Hs[:, kA0 .. kA0+K) . W[n][kB0 .. kB0+K)^T
+//   Hs: swizzled LDS activations, row stride ldw;  Wf: fragment-ordered matrix with Kp = ldb columns;  K % 8 == 0.
+template <int MT, int NT>
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[MT][NT], const f32x4 (&a)[MT], const f32x4 (&b)[NT]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+}
+
+// Two-stage software pipeline, written out with ping-pong register sets (no copies): the operands of k-group
+// t+1 are requested before the 4*MT*NT MFMAs of k-group t issue, so L2 / LDS latency hides under ~1000 cycles of
+// matrix work.  (A rotating `cur = next` copy made hipcc wait for the prefetch inside the same iteration.)
+// K/8 must be even (every K in this library is a multiple of 16).
 template <int MT, int NT>
 __device__ __forceinline__ void mma_lds(f32x16 (&acc)[MT][NT], const float* Hs, int ldw, int row0, int kA0,
-                                        const float* __restrict__ Wp, int ldb, int n0, int kB0, int K, int lane) {
+                                        const float* __restrict__ Wf, int ldb, int n0, int kB0, int K, int lane) {
   const int i = lane & 31, hh = lane >> 5;
+  const int KT = ldb >> 3;
   const float* bp[NT];
-  int arow[MT];
+  int abase[MT], axor[MT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bp[nt] = Wp + (size_t)(n0 + 32 * nt + i) * ldb + kB0 + 4 * hh;
+  for (int nt = 0; nt < NT; ++nt) bp[nt] = Wf + ((size_t)((n0 >> 5) + nt) * KT + (kB0 >> 3)) * 256 + lane * 4;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) arow[mt] = row0 + 32 * mt + i;
-  f32x4 bcur[NT], bnxt[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bcur[nt] = *(const f32x4*)(bp[nt]);
+  for (int mt = 0; mt < MT; ++mt) {
+    const int r = row0 + 32 * mt + i;
+    abase[mt] = r * ldw;
+    axor[mt] = r & 15;
+  }
+  const int g0 = (kA0 >> 2) + hh;
   const int T = K >> 3;
-  for (int t = 0; t < T; ++t) {
-    const int tn = (t + 1 < T) ? t + 1 : t;
+  f32x4 a0[MT], a1[MT], b0[NT], b1[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bnxt[nt] = *(const f32x4*)(bp[nt] + 8 * tn);
-    f32x4 a[MT];
-    const int g = ((kA0 + 8 * t) >> 2) + hh;
+  for (int nt = 0; nt < NT; ++nt) b0[nt] = *(const f32x4*)(bp[nt]);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)&Hs[arow[mt] * ldw + ((g ^ (arow[mt] & 15)) << 2)];
+  for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const f32x4*)&Hs[abase[mt] + ((g0 ^ axor[mt]) << 2)];
+  for (int t = 0; t < T; t += 2) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int nt = 0; nt < NT; ++nt) b1[nt] = *(const f32x4*)(bp[nt] + 256 * (t + 1));
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) a1[mt] = *(const f32x4*)&Hs[abase[mt] + (((g0 + 2 * (t + 1)) ^ axor[mt]) << 2)];
+    // keep the requests ABOVE the matrix work: without the fence hipcc sinks them to just before their first
+    // use (shorter live ranges) and every half-iteration then waits out the full L2 / LDS latency
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(acc, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int t2 = (t + 2 < T) ? t + 2 : t;  // last trip: harmless re-read
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], bcur[nt][s], acc[mt][nt], 0, 0, 0);
+    for (int nt = 0; nt < NT; ++nt) b0[nt] = *(const f32x4*)(bp[nt] + 256 * t2);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
+    for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const f32x4*)&Hs[abase[mt] + (((g0 + 2 * t2) ^ axor[mt]) << 2)];
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(acc, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -100,13 +133,14 @@ __device__ __forceinline__ void mma_lds(f32x16 (&acc)[MT][NT], const float* Hs, 
 // (skip-connection encoding, per-ray embedding rows) that are not staged in LDS.
 template <int MT, int NT>
 __device__ __forceinline__ void mma_glb(f32x16 (&acc)[MT][NT], const float* const (&arow_ptr)[MT],
-                                        const float* __restrict__ Wp, int ldb, int n0, int kB0, int K, int lane) {
-  const int i = lane & 31, hh = lane >> 5;
+                                        const float* __restrict__ Wf, int ldb, int n0, int kB0, int K, int lane) {
+  const int KT = ldb >> 3;
   const int T = K >> 3;
   for (int t = 0; t < T; ++t) {
     f32x4 a[MT], b[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(Wp + (size_t)(n0 + 32 * nt + i) * ldb + kB0 + 4 * hh + 8 * t);
+    for (int nt = 0; nt < NT; ++nt)
+      b[nt] = *(const f32x4*)(Wf + ((size_t)((n0 >> 5) + nt) * KT + (kB0 >> 3) + t) * 256 + lane * 4);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(arow_ptr[mt] + 8 * t);
 #pragma unroll
@@ -151,7 +185,8 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[MT][NT], float* H
       }
 }
 
-// Copy LDS columns [c0, c0+ncols) of all 128 rows to global dst[(m0+row)*ldg + col-c0], rows >= M skipped.
+// Copy LDS columns [c0, c0+ncols) of all TILE rows to global dst[(m0+row)*ldg + col-c0], rows >= M skipped.
+template <int TILE>
 __device__ __forceinline__ void tile_store(const float* Hs, int ldw, int c0, int ncols, float* __restrict__ dst, int ldg,
                                            int m0, int M, int tid) {
   const int gpr = ncols >> 2;  // granules per row
@@ -167,6 +202,7 @@ __device__ __forceinline__ void tile_store(const float* Hs, int ldw, int c0, int
 // Backward epilogue pass over LDS columns [c0, c0+ncols): zero the entries whose saved forward activation
 // (global act[(m0+row)*ldg + col-c0], post-ReLU) is not positive, write the result back to LDS (operand of the
 // next contraction) and to global gz (operand of the weight-gradient kernel).  Coalesced 16-byte accesses.
+template <int TILE>
 __device__ __forceinline__ void tile_mask_store(float* Hs, int ldw, int c0, int ncols, const float* __restrict__ act,
                                                 float* __restrict__ gz, int ldg, int m0, int M, int tid) {
   const int gpr = ncols >> 2;

@@ -13,6 +13,11 @@
 #include "common.cuh"
 
 #define PI_F 3.14159274101257324f  // float32(torch.pi)
+// Rows of samples per workgroup.  64 rows x 256 floats = 64 KiB of LDS, so TWO workgroups share a CU (two waves per
+// SIMD): while one is in a layer epilogue (bias/ReLU, LDS write-back, activation store, barriers) the other keeps
+// the matrix pipe busy.  With 128-row tiles (one workgroup per CU) those phases were exposed: 61 % / 40 % of the
+// fp32 MFMA peak in the forward / backward kernels (profiles/r01_a_*).
+#define FIELD_TILE UPNERF_TILE_ROWS
 
 namespace {
 
@@ -24,24 +29,28 @@ __device__ __forceinline__ float mul_then_add(float o, float d, float z) {
   return o + p;
 }
 
-// dot of LDS row segment [c0, c0+K) with w[0..K), split over the two threads of a row pair
-__device__ __forceinline__ float rowdot(const float* Hs, int ldw, int row, int half, int c0, int K, const float* __restrict__ w) {
+// dot of LDS row segment [c0, c0+K) with w[0..K), split over the TPR adjacent threads that share a row
+template <int TPR>
+__device__ __forceinline__ float rowdot(const float* Hs, int ldw, int row, int part, int c0, int K, const float* __restrict__ w) {
   float s = 0.0f;
-  const int kb = half * (K >> 1);
-  for (int k = 0; k < (K >> 1); k += 4) {
+  const int kb = part * (K / TPR);
+  for (int k = 0; k < K / TPR; k += 4) {
     const f32x4 a = *(const f32x4*)&Hs[swz4(row, c0 + kb + k, ldw)];
     const f32x4 ww = *(const f32x4*)&w[kb + k];
     s += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
   }
-  return s + __shfl_xor(s, 1);
+#pragma unroll
+  for (int d = 1; d < TPR; d <<= 1) s += __shfl_xor(s, d);
+  return s;
 }
 
-template <int W>
-__global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
+template <int W, int TILE>
+__global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void field_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
   __shared__ __attribute__((aligned(16))) float Hs[TILE * W];
   constexpr int W2 = W / 2;
-  using TW = WaveTile<W>;
-  using TH = WaveTile<W2>;
+  constexpr int TPR = NTHREADS / TILE;  // threads per row in the per-row stages
+  using TW = WaveTile<W, TILE>;
+  using TH = WaveTile<W2, TILE>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE;
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L,
   for (int it = tid; it < TILE * 3; it += NTHREADS) {
     const int row = it / 3, n = it - row * 3;
     const float xv = Hs[swz(row, n, W)];
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 10; ++k) {
       const float arg = xv * ldexpf(PI_F, k);
       float sv, cv;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L,
     }
   }
   __syncthreads();
-  tile_store(Hs, W, 0, UPNERF_X0, a.x0, UPNERF_X0, m0, M, tid);
+  tile_store<TILE>(Hs, W, 0, UPNERF_X0, a.x0, UPNERF_X0, m0, M, tid);
 
   // ---- trunk (nerf.py:84-87)
   for (int l = 0; l < L.D; ++l) {
@@ -106,13 +115,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L,
     __syncthreads();
     acc_to_lds(acc, Hs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_store(Hs, W, 0, W, a.h + (size_t)l * M * W, W, m0, M, tid);
+    tile_store<TILE>(Hs, W, 0, W, a.h + (size_t)l * M * W, W, m0, M, tid);
   }
 
-  const int prow = tid >> 1, phalf = tid & 1, pm = m0 + prow;
+  const int prow = tid / TPR, phalf = tid % TPR, pm = m0 + prow;
   // ---- shared density head (nerf.py:89): softplus(w . h + b)
   {
-    const float pre = rowdot(Hs, W, prow, phalf, 0, W, P + L.wsig) + P[L.bsig];
+    const float pre = rowdot<TPR>(Hs, W, prow, phalf, 0, W, P + L.wsig) + P[L.bsig];
     if (phalf == 0 && pm < M) a.sigma_s[pm] = softplus_f(pre);
   }
   // ---- xyz_encoding_final (nerf.py:93), no activation
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L,
     __syncthreads();
     acc_to_lds(acc, Hs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_store(Hs, W, 0, W, a.e, W, m0, M, tid);
+    tile_store<TILE>(Hs, W, 0, W, a.e, W, m0, M, tid);
   }
   if (!a.use_rgb && !a.use_cand) return;
 
@@ -167,16 +176,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L,
   }
   __syncthreads();
   if (a.use_rgb) {
-    tile_store(Hs, W, 0, W2, a.r1, W2, m0, M, tid);
+    tile_store<TILE>(Hs, W, 0, W2, a.r1, W2, m0, M, tid);
     // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float pre = rowdot(Hs, W, prow, phalf, 0, W2, P + L.wr2 + c * W2) + P[L.br2 + c];
+      const float pre = rowdot<TPR>(Hs, W, prow, phalf, 0, W2, P + L.wr2 + c * W2) + P[L.br2 + c];
       if (phalf == 0 && pm < M) a.rgb[(size_t)pm * 3 + c] = sigmoid_f(pre);
     }
   }
   if (a.use_cand) {
-    tile_store(Hs, W, W2, W2, a.g1, W2, m0, M, tid);
+    tile_store<TILE>(Hs, W, W2, W2, a.g1, W2, m0, M, tid);
     f32x16 acc[TH::MT][TH::NT];
     acc_zero(acc);
     mma_lds(acc, Hs, W, hrow0, W2, P + L.wc2, W2, hn0, 0, W2, lane);
@@ -185,8 +194,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L,
     __syncthreads();
     acc_to_lds(acc, Hs, W, hrow0, hn0, W2, lane);
     __syncthreads();
-    tile_store(Hs, W, W2, W2, a.g2, W2, m0, M, tid);
-    const float pre = rowdot(Hs, W, prow, phalf, W2, W2, P + L.wcsig) + P[L.bcsig];
+    tile_store<TILE>(Hs, W, W2, W2, a.g2, W2, m0, M, tid);
+    const float pre = rowdot<TPR>(Hs, W, prow, phalf, W2, W2, P + L.wcsig) + P[L.bcsig];
     if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
   }
 }
@@ -194,14 +203,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_fwd_kernel(upnerf_layout L,
 // ------------------------------------------------------------------------------------------------------
 // Backward data-gradient chain.  Every stage leaves the pre-activation gradient of one layer in LDS (the A
 // operand of the next contraction) and in HBM (the A operand of upnerf_wgrad).
-template <int W>
-__global__ __launch_bounds__(NTHREADS, 1) void field_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
+template <int W, int TILE>
+__global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void field_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
   __shared__ __attribute__((aligned(16))) float Gs[TILE * W];
   __shared__ float pre_s[TILE];
   constexpr int W2 = W / 2;
-  using TW = WaveTile<W>;
-  using TH = WaveTile<W2>;
-  using TX = WaveTile<UPNERF_X0>;
+  using TW = WaveTile<W, TILE>;
+  using TH = WaveTile<W2, TILE>;
+  using TX = WaveTile<UPNERF_X0, TILE>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE, D = L.D;
   const float* __restrict__ P = a.P;
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_bwd_kernel(upnerf_layout L,
     __syncthreads();
     acc_to_lds(acc, Gs, W, hrow0, hn0, W2, lane);
     __syncthreads();
-    tile_mask_store(Gs, W, W2, W2, a.g1, a.gz_g1, W2, m0, M, tid);
+    tile_mask_store<TILE>(Gs, W, W2, W2, a.g1, a.gz_g1, W2, m0, M, tid);
   }
   if (a.use_rgb) {
     // d r1 = W_r2^T (d rgb * rgb (1-rgb))   (rgb_share_layer.2 + sigmoid)
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_bwd_kernel(upnerf_layout L,
     __syncthreads();
     acc_to_lds(acc, Gs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_store(Gs, W, 0, W, a.gz_e, W, m0, M, tid);
+    tile_store<TILE>(Gs, W, 0, W, a.gz_e, W, m0, M, tid);
   }
   // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu
   {
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_bwd_kernel(upnerf_layout L,
     __syncthreads();
     acc_to_lds(acc, Gs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_mask_store(Gs, W, 0, W, a.h + (size_t)(D - 1) * M * W, a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, tid);
+    tile_mask_store<TILE>(Gs, W, 0, W, a.h + (size_t)(D - 1) * M * W, a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, tid);
     __syncthreads();
   }
   // ---- trunk, last layer to first
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_bwd_kernel(upnerf_layout L,
     __syncthreads();
     acc_to_lds(acc, Gs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_mask_store(Gs, W, 0, W, a.h + (size_t)(l - 1) * M * W, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, tid);
+    tile_mask_store<TILE>(Gs, W, 0, W, a.h + (size_t)(l - 1) * M * W, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, tid);
     __syncthreads();
   }
   if (!a.need_dxyz) return;
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void field_bwd_kernel(upnerf_layout L,
     if (m >= M) continue;
     const float* __restrict__ x0 = a.x0 + (size_t)m * UPNERF_X0;
     float g = Gs[swz(row, n, W)];
-#pragma unroll
+#pragma unroll 2
     for (int k = 0; k < 10; ++k) {
       const float f = ldexpf(PI_F, k);
       g += f * (x0[3 + 20 * n + 10 + k] * Gs[swz(row, 3 + 20 * n + k, W)] -
@@ -376,12 +385,12 @@ extern "C" int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_a
   if (a->use_rgb && (!a->aux || !a->r1 || !a->rgb)) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
-  const int grid = (int)((M + TILE - 1) / TILE);
+  const int grid = (int)((M + FIELD_TILE - 1) / FIELD_TILE);
   hipStream_t st = (hipStream_t)stream;
   if (L->W == 256)
-    hipLaunchKernelGGL(field_fwd_kernel<256>, dim3(grid), dim3(NTHREADS), 0, st, *L, *a);
+    hipLaunchKernelGGL((field_fwd_kernel<256, FIELD_TILE>), dim3(grid), dim3(NTHREADS), 0, st, *L, *a);
   else
-    hipLaunchKernelGGL(field_fwd_kernel<64>, dim3(grid), dim3(NTHREADS), 0, st, *L, *a);
+    hipLaunchKernelGGL((field_fwd_kernel<64, FIELD_TILE>), dim3(grid), dim3(NTHREADS), 0, st, *L, *a);
   return (int)hipGetLastError();
 }
 
@@ -399,11 +408,11 @@ extern "C" int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_a
   if (a->need_dxyz && (!a->dxyz || !a->x0)) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
-  const int grid = (int)((M + TILE - 1) / TILE);
+  const int grid = (int)((M + FIELD_TILE - 1) / FIELD_TILE);
   hipStream_t st = (hipStream_t)stream;
   if (L->W == 256)
-    hipLaunchKernelGGL(field_bwd_kernel<256>, dim3(grid), dim3(NTHREADS), 0, st, *L, *a);
+    hipLaunchKernelGGL((field_bwd_kernel<256, FIELD_TILE>), dim3(grid), dim3(NTHREADS), 0, st, *L, *a);
   else
-    hipLaunchKernelGGL(field_bwd_kernel<64>, dim3(grid), dim3(NTHREADS), 0, st, *L, *a);
+    hipLaunchKernelGGL((field_bwd_kernel<64, FIELD_TILE>), dim3(grid), dim3(NTHREADS), 0, st, *L, *a);
   return (int)hipGetLastError();
 }

@@ -118,9 +118,15 @@ __global__ void wgrad_reduce_kernel(int N, int K, int TN, int TK, int nsplit, co
     const int by = n / TN, bz = k / TK;
     const size_t off = ((size_t)by * gz + bz) * TN * TK + (size_t)(n - by * TN) * TK + (k - bz * TK);
     const size_t stride = (size_t)gy * gz * TN * TK;
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += slabs[off + sp * stride];
-    dW[(size_t)n * ldo + k] = s;
+    // 8 independent partial sums keep 8 loads in flight (the loop is latency bound); fixed order -> reproducible
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += slabs[off + (size_t)(sp + u) * stride];
+    }
+    for (; sp < nsplit; ++sp) p[0] += slabs[off + (size_t)sp * stride];
+    dW[(size_t)n * ldo + k] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   }
   if (db && idx < N) {
     const int by = idx / TN;
@@ -130,29 +136,54 @@ __global__ void wgrad_reduce_kernel(int N, int K, int TN, int TK, int nsplit, co
   }
 }
 
-// ---- N = 1 / 3 heads: dw[c][k] = sum_m v[m][c] X[m][k]
+// ---- N = 1 / 3 heads: dw[c][k] = sum_m v[m][c] X[m][k].  HBM-bound stream of X: every lane owns 4 columns
+//      (16-byte loads, one full row per K/4 lanes), row groups run 4 rows ahead, partials meet in LDS.
+template <int K>
 __global__ __launch_bounds__(NTHREADS) void vec_wgrad_kernel(int M, const float* __restrict__ v, int ldv, int nvec,
-                                                            const float* __restrict__ X, int ldx, int K,
+                                                            const float* __restrict__ X, int ldx,
                                                             float* __restrict__ part, int rows_per_split) {
-  const int k = threadIdx.x, split = blockIdx.x;
+  constexpr int CPR = K / 4, RG = NTHREADS / CPR;  // lanes per row, row groups per block
+  __shared__ float red[RG][3][K + 4];
+  const int tid = threadIdx.x, c4 = tid % CPR, rg = tid / CPR, split = blockIdx.x;
   const int mbeg = split * rows_per_split;
   const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bacc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int m = mbeg; m < mend; ++m) {
-    const float x = k < K ? X[(size_t)m * ldx + k] : 0.f;
+  f32x4 acc[3];
+  float bacc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c < nvec) {
-        const float vv = v[(size_t)m * ldv + c];
-        acc[c] += vv * x;
-        bacc[c] += vv;
-      }
+  for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = mbeg + rg; m < mend; m += 4 * RG) {
+    f32x4 x[4];
+    float vv[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mm = m + u * RG;
+      const bool ok = mm < mend;
+      x[u] = ok ? *(const f32x4*)&X[(size_t)mm * ldx + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vv[u][c] = (ok && c < nvec) ? v[(size_t)mm * ldv + c] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        acc[c].x += vv[u][c] * x[u].x; acc[c].y += vv[u][c] * x[u].y;
+        acc[c].z += vv[u][c] * x[u].z; acc[c].w += vv[u][c] * x[u].w;
+        bacc[c] += vv[u][c];
+      }
   }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    *(f32x4*)&red[rg][c][4 * c4] = acc[c];
+    if (c4 == 0) red[rg][c][K] = bacc[c];
+  }
+  __syncthreads();
   // part layout [split][4][K+1]: last column = sum of v
-  for (int c = 0; c < nvec; ++c) {
-    if (k < K) part[((size_t)split * 4 + c) * (K + 1) + k] = acc[c];
-    if (k == 0) part[((size_t)split * 4 + c) * (K + 1) + K] = bacc[c];
+  for (int idx = tid; idx < nvec * (K + 1); idx += NTHREADS) {
+    const int c = idx / (K + 1), k = idx - c * (K + 1);
+    float s = 0.f;
+#pragma unroll 4
+    for (int g = 0; g < RG; ++g) s += red[g][c][k];
+    part[((size_t)split * 4 + c) * (K + 1) + k] = s;
   }
 }
 
@@ -169,12 +200,13 @@ __global__ void vec_wgrad_reduce_kernel(int nvec, int K, int nsplit, const float
 
 // ---- generic linear: C = act(A B^T + bias); A tile staged in LDS in K-chunks of 128
 #define LIN_KC 128
+#define TILE 128  // rows per workgroup of the generic linear kernel
 __global__ __launch_bounds__(NTHREADS, 1) void linear_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                              const float* __restrict__ B, int ldb,
                                                              const float* __restrict__ bias, float* __restrict__ C,
                                                              int ldc, int act) {
   __shared__ __attribute__((aligned(16))) float As[TILE * LIN_KC];
-  using TW = WaveTile<256>;
+  using TW = WaveTile<256, TILE>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * TILE, nb = blockIdx.y * 256;
   const int n0 = TW::n0(wave), row0 = TW::row0(wave);
@@ -298,7 +330,12 @@ extern "C" int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const 
     return UPNERF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int rows = (M + nsplit - 1) / nsplit;
-  hipLaunchKernelGGL(vec_wgrad_kernel, dim3(nsplit), dim3(NTHREADS), 0, st, M, v, ldv, nvec, X, ldx, K, scratch, rows);
+  if (nvec > 3 || (ldx & 3)) return UPNERF_EINVAL;
+  if (K == 256) hipLaunchKernelGGL(vec_wgrad_kernel<256>, dim3(nsplit), dim3(NTHREADS), 0, st, M, v, ldv, nvec, X, ldx, scratch, rows);
+  else if (K == 128) hipLaunchKernelGGL(vec_wgrad_kernel<128>, dim3(nsplit), dim3(NTHREADS), 0, st, M, v, ldv, nvec, X, ldx, scratch, rows);
+  else if (K == 64) hipLaunchKernelGGL(vec_wgrad_kernel<64>, dim3(nsplit), dim3(NTHREADS), 0, st, M, v, ldv, nvec, X, ldx, scratch, rows);
+  else if (K == 32) hipLaunchKernelGGL(vec_wgrad_kernel<32>, dim3(nsplit), dim3(NTHREADS), 0, st, M, v, ldv, nvec, X, ldx, scratch, rows);
+  else return UPNERF_EUNSUP;
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   const int total = nvec * (K + 1);

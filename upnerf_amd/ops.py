@@ -127,9 +127,9 @@ class HipLinear(torch.autograd.Function):
             xc = x.contiguous()
             gw = torch.empty(N, K, device=x.device, dtype=torch.float32)
             gb = torch.empty(N, device=x.device, dtype=torch.float32)
-            if N <= 4:
-                vec_wgrad_into(M, gy, N, N, xc, K, K, gw.data_ptr(), gb.data_ptr(), x.device) if K <= 256 else \
-                    _vec_wgrad_wide(M, gy, N, xc, K, gw, gb)
+            if N <= 3:
+                vec_wgrad_into(M, gy, N, N, xc, K, K, gw.data_ptr(), gb.data_ptr(), x.device) \
+                    if K in (32, 64, 128, 256) else _vec_wgrad_wide(M, gy, N, xc, K, gw, gb)
             else:
                 Kp, Np = (K + 3) // 4 * 4, (N + 3) // 4 * 4
                 assert Kp == K and Np == N, "HipLinear needs in/out features that are multiples of 4 (or out <= 4)"

@@ -127,6 +127,39 @@ class NerfPacker:
         assert P.numel() == L.total
         return P
 
+    # ------------------------------------------------------------------ MFMA fragment order (no grad)
+    @staticmethod
+    def _frag_into(dst, src, off, n, kp):
+        """dst[off:off+n*kp] = fragment-ordered copy of the row-major [n][kp] matrix at src[off:]:
+        [n/32][kp/8][half(2)][lane%32][4]  (csrc/common.cuh:mma_lds)."""
+        v = src[off:off + n * kp].view(n // 32, 32, kp // 8, 2, 4).permute(0, 2, 3, 1, 4)
+        dst[off:off + n * kp].view(n // 32, kp // 8, 2, 32, 4).copy_(v)
+
+    @torch.no_grad()
+    def frag(self, P: torch.Tensor) -> torch.Tensor:
+        """Kernel-side copy of P: matrices in fragment order, vectors (biases, 1/3-wide heads) unchanged."""
+        W, W2, D, L = self.W, self.W2, self.D, self.L
+        out = P.clone()
+        for l in range(D):
+            self._frag_into(out, P, L.w[l], W, X0 if l == 0 else (X0 + W if l == self.skip else W))
+        self._frag_into(out, P, L.we, W, W)
+        self._frag_into(out, P, L.wc1, W2, W + CK)
+        self._frag_into(out, P, L.wc2, W2, W2)
+        self._frag_into(out, P, L.wr1, W2, W + AUXK)
+        return out
+
+    @torch.no_grad()
+    def frag_t(self, PT: torch.Tensor) -> torch.Tensor:
+        W, W2, D, L = self.W, self.W2, self.D, self.L
+        out = PT.clone()
+        for l in range(D):
+            self._frag_into(out, PT, L.t_w[l], X0 if l == 0 else W, W)
+        self._frag_into(out, PT, L.t_skipx, X0, W)
+        self._frag_into(out, PT, L.t_we, W, W)
+        self._frag_into(out, PT, L.t_head, W, W)
+        self._frag_into(out, PT, L.t_wc2, W2, W2)
+        return out
+
     # ------------------------------------------------------------------ transposed copies (no grad)
     @torch.no_grad()
     def pack_t(self, P: torch.Tensor) -> torch.Tensor:

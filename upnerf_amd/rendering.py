@@ -79,6 +79,7 @@ class _FieldPass(torch.autograd.Function):
         st = stream()
         rays_o, rays_d, z = rays_o.detach().contiguous(), rays_d.detach().contiguous(), z.detach().contiguous()
         P = P.detach().contiguous()
+        PF = pk.frag(P)  # what the kernels read: matrices in MFMA fragment order
         c_rows = c_rows.detach().contiguous() if (c_rows is not None and cfg.use_cand) else None
         a_rows_c = a_rows.detach().contiguous() if a_rows is not None else None
         joint, want_feat = cfg.mode <= 1, cfg.mode != 2
@@ -98,7 +99,7 @@ class _FieldPass(torch.autograd.Function):
         r1 = _empty(M, W2, device=dev) if cfg.use_rgb else None
         fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
-                          wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(P), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
+                          wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
                           rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1))
         check(TIMER.run("field_fwd", lambda: lib.upnerf_field_fwd(C.byref(L), C.byref(fa), st), units=M),
               "upnerf_field_fwd")
@@ -163,7 +164,7 @@ class _FieldPass(torch.autograd.Function):
 
         need_dxyz = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         P = sv["P"]
-        PT = pk.pack_t(P)
+        PT = pk.frag_t(pk.pack_t(P))
         gz_h, gz_e = _empty(D, M, W, device=dev), _empty(M, W, device=dev)
         gz_g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
         gz_g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
