@@ -1,0 +1,90 @@
+"""Data-parallel gradient averaging (upnerf_amd/parallel.py) on CPU with the gloo backend, world_size 2:
+the N>1 path of bench.py / NeRFSystem.enable_data_parallel() without GPUs.
+
+Checked: (1) the flat all-reduce equals the mean of the per-rank gradients for every parameter that has one;
+(2) parameters without a gradient (phase-dependent heads, `progress`, TransientNet.rgb_layer -- SURVEY.md Q12) are
+left untouched and do not desynchronise the ranks; (3) two ranks that each see half of a batch end up with the
+gradient a single process computes on the full batch (mean-of-means with equal shards)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(7, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    m.unused = torch.nn.Parameter(torch.zeros(5))          # never receives a gradient
+    m.table = torch.nn.Embedding(10, 4)                    # row-sparse gradient, reduced densely
+    return m
+
+
+def _loss(m, x, idx):
+    return (m(x) ** 2).mean() + (m.table(idx) ** 2).mean()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from upnerf_amd import parallel
+    r, _, w = parallel.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    m = _model()
+    g = torch.Generator().manual_seed(123)
+    x, idx = torch.randn(8, 7, generator=g), torch.randint(0, 10, (8,), generator=g)
+    xs, ids = x[rank * 4:(rank + 1) * 4], idx[rank * 4:(rank + 1) * 4]
+    _loss(m, xs, ids).backward()
+    local = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    sync = parallel.GradSync(m.parameters(), check=True)
+    n = sync()
+    out = {n_: p.grad.clone() for n_, p in m.named_parameters() if p.grad is not None}
+    q.put((rank, n, local, out, m.unused.grad is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, loc0, out0, un0), (_, n1, loc1, out1, un1) = res
+    assert n0 == n1 == sum(v.numel() for v in loc0.values())
+    assert un0 and un1                                   # unused parameter still has no gradient
+    for k in loc0:
+        mean = (loc0[k] + loc1[k]) / 2
+        assert torch.allclose(out0[k], mean, atol=1e-7) and torch.equal(out0[k], out1[k]), k
+    # equal shards: mean of shard gradients == full-batch gradient
+    m = _model()
+    g = torch.Generator().manual_seed(123)
+    x, idx = torch.randn(8, 7, generator=g), torch.randint(0, 10, (8,), generator=g)
+    _loss(m, x, idx).backward()
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(out0[n], p.grad, atol=1e-6), n
+
+
+def test_single_process_is_a_noop():
+    from upnerf_amd import parallel
+    m = _model()
+    _loss(m, torch.randn(4, 7), torch.randint(0, 10, (4,))).backward()
+    before = m[0].weight.grad.clone()
+    assert parallel.GradSync(m.parameters())() == 0
+    assert torch.equal(m[0].weight.grad, before)

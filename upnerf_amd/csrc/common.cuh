@@ -107,6 +107,7 @@ __device__ __forceinline__ void mma_lds(f32x16 (&acc)[MT][NT], const float* Hs, 
   for (int nt = 0; nt < NT; ++nt) b0[nt] = *(const f32x4*)(bp[nt]);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const f32x4*)&Hs[abase[mt] + ((g0 ^ axor[mt]) << 2)];
+#pragma unroll 1  // (a compile-time K would otherwise be unrolled 16x with all LDS addresses hoisted: spills)
   for (int t = 0; t < T; t += 2) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b1[nt] = *(const f32x4*)(bp[nt] + 256 * (t + 1));
@@ -136,6 +137,7 @@ __device__ __forceinline__ void mma_glb(f32x16 (&acc)[MT][NT], const float* cons
                                         const float* __restrict__ Wf, int ldb, int n0, int kB0, int K, int lane) {
   const int KT = ldb >> 3;
   const int T = K >> 3;
+#pragma unroll 1
   for (int t = 0; t < T; ++t) {
     f32x4 a[MT], b[NT];
 #pragma unroll
@@ -219,6 +221,30 @@ __device__ __forceinline__ void tile_mask_store(float* Hs, int ldw, int c0, int 
       v.z = av.z > 0.f ? v.z : 0.f;
       v.w = av.w > 0.f ? v.w : 0.f;
       *(f32x4*)&gz[off] = v;
+    }
+    *(f32x4*)p = v;
+  }
+}
+
+// Pass over LDS columns [0, ncols): add the rank-1 term wrow[m] * grow[(m / S)][col] (feature-map gradient: per-sample
+// compositing weight times the per-ray upstream vector), write back to LDS and store to global gz.
+template <int TILE>
+__device__ __forceinline__ void tile_rank1_store(float* Hs, int ldw, int ncols, const float* __restrict__ wrow,
+                                                 const float* __restrict__ grow, int S, float* __restrict__ gz,
+                                                 int m0, int M, int tid) {
+  const int gpr = ncols >> 2;
+  for (int idx = tid; idx < TILE * gpr; idx += NTHREADS) {
+    const int row = idx / gpr, g = idx - row * gpr, m = m0 + row;
+    float* p = &Hs[swz4(row, 4 * g, ldw)];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+      v = *(const f32x4*)p;
+      if (grow) {
+        const float w = wrow[m];
+        const f32x4 gv = *(const f32x4*)&grow[(size_t)(m / S) * ncols + 4 * g];
+        v.x += w * gv.x; v.y += w * gv.y; v.z += w * gv.z; v.w += w * gv.w;
+      }
+      *(f32x4*)&gz[(size_t)m * ncols + 4 * g] = v;
     }
     *(f32x4*)p = v;
   }

@@ -304,18 +304,13 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
     const int ks = a.use_rgb ? 0 : W2;
     const int kl = (a.use_rgb ? W2 : 0) + (a.use_cand ? W2 : 0);
     if (kl > 0) mma_lds(acc, Gs, W, row0, ks, PT + L.t_head, W, n0, ks, kl, lane);
-    if (a.g_E_s) {
-      const float* __restrict__ ge = a.g_E_s;
-      const float* __restrict__ wf = a.w_feat_s;
-      acc_map(acc, row0, n0, lane, [&](float v, int row, int col) {
-        const int m = m0 + row;
-        return m < M ? v + wf[m] * ge[(size_t)(m / S) * W + col] : 0.0f;
-      });
-    }
     __syncthreads();
     acc_to_lds(acc, Gs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_store<TILE>(Gs, W, 0, W, a.gz_e, W, m0, M, tid);
+    // + w_feat[m] * g_E_s[ray] in a coalesced pass (per-element loads in the accumulator layout were 64 dependent
+    // L2 round trips per lane)
+    tile_rank1_store<TILE>(Gs, W, W, a.w_feat_s, a.g_E_s, S, a.gz_e, m0, M, tid);
+    __syncthreads();
   }
   // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu
   {

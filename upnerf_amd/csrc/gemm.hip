@@ -67,15 +67,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_kernel(int M, int N, int K,
     lstore(buf);
     __syncthreads();
     if (mc + WG_CHUNK < mend) gload(mc + WG_CHUNK);
-    const float* as = As[buf];
-    const float* bs = Bs[buf];
-#pragma unroll 4
-    for (int mm = 0; mm < WG_CHUNK; mm += 2) {
-      float av[MTW], bv[NTW];
+    const float* as = As[buf] + hh * TN + n0 + li;
+    const float* bs = Bs[buf] + hh * TK + k0 + li;
+    // ping-pong operand sets, requests fenced above the matrix work (see common.cuh:mma_lds)
+    float a0[MTW], b0[NTW], a1[MTW], b1[NTW];
+    auto fetch = [&](float (&av)[MTW], float (&bv)[NTW], int mm) {
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) av[mt] = as[(mm + hh) * TN + n0 + 32 * mt + li];
+      for (int mt = 0; mt < MTW; ++mt) av[mt] = as[mm * TN + 32 * mt];
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) bv[nt] = bs[(mm + hh) * TK + k0 + 32 * nt + li];
+      for (int nt = 0; nt < NTW; ++nt) bv[nt] = bs[mm * TK + 32 * nt];
+    };
+    auto step = [&](const float (&av)[MTW], const float (&bv)[NTW]) {
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
         bsum[mt] += av[mt];
@@ -83,6 +85,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_kernel(int M, int N, int K,
         for (int nt = 0; nt < NTW; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
       }
+    };
+    fetch(a0, b0, 0);
+#pragma unroll 2
+    for (int mm = 0; mm < WG_CHUNK; mm += 4) {
+      fetch(a1, b1, mm + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      step(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(a0, b0, (mm + 4 < WG_CHUNK) ? mm + 4 : mm);
+      __builtin_amdgcn_sched_barrier(0);
+      step(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     buf ^= 1;
   }
@@ -107,32 +121,58 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_kernel(int M, int N, int K,
   }
 }
 
-// dW[n][k] = sum_split slab[split][by][bz][n%TN][k%TK]   (fixed order)
-__global__ void wgrad_reduce_kernel(int N, int K, int TN, int TK, int nsplit, const float* __restrict__ slabs,
-                                    const float* __restrict__ bslabs, float* __restrict__ dW, int ldo,
-                                    float* __restrict__ db) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// dW[n][k] = sum_split slab[split][by][bz][n%TN][k%TK]   (fixed order -> bitwise reproducible)
+// One thread per 4 consecutive k (16-byte loads); the splits are dealt round-robin to RG = 4 thread groups whose
+// partial sums meet in LDS; each group keeps 4 loads in flight.  The reduction is a pure HBM stream (nsplit x N x K x 4
+// bytes), so what matters is bytes in flight, not arithmetic.
+#define RED_RG 4
+__global__ __launch_bounds__(NTHREADS) void wgrad_reduce_kernel(int N, int K, int TN, int TK, int nsplit,
+                                                               const float* __restrict__ slabs,
+                                                               const float* __restrict__ bslabs, float* __restrict__ dW,
+                                                               int ldo, float* __restrict__ db) {
+  __shared__ f32x4 part[RED_RG][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + lane;  // index of a group of 4 consecutive k
+  const int K4 = K >> 2;
   const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
-  if (idx < N * K) {
-    const int n = idx / K, k = idx - n * K;
-    const int by = n / TN, bz = k / TK;
-    const size_t off = ((size_t)by * gz + bz) * TN * TK + (size_t)(n - by * TN) * TK + (k - bz * TK);
-    const size_t stride = (size_t)gy * gz * TN * TK;
-    // 8 independent partial sums keep 8 loads in flight (the loop is latency bound); fixed order -> reproducible
-    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int sp = 0;
-    for (; sp + 8 <= nsplit; sp += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) p[u] += slabs[off + (size_t)(sp + u) * stride];
+  const bool ok = q < N * K4;
+  const int n = ok ? q / K4 : 0, k = ok ? (q - n * K4) * 4 : 0;
+  const int by = n / TN, bz = k / TK;
+  const size_t off = ((size_t)by * gz + bz) * TN * TK + (size_t)(n - by * TN) * TK + (k - bz * TK);
+  const size_t stride = (size_t)gy * gz * TN * TK;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (ok) {
+    int sp = rg;
+    for (; sp + 3 * RED_RG < nsplit; sp += 4 * RED_RG) {
+      const f32x4 a = *(const f32x4*)&slabs[off + (size_t)sp * stride];
+      const f32x4 b = *(const f32x4*)&slabs[off + (size_t)(sp + RED_RG) * stride];
+      const f32x4 c = *(const f32x4*)&slabs[off + (size_t)(sp + 2 * RED_RG) * stride];
+      const f32x4 d = *(const f32x4*)&slabs[off + (size_t)(sp + 3 * RED_RG) * stride];
+      s0 += a; s1 += b; s2 += c; s3 += d;
     }
-    for (; sp < nsplit; ++sp) p[0] += slabs[off + (size_t)sp * stride];
-    dW[(size_t)n * ldo + k] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    for (; sp < nsplit; sp += RED_RG) s0 += *(const f32x4*)&slabs[off + (size_t)sp * stride];
   }
-  if (db && idx < N) {
-    const int by = idx / TN;
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += bslabs[((size_t)sp * gy + by) * TN + (idx - by * TN)];
-    db[idx] = s;
+  part[rg][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && ok) {
+    const f32x4 t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    *(f32x4*)&dW[(size_t)n * ldo + k] = t;
+  }
+  if (db) {
+    const int idx = blockIdx.x * NTHREADS + threadIdx.x;
+    if (idx < N) {
+      const int bby = idx / TN;
+      float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* src = bslabs + (size_t)bby * TN + (idx - bby * TN);
+      const size_t bst = (size_t)gy * TN;
+      int sp = 0;
+      for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] += src[(size_t)(sp + u) * bst];
+      }
+      for (; sp < nsplit; ++sp) p[0] += src[(size_t)sp * bst];
+      db[idx] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    }
   }
 }
 
@@ -192,8 +232,14 @@ __global__ void vec_wgrad_reduce_kernel(int nvec, int K, int nsplit, const float
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nvec * (K + 1)) return;
   const int c = idx / (K + 1), k = idx - c * (K + 1);
-  float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)sp * 4 + c) * (K + 1) + k];
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int sp = 0;
+  for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] += part[((size_t)(sp + u) * 4 + c) * (K + 1) + k];
+  }
+  for (; sp < nsplit; ++sp) p[0] += part[((size_t)sp * 4 + c) * (K + 1) + k];
+  const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   if (k < K) dw[(size_t)c * K + k] = s;
   else if (dbv) dbv[c] = s;
 }
@@ -318,9 +364,12 @@ extern "C" int upnerf_wgrad(int M, const float* A, int lda, int N, const float* 
   else if (TN == 64 && TK == 128) rc = launch_wgrad<1, 2>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
   else rc = launch_wgrad<1, 1>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
   if (rc) return rc;
-  const int total = N * K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, N, K, TN, TK, nsplit, slabs,
-                     bslabs, dW, ldo, db);
+  if (ldo & 3) return UPNERF_EINVAL;  // 16-byte stores into dW
+  const int quads = N * (K / 4);
+  int rblocks = (quads + 63) / 64;
+  if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;  // the bias sum needs one thread per row
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(NTHREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
+                     ldo, db);
   return (int)hipGetLastError();
 }
 

@@ -63,7 +63,9 @@ def workspace(tag: str, numel: int, device) -> torch.Tensor:
 
 
 def nsplit_for(M: int) -> int:
-    return max(1, min(256, M // 256))
+    """M-splits of the weight-gradient kernels: one workgroup per CU for the big per-sample reductions, and at
+    least 64 rows per split so that the small per-ray ones (M = rays) are not a serial chain of chunks."""
+    return max(1, min(256, M // 64))
 
 
 def wgrad_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor, ldb: int, K: int, dW_ptr: int, ldo: int,
