@@ -183,8 +183,14 @@ def main():
         line["kernels"] = kern
         dom = max((n for n in kern if n in per_sample), key=lambda n: kern[n]["ms_per_step"])
         ach = kern[dom]["tflops_algorithmic"]
+        traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected live)
+        pmc = os.path.join(ROOT, "profiles", "r01_b_pmc.json")
+        if os.path.exists(pmc):
+            t = json.load(open(pmc)).get(dom)
+            if t:
+                traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
         line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                             "avg_launch_ms": kern[dom]["avg_ms"],
                             "note": "average over the coarse (262144-sample) and fine (786432-sample) launches"}
     if world == 1 and not args.no_cpu_baseline:

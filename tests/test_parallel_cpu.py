@@ -22,16 +22,21 @@ def _free_port():
     return p
 
 
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(7, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+        self.unused = torch.nn.Parameter(torch.zeros(5))      # never receives a gradient
+        self.table = torch.nn.Embedding(10, 4)                # row-sparse gradient, reduced densely
+
+
 def _model():
     torch.manual_seed(0)
-    m = torch.nn.Sequential(torch.nn.Linear(7, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
-    m.unused = torch.nn.Parameter(torch.zeros(5))          # never receives a gradient
-    m.table = torch.nn.Embedding(10, 4)                    # row-sparse gradient, reduced densely
-    return m
+    return _Net()
 
 
 def _loss(m, x, idx):
-    return (m(x) ** 2).mean() + (m.table(idx) ** 2).mean()
+    return (m.mlp(x) ** 2).mean() + (m.table(idx) ** 2).mean()
 
 
 def _worker(rank, world, port, q):
@@ -85,6 +90,6 @@ def test_single_process_is_a_noop():
     from upnerf_amd import parallel
     m = _model()
     _loss(m, torch.randn(4, 7), torch.randint(0, 10, (4,))).backward()
-    before = m[0].weight.grad.clone()
+    before = m.mlp[0].weight.grad.clone()
     assert parallel.GradSync(m.parameters())() == 0
-    assert torch.equal(m[0].weight.grad, before)
+    assert torch.equal(m.mlp[0].weight.grad, before)
