@@ -116,6 +116,7 @@ typedef struct {
   /* activations kept for compositing and for the backward pass */
   float* x0;                     /* [M][64] */
   float* h;                      /* [D][M][W] post-ReLU trunk activations */
+  uint64_t* hmask;               /* [D][ceil(M/64)][256] ReLU sign bits of h in the kernels' accumulator layout */
   float* e;                      /* [M][W]   xyz_encoding_final output */
   float* g1;                     /* [M][W/2] (use_cand) */
   float* g2;                     /* [M][W/2] (use_cand) */
@@ -194,6 +195,7 @@ typedef struct {
   const float* g_E_s;            /* [R][W] or NULL */
   const float* g_G_c;            /* [R][W/2] or NULL */
   const float* x0; const float* h; const float* g1; const float* g2; const float* r1;
+  const uint64_t* hmask;         /* from upnerf_field_fwd */
   /* outputs */
   float* gz_h;                   /* [D][M][W] */
   float* gz_e;                   /* [M][W] */

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libupnerf_hip.so")
+LIB_PATH = os.environ.get("UPNERF_LIB") or os.path.join(_HERE, "libupnerf_hip.so")  # UPNERF_LIB: diagnostic builds only
 MAX_D = 8
 TILE_ROWS, X0, AUXK, CK = 64, 64, 80, 16
 
@@ -34,7 +34,7 @@ class FieldFwdArgs(C.Structure):
                 ("rays_o", _fp), ("rays_d", _fp), ("z", _fp), ("c_rows", _fp), ("aux", _fp),
                 ("wk_xyz", C.c_float * 10), ("P", _fp),
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
-                ("x0", _fp), ("h", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp)]
+                ("x0", _fp), ("h", _fp), ("hmask", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp)]
 
 
 class CompositeFwdArgs(C.Structure):
@@ -62,7 +62,7 @@ class FieldBwdArgs(C.Structure):
                 ("d_sigma_s", _fp), ("d_sigma_c", _fp), ("d_rgb", _fp),
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
                 ("w_feat_s", _fp), ("w_cj", _fp), ("g_E_s", _fp), ("g_G_c", _fp),
-                ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp),
+                ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp), ("hmask", _fp),
                 ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp)]
 

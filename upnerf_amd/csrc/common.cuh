@@ -136,22 +136,32 @@ template <int MT, int NT>
 __device__ __forceinline__ void mma_glb(f32x16 (&acc)[MT][NT], const float* const (&arow_ptr)[MT],
                                         const float* __restrict__ Wf, int ldb, int n0, int kB0, int K, int lane) {
   const int KT = ldb >> 3;
-  const int T = K >> 3;
+  const int T = K >> 3;  // even
+  const float* bp[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bp[nt] = Wf + ((size_t)((n0 >> 5) + nt) * KT + (kB0 >> 3)) * 256 + lane * 4;
+  f32x4 a0[MT], a1[MT], b0[NT], b1[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b0[nt] = *(const f32x4*)(bp[nt]);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const f32x4*)(arow_ptr[mt]);
 #pragma unroll 1
-  for (int t = 0; t < T; ++t) {
-    f32x4 a[MT], b[NT];
+  for (int t = 0; t < T; t += 2) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      b[nt] = *(const f32x4*)(Wf + ((size_t)((n0 >> 5) + nt) * KT + (kB0 >> 3) + t) * 256 + lane * 4);
+    for (int nt = 0; nt < NT; ++nt) b1[nt] = *(const f32x4*)(bp[nt] + 256 * (t + 1));
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(arow_ptr[mt] + 8 * t);
+    for (int mt = 0; mt < MT; ++mt) a1[mt] = *(const f32x4*)(arow_ptr[mt] + 8 * (t + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(acc, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int t2 = (t + 2 < T) ? t + 2 : t;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int nt = 0; nt < NT; ++nt) b0[nt] = *(const f32x4*)(bp[nt] + 256 * t2);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+    for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const f32x4*)(arow_ptr[mt] + 8 * t2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(acc, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -168,6 +178,48 @@ __device__ __forceinline__ void acc_map(f32x16 (&acc)[MT][NT], int row0, int n0,
         const int row = row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const int col = n0 + 32 * nt + i;
         acc[mt][nt][r] = f(acc[mt][nt][r], row, col);
+      }
+}
+
+// ReLU sign bits in the accumulator layout: bit e = (mt*NT + nt)*16 + r of a lane's 64-bit word says whether that
+// lane's accumulator element e was positive after bias + ReLU.  The forward kernel stores one word per lane per layer
+// (2 KiB per 64-row tile instead of the 64 KiB activation tile); the backward kernel, which uses the same wave tiling
+// for the gradient of that activation, reloads its own word and needs no activation read, no mask pass over LDS.
+template <int MT, int NT>
+__device__ __forceinline__ unsigned long long acc_bias_relu_pack(f32x16 (&acc)[MT][NT], const float* __restrict__ bias,
+                                                                 int n0, int lane) {
+  static_assert(MT * NT * 16 <= 64, "mask word is 64 bits");
+  const int i = lane & 31;
+  unsigned int lo = 0u, hi = 0u;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float b = bias[n0 + 32 * nt + i];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int e = (mt * NT + nt) * 16 + r;
+        const float v = fmaxf(acc[mt][nt][r] + b, 0.0f);
+        acc[mt][nt][r] = v;
+        if (e < 32) lo |= (v > 0.0f) ? (1u << e) : 0u;
+        else hi |= (v > 0.0f) ? (1u << (e - 32)) : 0u;
+      }
+    }
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void acc_apply_mask(f32x16 (&acc)[MT][NT], unsigned long long bits) {
+  const unsigned int lo = (unsigned int)bits, hi = (unsigned int)(bits >> 32);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int e = (mt * NT + nt) * 16 + r;
+        const bool on = e < 32 ? (lo >> e) & 1u : (hi >> (e - 32)) & 1u;
+        acc[mt][nt][r] = on ? acc[mt][nt][r] : 0.0f;
       }
 }
 

@@ -29,6 +29,27 @@ __device__ __forceinline__ float mul_then_add(float o, float d, float z) {
   return o + p;
 }
 
+// sin and cos of an fp32 angle (up to ~1e5 rad: 2^9 pi x) to within 1 ulp of fp32: Cody-Waite reduction by pi/2 and
+// the fdlibm kernel polynomials, all in fp64 -- a fraction of the instructions of the generic sincosf (whose large-
+// argument path is a Payne-Hanek reduction); the result is the correctly rounded fp32 value in 99.998 % of cases.
+__device__ __forceinline__ void sincos_f32_via_f64(float arg, float& sn, float& cs) {
+  const double x = (double)arg;
+  const double q = rint(x * 0.63661977236758134308);
+  double r = fma(-q, 1.57079632679489655800e+00, x);
+  r = fma(-q, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double s = r + r * z * ps;
+  const double c = 1.0 - 0.5 * z + z * z * pc;
+  const int n = (int)(long long)q & 3;
+  const double so = (n & 1) ? c : s, co = (n & 1) ? s : c;
+  sn = (float)((n & 2) ? -so : so);
+  cs = (float)(((n + 1) & 2) ? -co : co);
+}
+
 // dot of LDS row segment [c0, c0+K) with w[0..K), split over the TPR adjacent threads that share a row
 template <int TPR>
 __device__ __forceinline__ float rowdot(const float* Hs, int ldw, int row, int part, int c0, int K, const float* __restrict__ w) {
@@ -83,7 +104,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
     for (int k = 0; k < 10; ++k) {
       const float arg = xv * ldexpf(PI_F, k);
       float sv, cv;
-      sincosf(arg, &sv, &cv);
+      sincos_f32_via_f64(arg, sv, cv);
       Hs[swz(row, 3 + 20 * n + k, W)] = sv * a.wk_xyz[k];
       Hs[swz(row, 3 + 20 * n + 10 + k, W)] = cv * a.wk_xyz[k];
     }
@@ -110,8 +131,8 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
     } else {
       mma_lds(acc, Hs, W, row0, 0, P + L.w[l], W, n0, 0, W, lane);
     }
-    const float* __restrict__ bias = P + L.b[l];
-    acc_map(acc, row0, n0, lane, [&](float v, int, int col) { return fmaxf(v + bias[col], 0.0f); });
+    const unsigned long long bits = acc_bias_relu_pack(acc, P + L.b[l], n0, lane);
+    ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
     __syncthreads();
     acc_to_lds(acc, Hs, W, row0, n0, 0, lane);
     __syncthreads();
@@ -312,32 +333,36 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
     tile_rank1_store<TILE>(Gs, W, W, a.w_feat_s, a.g_E_s, S, a.gz_e, m0, M, tid);
     __syncthreads();
   }
-  // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu
+  // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu (sign bits from the forward, in this lane's layout)
+  const unsigned long long* __restrict__ hm = (const unsigned long long*)a.hmask + (size_t)blockIdx.x * NTHREADS + tid;
+  const size_t hm_stride = (size_t)gridDim.x * NTHREADS;
   {
+    const unsigned long long bits = hm[(size_t)(D - 1) * hm_stride];
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
     mma_lds(acc, Gs, W, row0, 0, PT + L.t_we, W, n0, 0, W, lane);
     const float* __restrict__ ws = P + L.wsig;
     acc_map(acc, row0, n0, lane, [&](float v, int row, int col) { return v + ws[col] * pre_s[row]; });
+    acc_apply_mask(acc, bits);
     __syncthreads();
     acc_to_lds(acc, Gs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_mask_store<TILE>(Gs, W, 0, W, a.h + (size_t)(D - 1) * M * W, a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, tid);
-    __syncthreads();
+    tile_store<TILE>(Gs, W, 0, W, a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, tid);
   }
   // ---- trunk, last layer to first
   f32x16 accx[TX::MT][TX::NT];
   acc_zero(accx);
   for (int l = D - 1; l >= 1; --l) {
+    const unsigned long long bits = hm[(size_t)(l - 1) * hm_stride];  // arrives under the contraction below
     if (a.need_dxyz && l == L.skip) mma_lds(accx, Gs, W, xrow0, 0, PT + L.t_skipx, W, xn0, 0, W, lane);
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
     mma_lds(acc, Gs, W, row0, 0, PT + L.t_w[l], W, n0, 0, W, lane);
+    acc_apply_mask(acc, bits);
     __syncthreads();
     acc_to_lds(acc, Gs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_mask_store<TILE>(Gs, W, 0, W, a.h + (size_t)(l - 1) * M * W, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, tid);
-    __syncthreads();
+    tile_store<TILE>(Gs, W, 0, W, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, tid);
   }
   if (!a.need_dxyz) return;
   // ---- d x0 (first layer + skip) -> d xyz through the encoding
@@ -374,7 +399,7 @@ extern "C" int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_a
   int rc = check_layout(L);
   if (rc) return rc;
   if (!a || a->R <= 0 || a->S <= 0 || !a->rays_o || !a->rays_d || !a->z || !a->P || !a->x0 || !a->h || !a->e ||
-      !a->sigma_s)
+      !a->sigma_s || !a->hmask)
     return UPNERF_EINVAL;
   if (a->use_cand && (!a->c_rows || !a->g1 || !a->g2 || !a->sigma_c)) return UPNERF_EINVAL;
   if (a->use_rgb && (!a->aux || !a->r1 || !a->rgb)) return UPNERF_EINVAL;
@@ -393,7 +418,7 @@ extern "C" int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_a
   int rc = check_layout(L);
   if (rc) return rc;
   if (!a || a->R <= 0 || a->S <= 0 || !a->P || !a->PT || !a->d_sigma_s || !a->sigma_s || !a->h || !a->gz_h ||
-      !a->gz_e || !a->dpre_sig_s)
+      !a->gz_e || !a->dpre_sig_s || !a->hmask)
     return UPNERF_EINVAL;
   if (a->use_cand && (!a->d_sigma_c || !a->sigma_c || !a->g1 || !a->g2 || !a->gz_g1 || !a->gz_g2 || !a->dpre_sig_c))
     return UPNERF_EINVAL;

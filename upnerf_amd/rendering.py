@@ -94,13 +94,14 @@ class _FieldPass(torch.autograd.Function):
         sigma_c = _empty(M, device=dev) if cfg.use_cand else None
         rgb = _empty(M, 3, device=dev) if cfg.use_rgb else None
         x0, h, e = _empty(M, X0, device=dev), _empty(D, M, W, device=dev), _empty(M, W, device=dev)
+        hmask = torch.empty(D * ((M + _lib.TILE_ROWS - 1) // _lib.TILE_ROWS) * 256, device=dev, dtype=torch.int64)
         g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
         g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
         r1 = _empty(M, W2, device=dev) if cfg.use_rgb else None
         fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
-                          rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1))
+                          rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1))
         check(TIMER.run("field_fwd", lambda: lib.upnerf_field_fwd(C.byref(L), C.byref(fa), st), units=M),
               "upnerf_field_fwd")
 
@@ -126,7 +127,7 @@ class _FieldPass(torch.autograd.Function):
         ctx.cfg, ctx.dims = cfg, (R, S)
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, e=e, g1=g1, g2=g2, r1=r1, w_all=w_all, w_sj=w_sj,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, hmask=hmask, e=e, g1=g1, g2=g2, r1=r1, w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s)
         z0 = torch.zeros(0, device=dev)
         outs = (E_s, G_c, sum_sfeat, t_weight, c_depth, s_depth, rgb_map, w_all, w_s)
@@ -179,7 +180,7 @@ class _FieldPass(torch.autograd.Function):
                           sigma_s=ptr(sv["sigma_s"]), sigma_c=ptr(sv["sigma_c"]), rgb=ptr(sv["rgb"]),
                           w_feat_s=ptr(w_feat), w_cj=ptr(sv["w_cj"]) if gG is not None else None, g_E_s=ptr(gE),
                           g_G_c=ptr(gG), x0=ptr(sv["x0"]), h=ptr(sv["h"]), g1=ptr(sv["g1"]), g2=ptr(sv["g2"]),
-                          r1=ptr(sv["r1"]), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
+                          r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz))
         check(TIMER.run("field_bwd", lambda: lib.upnerf_field_bwd(C.byref(L), C.byref(fb), st), units=M),
