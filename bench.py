@@ -72,7 +72,7 @@ def build_system(dev, progress):
     return sysm
 
 
-def cpu_baseline(progress, rays=192, iters=2):
+def cpu_baseline(progress, rays=768, iters=3):
     """Oracle forward+backward (no optimiser) on a bounded sample of the same workload; returns rays/s."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import upnerf_oracle as orc
@@ -197,8 +197,9 @@ def main():
         nthreads = torch.get_num_threads()
         v, sec = cpu_baseline(args.progress)
         line["cpu_baseline"] = {"value": v, "unit": "rays/s", "cores": nthreads, "kind": "port",
-                                "sample": f"oracle forward+backward (no optimiser step) on 192 rays of the same "
-                                          f"configuration, mean of 2 warm iterations ({sec:.1f} s each)"}
+                                "sample": f"oracle forward+backward (no optimiser step) on 768 rays of the same "
+                                          f"configuration (64+128 samples, 8x256 fields, pose opt ON), mean of 3 warm "
+                                          f"iterations ({sec:.1f} s each) after 1 warm-up"}
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -232,6 +232,17 @@ int upnerf_ray_geom_bwd(int R, int S, const float* dxyz, const float* z, float* 
 int upnerf_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                   const float* bias, float* C, int ldc, int act, void* stream);
 
+/* ---- parameter re-layout: row-major matrices of `src` -> MFMA fragment order in `dst` (optionally transposed) ------
+ * One launch re-packs every matrix of a field (forward copies and the transposed copies the backward chain reads).
+ * Logical matrix X[r][c], r < rows (multiple of 32), c < cols:
+ *     X[r][c] = transpose ? src[src_off + c*src_ld + r] : src[src_off + r*src_ld + c]
+ * is written as columns [dst_k0, dst_k0+cols) of a fragment-ordered [rows][dst_kp] matrix at dst + dst_off. */
+typedef struct {
+  int32_t src_off, src_ld, transpose, rows, cols, dst_off, dst_kp, dst_k0;
+} upnerf_frag_desc;
+#define UPNERF_MAX_FRAG_DESC 32
+int upnerf_frag_copy(const float* src, float* dst, const upnerf_frag_desc* descs /*host*/, int ndesc, void* stream);
+
 /* ---- a18: fused Adam on a flat fp32 buffer (torch.optim.Adam semantics, utils/optim.py:20-33) ---- */
 int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                 float eps, float bias_corr1, float bias_corr2, void* stream);

@@ -335,3 +335,20 @@ def test_field_pass_stage_by_stage(hip, name, typ):
     for k, (off, n) in pieces.items():
         ok &= cmp("dP_" + k, P_g.grad[off:off + n], P_ref.grad[off:off + n], TOL_GRAD)
     assert ok, "BWD over tolerance: " + repr(errs)
+
+
+# ------------------------------------------------------------------------------------------ parameter re-layout
+@pytest.mark.parametrize("W,D", [(256, 8), (64, 4)])
+def test_frag_copy_matches_torch_packing(hip, W, D):
+    from upnerf_amd.packing import NerfPacker
+    pk = NerfPacker(W, D, [4], 63, 27, 384, 48, 16)
+    P = gen((pk.L.total,), 60).cuda()
+    assert torch.equal(pk.frag_hip(P), pk.frag(P))
+    ref = pk.frag_t(pk.pack_t(P))
+    got = pk.frag_t_hip(P)
+    L = pk.L
+    W2 = W // 2
+    for off, n in [(L.t_w[l], (64 if l == 0 else W) * W) for l in range(D)] + [(L.t_we, W * W), (L.t_head, W * W),
+                                                                              (L.t_wc2, W2 * W2)] + \
+            ([(L.t_skipx, 64 * W)] if pk.skip >= 0 else []):
+        assert torch.equal(got[off:off + n], ref[off:off + n])

@@ -67,6 +67,11 @@ class FieldBwdArgs(C.Structure):
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp)]
 
 
+class FragDesc(C.Structure):
+    _fields_ = [("src_off", C.c_int32), ("src_ld", C.c_int32), ("transpose", C.c_int32), ("rows", C.c_int32),
+                ("cols", C.c_int32), ("dst_off", C.c_int32), ("dst_kp", C.c_int32), ("dst_k0", C.c_int32)]
+
+
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 _SIGNATURES = {
     "upnerf_abi_version": [],
@@ -85,6 +90,7 @@ _SIGNATURES = {
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],
     "upnerf_linear": [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p],
+    "upnerf_frag_copy": [_p, _p, C.POINTER(FragDesc), _i, _p],
     "upnerf_adam": [C.c_int64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p],
 }
 EXPORTS = tuple(_SIGNATURES)

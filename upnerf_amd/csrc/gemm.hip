@@ -310,6 +310,25 @@ __global__ __launch_bounds__(NTHREADS, 1) void linear_kernel(int M, int N, int K
       }
 }
 
+// ---- per-step re-layout of the weight matrices into MFMA fragment order (see common.cuh:mma_lds)
+struct FragDescs {
+  upnerf_frag_desc d[UPNERF_MAX_FRAG_DESC];
+  int start[UPNERF_MAX_FRAG_DESC + 1];  // prefix sums of rows*cols
+  int n;
+};
+__global__ void frag_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, FragDescs D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.start[D.n]) return;
+  int j = 0;
+  while (idx >= D.start[j + 1]) ++j;
+  const upnerf_frag_desc q = D.d[j];
+  const int e = idx - D.start[j];
+  const int r = e / q.cols, c = e - r * q.cols;
+  const float v = q.transpose ? src[q.src_off + (size_t)c * q.src_ld + r] : src[q.src_off + (size_t)r * q.src_ld + c];
+  const int k = q.dst_k0 + c;
+  dst[q.dst_off + ((size_t)(r >> 5) * (q.dst_kp >> 3) + (k >> 3)) * 256 + ((((k >> 2) & 1) << 5) + (r & 31)) * 4 + (k & 3)] = v;
+}
+
 // ---- Adam (torch.optim.Adam, no weight decay / amsgrad): same op order as torch's single-tensor path
 __global__ void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
@@ -399,6 +418,22 @@ extern "C" int upnerf_linear(int M, int N, int K, const float* A, int lda, const
   dim3 grid((M + TILE - 1) / TILE, (N + 255) / 256);
   hipLaunchKernelGGL(linear_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, M, N, K, A, lda, B, ldb, bias, C, ldc,
                      act);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_frag_copy(const float* src, float* dst, const upnerf_frag_desc* descs, int ndesc, void* stream) {
+  if (!src || !dst || !descs || ndesc <= 0 || ndesc > UPNERF_MAX_FRAG_DESC) return UPNERF_EINVAL;
+  FragDescs D;
+  D.n = ndesc;
+  D.start[0] = 0;
+  for (int j = 0; j < ndesc; ++j) {
+    const upnerf_frag_desc& q = descs[j];
+    if (q.rows <= 0 || q.cols <= 0 || (q.rows & 31) || (q.dst_kp & 7) || q.dst_k0 + q.cols > q.dst_kp) return UPNERF_EINVAL;
+    D.d[j] = q;
+    D.start[j + 1] = D.start[j] + q.rows * q.cols;
+  }
+  const int total = D.start[ndesc];
+  hipLaunchKernelGGL(frag_copy_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, D);
   return (int)hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ from typing import Dict
 import torch
 import torch.nn.functional as F
 
-from ._lib import AUXK, CK, MAX_D, X0, Layout
+from ._lib import AUXK, CK, MAX_D, X0, FragDesc, Layout
 
 
 def _align(n, a=4):
@@ -126,6 +126,53 @@ class NerfPacker:
         P = torch.cat(pieces)
         assert P.numel() == L.total
         return P
+
+    # ------------------------------------------------------------------ one-launch HIP re-layout (product path)
+    def _descs(self):
+        """(forward descriptors, transposed descriptors) for upnerf_frag_copy, built once."""
+        if getattr(self, "_desc_cache", None) is None:
+            W, W2, D, L = self.W, self.W2, self.D, self.L
+            fwd, bwd = [], []
+            kp = lambda l: X0 if l == 0 else (X0 + W if l == self.skip else W)
+            for l in range(D):
+                fwd.append((L.w[l], kp(l), 0, W, kp(l), L.w[l], kp(l), 0))
+            fwd.append((L.we, W, 0, W, W, L.we, W, 0))
+            fwd.append((L.wc1, W + CK, 0, W2, W + CK, L.wc1, W + CK, 0))
+            fwd.append((L.wc2, W2, 0, W2, W2, L.wc2, W2, 0))
+            fwd.append((L.wr1, W + AUXK, 0, W2, W + AUXK, L.wr1, W + AUXK, 0))
+            for l in range(D):
+                if l == 0:
+                    bwd.append((L.w[0], X0, 1, X0, W, L.t_w[0], W, 0))
+                elif l == self.skip:
+                    bwd.append((L.w[l], X0 + W, 1, X0, W, L.t_skipx, W, 0))
+                    bwd.append((L.w[l] + X0, X0 + W, 1, W, W, L.t_w[l], W, 0))
+                else:
+                    bwd.append((L.w[l], W, 1, W, W, L.t_w[l], W, 0))
+            bwd.append((L.we, W, 1, W, W, L.t_we, W, 0))
+            bwd.append((L.wr1, W + AUXK, 1, W, W2, L.t_head, W, 0))
+            bwd.append((L.wc1, W + CK, 1, W, W2, L.t_head, W, W2))
+            bwd.append((L.wc2, W2, 1, W2, W2, L.t_wc2, W2, 0))
+            mk = lambda lst: (FragDesc * len(lst))(*[FragDesc(*t) for t in lst])
+            self._desc_cache = (mk(fwd), len(fwd), mk(bwd), len(bwd))
+        return self._desc_cache
+
+    @torch.no_grad()
+    def frag_hip(self, P: torch.Tensor) -> torch.Tensor:
+        """Kernel-side copy of P (matrices in fragment order) with one HIP launch."""
+        from ._lib import check, lib, ptr, stream
+        fd, nf, _, _ = self._descs()
+        out = P.clone()
+        check(lib.upnerf_frag_copy(ptr(P), ptr(out), fd, nf, stream()), "upnerf_frag_copy")
+        return out
+
+    @torch.no_grad()
+    def frag_t_hip(self, P: torch.Tensor) -> torch.Tensor:
+        """Fragment-ordered transposed copies (layout t_*) straight from the row-major P, one HIP launch."""
+        from ._lib import check, lib, ptr, stream
+        _, _, bd, nb = self._descs()
+        out = torch.zeros(self.L.t_total, device=P.device, dtype=P.dtype)
+        check(lib.upnerf_frag_copy(ptr(P), ptr(out), bd, nb, stream()), "upnerf_frag_copy")
+        return out
 
     # ------------------------------------------------------------------ MFMA fragment order (no grad)
     @staticmethod

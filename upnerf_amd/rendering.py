@@ -79,7 +79,7 @@ class _FieldPass(torch.autograd.Function):
         st = stream()
         rays_o, rays_d, z = rays_o.detach().contiguous(), rays_d.detach().contiguous(), z.detach().contiguous()
         P = P.detach().contiguous()
-        PF = pk.frag(P)  # what the kernels read: matrices in MFMA fragment order
+        PF = pk.frag_hip(P)  # what the kernels read: matrices in MFMA fragment order
         c_rows = c_rows.detach().contiguous() if (c_rows is not None and cfg.use_cand) else None
         a_rows_c = a_rows.detach().contiguous() if a_rows is not None else None
         joint, want_feat = cfg.mode <= 1, cfg.mode != 2
@@ -165,7 +165,7 @@ class _FieldPass(torch.autograd.Function):
 
         need_dxyz = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         P = sv["P"]
-        PT = pk.frag_t(pk.pack_t(P))
+        PT = pk.frag_t_hip(P)
         gz_h, gz_e = _empty(D, M, W, device=dev), _empty(M, W, device=dev)
         gz_g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
         gz_g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
