@@ -232,6 +232,36 @@ int upnerf_ray_geom_bwd(int R, int S, const float* dxyz, const float* z, float* 
 int upnerf_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                   const float* bias, float* C, int ldc, int act, void* stream);
 
+/* ---- a15 + a17: depth-prior affine (models/nerf_system.py:169-177) fused with UPNeRFLoss (losses.py:21-64) --------
+ * Per-ray inputs only ([R], [R,3], [R,F]); any absent tensor is NULL.  `terms` receives the 8 loss terms in the order
+ * l_depth_c, l_feat_c, l_rgb_c, l_depth_f, l_feat_f, l_rgb_f, l_beta, l_alpha (zero where a term does not exist in
+ * the phase).  bwd: g_terms[8] are the upstream gradients of the terms (device memory); every non-NULL d_* receives
+ * the gradient of sum_k g_terms[k] * terms[k]. */
+typedef struct {
+  int32_t R, F, fine, has_tw;            /* rays, feature width, fine network present, t_weight_* present */
+  float sched, depth_mult, alpha_reg, near, far;
+  const float* depth_direct;             /* [R] depth targets given directly (losses.py calling convention), or NULL: */
+  const float* inv_depth;                /* [R] mono-depth prior, and */
+  const float* depth_scale_rows;         /* [R][2] per-image (scale, shift) rows -> target computed here (a15) */
+  const float* s_depth_c; const float* s_depth_f;     /* [R] */
+  const float* t_weight_c; const float* t_weight_f;   /* [R] (treated as constants, losses.py:27,48) */
+  const float* feat_c; const float* feat_f; const float* feat_gt;   /* [R][F] */
+  const float* rgb_c; const float* rgb_f; const float* rgb_gt;      /* [R][3] */
+  const float* beta; const float* alpha;                             /* [R] */
+} upnerf_loss_args;
+int upnerf_loss_fwd(const upnerf_loss_args* a, float* depth_out /*[R]*/, float* terms /*[8]*/,
+                    float* scratch /*[64*8]*/, void* stream);
+typedef struct {
+  float* d_depth_scale_rows;             /* [R][2] */
+  float* d_depth;                        /* [R] gradient w.r.t. the depth target (depth_direct mode) */
+  float* d_s_depth_c; float* d_s_depth_f;
+  float* d_feat_c; float* d_feat_f;
+  float* d_rgb_c; float* d_rgb_f;
+  float* d_beta; float* d_alpha;
+} upnerf_loss_grads;
+int upnerf_loss_bwd(const upnerf_loss_args* a, const float* g_terms /*[8] device*/, const upnerf_loss_grads* g,
+                    void* stream);
+
 /* ---- parameter re-layout: row-major matrices of `src` -> MFMA fragment order in `dst` (optionally transposed) ------
  * One launch re-packs every matrix of a field (forward copies and the transposed copies the backward chain reads).
  * Logical matrix X[r][c], r < rows (multiple of 32), c < cols:

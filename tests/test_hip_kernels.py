@@ -352,3 +352,60 @@ def test_frag_copy_matches_torch_packing(hip, W, D):
                                                                               (L.t_wc2, W2 * W2)] + \
             ([(L.t_skipx, 64 * W)] if pk.skip >= 0 else []):
         assert torch.equal(got[off:off + n], ref[off:off + n])
+
+
+# ------------------------------------------------------------------------------------------ a15 + a17
+@pytest.mark.parametrize("m,fine,has_tw", [(0, True, True), (0.37, True, True), (1, True, False), (0.5, False, True),
+                                           (0.5, True, False)])
+def test_fused_loss_and_depth_prior(hip, m, fine, has_tw):
+    from upnerf_amd.losses import UPNeRFLoss
+    R, F = 517, 384
+    res = {}
+    for typ in ("coarse", "fine") if fine else ("coarse",):
+        res[f"s_depth_{typ}"] = gen((R,), 70, 0.2, 4.0)
+        if m < 1:
+            res[f"feat_{typ}"] = gen((R, F), 71)
+            if has_tw:
+                res[f"t_weight_{typ}"] = gen((R,), 72, 0.0, 1.0)
+        if m > 0:
+            res[f"s_rgb_{typ}"] = gen((R, 3), 73, 0.0, 1.0)
+    if m > 0 and fine:
+        res["t_beta"], res["t_alpha"] = gen((R, 1), 74, 0.1, 1.0), gen((R, 1), 75, 0.0, 1.0)
+    rgb, feat = gen((R, 3), 76, 0.0, 1.0), gen((R, F), 77)
+    inv = 1.0 / gen((R,), 78, 0.05, 8.0)       # some rays hit the 1/far and the near clamps
+    rows = gen((R, 2), 79) * 0.3
+    wts = gen((8,), 80, 0.5, 1.5)
+
+    def run(dev, direct):
+        r = {k: v.clone().to(dev).requires_grad_(not k.startswith("t_weight")) for k, v in res.items()}
+        rw = rows.clone().to(dev).requires_grad_(True)
+        if dev == "cpu":
+            depth = orc.depth_prior(rw, inv, 0.1, 5.0)
+            out = orc.upnerf_loss(r, rgb, feat, depth, m, 1e-3, 1.0, fine)
+        else:
+            lf = UPNeRFLoss(depth_mult=1e-3, alpha_reg=1.0, fine=fine, near=0.1, far=5.0)
+            if direct:
+                depth = orc.depth_prior(rw.cpu(), inv, 0.1, 5.0).detach().cuda()
+                out = lf(r, rgb.cuda(), feat.cuda(), depth, m)
+            else:
+                out, _ = lf.forward_with_prior(r, rgb.cuda(), feat.cuda(), inv.cuda(), rw, m)
+        names = sorted(out)
+        tot = sum(out[k] * wts[i].to(dev) for i, k in enumerate(names))
+        tot.backward()
+        return out, r, rw
+
+    o_ref, r_ref, rw_ref = run("cpu", False)
+    for direct in (False, True):
+        o, r, rw = run("cuda", direct)
+        assert list(o.keys()) == [k for k in ("l_depth_c", "l_feat_c", "l_rgb_c", "l_depth_f", "l_feat_f", "l_rgb_f",
+                                              "l_beta", "l_alpha") if k in o_ref]
+        for k in o_ref:
+            assert abs(float(o[k]) - float(o_ref[k])) <= 2e-6 * max(1e-2, abs(float(o_ref[k]))), k
+        for k in r_ref:
+            if r_ref[k].grad is not None:
+                assert rel_err(cpu(r[k].grad), r_ref[k].grad) < 1e-5, k
+        if not direct:
+            if rw_ref.grad is None:  # sched == 1: the depth target is not used by any term
+                assert rw.grad is None or float(rw.grad.abs().max()) == 0.0
+            else:
+                assert rel_err(cpu(rw.grad), rw_ref.grad) < 1e-5

@@ -67,6 +67,22 @@ class FieldBwdArgs(C.Structure):
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp)]
 
 
+class LossArgs(C.Structure):
+    _fields_ = [("R", C.c_int32), ("F", C.c_int32), ("fine", C.c_int32), ("has_tw", C.c_int32),
+                ("sched", C.c_float), ("depth_mult", C.c_float), ("alpha_reg", C.c_float), ("near", C.c_float),
+                ("far", C.c_float),
+                ("depth_direct", _fp), ("inv_depth", _fp), ("depth_scale_rows", _fp),
+                ("s_depth_c", _fp), ("s_depth_f", _fp), ("t_weight_c", _fp), ("t_weight_f", _fp),
+                ("feat_c", _fp), ("feat_f", _fp), ("feat_gt", _fp),
+                ("rgb_c", _fp), ("rgb_f", _fp), ("rgb_gt", _fp), ("beta", _fp), ("alpha", _fp)]
+
+
+class LossGrads(C.Structure):
+    _fields_ = [("d_depth_scale_rows", _fp), ("d_depth", _fp), ("d_s_depth_c", _fp), ("d_s_depth_f", _fp),
+                ("d_feat_c", _fp), ("d_feat_f", _fp), ("d_rgb_c", _fp), ("d_rgb_f", _fp), ("d_beta", _fp),
+                ("d_alpha", _fp)]
+
+
 class FragDesc(C.Structure):
     _fields_ = [("src_off", C.c_int32), ("src_ld", C.c_int32), ("transpose", C.c_int32), ("rows", C.c_int32),
                 ("cols", C.c_int32), ("dst_off", C.c_int32), ("dst_kp", C.c_int32), ("dst_k0", C.c_int32)]
@@ -90,6 +106,8 @@ _SIGNATURES = {
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],
     "upnerf_linear": [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p],
+    "upnerf_loss_fwd": [C.POINTER(LossArgs), _p, _p, _p, _p],
+    "upnerf_loss_bwd": [C.POINTER(LossArgs), _p, C.POINTER(LossGrads), _p],
     "upnerf_frag_copy": [_p, _p, C.POINTER(FragDesc), _i, _p],
     "upnerf_adam": [C.c_int64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p],
 }

@@ -1,34 +1,112 @@
-"""UPNeRFLoss (losses.py:13-64): schedule-weighted depth / feature / colour / uncertainty terms on per-ray maps."""
+"""UPNeRFLoss (losses.py:13-64) fused with the depth-prior affine (models/nerf_system.py:169-177) on the GPU:
+one HIP reduction kernel forward (upnerf_loss_fwd) and one elementwise kernel backward (upnerf_loss_bwd) instead of
+~40 ATen launches.  Same constructor, call signature and term names as the reference."""
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 from torch import nn
 
+from ._lib import LossArgs, LossGrads, check, lib, ptr, stream
+
+TERMS = ("l_depth_c", "l_feat_c", "l_rgb_c", "l_depth_f", "l_feat_f", "l_rgb_f", "l_beta", "l_alpha")
+
+
+class _LossFn(torch.autograd.Function):
+    """inputs (any may be None): depth_direct, inv_depth, scale_rows, s_depth_c, s_depth_f, t_weight_c, t_weight_f,
+    feat_c, feat_f, feat_gt, rgb_c, rgb_f, rgb_gt, beta, alpha; returns (terms[8], depth_targets[R])."""
+
+    @staticmethod
+    def forward(ctx, cfg, *tensors):
+        m, depth_mult, alpha_reg, near, far, fine = cfg
+        t = [None if x is None else x.detach().contiguous().float() for x in tensors]
+        (dd, inv, rows, sdc, sdf, twc, twf, fc, ff, fg, rc, rf, rg, beta, alpha) = t
+        ref = next(x for x in (dd, inv) if x is not None)
+        R, dev = ref.shape[0], ref.device
+        F = fg.shape[1] if fg is not None else 0
+        a = LossArgs(R=R, F=F, fine=int(fine), has_tw=int(twc is not None), sched=float(m), depth_mult=depth_mult,
+                     alpha_reg=alpha_reg, near=near, far=far, depth_direct=ptr(dd), inv_depth=ptr(inv),
+                     depth_scale_rows=ptr(rows), s_depth_c=ptr(sdc), s_depth_f=ptr(sdf), t_weight_c=ptr(twc),
+                     t_weight_f=ptr(twf), feat_c=ptr(fc), feat_f=ptr(ff), feat_gt=ptr(fg), rgb_c=ptr(rc), rgb_f=ptr(rf),
+                     rgb_gt=ptr(rg), beta=ptr(beta), alpha=ptr(alpha))
+        depth = torch.empty(R, device=dev)
+        terms = torch.empty(8, device=dev)
+        scratch = torch.empty(64 * 8, device=dev)
+        check(lib.upnerf_loss_fwd(C.byref(a), ptr(depth), ptr(terms), ptr(scratch), stream()), "upnerf_loss_fwd")
+        ctx.args, ctx.keep = a, t  # `t` keeps the device buffers referenced by `a` alive
+        ctx.mark_non_differentiable(depth)
+        return terms, depth
+
+    @staticmethod
+    def backward(ctx, g_terms, _g_depth):
+        a, t = ctx.args, ctx.keep
+        (dd, inv, rows, sdc, sdf, twc, twf, fc, ff, fg, rc, rf, rg, beta, alpha) = t
+        need = ctx.needs_input_grad[1:]
+        new = lambda x, ok: torch.zeros_like(x) if (x is not None and ok) else None
+        d_dd, d_rows = new(dd, need[0]), new(rows, need[2])
+        d_sdc, d_sdf, d_fc, d_ff = new(sdc, need[3]), new(sdf, need[4]), new(fc, need[7]), new(ff, need[8])
+        d_rc, d_rf, d_beta, d_alpha = new(rc, need[10]), new(rf, need[11]), new(beta, need[13]), new(alpha, need[14])
+        g = LossGrads(d_depth_scale_rows=ptr(d_rows), d_depth=ptr(d_dd), d_s_depth_c=ptr(d_sdc), d_s_depth_f=ptr(d_sdf),
+                      d_feat_c=ptr(d_fc), d_feat_f=ptr(d_ff), d_rgb_c=ptr(d_rc), d_rgb_f=ptr(d_rf), d_beta=ptr(d_beta),
+                      d_alpha=ptr(d_alpha))
+        gt = g_terms.contiguous().float()
+        check(lib.upnerf_loss_bwd(C.byref(a), ptr(gt), C.byref(g), stream()), "upnerf_loss_bwd")
+        shp = lambda d, x: None if d is None else d.view_as(x)
+        return (None, d_dd, None, d_rows, d_sdc, d_sdf, None, None, d_fc, d_ff, None, d_rc, d_rf, None,
+                shp(d_beta, tensors_like(ctx, 13)), shp(d_alpha, tensors_like(ctx, 14)))
+
+
+def tensors_like(ctx, i):
+    return ctx.keep[i]
+
+
+def _terms_to_dict(terms, m, fine):
+    out = {}
+    if m < 1:
+        out["l_depth_c"], out["l_feat_c"] = terms[0], terms[1]
+    if m > 0:
+        out["l_rgb_c"] = terms[2]
+    if fine:
+        if m < 1:
+            out["l_depth_f"], out["l_feat_f"] = terms[3], terms[4]
+        if m > 0:
+            out["l_rgb_f"], out["l_beta"], out["l_alpha"] = terms[5], terms[6], terms[7]
+    # the reference's dict order (losses.py:24-63): coarse terms, then fine terms
+    order = ["l_depth_c", "l_feat_c", "l_rgb_c", "l_depth_f", "l_feat_f", "l_rgb_f", "l_beta", "l_alpha"]
+    return {k: out[k] for k in order if k in out}
+
 
 class UPNeRFLoss(nn.Module):
-    def __init__(self, depth_mult=1e-4, alpha_reg=1.0, encode_feat=True, fine=True):
+    def __init__(self, depth_mult=1e-4, alpha_reg=1.0, encode_feat=True, fine=True, near=0.1, far=5.0):
         super().__init__()
         self.depth_mult, self.alpha_reg, self.encode_feat, self.fine = depth_mult, alpha_reg, encode_feat, fine
+        self.near, self.far = near, far
         if not encode_feat:
             raise NotImplementedError("nerf.feat_dim = 0 is not implemented on the HIP path")
 
+    def _run(self, inputs, rgb, feat, m, depth_direct=None, inv_depth=None, scale_rows=None):
+        g = inputs.get
+        beta = g("t_beta")
+        alpha = g("t_alpha")
+        fine = self.fine
+        cfg = (m, self.depth_mult, self.alpha_reg, self.near, self.far, fine)
+        terms, depth = _LossFn.apply(
+            cfg, depth_direct, inv_depth, scale_rows,
+            g("s_depth_coarse") if m < 1 else None, g("s_depth_fine") if (m < 1 and fine) else None,
+            g("t_weight_coarse") if m < 1 else None, g("t_weight_fine") if (m < 1 and fine) else None,
+            g("feat_coarse") if m < 1 else None, g("feat_fine") if (m < 1 and fine) else None, feat if m < 1 else None,
+            g("s_rgb_coarse") if m > 0 else None, g("s_rgb_fine") if (m > 0 and fine) else None, rgb if m > 0 else None,
+            beta.reshape(-1) if (beta is not None and m > 0 and fine) else None,
+            alpha.reshape(-1) if (alpha is not None and m > 0 and fine) else None)
+        return _terms_to_dict(terms, m, fine), depth
+
     def forward(self, inputs, rgb_targets, feat_targets, depth_targets, schedule_mult):
-        m, ret = schedule_mult, {}
-        for typ, tag in (("coarse", "c"), ("fine", "f")):
-            if typ == "fine" and not self.fine:
-                break
-            if m < 1:
-                l = (inputs[f"s_depth_{typ}"] - depth_targets).abs()
-                if f"t_weight_{typ}" in inputs:
-                    l = l * (1 - inputs[f"t_weight_{typ}"].detach())
-                ret[f"l_depth_{tag}"] = l.mean() * self.depth_mult * (1 - m)
-                ret[f"l_feat_{tag}"] = ((inputs[f"feat_{typ}"] - feat_targets) ** 2).mean() * (1 - m)
-            if m > 0:
-                sq = (inputs[f"s_rgb_{typ}"] - rgb_targets) ** 2
-                if typ == "coarse":
-                    ret["l_rgb_c"] = sq.mean() * m / 2
-                else:
-                    ret["l_rgb_f"] = (sq / (2 * inputs["t_beta"] ** 2)).mean() * m
-                    ret["l_beta"] = torch.log(inputs["t_beta"]).mean() * m
-                    ret["l_alpha"] = inputs["t_alpha"].mean() * self.alpha_reg * m
-        return ret
+        """Reference calling convention (losses.py:21): depth targets already computed by the caller."""
+        return self._run(inputs, rgb_targets, feat_targets, schedule_mult, depth_direct=depth_targets)[0]
+
+    def forward_with_prior(self, inputs, rgb_targets, feat_targets, inv_depths, depth_scale_rows, schedule_mult):
+        """Fused form used by NeRFSystem.training_step: the depth-prior affine (nerf_system.py:169-177) is evaluated
+        inside the kernel and its gradient reaches depth_scale through `depth_scale_rows`."""
+        return self._run(inputs, rgb_targets, feat_targets, schedule_mult, inv_depth=inv_depths,
+                         scale_rows=depth_scale_rows)

@@ -71,7 +71,8 @@ class NeRFSystem(_Base):
         self.candidate_schedule = self.hparams["candidate_schedule"]
         self.fine = self.hparams["nerf.N_importance"] > 0
         self.loss = UPNeRFLoss(depth_mult=self.hparams["loss.depth_mult"], alpha_reg=self.hparams["loss.alpha_reg"],
-                               encode_feat=self.hparams["nerf.feat_dim"] > 0, fine=self.fine)
+                               encode_feat=self.hparams["nerf.feat_dim"] > 0, fine=self.fine,
+                               near=self.hparams["nerf.near"], far=self.hparams["nerf.far"])
         self.val_log_N = 0
         self.train_dataset, self.val_dataset = train_dataset, val_dataset
         self._host_progress = 0.0
@@ -181,10 +182,10 @@ class NeRFSystem(_Base):
     def compute_loss(self, batch, u_list=None, keep=None):
         rays = self.rays_from_batch(batch)
         self._last_rays = rays  # kept for tests (gradient w.r.t. the rays)
-        depth = self.depth_targets(batch)
         sched_mult = self.get_schedule_mult(self._host_progress)
         results = self(rays, batch["feats"], batch["img_idx"], sched_mult, u_list=u_list, keep=keep)
-        loss_d = self.loss(results, batch["rgbs"], batch["feats"], depth, sched_mult)
+        loss_d, _depth = self.loss.forward_with_prior(results, batch["rgbs"], batch["feats"], batch["inv_depths"],
+                                                      self.depth_scale(batch["img_idx"]), sched_mult)
         return sum(l for l in loss_d.values()), loss_d, results
 
     def set_progress(self, progress: float):
