@@ -409,3 +409,29 @@ def test_fused_loss_and_depth_prior(hip, m, fine, has_tw):
                 assert rw.grad is None or float(rw.grad.abs().max()) == 0.0
             else:
                 assert rel_err(cpu(rw.grad), rw_ref.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ a18
+def test_flat_adam_follows_torch_adam_including_skipped_parameters():
+    from upnerf_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    shapes = [(17, 5), (33,), (8, 8), (1,), (64, 3)]
+    ref = [torch.nn.Parameter(gen(s, 90 + i)) for i, s in enumerate(shapes)]
+    mine = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=5e-4, eps=1e-8)
+    o_me = FlatAdam(mine, lr=5e-4, eps=1e-8)
+    s_ref = torch.optim.lr_scheduler.ExponentialLR(o_ref, gamma=0.9)
+    s_me = torch.optim.lr_scheduler.ExponentialLR(o_me, gamma=0.9)
+    live_sets = [[0, 1, 2, 3, 4], [0, 1, 4], [0, 1, 4], [0, 1, 2, 3, 4], [2, 3], [0, 1, 2, 3, 4]]
+    for step, live in enumerate(live_sets):
+        for i in range(len(shapes)):
+            g = gen(shapes[i], 200 + 10 * step + i) if i in live else None
+            ref[i].grad = None if g is None else g.clone()
+            mine[i].grad = None if g is None else g.cuda()
+        o_ref.step(); s_ref.step()
+        o_me.step(); s_me.step()
+        for a, b in zip(mine, ref):
+            assert rel_err(cpu(a), b.detach()) < 2e-6
+    sd = o_me.state_dict()
+    assert int(sd["state"][2]["step"]) == 4 and int(sd["state"][0]["step"]) == 5
+    assert rel_err(sd["state"][4]["exp_avg"].cpu(), o_ref.state_dict()["state"][4]["exp_avg"]) < 2e-6

@@ -7,6 +7,85 @@ from torch.optim import SGD, Adam, AdamW
 from torch.optim.lr_scheduler import CosineAnnealingLR
 
 
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (lr, betas, eps; no weight decay / amsgrad) on ONE flat fp32 buffer, updated by the
+    upnerf_adam HIP kernel.
+
+    * every parameter's storage becomes a view into `flat_p` (so one kernel covers all tensors, and a data-parallel
+      run has a single gradient buffer to all-reduce);
+    * parameters whose `.grad` is None are skipped exactly like torch.optim.Adam skips them -- their moments and their
+      per-parameter step count do not advance (which heads receive gradients depends on the schedule
+      phase); the update is launched once per maximal run of consecutive live parameters with equal step count.
+    Only fp32 CUDA parameters are supported (the HIP path has no CPU fallback)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if not ps or any((not p.is_cuda) or p.dtype != torch.float32 for p in ps):
+            raise ValueError("FlatAdam needs fp32 CUDA parameters")
+        n = sum(p.numel() for p in ps)
+        dev = ps[0].device
+        self.flat_p = torch.empty(n, device=dev)
+        self.flat_g = torch.zeros(n, device=dev)
+        self.flat_m = torch.zeros(n, device=dev)
+        self.flat_v = torch.zeros(n, device=dev)
+        self._spans, off = [], 0
+        with torch.no_grad():
+            for p in ps:
+                k = p.numel()
+                self.flat_p[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_p[off:off + k].view_as(p)
+                self._spans.append((p, off, k))
+                off += k
+        self._steps = [0] * len(ps)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from .ops import adam_flat_
+        group = self.param_groups[0]
+        lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
+        live = [i for i, (p, _, _) in enumerate(self._spans) if p.grad is not None]
+        if not live:
+            return None
+        torch._foreach_copy_([self.flat_g[self._spans[i][1]:self._spans[i][1] + self._spans[i][2]].view_as(self._spans[i][0])
+                              for i in live], [self._spans[i][0].grad for i in live])
+        run = [live[0]]
+        runs = []
+        for i in live[1:]:
+            if i == run[-1] + 1 and self._steps[i] == self._steps[run[0]]:
+                run.append(i)
+            else:
+                runs.append(run)
+                run = [i]
+        runs.append(run)
+        for run in runs:
+            a, b = self._spans[run[0]][1], self._spans[run[-1]][1] + self._spans[run[-1]][2]
+            for i in run:
+                self._steps[i] += 1
+            adam_flat_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], self._steps[run[0]],
+                       lr, b1, b2, eps)
+        return None
+
+    def state_dict(self):
+        """torch.optim.Adam-shaped state (per-parameter step / exp_avg / exp_avg_sq) for checkpoint compatibility."""
+        state = {i: {"step": torch.tensor(float(self._steps[i])), "exp_avg": self.flat_m[o:o + k].view_as(p).clone(),
+                     "exp_avg_sq": self.flat_v[o:o + k].view_as(p).clone()}
+                 for i, (p, o, k) in enumerate(self._spans) if self._steps[i] > 0}
+        groups = [{**{k: v for k, v in g.items() if k != "params"}, "params": list(range(len(self._spans)))}
+                  for g in self.param_groups]
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        for i, st in sd["state"].items():
+            p, o, k = self._spans[int(i)]
+            self._steps[int(i)] = int(st["step"])
+            self.flat_m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.flat_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+        for g, gs in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in gs.items() if k != "params"})
+
+
 def get_parameters(models):
     if isinstance(models, (list, tuple)):
         return [p for m in models for p in get_parameters(m)]
@@ -20,6 +99,8 @@ def get_optimizer(type, lr, models):
     if type == "sgd":
         return SGD(params, lr=lr)
     if type == "adam":
+        if params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            return FlatAdam(params, lr=lr, eps=1e-8)  # same update rule, one HIP launch per live run
         return Adam(params, lr=lr, eps=1e-8)
     if type == "adamw":
         return AdamW(params, lr=lr)
