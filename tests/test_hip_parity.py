@@ -165,3 +165,48 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         L._load()
+
+
+def test_tto_step_frozen_field_matches_oracle_and_skips_weight_gradients():
+    """TTO shape (a19): sched 1, candidate head off, frozen fields; gradients reach only the test image's appearance row
+    and se(3) row, and equal the oracle's."""
+    from golden_util import orc
+    from upnerf_amd.nerf_system import SyntheticDataset, default_hparams
+    from upnerf_amd.nerf_system_optimize import NeRFSystemOptimize
+    c = Case("small_tto")
+    trained = build_system(c)
+    hp = default_hparams(**{"nerf.N_samples": c.Nc, "nerf.N_importance": c.Nf, "nerf.perturb": 0.0, "pose.c2f": c.c2f,
+                            "nerf.D": c.D, "nerf.W": c.W, "val.chunk_size": 4})
+    tto = NeRFSystemOptimize(hp, SyntheticDataset(c.n_img), pose_optimize=True)
+    tto.train_dataset = SyntheticDataset(c.n_img)
+    tto.model_setup(trained_state=trained.state_dict(), n_test_images=1)
+    tto.cuda()
+    with torch.no_grad():
+        tto.embedding_fine_a.weight.copy_(trained.embedding_fine_a.weight[3:4])
+        tto.se3_refine.weight.copy_(trained.se3_refine.weight[5:6])
+    b = c.batch()
+    batch = {k: v.cuda() for k, v in b.items()}
+    batch["img_idx"] = torch.zeros_like(batch["img_idx"])
+    loss, _, res = tto.compute_loss(batch)
+    loss.backward()
+    assert all(p.grad is None for p in tto.nerf_fine.parameters())
+    # oracle on the same single-image problem
+    st = c.state()
+    st["embedding_fine_a"] = st["embedding_fine_a"][3:4].detach().clone().requires_grad_(True)
+    st["se3_refine"] = st["se3_refine"][5:6].detach().clone().requires_grad_(True)
+    idx0 = torch.zeros_like(b["img_idx"])
+    pose = orc.compose_pair(orc.se3_exp(st["se3_refine"][idx0]), b["c2w"])
+    o, d = orc.get_rays(b["directions"], pose)
+    rays = torch.cat([o, d, b["ray_infos"]], 1)
+    emb = {k[len("embedding_"):]: v for k, v in st.items() if k.startswith("embedding_")}
+    ref = orc.render_rays({k: st[k] for k in ("nerf_coarse", "nerf_fine")}, c.cfgs(), emb, rays, idx0, 1.0,
+                          N_samples=c.Nc, perturb=0, N_importance=c.Nf, progress=1.0)
+    l_ref = ((ref["s_rgb_fine"] - b["rgbs"]) ** 2).mean()
+    l_ref.backward()
+    assert abs(float(loss) - float(l_ref)) < 1e-6 * max(1e-2, abs(float(l_ref)))
+    assert rel_err(tto.embedding_fine_a.weight.grad.cpu().numpy(), st["embedding_fine_a"].grad.numpy()) < 1e-3
+    assert rel_err(tto.se3_refine.weight.grad.cpu().numpy(), st["se3_refine"].grad.numpy()) < 5e-3
+    # full-"image" validation path: chunked, no grad
+    out = tto.validation_step(batch)
+    assert out["s_rgb_fine"].shape == (c.R, 3) and torch.isfinite(out["val_psnr"])
+    assert rel_err(out["s_rgb_fine"].cpu().numpy(), ref["s_rgb_fine"].detach().numpy()) < 1e-4

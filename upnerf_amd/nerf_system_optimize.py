@@ -1,0 +1,91 @@
+"""Test-time optimisation (TTO) on the HIP path: the callers of render_rays in models/nerf_system_optmize.py
+(forward 84-111, training_step 113-150, validation_step 152-188) for ONE held-out image -- frozen NeRF weights, a
+fresh appearance embedding and (pose stage) the image's se(3) refinement are optimised against the colour loss.
+
+Differences by design: the reference leaves the NeRF weights trainable-but-unused (it computes and discards all
+weight gradients); here they are frozen, so the backward pass skips every weight-gradient
+kernel.  Pose initialisation by Sim(3) alignment to GT (nerf_system_optmize.py:267-332), SSIM/LPIPS and the pickle
+bookkeeping are outside the accelerated path: the caller passes the initial pose."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .camera import refine_and_get_rays
+from .nerf_system import NeRFSystem
+from .optim import get_optimizer
+from .rendering import render_rays
+
+
+class NeRFSystemOptimize(NeRFSystem):
+    def __init__(self, hparams, train_dataset=None, val_dataset=None, pose_optimize=True):
+        super().__init__(hparams, train_dataset, val_dataset)
+        self.pose_optimize = pose_optimize
+
+    def model_setup(self, trained_state=None, n_test_images: int = 1):
+        super().model_setup()
+        if trained_state is not None:
+            self.load_state_dict(trained_state, strict=False)
+        hp = self.hparams
+        # only trainable appearance table: one row per test image (nerf_system_optmize.py:254-256)
+        self.embedding_fine_a = nn.Embedding(n_test_images, hp["nerf.appearance_dim"])
+        self.embeddings["fine_a"] = self.embedding_fine_a
+        self.se3_refine = nn.Embedding(n_test_images, 6)
+        nn.init.zeros_(self.se3_refine.weight)
+        for m in (self.nerf_coarse, self.nerf_fine):
+            m.encode_candidate = False  # nerf_system_optmize.py:265-266
+            for p in m.parameters():
+                p.requires_grad_(False)
+        for k in ("coarse_a", "coarse_c", "fine_c"):
+            if k in self.embeddings:
+                self.embeddings[k].weight.requires_grad_(False)
+        self.set_progress(1.0)  # all encoding bands on, schedule finished
+
+    def configure_optimizers(self):
+        if self.pose_optimize:  # nerf_system_optmize.py:48-58
+            opts = [get_optimizer("adam", 5e-3, [self.embedding_fine_a]), get_optimizer("adam", 1e-4, [self.se3_refine])]
+        else:  # appearance stage: AdamW(1e-1) (lines 59-64)
+            opts = [torch.optim.AdamW(self.embedding_fine_a.parameters(), lr=1e-1)]
+        scheds = [{"scheduler": torch.optim.lr_scheduler.ConstantLR(o, factor=1.0, total_iters=0), "interval": "step"}
+                  for o in opts]
+        return opts, scheds
+
+    def forward(self, rays, img_idx, train=True, u_list=None):
+        hp = self.hparams
+        chunk = rays.shape[0] if train else hp["val.chunk_size"]
+        outs = []
+        for i in range(0, rays.shape[0], chunk):
+            outs.append(render_rays(models=self.models, embeddings=self.embeddings, rays=rays[i:i + chunk],
+                                    img_idx=img_idx[i:i + chunk], sched_mult=1.0, N_samples=hp["nerf.N_samples"],
+                                    use_disp=hp["nerf.use_disp"], perturb=hp["nerf.perturb"] if train else 0,
+                                    N_importance=hp["nerf.N_importance"], encode_feat=True, u_list=u_list))
+        return {k: (outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], 0)) for k in outs[0]}
+
+    def rays_from_batch(self, batch):
+        se3 = self.se3_refine(batch["img_idx"]) if self.pose_optimize else None
+        o, d = refine_and_get_rays(se3, batch["c2w"], batch["directions"])
+        return torch.cat([o, d, batch["ray_infos"]], 1)
+
+    def compute_loss(self, batch, u_list=None):
+        res = self(self.rays_from_batch(batch), batch["img_idx"], u_list=u_list)
+        loss = ((res["s_rgb_fine"] - batch["rgbs"]) ** 2).mean()  # nerf_system_optmize.py:129
+        return loss, {"rgb": loss}, res
+
+    def training_step(self, batch, batch_nb=0, u_list=None):
+        loss, _, _ = self.compute_loss(batch, u_list=u_list)
+        opts = self.optimizers()
+        opts = opts if isinstance(opts, (list, tuple)) else [opts]
+        for o in opts:
+            o.zero_grad()
+        self.manual_backward(loss)
+        for o in opts:
+            o.step()
+        self.global_step += len(opts)
+        return loss
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_nb=0):
+        """Full-image render in val.chunk_size chunks, perturb = 0; returns the PSNR on s_rgb_fine."""
+        res = self(self.rays_from_batch(batch), batch["img_idx"], train=False)
+        mse = ((res["s_rgb_fine"] - batch["rgbs"]) ** 2).mean()
+        return {"val_psnr": -10.0 * torch.log10(mse), "s_rgb_fine": res["s_rgb_fine"], "s_depth_fine": res["s_depth_fine"]}
