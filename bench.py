@@ -172,7 +172,8 @@ def main():
         summ = TIMER.summary()
         # algorithmic FLOPs per sample of each kernel class: forward, data-gradient and weight-gradient passes each
         # contract every layer once ("training step = fwd + dgrad + wgrad ~ 3x fwd")
-        per_sample = {"field_fwd": 2 * mac, "field_bwd": 2 * mac, "wgrad_256x256": 2 * 256 * 256}
+        per_sample = {"field_fwd": 2 * mac, "field_bwd": 2 * mac, "wgrad_256x256": 2 * 256 * 256,
+                      "wgrad16_256x256": 2 * 256 * 256}
         kern = {}
         for name, s in summ.items():
             k = dict(launches_per_step=s["launches"] / args.steps, avg_ms=s["avg_ms"],

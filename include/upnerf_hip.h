@@ -29,7 +29,9 @@ extern "C" {
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
+#ifndef UPNERF_TILE_ROWS
 #define UPNERF_TILE_ROWS 64  /* rows of samples per workgroup in the fused field kernels */
+#endif
 #define UPNERF_X0 64         /* positional encoding 3+6*10 = 63 padded to 64 floats per row */
 #define UPNERF_AUXK 80       /* per-ray rgb-head side input [dirPE(27) | appearance(48) | 0 x5] */
 #define UPNERF_CK 16         /* candidate embedding width */
@@ -117,6 +119,8 @@ typedef struct {
   float* x0;                     /* [M][64] */
   float* h;                      /* [D][M][W] post-ReLU trunk activations */
   uint64_t* hmask;               /* [D][ceil(M/64)][256] ReLU sign bits of h in the kernels' accumulator layout */
+  float* amax;                   /* [16] or NULL: running max|.| (atomicMax; zero it first) of h_0..h_{D-1} (slots 0..D-1),
+                                    e (D), g1 (D+1), r1 (D+3), x0 (D+4) -- scale exponents of upnerf_wgrad_f16x3 */
   float* e;                      /* [M][W]   xyz_encoding_final output */
   float* g1;                     /* [M][W/2] (use_cand) */
   float* g2;                     /* [M][W/2] (use_cand) */
@@ -196,6 +200,8 @@ typedef struct {
   const float* g_G_c;            /* [R][W/2] or NULL */
   const float* x0; const float* h; const float* g1; const float* g2; const float* r1;
   const uint64_t* hmask;         /* from upnerf_field_fwd */
+  float* gmax;                   /* [16] or NULL: running max|.| of gz_h[0..D-1] (slots 0..D-1), gz_e (D), gz_g1 (D+1),
+                                    gz_g2 (D+2), gz_r1 (D+3) */
   /* outputs */
   float* gz_h;                   /* [D][M][W] */
   float* gz_e;                   /* [M][W] */
@@ -215,6 +221,13 @@ int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_args* a, voi
  * result is bitwise reproducible.  db may be NULL. */
 int upnerf_wgrad(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
                  float* dW, int ldo, float* db, float* slabs, int nsplit, void* stream);
+
+/* Same contract, contraction on the f16 matrix cores with fp32-level accuracy: A and B are scaled by 2^*expo_a,
+ * 2^*expo_b (DEVICE ints, chosen so that the scaled maxima are ~2^14), split into fp16 hi + lo parts, and
+ * Ah Bh + Ah Bl + Al Bh is accumulated in fp32 (5.3x fewer matrix cycles than the fp32 MFMA; HBM-bound). */
+int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
+                       float* dW, int ldo, float* db, float* slabs, int nsplit, const int* expo_a,
+                       const int* expo_b, void* stream);
 
 /* dw[c][k] = sum_m v[m*ldv + c] * X[m][k], c < nvec <= 3; dbv[c] = sum_m v[m*ldv + c]   (N=1/3 heads);
  * K in {32, 64, 128, 256}; scratch: nsplit * 4 * (K+1) floats */

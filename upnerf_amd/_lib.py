@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UPNERF_LIB") or os.path.join(_HERE, "libupnerf_hip.so")  # UPNERF_LIB: diagnostic builds only
 MAX_D = 8
-TILE_ROWS, X0, AUXK, CK = 64, 64, 80, 16
+TILE_ROWS, X0, AUXK, CK = int(os.environ.get("UPNERF_TILE_ROWS", 64)), 64, 80, 16  # env: diagnostic builds only
 
 _fp = C.c_void_p
 
@@ -34,7 +34,7 @@ class FieldFwdArgs(C.Structure):
                 ("rays_o", _fp), ("rays_d", _fp), ("z", _fp), ("c_rows", _fp), ("aux", _fp),
                 ("wk_xyz", C.c_float * 10), ("P", _fp),
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
-                ("x0", _fp), ("h", _fp), ("hmask", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp)]
+                ("x0", _fp), ("h", _fp), ("hmask", _fp), ("amax", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp)]
 
 
 class CompositeFwdArgs(C.Structure):
@@ -62,7 +62,7 @@ class FieldBwdArgs(C.Structure):
                 ("d_sigma_s", _fp), ("d_sigma_c", _fp), ("d_rgb", _fp),
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
                 ("w_feat_s", _fp), ("w_cj", _fp), ("g_E_s", _fp), ("g_G_c", _fp),
-                ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp), ("hmask", _fp),
+                ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp), ("hmask", _fp), ("gmax", _fp),
                 ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp)]
 
@@ -102,6 +102,7 @@ _SIGNATURES = {
     "upnerf_composite_bwd": [C.POINTER(CompositeBwdArgs), _p],
     "upnerf_field_bwd": [C.POINTER(Layout), C.POINTER(FieldBwdArgs), _p],
     "upnerf_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
+    "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],

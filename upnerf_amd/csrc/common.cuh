@@ -223,6 +223,28 @@ __device__ __forceinline__ void acc_apply_mask(f32x16 (&acc)[MT][NT], unsigned l
       }
 }
 
+// max|acc| over the wave, folded into a global running maximum (non-negative floats order like their bit patterns).
+template <int MT, int NT>
+__device__ __forceinline__ void acc_track_max(const f32x16 (&acc)[MT][NT], float* __restrict__ slot, int lane) {
+  if (!slot) return;
+  float m = 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[mt][nt][r]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if (lane == 0) atomicMax((unsigned int*)slot, __float_as_uint(m));
+}
+__device__ __forceinline__ void wave_track_max(float m, float* __restrict__ slot, int lane) {
+  if (!slot) return;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if (lane == 0) atomicMax((unsigned int*)slot, __float_as_uint(m));
+}
+
 // Write accumulators into the swizzled LDS tile at column offset c0.
 template <int MT, int NT>
 __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[MT][NT], float* Hs, int ldw, int row0, int n0, int c0,
@@ -283,8 +305,9 @@ __device__ __forceinline__ void tile_mask_store(float* Hs, int ldw, int c0, int 
 template <int TILE>
 __device__ __forceinline__ void tile_rank1_store(float* Hs, int ldw, int ncols, const float* __restrict__ wrow,
                                                  const float* __restrict__ grow, int S, float* __restrict__ gz,
-                                                 int m0, int M, int tid) {
+                                                 int m0, int M, int tid, float* __restrict__ maxslot = nullptr) {
   const int gpr = ncols >> 2;
+  float lmax = 0.0f;
   for (int idx = tid; idx < TILE * gpr; idx += NTHREADS) {
     const int row = idx / gpr, g = idx - row * gpr, m = m0 + row;
     float* p = &Hs[swz4(row, 4 * g, ldw)];
@@ -299,7 +322,9 @@ __device__ __forceinline__ void tile_rank1_store(float* Hs, int ldw, int ncols, 
       *(f32x4*)&gz[(size_t)m * ncols + 4 * g] = v;
     }
     *(f32x4*)p = v;
+    lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   }
+  wave_track_max(lmax, maxslot, tid & 63);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -66,7 +66,7 @@ __device__ __forceinline__ float rowdot(const float* Hs, int ldw, int row, int p
 }
 
 template <int W, int TILE>
-__global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void field_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
+__global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W * 4 <= 65536) ? 2 : 1)) void field_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
   __shared__ __attribute__((aligned(16))) float Hs[TILE * W];
   constexpr int W2 = W / 2;
   constexpr int TPR = NTHREADS / TILE;  // threads per row in the per-row stages
@@ -94,6 +94,8 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
     Hs[swz(tid, 1, W)] = y;
     Hs[swz(tid, 2, W)] = zc;
     Hs[swz(tid, 63, W)] = 0.0f;
+    // max|x0| = max(|xyz|, |sin/cos| <= 1)
+    wave_track_max(fmaxf(fmaxf(fabsf(x), fabsf(y)), fmaxf(fabsf(zc), 1.0f)), a.amax ? a.amax + L.D + 4 : nullptr, lane);
   }
   __syncthreads();
   // ---- BARF-masked encoding (nerf.py:126-147): [x, sin(2^k pi x_n) w_k, cos(2^k pi x_n) w_k]
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
       mma_lds(acc, Hs, W, row0, 0, P + L.w[l], W, n0, 0, W, lane);
     }
     const unsigned long long bits = acc_bias_relu_pack(acc, P + L.b[l], n0, lane);
+    acc_track_max(acc, a.amax ? a.amax + l : nullptr, lane);
     ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
     __syncthreads();
     acc_to_lds(acc, Hs, W, row0, n0, 0, lane);
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
     mma_lds(acc, Hs, W, row0, 0, P + L.we, W, n0, 0, W, lane);
     const float* __restrict__ bias = P + L.be;
     acc_map(acc, row0, n0, lane, [&](float v, int, int col) { return v + bias[col]; });
+    acc_track_max(acc, a.amax ? a.amax + L.D : nullptr, lane);
     __syncthreads();
     acc_to_lds(acc, Hs, W, row0, n0, 0, lane);
     __syncthreads();
@@ -188,11 +192,13 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
   if (a.use_rgb) {
     const float* __restrict__ bias = P + L.br1;
     acc_map(accr, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(v + bias[col], 0.0f); });
+    acc_track_max(accr, a.amax ? a.amax + L.D + 3 : nullptr, lane);
     acc_to_lds(accr, Hs, W, hrow0, hn0, 0, lane);
   }
   if (a.use_cand) {
     const float* __restrict__ bias = P + L.bc1;
     acc_map(accc, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(v + bias[col], 0.0f); });
+    acc_track_max(accc, a.amax ? a.amax + L.D + 1 : nullptr, lane);
     acc_to_lds(accc, Hs, W, hrow0, hn0, W2, lane);
   }
   __syncthreads();
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
 // Backward data-gradient chain.  Every stage leaves the pre-activation gradient of one layer in LDS (the A
 // operand of the next contraction) and in HBM (the A operand of upnerf_wgrad).
 template <int W, int TILE>
-__global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void field_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
+__global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W * 4 <= 65536) ? 2 : 1)) void field_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
   __shared__ __attribute__((aligned(16))) float Gs[TILE * W];
   __shared__ float pre_s[TILE];
   constexpr int W2 = W / 2;
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
   if (a.use_cand) {
     // d g2 = w_csig * dpre_c + w_cj * g_G_c[ray]   (candidate_sigma / feat_candidate_layer, nerf.py:99-100)
     constexpr int GPR = W2 / 4;
+    float lmax = 0.0f;
     for (int idx = tid; idx < TILE * GPR; idx += NTHREADS) {
       const int row = idx / GPR, g = idx - row * GPR, m = m0 + row;
       f32x4 out = {0.f, 0.f, 0.f, 0.f};
@@ -275,11 +282,14 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
         *(f32x4*)&a.gz_g2[(size_t)m * W2 + 4 * g] = out;
       }
       *(f32x4*)&Gs[swz4(row, W2 + 4 * g, W)] = out;
+      lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out.x), fabsf(out.y)), fmaxf(fabsf(out.z), fabsf(out.w))));
     }
+    wave_track_max(lmax, a.gmax ? a.gmax + D + 2 : nullptr, lane);
     __syncthreads();
     f32x16 acc[TH::MT][TH::NT];
     acc_zero(acc);
     mma_lds(acc, Gs, W, hrow0, W2, PT + L.t_wc2, W2, hn0, 0, W2, lane);
+    acc_track_max(acc, a.gmax ? a.gmax + D + 1 : nullptr, lane);  // (before the ReLU mask: an upper bound)
     __syncthreads();
     acc_to_lds(acc, Gs, W, hrow0, hn0, W2, lane);
     __syncthreads();
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
   if (a.use_rgb) {
     // d r1 = W_r2^T (d rgb * rgb (1-rgb))   (rgb_share_layer.2 + sigmoid)
     constexpr int GPR = W2 / 4;
+    float lmax = 0.0f;
     for (int idx = tid; idx < TILE * GPR; idx += NTHREADS) {
       const int row = idx / GPR, g = idx - row * GPR, m = m0 + row;
       f32x4 out = {0.f, 0.f, 0.f, 0.f};
@@ -314,7 +325,9 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
         *(f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * g] = out;
       }
       *(f32x4*)&Gs[swz4(row, 4 * g, W)] = out;
+      lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out.x), fabsf(out.y)), fmaxf(fabsf(out.z), fabsf(out.w))));
     }
+    wave_track_max(lmax, a.gmax ? a.gmax + D + 3 : nullptr, lane);
   }
   __syncthreads();
 
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
     __syncthreads();
     // + w_feat[m] * g_E_s[ray] in a coalesced pass (per-element loads in the accumulator layout were 64 dependent
     // L2 round trips per lane)
-    tile_rank1_store<TILE>(Gs, W, W, a.w_feat_s, a.g_E_s, S, a.gz_e, m0, M, tid);
+    tile_rank1_store<TILE>(Gs, W, W, a.w_feat_s, a.g_E_s, S, a.gz_e, m0, M, tid, a.gmax ? a.gmax + D : nullptr);
     __syncthreads();
   }
   // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu (sign bits from the forward, in this lane's layout)
@@ -344,6 +357,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
     const float* __restrict__ ws = P + L.wsig;
     acc_map(acc, row0, n0, lane, [&](float v, int row, int col) { return v + ws[col] * pre_s[row]; });
     acc_apply_mask(acc, bits);
+    acc_track_max(acc, a.gmax ? a.gmax + (D - 1) : nullptr, lane);
     __syncthreads();
     acc_to_lds(acc, Gs, W, row0, n0, 0, lane);
     __syncthreads();
@@ -359,6 +373,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 65536) ? 2 : 1) void fie
     acc_zero(acc);
     mma_lds(acc, Gs, W, row0, 0, PT + L.t_w[l], W, n0, 0, W, lane);
     acc_apply_mask(acc, bits);
+    acc_track_max(acc, a.gmax ? a.gmax + (l - 1) : nullptr, lane);
     __syncthreads();
     acc_to_lds(acc, Gs, W, row0, n0, 0, lane);
     __syncthreads();

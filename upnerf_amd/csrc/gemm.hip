@@ -392,6 +392,35 @@ extern "C" int upnerf_wgrad(int M, const float* A, int lda, int N, const float* 
   return (int)hipGetLastError();
 }
 
+extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
+                                          const int* expo_a, const int* expo_b, float* slabs, float* bslabs,
+                                          int nsplit, int rows, int TN, int TK, void* stream);
+
+// Same contract as upnerf_wgrad, contraction on the f16 matrix cores with a 3-term hi/lo split (wgrad_f16x3.hip).
+// expo_a, expo_b: DEVICE ints: A is scaled by 2^*expo_a and B by 2^*expo_b before the fp16 split.
+extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW,
+                                  int ldo, float* db, float* slabs, int nsplit, const int* expo_a, const int* expo_b,
+                                  void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b)
+    return UPNERF_EINVAL;
+  if ((N & 3) || (K & 3) || (lda & 3) || (ldb & 3) || (ldo & 3)) return UPNERF_EINVAL;
+  int TN, TK;
+  wgrad_shape(N, K, &TN, &TK);
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = (((M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
+  float* bslabs = slabs + (size_t)nsplit * gy * gz * TN * TK;
+  int rc = upnerf_wgrad_f16x3_partial(M, A, lda, N, B, ldb, K, expo_a, expo_b, slabs, bslabs, nsplit, rows, TN, TK,
+                                      stream);
+  if (rc) return rc;
+  const int quads = N * (K / 4);
+  int rblocks = (quads + 63) / 64;
+  if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(NTHREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
+                     ldo, db);
+  return (int)hipGetLastError();
+}
+
 extern "C" int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const float* X, int ldx, int K, float* dw,
                                 float* dbv, float* scratch, int nsplit, void* stream) {
   if (M <= 0 || nvec <= 0 || nvec > 4 || K <= 0 || K > 256 || !v || !X || !dw || !scratch || nsplit <= 0)

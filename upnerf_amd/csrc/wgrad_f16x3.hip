@@ -1,0 +1,199 @@
+// Weight-gradient contraction on the f16 matrix cores with fp32-level accuracy ("f16x3"):
+//     dW[n][k] = sum_m A[m][n] B[m][k],   A = 2^-ea (Ah + Al),  B = 2^-eb (Bh + Bl),   Ah, Al, Bh, Bl in fp16
+//     dW ~= 2^-(ea+eb) sum_m (Ah Bh + Ah Bl + Al Bh)                      (the Al Bl term is below 2^-22 relative)
+// Three v_mfma_f32_32x32x16_f16 per 32x32x16 block replace eight v_mfma_f32_32x32x2_f32: 5.3x fewer matrix cycles,
+// which moves this kernel from MFMA-bound to HBM-bound (it streams 2 KB per sample per layer).  Products of fp16 values
+// are exact in fp32 and accumulation is fp32, so the only extra error over the fp32 kernel is the 2^-22 split residue.
+// ea, eb are power-of-two exponents chosen by the caller from max|A|, max|B| so that the scaled values peak near 2^14
+// (fp16 overflows at 65504; values more than 2^17 below the peak keep fewer than 22 bits, their products are then
+// negligible against the peak-sized terms of the same sum).
+//
+// The reduction index m is the ROW index of both row-major operands, i.e. it is strided in memory, while the f16 MFMA
+// wants 8 consecutive m per lane: the tiles are staged in LDS row-major (fp32 -> (hi, lo) fp16 on the way in) and read
+// back with ds_read_b64_tr_b16, gfx950's transposing LDS read (4 rows x 16 columns per 16-lane group, delivered
+// column-major).  LDS image: 256-byte rows of 128 fp16 with the 16-byte-chunk XOR that makes the transposed reads
+// conflict-free (cdna_hip_programming.md T10, image (b)).
+#include "common.cuh"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+
+#define FX_CHUNK 32  // rows per staged chunk = two 16-deep MFMA steps
+
+// byte offset of fp16 element (row, col) inside one plane; col % 4 == 0 for 8-byte accesses
+__device__ __forceinline__ int himg(int row, int col) {
+  const int panel = col >> 7, c = col & 127;
+  return panel * (FX_CHUNK * 256) + 256 * row + 16 * ((c >> 3) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 2 * (c & 7);
+}
+
+__device__ __forceinline__ h4 tr_read(const char* base, int byteoff) {
+  s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(base + byteoff));
+  return __builtin_bit_cast(h4, v);
+}
+
+template <int MTW, int NTW>
+__global__ __launch_bounds__(NTHREADS, 1) void wgrad_f16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                                  const float* __restrict__ B, int ldb,
+                                                                  const int* __restrict__ expo_a, const int* __restrict__ expo_b,
+                                                                  float* __restrict__ slabs, float* __restrict__ bslabs,
+                                                                  int rows_per_split) {
+  constexpr int TN = 64 * MTW, TK = 64 * NTW;
+  constexpr int PN = (TN + 127) / 128, PK = (TK + 127) / 128;           // 128-column panels per plane
+  constexpr int SZA = PN * FX_CHUNK * 256, SZB = PK * FX_CHUNK * 256;  // bytes per plane
+  constexpr int A4 = FX_CHUNK * TN / 4 / NTHREADS, B4 = FX_CHUNK * TK / 4 / NTHREADS;
+  // [buffer][A hi | A lo | B hi | B lo]
+  __shared__ __attribute__((aligned(16))) char lds[2 * (2 * SZA + 2 * SZB)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int n0 = (wave >> 1) * 32 * MTW, k0 = (wave & 1) * 32 * NTW;
+  const int split = blockIdx.x;
+  const int nblk = blockIdx.y * TN, kblk = blockIdx.z * TK;
+  const int mbeg = split * rows_per_split;
+  const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  const int ea = expo_a[0], eb = expo_b[0];
+  const float sa = ldexpf(1.0f, ea), sb = ldexpf(1.0f, eb);
+
+  f32x16 acc[MTW][NTW];
+  acc_zero(acc);
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // this thread's 4 columns of A, summed over its rows (fp32, unscaled)
+
+  f32x4 ra[A4], rb[B4];
+  auto gload = [&](int mc) {
+#pragma unroll
+    for (int q = 0; q < A4; ++q) {
+      const int idx = tid + q * NTHREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
+      const int m = mc + row;
+      ra[q] = (m < mend && nblk + 4 * c4 < N) ? *(const f32x4*)&A[(size_t)m * lda + nblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < B4; ++q) {
+      const int idx = tid + q * NTHREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
+      const int m = mc + row;
+      rb[q] = (m < mend && kblk + 4 * c4 < K) ? *(const f32x4*)&B[(size_t)m * ldb + kblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto split_store = [&](char* hi, char* lo, f32x4 v, float s, int row, int col) {
+    h4 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = v[j] * s;
+      vh[j] = (_Float16)x;
+      vl[j] = (_Float16)(x - (float)vh[j]);
+    }
+    const int off = himg(row, col);
+    *(h4*)(hi + off) = vh;
+    *(h4*)(lo + off) = vl;
+  };
+  auto lstore = [&](int buf) {
+    char* base = lds + buf * (2 * SZA + 2 * SZB);
+#pragma unroll
+    for (int q = 0; q < A4; ++q) {
+      const int idx = tid + q * NTHREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
+      bsum += ra[q];
+      split_store(base, base + SZA, ra[q], sa, row, 4 * c4);
+    }
+#pragma unroll
+    for (int q = 0; q < B4; ++q) {
+      const int idx = tid + q * NTHREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
+      split_store(base + 2 * SZA, base + 2 * SZA + SZB, rb[q], sb, row, 4 * c4);
+    }
+  };
+  // transposed-read address pieces of this lane (cdna_hip_programming.md T10): group g, row q, column quad p
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int trow = 8 * (g >> 1) + tq, tcol = 16 * (g & 1) + 4 * tp;
+
+  int buf = 0;
+  if (mbeg < mend) gload(mbeg);
+  for (int mc = mbeg; mc < mend; mc += FX_CHUNK) {
+    lstore(buf);
+    __syncthreads();
+    if (mc + FX_CHUNK < mend) gload(mc + FX_CHUNK);
+    const char* base = lds + buf * (2 * SZA + 2 * SZB);
+#pragma unroll
+    for (int kk = 0; kk < FX_CHUNK / 16; ++kk) {
+      h8 ah[MTW], al[MTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const int o0 = himg(16 * kk + trow, n0 + 32 * mt + tcol), o1 = himg(16 * kk + trow + 4, n0 + 32 * mt + tcol);
+        const h4 x0 = tr_read(base, o0), x1 = tr_read(base, o1);
+        const h4 y0 = tr_read(base + SZA, o0), y1 = tr_read(base + SZA, o1);
+        ah[mt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+        al[mt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int o0 = himg(16 * kk + trow, k0 + 32 * nt + tcol), o1 = himg(16 * kk + trow + 4, k0 + 32 * nt + tcol);
+        const h4 x0 = tr_read(base + 2 * SZA, o0), x1 = tr_read(base + 2 * SZA, o1);
+        const h4 y0 = tr_read(base + 2 * SZA + SZB, o0), y1 = tr_read(base + 2 * SZA + SZB, o1);
+        const h8 bh = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const h8 bl = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+    buf ^= 1;
+  }
+  // partial slab [split][by][bz][TN][TK], unscaled
+  const float unscale = ldexpf(1.0f, -(ea + eb));
+  const size_t blk = ((size_t)split * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+  float* slab = slabs + blk * TN * TK;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        slab[n * TK + k0 + 32 * nt + li] = acc[mt][nt][r] * unscale;
+      }
+  if (bslabs && blockIdx.z == 0) {
+    // column sums: thread t owns columns 4*(t % (TN/4)) ..+3; the NTHREADS/(TN/4) threads sharing them meet in LDS
+    __syncthreads();
+    f32x4* red = (f32x4*)lds;
+    red[tid] = bsum;
+    __syncthreads();
+    constexpr int Q = TN / 4, G = NTHREADS / Q;
+    if (tid < Q) {
+      f32x4 s = red[tid];
+#pragma unroll
+      for (int j = 1; j < G; ++j) s += red[tid + j * Q];
+      *(f32x4*)&bslabs[((size_t)split * gridDim.y + blockIdx.y) * TN + 4 * tid] = s;
+    }
+  }
+}
+
+template <int MTW, int NTW>
+int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const int* expo_a, const int* expo_b, float* slabs,
+           float* bslabs, int nsplit, int rows, hipStream_t st) {
+  constexpr int TN = 64 * MTW, TK = 64 * NTW;
+  dim3 grid(nsplit, (N + TN - 1) / TN, (K + TK - 1) / TK);
+  hipLaunchKernelGGL((wgrad_f16x3_kernel<MTW, NTW>), grid, dim3(NTHREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs,
+                     bslabs, rows);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// Same contract as upnerf_wgrad_partial in gemm.hip: writes nsplit slabs (+ bias slabs) that upnerf_wgrad's reduce
+// kernel sums.  expo_a, expo_b: DEVICE pointers to the two exponents.  Returns the block shape through TN/TK.
+extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
+                                          const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows, int TN,
+                                          int TK, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (TN == 256 && TK == 256) return launch<4, 4>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 256 && TK == 128) return launch<4, 2>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 256 && TK == 64) return launch<4, 1>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 128 && TK == 256) return launch<2, 4>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 128 && TK == 128) return launch<2, 2>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 128 && TK == 64) return launch<2, 1>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 64 && TK == 256) return launch<1, 4>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 64 && TK == 128) return launch<1, 2>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  return launch<1, 1>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+}

@@ -80,6 +80,30 @@ def wgrad_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor, ldb: 
     check(rc, "upnerf_wgrad")
 
 
+def scale_exponents(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """Device int32 [2]: power-of-two exponents that bring max|A|, max|B| to ~2^14 (no host sync)."""
+    amax = torch.stack([A.abs().amax(), B.abs().amax()]).clamp_min(1e-30)
+    return (14 - torch.ceil(torch.log2(amax))).to(torch.int32)
+
+
+def wgrad_f16x3_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor, ldb: int, K: int, dW_ptr: int, ldo: int,
+                     db_ptr: Optional[int], device, expo: Optional[torch.Tensor] = None, expo_a: Optional[int] = None,
+                     expo_b: Optional[int] = None, a_off: int = 0, b_off: int = 0):
+    """upnerf_wgrad with the contraction on the f16 matrix cores (3-term hi/lo split, fp32-level accuracy).
+    Scale exponents: `expo` (device int32 [2]) or raw device pointers expo_a / expo_b; computed from A, B if absent."""
+    ns = nsplit_for(M)
+    ws = workspace("wgrad", ns * (256 * 256 + 256), device)
+    if expo_a is None:
+        if expo is None:
+            expo = scale_exponents(A, B)
+        expo_a, expo_b = expo.data_ptr(), expo.data_ptr() + 4
+    rc = TIMER.run(f"wgrad16_{N}x{K}", lambda: lib.upnerf_wgrad_f16x3(M, A.data_ptr() + 4 * a_off, lda, N,
+                                                                      B.data_ptr() + 4 * b_off, ldb, K, dW_ptr, ldo,
+                                                                      db_ptr, ptr(ws), ns, expo_a, expo_b, stream()),
+                   units=M)
+    check(rc, "upnerf_wgrad_f16x3")
+
+
 def vec_wgrad_into(M: int, v: torch.Tensor, ldv: int, nvec: int, X: torch.Tensor, ldx: int, K: int, dw_ptr: int,
                    dbv_ptr: Optional[int], device):
     ns = nsplit_for(M)

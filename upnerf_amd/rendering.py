@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, X0, check, lib, ptr,
                    stream)
-from .ops import TIMER, hip_linear, linear_raw, nsplit_for, vec_wgrad_into, wgrad_into
+from .ops import TIMER, hip_linear, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16x3_into, wgrad_into
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
@@ -95,13 +95,14 @@ class _FieldPass(torch.autograd.Function):
         rgb = _empty(M, 3, device=dev) if cfg.use_rgb else None
         x0, h, e = _empty(M, X0, device=dev), _empty(D, M, W, device=dev), _empty(M, W, device=dev)
         hmask = torch.empty(D * ((M + _lib.TILE_ROWS - 1) // _lib.TILE_ROWS) * 256, device=dev, dtype=torch.int64)
+        amax = torch.zeros(16, device=dev)  # running max|.| of the activations (scales of the f16x3 weight gradients)
         g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
         g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
         r1 = _empty(M, W2, device=dev) if cfg.use_rgb else None
         fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
-                          rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1))
+                          rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1))
         check(TIMER.run("field_fwd", lambda: lib.upnerf_field_fwd(C.byref(L), C.byref(fa), st), units=M),
               "upnerf_field_fwd")
 
@@ -127,7 +128,7 @@ class _FieldPass(torch.autograd.Function):
         ctx.cfg, ctx.dims = cfg, (R, S)
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, hmask=hmask, e=e, g1=g1, g2=g2, r1=r1, w_all=w_all, w_sj=w_sj,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, hmask=hmask, amax=amax, e=e, g1=g1, g2=g2, r1=r1, w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s)
         z0 = torch.zeros(0, device=dev)
         outs = (E_s, G_c, sum_sfeat, t_weight, c_depth, s_depth, rgb_map, w_all, w_s)
@@ -174,13 +175,14 @@ class _FieldPass(torch.autograd.Function):
         dpre_c = _empty(M, device=dev) if cfg.use_cand else None
         dpre_rgb = _empty(M, 4, device=dev) if cfg.use_rgb else None
         dxyz = _empty(M, 3, device=dev) if need_dxyz else None
+        gmax = torch.zeros(16, device=dev)
         w_feat = (sv["w_sj"] if joint else sv["w_s"]) if gE is not None else None
         fb = FieldBwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), need_dxyz=int(need_dxyz),
                           PT=ptr(PT), P=ptr(P), d_sigma_s=ptr(d_sigma_s), d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb),
                           sigma_s=ptr(sv["sigma_s"]), sigma_c=ptr(sv["sigma_c"]), rgb=ptr(sv["rgb"]),
                           w_feat_s=ptr(w_feat), w_cj=ptr(sv["w_cj"]) if gG is not None else None, g_E_s=ptr(gE),
                           g_G_c=ptr(gG), x0=ptr(sv["x0"]), h=ptr(sv["h"]), g1=ptr(sv["g1"]), g2=ptr(sv["g2"]),
-                          r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
+                          r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz))
         check(TIMER.run("field_bwd", lambda: lib.upnerf_field_bwd(C.byref(L), C.byref(fb), st), units=M),
@@ -196,24 +198,36 @@ class _FieldPass(torch.autograd.Function):
             base = dP.data_ptr()
             at = lambda off: base + 4 * off
             h, x0 = sv["h"], sv["x0"]
+            # power-of-two scales of the f16x3 contraction: 2^14 / max|.| per tensor, from the maxima the field kernels
+            # tracked (device side, no host sync).  ea[i] pairs with gmax slot i, eb[i] with amax slot i.
+            ea = (14 - torch.ceil(torch.log2(gmax.clamp_min(1e-30)))).to(torch.int32)
+            eb = (14 - torch.ceil(torch.log2(sv["amax"].clamp_min(1e-30)))).to(torch.int32)
+            EA = lambda i: ea.data_ptr() + 4 * i
+            EB = lambda i: eb.data_ptr() + 4 * i
+            ctx_keep = (ea, eb)
+
+            def wg(gz, lda, N, Bt, ldb, K, off, ldo, boff, ia, ib, b_off=0):
+                wgrad_f16x3_into(M, gz, lda, N, Bt, ldb, K, at(off), ldo, None if boff is None else at(boff), dev,
+                                 expo_a=EA(ia), expo_b=EB(ib), b_off=b_off)
+
             for l in range(D):
                 gz = gz_h[l]
                 if l == 0:
-                    wgrad_into(M, gz, W, W, x0, X0, X0, at(L.w[0]), X0, at(L.b[0]), dev)
+                    wg(gz, W, W, x0, X0, X0, L.w[0], X0, L.b[0], 0, D + 4)
                 elif l == pk.skip:
-                    wgrad_into(M, gz, W, W, x0, X0, X0, at(L.w[l]), X0 + W, at(L.b[l]), dev)
-                    wgrad_into(M, gz, W, W, h[l - 1], W, W, at(L.w[l] + X0), X0 + W, None, dev)
+                    wg(gz, W, W, x0, X0, X0, L.w[l], X0 + W, L.b[l], l, D + 4)
+                    wg(gz, W, W, h[l - 1], W, W, L.w[l] + X0, X0 + W, None, l, l - 1)
                 else:
-                    wgrad_into(M, gz, W, W, h[l - 1], W, W, at(L.w[l]), W, at(L.b[l]), dev)
-            wgrad_into(M, gz_e, W, W, h[D - 1], W, W, at(L.we), W, at(L.be), dev)
+                    wg(gz, W, W, h[l - 1], W, W, L.w[l], W, L.b[l], l, l - 1)
+            wg(gz_e, W, W, h[D - 1], W, W, L.we, W, L.be, D, D - 1)
             vec_wgrad_into(M, dpre_s, 1, 1, h[D - 1], W, W, at(L.wsig), at(L.bsig), dev)
         if cfg.use_cand:
             rs = _empty(R, W2, device=dev)
             check(lib.upnerf_ray_sum(R, S, ptr(gz_g1), W2, ptr(rs), st), "upnerf_ray_sum")
             if dP is not None:
-                wgrad_into(M, gz_g1, W2, W2, sv["e"], W, W, at(L.wc1), W + CK, at(L.bc1), dev)
+                wg(gz_g1, W2, W2, sv["e"], W, W, L.wc1, W + CK, L.bc1, D + 1, D)
                 wgrad_into(R, rs, W2, W2, sv["c_rows"], CK, CK, at(L.wc1 + W), W + CK, None, dev)
-                wgrad_into(M, gz_g2, W2, W2, sv["g1"], W2, W2, at(L.wc2), W2, at(L.bc2), dev)
+                wg(gz_g2, W2, W2, sv["g1"], W2, W2, L.wc2, W2, L.bc2, D + 2, D + 1)
                 vec_wgrad_into(M, dpre_c, 1, 1, sv["g2"], W2, W2, at(L.wcsig), at(L.bcsig), dev)
             if ctx.needs_input_grad[3]:
                 wc = P[L.wc1:L.wc1 + W2 * (W + CK)].view(W2, W + CK)[:, W:]
@@ -222,7 +236,7 @@ class _FieldPass(torch.autograd.Function):
             rs = _empty(R, W2, device=dev)
             check(lib.upnerf_ray_sum(R, S, ptr(gz_r1), W2, ptr(rs), st), "upnerf_ray_sum")
             if dP is not None:
-                wgrad_into(M, gz_r1, W2, W2, sv["e"], W, W, at(L.wr1), W + AUXK, at(L.br1), dev)
+                wg(gz_r1, W2, W2, sv["e"], W, W, L.wr1, W + AUXK, L.br1, D + 3, D)
                 wgrad_into(R, rs, W2, W2, sv["aux"], AUXK, AUXK, at(L.wr1 + W), W + AUXK, None, dev)
                 vec_wgrad_into(M, dpre_rgb, 4, 3, sv["r1"], W2, W2, at(L.wr2), at(L.br2), dev)
             if ctx.has_a and ctx.needs_input_grad[4]:
