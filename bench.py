@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+# f16 dense MFMA: 1024 FLOP/clk/SIMD (v_mfma_f32_32x32x16_f16 = 32 cycles) x 1024 SIMDs x 2.4 GHz (same guide, "~2.5 PF")
+PEAK_F16_MFMA_TFLOPS = 2516.6
+# the f16x3 kernels issue three f16 MFMAs (hi*hi + hi*lo + lo*hi) per fp32-accurate multiply-accumulate
+PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3
 N_IMAGES = 763                 # Brandenburg Gate train split
 RAYS, NC, NF = 4096, 64, 128
 
@@ -108,6 +112,9 @@ def main():
     ap.add_argument("--progress", type=float, default=0.3,
                     help="training progress in [0,1]: 0.05 -> sched 0 (candidate only), 0.3 -> sched 0.5 (all heads, "
                          "the heaviest phase; default), 0.8 -> sched 1 (colour only)")
+    ap.add_argument("--field", choices=["f16x3", "f32"], default="f16x3",
+                    help="arithmetic of the field contractions: f16x3 = 3-term fp16 split on the f16 matrix cores "
+                         "(fp32-level accuracy, default); f32 = fp32 MFMA kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -123,6 +130,8 @@ def main():
     import torch.distributed as dist
     from upnerf_amd.ops import TIMER
 
+    from upnerf_amd import rendering
+    rendering.FIELD_MODE = args.field
     sysm = build_system(dev, args.progress)
     if world > 1:
         sysm.enable_data_parallel()
@@ -160,7 +169,9 @@ def main():
     line = {
         "metric": "training rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32" if args.field == "f32" else "f32 (contractions as 3-term f16 split on f16 MFMA, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: Brandenburg Gate shape, 4096 rays/GPU/step, 64 coarse + 128 "
                                "fine samples, two 8x256 fields + candidate/colour heads + TransientNet + appearance/"
                                "candidate embeddings (763 images), pose optimisation ON, full step incl. both Adam updates",
@@ -190,10 +201,16 @@ def main():
             t = json.load(open(pmc)).get(dom)
             if t:
                 traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
-        line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+        f16 = dom.startswith("wgrad16") or (dom.startswith("field") and args.field == "f16x3")
+        peak = PEAK_F16X3_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
+        line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak,
+                            "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                             "avg_launch_ms": kern[dom]["avg_ms"],
-                            "note": "average over the coarse (262144-sample) and fine (786432-sample) launches"}
+                            "note": "achieved = algorithmic (fp32-equivalent) FLOPs / HIP-event launch time, averaged "
+                                    "over the coarse (262144-sample) and fine (786432-sample) launches; " +
+                                    ("peak = f16 dense MFMA 2516.6 TF / 3 MFMAs per fp32-accurate MAC (the hardware "
+                                     "executes 3x the algorithmic FLOPs); for scale: fp32 MFMA peak is 157.3 TF"
+                                     if f16 else "peak = fp32 MFMA")}
     if world == 1 and not args.no_cpu_baseline:
         nthreads = torch.get_num_threads()
         v, sec = cpu_baseline(args.progress)

@@ -125,9 +125,16 @@ typedef struct {
   float* g1;                     /* [M][W/2] (use_cand) */
   float* g2;                     /* [M][W/2] (use_cand) */
   float* r1;                     /* [M][W/2] (use_rgb) */
+  /* f16x3 variant only (upnerf_field_fwd_f16x3): */
+  const void* P16;               /* matrices of P as scaled fp16 (hi, lo) fragments, from upnerf_frag16 (forward set) */
+  const int32_t* wexp;           /* [16] per-matrix exponents from upnerf_frag16 */
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
+/* Same contract, contractions on the f16 matrix cores with the 3-term hi/lo split (fp32-level accuracy, see
+ * csrc/common16.cuh).  W = 256 only; `P` is read for the vectors only (biases, wsig, wcsig, wr2: any ordering of P has
+ * them in place); hmask needs D+1 slots (slot D = sign bits of g1). */
+int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
 
 /* ---- a10: alpha compositing, forward (models/rendering.py:125-218) -------------------------------
  * Features are composited in the W-wide space of xyz_encoding_final / candidate_encoding and projected
@@ -211,9 +218,14 @@ typedef struct {
   float* dpre_sig_c;             /* [M] */
   float* dpre_rgb;               /* [M][4] (3 used) */
   float* dxyz;                   /* [M][3] (need_dxyz) */
+  /* f16x3 variant only (upnerf_field_bwd_f16x3): */
+  const void* PT16;              /* transposed set of upnerf_frag16 */
+  const int32_t* wexp;           /* [16] */
 } upnerf_field_bwd_args;
 
 int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream);
+/* f16x3 variant: W = 256 and S >= 32 (at most 3 rays per 64-sample tile); hmask from upnerf_field_fwd_f16x3. */
+int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream);
 
 /* ---- weight gradients: dW[N][ldo] (+)= sum_m A[m][n] * B[m][k], db[n] = sum_m A[m][n] ------------
  * A [M][lda] (N columns used), B [M][ldb] (K columns used); K, N multiples of 32 (N <= 256, K <= 256).
@@ -285,6 +297,19 @@ typedef struct {
 } upnerf_frag_desc;
 #define UPNERF_MAX_FRAG_DESC 32
 int upnerf_frag_copy(const float* src, float* dst, const upnerf_frag_desc* descs /*host*/, int ndesc, void* stream);
+
+/* ---- f16x3 weight re-layout: every matrix of `src` -> scaled fp16 (hi, lo) pairs in MFMA fragment order ------------
+ * Same descriptors as upnerf_frag_copy plus `exp_id`: matrices sharing an id share one power-of-two exponent
+ * (2^14 / max|.| over all their elements), written to wexp[exp_id].  Destination element (r, k) of a [rows][dst_kp]
+ * matrix at float offset dst_off:  byte dst_off*4 + (((r/32)*(dst_kp/16) + k/16)*2 + plane)*1024
+ *                                       + (((k/8)%2)*32 + r%32)*16 + (k%8)*2,   plane 0 = hi, 1 = lo.
+ * `amax_scratch` [16] floats is zeroed and used inside. */
+typedef struct {
+  int32_t src_off, src_ld, transpose, rows, cols, dst_off, dst_kp, dst_k0, exp_id;
+} upnerf_frag16_desc;
+int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, const upnerf_frag16_desc* fwd, int nfwd,
+                  const upnerf_frag16_desc* bwd, int nbwd, float* amax_scratch /*[16]*/, int32_t* wexp /*[16]*/,
+                  void* stream);
 
 /* ---- a18: fused Adam on a flat fp32 buffer (torch.optim.Adam semantics, utils/optim.py:20-33) ---- */
 int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,

@@ -242,9 +242,22 @@ STAGE_CASES = [("cfg1_small", "coarse"), ("cfg2_phase0", "coarse"), ("cfg2_phase
                ("small_nocand", "fine"), ("small_round_half", "fine"), ("small_allmasked", "coarse")]
 
 
+@pytest.fixture
+def field_mode(hip, request):
+    """Run a test with the field contractions in the given arithmetic ("f16x3" is the default of the product path)."""
+    rd = hip["rendering"]
+    old = rd.FIELD_MODE
+    rd.FIELD_MODE = request.param
+    yield request.param
+    rd.FIELD_MODE = old
+
+
+@pytest.mark.parametrize("field_mode", ["f16x3", "f32"], indirect=True)
 @pytest.mark.parametrize("name,typ", STAGE_CASES)
-def test_field_pass_stage_by_stage(hip, name, typ):
+def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     c = Case(name)
+    if field_mode == "f32" and c.cfgs()["nerf_coarse"].W != 256:
+        pytest.skip("64-wide fields run the fp32 kernels in either mode")
     s = _setup_pass(c, typ, hip)
     rd = hip["rendering"]
     model, pk = s["model"], s["model"].packer
@@ -335,6 +348,113 @@ def test_field_pass_stage_by_stage(hip, name, typ):
     for k, (off, n) in pieces.items():
         ok &= cmp("dP_" + k, P_g.grad[off:off + n], P_ref.grad[off:off + n], TOL_GRAD)
     assert ok, "BWD over tolerance: " + repr(errs)
+
+
+@pytest.mark.parametrize("R,S,mode,use_cand,use_rgb", [(7, 40, 1, True, True), (5, 33, 0, True, False),
+                                                         (3, 200, 2, False, True), (9, 32, 3, False, False)])
+def test_field_f16x3_matches_fp32_kernels_on_ragged_tiles(hip, R, S, mode, use_cand, use_rgb):
+    """f16x3 kernels against the fp32 kernels on shapes whose tiles are ragged (M % 64 != 0) and straddle up to three
+    rays; large and tiny magnitudes mixed so that the per-tile exponents differ between tiles and stages."""
+    from upnerf_amd import synth
+    from upnerf_amd.nerf import NeRF
+    rd = hip["rendering"]
+    kw = dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    model = NeRF("coarse", c2f=None, **kw)
+    model.load_state_dict(synth.nerf_state("coarse", seed=3, **kw))
+    model = model.cuda()
+    pk = model.packer
+    o = (gen((R, 3), 70) * 0.3).cuda()
+    d = torch.nn.functional.normalize(gen((R, 3), 71), dim=-1).cuda()
+    z = (torch.sort(gen((R, S), 72).abs() * 3 + 0.1, dim=-1).values).cuda()
+    scale = torch.logspace(-3, 2, R).reshape(R, 1)  # per-ray magnitudes of the side inputs span 5 decades
+    c_rows, a_rows = (gen((R, 16), 73) * scale).cuda(), (gen((R, 48), 74) * scale.flip(0)).cuda()
+    cfg = rd._PassCfg(pk, mode, use_cand, use_rgb, [1.0] * 10, [1.0] * 4)
+    res = {}
+    old = rd.FIELD_MODE
+    try:
+        for fm in ("f32", "f16x3"):
+            rd.FIELD_MODE = fm
+            leaves = [t.clone().requires_grad_(True) for t in (o, d, c_rows, a_rows, model.packed().detach())]
+            outs = rd._FieldPass.apply(leaves[0], leaves[1], z, leaves[2], leaves[3], leaves[4], cfg)
+            sv = next(t.grad_fn for t in outs if t.grad_fn is not None).saved
+            sink = {}
+            rd._DEBUG_SINK = sink
+            sum((t * gen(tuple(t.shape), 80 + i).cuda()).sum() for i, t in enumerate(outs) if t.numel()).backward()
+            rd._DEBUG_SINK = None
+            res[fm] = dict(outs=[cpu(t) for t in outs], sv={k: cpu(v) for k, v in sv.items()
+                                                              if torch.is_tensor(v) and v.dtype == torch.float32},
+                           sink={k: cpu(v) for k, v in sink.items() if v is not None},
+                           grads=[cpu(t.grad) if t.grad is not None else None for t in leaves])
+    finally:
+        rd.FIELD_MODE, rd._DEBUG_SINK = old, None
+    a, b = res["f32"], res["f16x3"]
+    bad = {}
+
+    def chk(tag, x, y, tol):
+        if x is None or x.numel() == 0:
+            return
+        e = rel_err(y.reshape(-1), x.reshape(-1))
+        if not e < tol:
+            bad[tag] = float(f"{e:.3g}")
+
+    for k in ("x0", "h", "e", "g1", "g2", "r1", "sigma_s", "sigma_c", "rgb"):
+        if k in a["sv"]:
+            chk(k, a["sv"][k], b["sv"][k], 2e-6)
+    for i, (x, y) in enumerate(zip(a["outs"], b["outs"])):
+        chk(f"out{i}", x, y, 2e-6)
+    # A pre-activation within rounding of zero can come out on different sides of the ReLU in the two arithmetics;
+    # the gradient of that sample then legitimately differs.  Compare the per-sample gradients on all other samples.
+    M = R * S
+    flipped = torch.zeros(M, dtype=torch.bool)
+    for k in ("h", "g1", "g2", "r1"):
+        if k in a["sv"]:
+            f = ((a["sv"][k] > 0) != (b["sv"][k] > 0)).reshape(-1, M, a["sv"][k].shape[-1]).any(-1).any(0)
+            flipped |= f
+    assert int(flipped.sum()) <= 2, f"{int(flipped.sum())} samples changed ReLU side"
+    keep = (~flipped).float()
+    for k in a["sink"]:
+        x, y = a["sink"][k], b["sink"][k]
+        w = keep.reshape(M, *([1] * (x.dim() - 1))) if x.shape[0] == M else keep.reshape(1, M, 1)
+        chk("bwd_" + k, x * w, y * w, 2e-5)
+    if not flipped.any():
+        for i, (x, y) in enumerate(zip(a["grads"], b["grads"])):
+            chk(f"grad{i}", x, y, 2e-5)
+    assert not bad, bad
+
+
+def test_frag16_layout_and_exponents(hip):
+    """upnerf_frag16: hi + lo reproduces every matrix element to 2^-22 of the matrix maximum, at the documented byte
+    offsets, with exponents that put the maximum in [2^13, 2^14)."""
+    from upnerf_amd.packing import NerfPacker
+    pk = NerfPacker(256, 8, [4], 63, 27, 384, 48, 16)
+    L = pk.L
+    P = (gen((L.total,), 61) * torch.logspace(-2, 1, L.total)).cuda()
+    P16, PT16, wexp = pk.frag16_hip(P)
+    wexp = cpu(wexp)
+    Pc = cpu(P)
+
+    def unpack(buf, off, n, kp):
+        raw = cpu(buf)[off:off + n * kp].view(torch.float16).view(n // 32, kp // 16, 2, 2, 32, 8)
+        # [ntile][t][plane][khalf][n%32][k%8] -> [plane][n][k]
+        return raw.permute(2, 0, 4, 1, 3, 5).reshape(2, n, kp).float()
+
+    W, W2 = 256, 128
+    checks = [(P16, L.w[0], W, 64, Pc[L.w[0]:L.w[0] + W * 64].view(W, 64), 0),
+              (P16, L.w[4], W, 320, Pc[L.w[4]:L.w[4] + W * 320].view(W, 320), 4),
+              (P16, L.wr1, W2, 336, Pc[L.wr1:L.wr1 + W2 * 336].view(W2, 336), pk.EXP_R1),
+              (PT16, L.t_we, W, W, Pc[L.we:L.we + W * W].view(W, W).t(), pk.EXP_FINAL),
+              (PT16, L.t_skipx, 64, W, Pc[L.w[4]:L.w[4] + W * 320].view(W, 320)[:, :64].t(), 4),
+              (PT16, L.t_head, W, W, torch.cat([Pc[L.wr1:L.wr1 + W2 * 336].view(W2, 336)[:, :W].t(),
+                                               Pc[L.wc1:L.wc1 + W2 * 272].view(W2, 272)[:, :W].t()], 1), pk.EXP_HEAD_T)]
+    for buf, off, n, kp, ref, eid in checks:
+        hl = unpack(buf, off, n, kp)
+        e = int(wexp[eid])
+        got = (hl[0] + hl[1]) * 2.0 ** (-e)
+        assert (got - ref).abs().max() <= ref.abs().max() * 2.0 ** -21, (off, eid)
+        assert hl[0].abs().max() < 2 ** 14.01
+    for eid, (off, n, kp) in {0: (L.w[0], W, 64), pk.EXP_FINAL: (L.we, W, W), pk.EXP_C2: (L.wc2, W2, W2)}.items():
+        mx = float(Pc[off:off + n * kp].abs().max())
+        assert 2 ** 13 <= mx * 2.0 ** int(wexp[eid]) < 2 ** 14
 
 
 # ------------------------------------------------------------------------------------------ parameter re-layout

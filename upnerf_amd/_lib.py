@@ -34,7 +34,8 @@ class FieldFwdArgs(C.Structure):
                 ("rays_o", _fp), ("rays_d", _fp), ("z", _fp), ("c_rows", _fp), ("aux", _fp),
                 ("wk_xyz", C.c_float * 10), ("P", _fp),
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
-                ("x0", _fp), ("h", _fp), ("hmask", _fp), ("amax", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp)]
+                ("x0", _fp), ("h", _fp), ("hmask", _fp), ("amax", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp),
+                ("P16", _fp), ("wexp", _fp)]
 
 
 class CompositeFwdArgs(C.Structure):
@@ -64,7 +65,8 @@ class FieldBwdArgs(C.Structure):
                 ("w_feat_s", _fp), ("w_cj", _fp), ("g_E_s", _fp), ("g_G_c", _fp),
                 ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp), ("hmask", _fp), ("gmax", _fp),
                 ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
-                ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp)]
+                ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp),
+                ("PT16", _fp), ("wexp", _fp)]
 
 
 class LossArgs(C.Structure):
@@ -88,6 +90,10 @@ class FragDesc(C.Structure):
                 ("cols", C.c_int32), ("dst_off", C.c_int32), ("dst_kp", C.c_int32), ("dst_k0", C.c_int32)]
 
 
+class Frag16Desc(C.Structure):
+    _fields_ = FragDesc._fields_ + [("exp_id", C.c_int32)]
+
+
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 _SIGNATURES = {
     "upnerf_abi_version": [],
@@ -101,6 +107,9 @@ _SIGNATURES = {
     "upnerf_composite_fwd": [C.POINTER(CompositeFwdArgs), _p],
     "upnerf_composite_bwd": [C.POINTER(CompositeBwdArgs), _p],
     "upnerf_field_bwd": [C.POINTER(Layout), C.POINTER(FieldBwdArgs), _p],
+    "upnerf_field_fwd_f16x3": [C.POINTER(Layout), C.POINTER(FieldFwdArgs), _p],
+    "upnerf_field_bwd_f16x3": [C.POINTER(Layout), C.POINTER(FieldBwdArgs), _p],
+    "upnerf_frag16": [_p, _p, _p, C.POINTER(Frag16Desc), _i, C.POINTER(Frag16Desc), _i, _p, _p, _p],
     "upnerf_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],

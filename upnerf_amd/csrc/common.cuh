@@ -327,6 +327,37 @@ __device__ __forceinline__ void tile_rank1_store(float* Hs, int ldw, int ncols, 
   wave_track_max(lmax, maxslot, tid & 63);
 }
 
+#define PI_F 3.14159274101257324f  // float32(torch.pi)
+
+// o + d*z with two roundings (the reference's `rays_o + rays_d * z` is two ATen ops, rendering.py:251); the
+// __f*_rn intrinsics are plain operators in HIP and would be contracted into one fma.
+__device__ __forceinline__ float mul_then_add(float o, float d, float z) {
+#pragma clang fp contract(off)
+  const float p = d * z;
+  return o + p;
+}
+
+// sin and cos of an fp32 angle (up to ~1e5 rad: 2^9 pi x) to within 1 ulp of fp32: Cody-Waite reduction by pi/2 and
+// the fdlibm kernel polynomials, all in fp64 -- a fraction of the instructions of the generic sincosf (whose large-
+// argument path is a Payne-Hanek reduction); the result is the correctly rounded fp32 value in 99.998 % of cases.
+__device__ __forceinline__ void sincos_f32_via_f64(float arg, float& sn, float& cs) {
+  const double x = (double)arg;
+  const double q = rint(x * 0.63661977236758134308);
+  double r = fma(-q, 1.57079632679489655800e+00, x);
+  r = fma(-q, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double s = r + r * z * ps;
+  const double c = 1.0 - 0.5 * z + z * z * pc;
+  const int n = (int)(long long)q & 3;
+  const double so = (n & 1) ? c : s, co = (n & 1) ? s : c;
+  sn = (float)((n & 2) ? -so : so);
+  cs = (float)(((n + 1) & 2) ? -co : co);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);

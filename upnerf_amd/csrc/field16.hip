@@ -1,0 +1,644 @@
+// Fused NeRF field on the f16 matrix cores with the 3-term hi/lo split (csrc/common16.cuh): same stages, same
+// outputs and the same wave tiling as csrc/field.hip, fp32-level accuracy, ~5x less matrix-pipe time per contraction.
+//
+// Reference behaviour: models/nerf.py:80-124 (NeRF.forward), 126-147 (positional_encoding), evaluated by
+// models/rendering.py:102-122.  What differs from field.hip:
+//   * the 64-sample tile lives in LDS as two fp16 planes (hi, lo) carrying  value * 2^e  with one exponent per tile
+//     and stage, picked from the tile's running maximum (wave max -> 4 floats in LDS -> the barrier every epilogue
+//     already has);
+//   * weights arrive pre-split (upnerf_frag16) with one exponent per matrix (table wexp); the epilogue folds both
+//     exponents into the fma that adds the bias:  v = fma(acc, 2^-(e_tile + e_w), bias);
+//   * every tensor kept for the backward pass is written from the planes (hi + lo is the fp32 value to ~2^-24), i.e.
+//     the weight-gradient kernels see exactly the operand the forward contraction used.
+#include "common16.cuh"
+
+#define F16_TILE 64
+
+namespace {
+
+__device__ __forceinline__ float pow2f(int n) { return ldexpf(1.0f, n); }
+
+// LDS planes -> row-major fp32 global tensor, coalesced (8 columns = 32 bytes per thread, whole rows per wave).
+template <int W, int TILE>
+__device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, int ncols, float unscale,
+                                             float* __restrict__ dst, int ldg, int m0, int M, int tid) {
+  const int gpr = ncols >> 3;
+  for (int idx = tid; idx < TILE * gpr; idx += NTHREADS) {
+    const int row = idx / gpr, g = idx - row * gpr;
+    if (m0 + row < M) {
+      const int o = poff<W>(row, c0 + 8 * g);
+      const h8 vh = *(const h8*)(Ph + o), vl = *(const h8*)(Pl + o);
+      f32x4 o0, o1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o0[j] = ((float)vh[j] + (float)vl[j]) * unscale;
+        o1[j] = ((float)vh[4 + j] + (float)vl[4 + j]) * unscale;
+      }
+      float* p = &dst[(size_t)(m0 + row) * ldg + 8 * g];
+      *(f32x4*)p = o0;
+      *(f32x4*)(p + 4) = o1;
+    }
+  }
+}
+
+// v = relu(fma(acc, un, bias[col])) with the sign bits packed in the accumulator layout (common.cuh)
+template <int MT, int NT>
+__device__ __forceinline__ unsigned long long acc_fma_relu_pack(f32x16 (&acc)[MT][NT], float un,
+                                                                const float* __restrict__ bias, int n0, int lane) {
+  static_assert(MT * NT * 16 <= 64, "mask word is 64 bits");
+  const int i = lane & 31;
+  unsigned int lo = 0u, hi = 0u;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float b = bias[n0 + 32 * nt + i];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int e = (mt * NT + nt) * 16 + r;
+        const float v = fmaxf(fmaf(acc[mt][nt][r], un, b), 0.0f);
+        acc[mt][nt][r] = v;
+        if (e < 32) lo |= (v > 0.0f) ? (1u << e) : 0u;
+        else hi |= (v > 0.0f) ? (1u << (e - 32)) : 0u;
+      }
+    }
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void acc_scale(f32x16 (&acc)[MT][NT], float un) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= un;
+}
+
+__device__ __forceinline__ float wave_max(float m) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  return m;
+}
+
+__device__ __forceinline__ void track(float* __restrict__ slot, float mx, int tid) {
+  if (slot && tid == 0) atomicMax((unsigned int*)slot, __float_as_uint(mx));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int TILE>
+__global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
+  constexpr int W = 256, W2 = 128;
+  constexpr int TPR = NTHREADS / TILE;
+  __shared__ __attribute__((aligned(16))) char planes[2 * TILE * W * 2];
+  __shared__ float smax[4], smaxb[4];
+  __shared__ float xyz_s[TILE * 3];
+  char* Ph = planes;
+  char* Pl = planes + TILE * W * 2;
+  using TW = WaveTile<W, TILE>;
+  using TH = WaveTile<W2, TILE>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE;
+  const float* __restrict__ P = a.P;
+  const char* __restrict__ P16 = (const char*)a.P16;
+  const int* __restrict__ wexp = a.wexp;
+  const int n0 = TW::n0(wave), row0 = TW::row0(wave);
+  const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
+  const int D = L.D;
+
+  // ---- sample positions (rendering.py:251 / 308) and the maxima that bound the side inputs of this tile
+  {
+    float xm = 0.0f;
+    if (tid < TILE) {
+      const int m = m0 + tid;
+      float x = 0.f, y = 0.f, zc = 0.f;
+      if (m < M) {
+        const int r = m / S;
+        const float zz = a.z[m];
+        x = mul_then_add(a.rays_o[3 * r + 0], a.rays_d[3 * r + 0], zz);
+        y = mul_then_add(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], zz);
+        zc = mul_then_add(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], zz);
+      }
+      xyz_s[tid * 3 + 0] = x;
+      xyz_s[tid * 3 + 1] = y;
+      xyz_s[tid * 3 + 2] = zc;
+      xm = fmaxf(fmaxf(fabsf(x), fabsf(y)), fmaxf(fabsf(zc), 1.0f));  // |sin|, |cos| <= 1
+    }
+    float sm = 0.0f;
+    const int mlast = (m0 + TILE < M ? m0 + TILE : M) - 1;
+    const int ray0 = m0 / S, nr = mlast / S - ray0 + 1;
+    if (a.use_rgb)
+      for (int idx = tid; idx < nr * UPNERF_AUXK; idx += NTHREADS) sm = fmaxf(sm, fabsf(a.aux[(size_t)ray0 * UPNERF_AUXK + idx]));
+    if (a.use_cand)
+      for (int idx = tid; idx < nr * UPNERF_CK; idx += NTHREADS) sm = fmaxf(sm, fabsf(a.c_rows[(size_t)ray0 * UPNERF_CK + idx]));
+    xm = wave_max(xm);
+    sm = wave_max(sm);
+    if (lane == 0) {
+      smax[wave] = xm;
+      smaxb[wave] = sm;
+    }
+  }
+  __syncthreads();
+  const float x0max = wg_max4(smax), sidemax = wg_max4(smaxb);
+  track(a.amax ? a.amax + D + 4 : nullptr, x0max, tid);
+  int ecur = scale_exp(x0max);
+  // ---- BARF-masked encoding (nerf.py:126-147) straight into the planes
+  {
+    const float sc = pow2f(ecur);
+    auto put = [&](int row, int col, float v) {
+      _Float16 h, l;
+      split16(v * sc, h, l);
+      const int o = poff<W>(row, col);
+      *(_Float16*)(Ph + o) = h;
+      *(_Float16*)(Pl + o) = l;
+    };
+    for (int it = tid; it < TILE * 3; it += NTHREADS) {
+      const int row = it / 3, n = it - row * 3;
+      const float xv = xyz_s[row * 3 + n];
+      put(row, n, xv);
+      if (n == 0) put(row, 63, 0.0f);
+#pragma unroll 1
+      for (int k = 0; k < 10; ++k) {
+        const float arg = xv * ldexpf(PI_F, k);
+        float sv, cv;
+        sincos_f32_via_f64(arg, sv, cv);
+        put(row, 3 + 20 * n + k, sv * a.wk_xyz[k]);
+        put(row, 3 + 20 * n + 10 + k, cv * a.wk_xyz[k]);
+      }
+    }
+  }
+  __syncthreads();
+  tile_store16<W, TILE>(Ph, Pl, 0, UPNERF_X0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
+
+  // ---- trunk (nerf.py:84-87)
+  for (int l = 0; l < D; ++l) {
+    f32x16 acc[TW::MT][TW::NT];
+    acc_zero(acc);
+    if (l == 0) {
+      mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[0], UPNERF_X0 / 16, n0, 0, UPNERF_X0, lane);
+    } else if (l == L.skip) {
+      const float* ap[TW::MT];
+#pragma unroll
+      for (int mt = 0; mt < TW::MT; ++mt) {
+        int m = m0 + row0 + 32 * mt + li;
+        m = m < M ? m : M - 1;
+        ap[mt] = a.x0 + (size_t)m * UPNERF_X0 + 8 * hh;
+      }
+      mma16_glb(acc, ap, pow2f(ecur), P16 + 4 * (size_t)L.w[l], (UPNERF_X0 + W) / 16, n0, 0, UPNERF_X0, lane);
+      mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[l], (UPNERF_X0 + W) / 16, n0, UPNERF_X0, W, lane);
+    } else {
+      mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[l], W / 16, n0, 0, W, lane);
+    }
+    const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wexp[l])), P + L.b[l], n0, lane);
+    const float wm = acc_absmax(acc);
+    if (lane == 0) smax[wave] = wm;
+    ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
+    __syncthreads();
+    float mx = wg_max4(smax);
+    track(a.amax ? a.amax + l : nullptr, mx, tid);
+    if (l + 1 == L.skip) mx = fmaxf(mx, x0max);  // the skip layer feeds x0 rows through the same accumulators
+    ecur = scale_exp(mx);
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.h + (size_t)l * M * W, W, m0, M, tid);
+  }
+
+  const int prow = tid / TPR, phalf = tid % TPR, pm = m0 + prow;
+  // ---- shared density head (nerf.py:89): softplus(w . h + b)
+  {
+    const float pre = rowdot16<W, TPR>(Ph, Pl, prow, phalf, 0, W, P + L.wsig, pow2f(-ecur)) + P[L.bsig];
+    if (phalf == 0 && pm < M) a.sigma_s[pm] = softplus_f(pre);
+  }
+  // ---- xyz_encoding_final (nerf.py:93), no activation
+  {
+    f32x16 acc[TW::MT][TW::NT];
+    acc_zero(acc);
+    mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, W, lane);
+    const float* __restrict__ bias = P + L.be;
+    const float un = pow2f(-(ecur + wexp[8]));
+    acc_map(acc, row0, n0, lane, [&](float v, int, int col) { return fmaf(v, un, bias[col]); });
+    const float wm = acc_absmax(acc);
+    if (lane == 0) smax[wave] = wm;
+    __syncthreads();
+    const float mx = wg_max4(smax);
+    track(a.amax ? a.amax + D : nullptr, mx, tid);
+    ecur = scale_exp(fmaxf(mx, sidemax));  // the heads feed per-ray rows through the same accumulators
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.e, W, m0, M, tid);
+  }
+  if (!a.use_rgb && !a.use_cand) return;
+
+  // ---- first layer of the colour head (folded, nerf.py:95+102-109) and of the candidate head (nerf.py:97-98)
+  f32x16 accr[TH::MT][TH::NT], accc[TH::MT][TH::NT];
+  int rayrow[TH::MT];
+#pragma unroll
+  for (int mt = 0; mt < TH::MT; ++mt) {
+    int m = m0 + hrow0 + 32 * mt + li;
+    m = m < M ? m : M - 1;
+    rayrow[mt] = m / S;
+  }
+  float mr = 0.0f, mc = 0.0f;
+  if (a.use_rgb) {
+    acc_zero(accr);
+    mma16_lds<W>(accr, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, 0, W, lane);
+    const float* ap[TH::MT];
+#pragma unroll
+    for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.aux + (size_t)rayrow[mt] * UPNERF_AUXK + 8 * hh;
+    mma16_glb(accr, ap, pow2f(ecur), P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, W, UPNERF_AUXK, lane);
+    const float* __restrict__ bias = P + L.br1;
+    const float un = pow2f(-(ecur + wexp[11]));
+    acc_map(accr, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(fmaf(v, un, bias[col]), 0.0f); });
+    mr = acc_absmax(accr);
+  }
+  if (a.use_cand) {
+    acc_zero(accc);
+    mma16_lds<W>(accc, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, 0, W, lane);
+    const float* ap[TH::MT];
+#pragma unroll
+    for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.c_rows + (size_t)rayrow[mt] * UPNERF_CK + 8 * hh;
+    mma16_glb(accc, ap, pow2f(ecur), P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, UPNERF_CK, lane);
+    const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), P + L.bc1, hn0, lane);
+    ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
+    mc = acc_absmax(accc);
+  }
+  if (lane == 0) {
+    smax[wave] = mr;
+    smaxb[wave] = mc;
+  }
+  __syncthreads();
+  {
+    const float mxr = wg_max4(smax), mxc = wg_max4(smaxb);
+    track(a.amax && a.use_rgb ? a.amax + D + 3 : nullptr, mxr, tid);
+    track(a.amax && a.use_cand ? a.amax + D + 1 : nullptr, mxc, tid);
+    ecur = scale_exp(fmaxf(mxr, mxc));
+  }
+  if (a.use_rgb) acc_to_planes<W>(accr, Ph, Pl, hrow0, hn0, 0, pow2f(ecur), lane);
+  if (a.use_cand) acc_to_planes<W>(accc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
+  __syncthreads();
+  if (a.use_rgb) {
+    tile_store16<W, TILE>(Ph, Pl, 0, W2, pow2f(-ecur), a.r1, W2, m0, M, tid);
+    // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float pre = rowdot16<W, TPR>(Ph, Pl, prow, phalf, 0, W2, P + L.wr2 + c * W2, pow2f(-ecur)) + P[L.br2 + c];
+      if (phalf == 0 && pm < M) a.rgb[(size_t)pm * 3 + c] = sigmoid_f(pre);
+    }
+  }
+  if (a.use_cand) {
+    tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
+    f32x16 acc[TH::MT][TH::NT];
+    acc_zero(acc);
+    mma16_lds<W>(acc, Ph, Pl, hrow0, W2, P16 + 4 * (size_t)L.wc2, W2 / 16, hn0, 0, W2, lane);
+    const float* __restrict__ bias = P + L.bc2;
+    const float un = pow2f(-(ecur + wexp[10]));
+    acc_map(acc, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(fmaf(v, un, bias[col]), 0.0f); });
+    const float wm = acc_absmax(acc);
+    if (lane == 0) smax[wave] = wm;
+    __syncthreads();
+    ecur = scale_exp(wg_max4(smax));
+    acc_to_planes<W>(acc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
+    __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
+    const float pre = rowdot16<W, TPR>(Ph, Pl, prow, phalf, W2, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
+    if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward data-gradient chain (autograd of nerf.py:80-124), stage for stage as field.hip:field_bwd_kernel.
+template <int TILE>
+__global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
+  constexpr int W = 256, W2 = 128;
+  constexpr int MAXRAYS = 3;            // rays a 64-sample tile can touch when S >= 32
+  constexpr int GPR = W2 / 4;           // 16-byte groups per half-width row
+  constexpr int EPT = TILE * GPR / NTHREADS;  // groups per thread in the elementwise stages
+  __shared__ __attribute__((aligned(16))) char planes[2 * TILE * W * 2];
+  __shared__ float smax[4], smaxb[4];
+  __shared__ float pre_s[TILE];
+  __shared__ __attribute__((aligned(16))) float wfj[MAXRAYS][TILE];  // w_feat[row] on the row's ray slot, else 0
+  char* Ph = planes;
+  char* Pl = planes + TILE * W * 2;
+  using TW = WaveTile<W, TILE>;
+  using TH = WaveTile<W2, TILE>;
+  using TX = WaveTile<UPNERF_X0, TILE>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE, D = L.D;
+  const float* __restrict__ P = a.P;
+  const char* __restrict__ PT16 = (const char*)a.PT16;
+  const int* __restrict__ wexp = a.wexp;
+  const int n0 = TW::n0(wave), row0 = TW::row0(wave);
+  const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
+  const int xn0 = TX::n0(wave), xrow0 = TX::row0(wave);
+  const int ray0 = m0 / S;
+  const unsigned long long* __restrict__ hm = (const unsigned long long*)a.hmask + (size_t)blockIdx.x * NTHREADS + tid;
+  const size_t hm_stride = (size_t)gridDim.x * NTHREADS;
+
+  // softplus'(x) = 1 - exp(-softplus(x)); per-row feature weight on its ray slot
+  if (tid < TILE) {
+    const int m = m0 + tid;
+    float v = 0.0f, wf = 0.0f;
+    int j = 0;
+    if (m < M) {
+      v = a.d_sigma_s[m] * (1.0f - expf(-a.sigma_s[m]));
+      a.dpre_sig_s[m] = v;
+      if (a.g_E_s) wf = a.w_feat_s[m];
+      j = m / S - ray0;
+    }
+    pre_s[tid] = v;
+#pragma unroll
+    for (int q = 0; q < MAXRAYS; ++q) wfj[q][tid] = (q == j) ? wf : 0.0f;
+  }
+
+  int erg = 0;  // exponent of the [gz_r1 | gz_g1] planes
+  {
+    f32x16 accg[TH::MT][TH::NT];
+    acc_zero(accg);
+    float mg1 = 0.0f;
+    if (a.use_cand) {
+      // d g2 = w_csig * dpre_c + w_cj * g_G_c[ray]   (candidate_sigma / feat_candidate_layer, nerf.py:99-100)
+      f32x4 vals[EPT];
+      float lmax = 0.0f;
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        const int idx = tid + q * NTHREADS;
+        const int row = idx / GPR, g = idx - row * GPR, m = m0 + row;
+        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+          const float dp = a.d_sigma_c[m] * (1.0f - expf(-a.sigma_c[m]));
+          if (g == 0) a.dpre_sig_c[m] = dp;
+          const f32x4 gv = *(const f32x4*)&a.g2[(size_t)m * W2 + 4 * g];
+          const f32x4 wv = *(const f32x4*)&P[L.wcsig + 4 * g];
+          f32x4 gg = {0.f, 0.f, 0.f, 0.f};
+          float cw = 0.0f;
+          if (a.g_G_c) {
+            gg = *(const f32x4*)&a.g_G_c[(size_t)(m / S) * W2 + 4 * g];
+            cw = a.w_cj[m];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) out[c] = gv[c] > 0.f ? wv[c] * dp + cw * gg[c] : 0.f;
+          *(f32x4*)&a.gz_g2[(size_t)m * W2 + 4 * g] = out;
+        }
+        vals[q] = out;
+        lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
+      }
+      lmax = wave_max(lmax);
+      if (lane == 0) smax[wave] = lmax;
+      __syncthreads();
+      const float mx = wg_max4(smax);
+      track(a.gmax ? a.gmax + D + 2 : nullptr, mx, tid);
+      const int eg2 = scale_exp(mx);
+      const float sc = pow2f(eg2);
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        const int idx = tid + q * NTHREADS;
+        const int row = idx / GPR, g = idx - row * GPR;
+        h4 vh, vl;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          _Float16 h, l;
+          split16(vals[q][c] * sc, h, l);
+          vh[c] = h;
+          vl[c] = l;
+        }
+        const int o = poff<W>(row, W2 + 4 * g);
+        *(h4*)(Ph + o) = vh;
+        *(h4*)(Pl + o) = vl;
+      }
+      __syncthreads();
+      mma16_lds<W>(accg, Ph, Pl, hrow0, W2, PT16 + 4 * (size_t)L.t_wc2, W2 / 16, hn0, 0, W2, lane);
+      acc_scale(accg, pow2f(-(eg2 + wexp[10])));
+      acc_apply_mask(accg, hm[(size_t)D * hm_stride]);
+      mg1 = acc_absmax(accg);
+    }
+    f32x4 valr[EPT];
+    float mr1 = 0.0f;
+    if (a.use_rgb) {
+      // d r1 = W_r2^T (d rgb * rgb (1-rgb))   (rgb_share_layer.2 + sigmoid)
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        const int idx = tid + q * NTHREADS;
+        const int row = idx / GPR, g = idx - row * GPR, m = m0 + row;
+        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+          float dp[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float y = a.rgb[(size_t)m * 3 + c];
+            dp[c] = a.d_rgb[(size_t)m * 3 + c] * (y * (1.0f - y));
+            if (g == 0) a.dpre_rgb[(size_t)m * 4 + c] = dp[c];
+          }
+          if (g == 0) a.dpre_rgb[(size_t)m * 4 + 3] = 0.0f;
+          const f32x4 rv = *(const f32x4*)&a.r1[(size_t)m * W2 + 4 * g];
+          f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const f32x4 wv = *(const f32x4*)&P[L.wr2 + c * W2 + 4 * g];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc4[u] += wv[u] * dp[c];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) out[u] = rv[u] > 0.f ? acc4[u] : 0.f;
+          *(f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * g] = out;
+        }
+        valr[q] = out;
+        mr1 = fmaxf(mr1, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
+      }
+      mr1 = wave_max(mr1);
+    }
+    if (lane == 0) {
+      smax[wave] = mg1;
+      smaxb[wave] = mr1;
+    }
+    __syncthreads();  // also: every wave is done reading the gz_g2 planes
+    {
+      const float mxg = wg_max4(smax), mxr = wg_max4(smaxb);
+      track(a.gmax && a.use_cand ? a.gmax + D + 1 : nullptr, mxg, tid);
+      track(a.gmax && a.use_rgb ? a.gmax + D + 3 : nullptr, mxr, tid);
+      erg = scale_exp(fmaxf(mxg, mxr));
+    }
+    const float sc = pow2f(erg);
+    if (a.use_cand) acc_to_planes<W>(accg, Ph, Pl, hrow0, hn0, W2, sc, lane);
+    if (a.use_rgb) {
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        const int idx = tid + q * NTHREADS;
+        const int row = idx / GPR, g = idx - row * GPR;
+        h4 vh, vl;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          _Float16 h, l;
+          split16(valr[q][c] * sc, h, l);
+          vh[c] = h;
+          vl[c] = l;
+        }
+        const int o = poff<W>(row, 4 * g);
+        *(h4*)(Ph + o) = vh;
+        *(h4*)(Pl + o) = vl;
+      }
+    }
+    __syncthreads();
+    if (a.use_cand) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
+  }
+
+  int ecur;
+  // ---- d e = [gz_r1 | gz_g1] . [W_fold | W_c1e] + w_feat * g_E_s[ray]   (e has no activation)
+  {
+    f32x16 acc[TW::MT][TW::NT];
+    acc_zero(acc);
+    const int ks = a.use_rgb ? 0 : W2;
+    const int kl = (a.use_rgb ? W2 : 0) + (a.use_cand ? W2 : 0);
+    if (kl > 0) mma16_lds<W>(acc, Ph, Pl, row0, ks, PT16 + 4 * (size_t)L.t_head, W / 16, n0, ks, kl, lane);
+    acc_scale(acc, pow2f(-(erg + wexp[12])));
+    if (a.g_E_s) {
+      const int mlast = (m0 + TILE < M ? m0 + TILE : M) - 1;
+      const int nr = mlast / S - ray0 + 1;
+#pragma unroll
+      for (int j = 0; j < MAXRAYS; ++j) {
+        if (j < nr) {
+          float gv[TW::NT];
+#pragma unroll
+          for (int nt = 0; nt < TW::NT; ++nt) gv[nt] = a.g_E_s[(size_t)(ray0 + j) * W + n0 + 32 * nt + li];
+#pragma unroll
+          for (int mt = 0; mt < TW::MT; ++mt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              const f32x4 wv = *(const f32x4*)&wfj[j][row0 + 32 * mt + 8 * rq + 4 * hh];
+#pragma unroll
+              for (int nt = 0; nt < TW::NT; ++nt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[mt][nt][4 * rq + u] = fmaf(wv[u], gv[nt], acc[mt][nt][4 * rq + u]);
+            }
+        }
+      }
+    }
+    const float wm = acc_absmax(acc);
+    if (lane == 0) smax[wave] = wm;
+    __syncthreads();
+    const float mx = wg_max4(smax);
+    track(a.gmax ? a.gmax + D : nullptr, mx, tid);
+    ecur = scale_exp(mx);
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_e, W, m0, M, tid);
+  }
+  // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu (sign bits from the forward, in this lane's layout)
+  {
+    const unsigned long long bits = hm[(size_t)(D - 1) * hm_stride];
+    f32x16 acc[TW::MT][TW::NT];
+    acc_zero(acc);
+    mma16_lds<W>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_we, W / 16, n0, 0, W, lane);
+    const float* __restrict__ ws = P + L.wsig;
+    const float un = pow2f(-(ecur + wexp[8]));
+    acc_map(acc, row0, n0, lane, [&](float v, int row, int col) { return fmaf(v, un, ws[col] * pre_s[row]); });
+    acc_apply_mask(acc, bits);
+    const float wm = acc_absmax(acc);
+    if (lane == 0) smax[wave] = wm;
+    __syncthreads();
+    const float mx = wg_max4(smax);
+    track(a.gmax ? a.gmax + (D - 1) : nullptr, mx, tid);
+    ecur = scale_exp(mx);
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, tid);
+  }
+  // ---- trunk, last layer to first
+  f32x16 accx[TX::MT][TX::NT];
+  acc_zero(accx);
+  for (int l = D - 1; l >= 1; --l) {
+    const unsigned long long bits = hm[(size_t)(l - 1) * hm_stride];  // arrives under the contraction below
+    if (a.need_dxyz && l == L.skip) {
+      mma16_lds<W>(accx, Ph, Pl, xrow0, 0, PT16 + 4 * (size_t)L.t_skipx, W / 16, xn0, 0, W, lane);
+      acc_scale(accx, pow2f(-(ecur + wexp[l])));  // natural units: the layer-0 term arrives at another exponent
+    }
+    f32x16 acc[TW::MT][TW::NT];
+    acc_zero(acc);
+    mma16_lds<W>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_w[l], W / 16, n0, 0, W, lane);
+    acc_scale(acc, pow2f(-(ecur + wexp[l])));
+    acc_apply_mask(acc, bits);
+    const float wm = acc_absmax(acc);
+    if (lane == 0) smax[wave] = wm;
+    __syncthreads();
+    const float mx = wg_max4(smax);
+    track(a.gmax ? a.gmax + (l - 1) : nullptr, mx, tid);
+    ecur = scale_exp(mx);
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, tid);
+  }
+  if (!a.need_dxyz) return;
+  // ---- d x0 (first layer + skip) -> d xyz through the encoding
+  {
+    f32x16 acc0[TX::MT][TX::NT];
+    acc_zero(acc0);
+    mma16_lds<W>(acc0, Ph, Pl, xrow0, 0, PT16 + 4 * (size_t)L.t_w[0], W / 16, xn0, 0, W, lane);
+    const float un = pow2f(-(ecur + wexp[0]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[0][0][r] = fmaf(acc0[0][0][r], un, accx[0][0][r]);
+  }
+  static_assert(TX::MT == 1 && TX::NT == 1, "d x0 tiling");
+  __syncthreads();
+  float* Gs = (float*)planes;  // fp32 [TILE][64] scratch over the (now dead) hi plane
+  acc_to_lds(accx, Gs, UPNERF_X0, xrow0, xn0, 0, lane);
+  __syncthreads();
+  for (int it = tid; it < TILE * 3; it += NTHREADS) {
+    const int row = it / 3, n = it - row * 3, m = m0 + row;
+    if (m >= M) continue;
+    const float* __restrict__ x0 = a.x0 + (size_t)m * UPNERF_X0;
+    float g = Gs[swz(row, n, UPNERF_X0)];
+#pragma unroll 2
+    for (int k = 0; k < 10; ++k) {
+      const float f = ldexpf(PI_F, k);
+      g += f * (x0[3 + 20 * n + 10 + k] * Gs[swz(row, 3 + 20 * n + k, UPNERF_X0)] -
+                x0[3 + 20 * n + k] * Gs[swz(row, 3 + 20 * n + 10 + k, UPNERF_X0)]);
+    }
+    a.dxyz[(size_t)m * 3 + n] = g;
+  }
+}
+
+int check_layout16(const upnerf_layout* L) {
+  if (!L) return UPNERF_EINVAL;
+  if (L->W != 256) return UPNERF_EUNSUP;
+  if (L->D < 1 || L->D > UPNERF_MAX_D) return UPNERF_EUNSUP;
+  if (L->skip >= L->D) return UPNERF_EINVAL;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream) {
+  int rc = check_layout16(L);
+  if (rc) return rc;
+  if (!a || a->R <= 0 || a->S <= 0 || !a->rays_o || !a->rays_d || !a->z || !a->P || !a->P16 || !a->wexp || !a->x0 ||
+      !a->h || !a->e || !a->sigma_s || !a->hmask)
+    return UPNERF_EINVAL;
+  if (a->use_cand && (!a->c_rows || !a->g1 || !a->g2 || !a->sigma_c)) return UPNERF_EINVAL;
+  if (a->use_rgb && (!a->aux || !a->r1 || !a->rgb)) return UPNERF_EINVAL;
+  const long long M = (long long)a->R * a->S;
+  if (M > 0x7fffffffLL) return UPNERF_EINVAL;
+  const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
+  hipLaunchKernelGGL((field16_fwd_kernel<F16_TILE>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, *L, *a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream) {
+  int rc = check_layout16(L);
+  if (rc) return rc;
+  if (!a || a->R <= 0 || a->S <= 0 || !a->P || !a->PT16 || !a->wexp || !a->d_sigma_s || !a->sigma_s || !a->gz_h ||
+      !a->gz_e || !a->dpre_sig_s || !a->hmask)
+    return UPNERF_EINVAL;
+  if (a->S < 32) return UPNERF_EUNSUP;  // at most 3 rays per 64-sample tile
+  if (a->use_cand && (!a->d_sigma_c || !a->sigma_c || !a->g2 || !a->gz_g1 || !a->gz_g2 || !a->dpre_sig_c))
+    return UPNERF_EINVAL;
+  if (a->use_cand && a->g_G_c && !a->w_cj) return UPNERF_EINVAL;
+  if (a->use_rgb && (!a->d_rgb || !a->rgb || !a->r1 || !a->gz_r1 || !a->dpre_rgb)) return UPNERF_EINVAL;
+  if (a->g_E_s && !a->w_feat_s) return UPNERF_EINVAL;
+  if (a->need_dxyz && (!a->dxyz || !a->x0)) return UPNERF_EINVAL;
+  const long long M = (long long)a->R * a->S;
+  if (M > 0x7fffffffLL) return UPNERF_EINVAL;
+  const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
+  hipLaunchKernelGGL((field16_bwd_kernel<F16_TILE>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, *L, *a);
+  return (int)hipGetLastError();
+}

@@ -329,6 +329,64 @@ __global__ void frag_copy_kernel(const float* __restrict__ src, float* __restric
   dst[q.dst_off + ((size_t)(r >> 5) * (q.dst_kp >> 3) + (k >> 3)) * 256 + ((((k >> 2) & 1) << 5) + (r & 31)) * 4 + (k & 3)] = v;
 }
 
+// ---- f16x3 weight re-layout (hi/lo fp16, fragment order, one power-of-two exponent per matrix id)
+struct Frag16Descs {
+  upnerf_frag16_desc d[UPNERF_MAX_FRAG_DESC];
+  int start[UPNERF_MAX_FRAG_DESC + 1];
+  int n;
+};
+__device__ __forceinline__ int frag16_exp(float mx) {
+  if (!(mx > 0.0f)) return 0;
+  int ex;
+  (void)frexpf(mx, &ex);
+  const int e = 14 - ex;
+  return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+__device__ __forceinline__ float frag16_src(const float* __restrict__ src, const upnerf_frag16_desc& q, int r, int c) {
+  return q.transpose ? src[q.src_off + (size_t)c * q.src_ld + r] : src[q.src_off + (size_t)r * q.src_ld + c];
+}
+__global__ void frag16_amax_kernel(const float* __restrict__ src, Frag16Descs D, float* __restrict__ amax) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  float v = 0.0f;
+  int id = 0;
+  if (idx < D.start[D.n]) {
+    int j = 0;
+    while (idx >= D.start[j + 1]) ++j;
+    const upnerf_frag16_desc q = D.d[j];
+    const int e = idx - D.start[j];
+    const int r = e / q.cols, c = e - r * q.cols;
+    v = fabsf(frag16_src(src, q, r, c));
+    id = q.exp_id;
+  }
+  // descriptors are long runs: a wave almost always holds a single id; fall back to per-lane atomics otherwise
+  const int id0 = __shfl(id, 0);
+  if (__all(id == id0)) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)&amax[id0], __float_as_uint(v));
+  } else if (idx < D.start[D.n]) {
+    atomicMax((unsigned int*)&amax[id], __float_as_uint(v));
+  }
+}
+__global__ void frag16_write_kernel(const float* __restrict__ src, char* __restrict__ dst, Frag16Descs D,
+                                    const float* __restrict__ amax, int* __restrict__ wexp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wexp && blockIdx.x == 0 && threadIdx.x < 16) wexp[threadIdx.x] = frag16_exp(amax[threadIdx.x]);
+  if (idx >= D.start[D.n]) return;
+  int j = 0;
+  while (idx >= D.start[j + 1]) ++j;
+  const upnerf_frag16_desc q = D.d[j];
+  const int e = idx - D.start[j];
+  const int r = e / q.cols, c = e - r * q.cols;
+  const float x = ldexpf(frag16_src(src, q, r, c), frag16_exp(amax[q.exp_id]));
+  const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+  const int k = q.dst_k0 + c;
+  const size_t base = (size_t)q.dst_off * 4 + ((size_t)(r >> 5) * (q.dst_kp >> 4) + (k >> 4)) * 2048 +
+                      ((((k >> 3) & 1) << 5) + (r & 31)) * 16 + (k & 7) * 2;
+  *(_Float16*)(dst + base) = hi;
+  *(_Float16*)(dst + base + 1024) = lo;
+}
+
 // ---- Adam (torch.optim.Adam, no weight decay / amsgrad): same op order as torch's single-tensor path
 __global__ void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
@@ -463,6 +521,41 @@ extern "C" int upnerf_frag_copy(const float* src, float* dst, const upnerf_frag_
   }
   const int total = D.start[ndesc];
   hipLaunchKernelGGL(frag_copy_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, D);
+  return (int)hipGetLastError();
+}
+
+static int frag16_build(const upnerf_frag16_desc* descs, int n, Frag16Descs* D) {
+  if (!descs || n <= 0 || n > UPNERF_MAX_FRAG_DESC) return UPNERF_EINVAL;
+  D->n = n;
+  D->start[0] = 0;
+  for (int j = 0; j < n; ++j) {
+    const upnerf_frag16_desc& q = descs[j];
+    if (q.rows <= 0 || q.cols <= 0 || (q.rows & 31) || (q.dst_kp & 15) || q.dst_k0 + q.cols > q.dst_kp || q.exp_id < 0 ||
+        q.exp_id >= 16)
+      return UPNERF_EINVAL;
+    D->d[j] = q;
+    D->start[j + 1] = D->start[j] + q.rows * q.cols;
+  }
+  return 0;
+}
+
+extern "C" int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, const upnerf_frag16_desc* fwd, int nfwd,
+                             const upnerf_frag16_desc* bwd, int nbwd, float* amax_scratch, int32_t* wexp, void* stream) {
+  if (!src || !dst_fwd || !dst_bwd || !amax_scratch || !wexp) return UPNERF_EINVAL;
+  Frag16Descs F, Bd;
+  int rc = frag16_build(fwd, nfwd, &F);
+  if (rc) return rc;
+  rc = frag16_build(bwd, nbwd, &Bd);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(amax_scratch, 0, 16 * sizeof(float), st));
+  // maxima over the forward matrices and over the transposed ones (ids that exist only there, e.g. the fused head)
+  hipLaunchKernelGGL(frag16_amax_kernel, dim3((F.start[nfwd] + 255) / 256), dim3(256), 0, st, src, F, amax_scratch);
+  hipLaunchKernelGGL(frag16_amax_kernel, dim3((Bd.start[nbwd] + 255) / 256), dim3(256), 0, st, src, Bd, amax_scratch);
+  hipLaunchKernelGGL(frag16_write_kernel, dim3((F.start[nfwd] + 255) / 256), dim3(256), 0, st, src, (char*)dst_fwd, F,
+                     amax_scratch, wexp);
+  hipLaunchKernelGGL(frag16_write_kernel, dim3((Bd.start[nbwd] + 255) / 256), dim3(256), 0, st, src, (char*)dst_bwd, Bd,
+                     amax_scratch, (int*)nullptr);
   return (int)hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ from typing import Dict
 import torch
 import torch.nn.functional as F
 
-from ._lib import AUXK, CK, MAX_D, X0, FragDesc, Layout
+from ._lib import AUXK, CK, MAX_D, X0, Frag16Desc, FragDesc, Layout
 
 
 def _align(n, a=4):
@@ -173,6 +173,41 @@ class NerfPacker:
         out = torch.zeros(self.L.t_total, device=P.device, dtype=P.dtype)
         check(lib.upnerf_frag_copy(ptr(P), ptr(out), bd, nb, stream()), "upnerf_frag_copy")
         return out
+
+    # ------------------------------------------------------------------ f16x3 re-layout (product path, W = 256)
+    EXP_FINAL, EXP_C1, EXP_C2, EXP_R1, EXP_HEAD_T = 8, 9, 10, 11, 12  # exponent ids; trunk layer l uses id l
+
+    def _descs16(self):
+        if getattr(self, "_desc16_cache", None) is None:
+            D = self.D
+            fd, nf, bd, nb = self._descs()
+            fid = list(range(D)) + [self.EXP_FINAL, self.EXP_C1, self.EXP_C2, self.EXP_R1]
+            bid = []
+            for l in range(D):
+                bid += [l, l] if l == self.skip else [l]
+            bid += [self.EXP_FINAL, self.EXP_HEAD_T, self.EXP_HEAD_T, self.EXP_C2]
+            assert len(fid) == nf and len(bid) == nb
+
+            def mk(src, n, ids):
+                fields = [f for f, _ in FragDesc._fields_]
+                return (Frag16Desc * n)(*[Frag16Desc(*[getattr(src[i], f) for f in fields], ids[i]) for i in range(n)])
+
+            self._desc16_cache = (mk(fd, nf, fid), nf, mk(bd, nb, bid), nb)
+        return self._desc16_cache
+
+    @torch.no_grad()
+    def frag16_hip(self, P: torch.Tensor):
+        """(P16, PT16, wexp): every matrix of P (and its transposed copy) as scaled fp16 (hi, lo) MFMA fragments with
+        one power-of-two exponent per matrix id -- what upnerf_field_fwd_f16x3 / upnerf_field_bwd_f16x3 read."""
+        from ._lib import check, lib, ptr, stream
+        fd, nf, bd, nb = self._descs16()
+        P16 = torch.zeros(self.L.total, device=P.device, dtype=torch.float32)
+        PT16 = torch.zeros(self.L.t_total, device=P.device, dtype=torch.float32)
+        scratch = torch.empty(16, device=P.device, dtype=torch.float32)
+        wexp = torch.empty(16, device=P.device, dtype=torch.int32)
+        check(lib.upnerf_frag16(ptr(P), ptr(P16), ptr(PT16), fd, nf, bd, nb, ptr(scratch), ptr(wexp), stream()),
+              "upnerf_frag16")
+        return P16, PT16, wexp
 
     # ------------------------------------------------------------------ MFMA fragment order (no grad)
     @staticmethod

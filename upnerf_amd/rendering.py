@@ -24,6 +24,16 @@ from .ops import TIMER, hip_linear, linear_raw, nsplit_for, vec_wgrad_into, wgra
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
+# Arithmetic of the field contractions: "f16x3" = 3-term fp16 split on the f16 matrix cores (fp32-level accuracy,
+# csrc/field16.hip; needs W = 256 and >= 32 samples per ray, other shapes use the fp32 kernels), "f32" = fp32 MFMA
+# (csrc/field.hip) everywhere.  Both are HIP kernels of libupnerf_hip.so; there is no non-HIP path.
+FIELD_MODE = "f16x3"
+
+
+def _field16_ok(pk, S: int) -> bool:
+    return FIELD_MODE == "f16x3" and pk.W == 256 and S >= 32
+
+
 _LINSPACE: Dict[tuple, torch.Tensor] = {}
 _DEBUG_SINK: Optional[dict] = None  # tests set this to a dict to receive the backward's intermediate buffers
 
@@ -79,7 +89,13 @@ class _FieldPass(torch.autograd.Function):
         st = stream()
         rays_o, rays_d, z = rays_o.detach().contiguous(), rays_d.detach().contiguous(), z.detach().contiguous()
         P = P.detach().contiguous()
-        PF = pk.frag_hip(P)  # what the kernels read: matrices in MFMA fragment order
+        use16 = _field16_ok(pk, S)
+        P16 = PT16 = wexp = None
+        if use16:  # matrices as scaled fp16 (hi, lo) fragments, forward and transposed sets in one pass
+            P16, PT16, wexp = pk.frag16_hip(P)
+            PF = P  # the kernel reads only the vectors from it
+        else:
+            PF = pk.frag_hip(P)  # what the kernels read: matrices in MFMA fragment order
         c_rows = c_rows.detach().contiguous() if (c_rows is not None and cfg.use_cand) else None
         a_rows_c = a_rows.detach().contiguous() if a_rows is not None else None
         joint, want_feat = cfg.mode <= 1, cfg.mode != 2
@@ -94,7 +110,8 @@ class _FieldPass(torch.autograd.Function):
         sigma_c = _empty(M, device=dev) if cfg.use_cand else None
         rgb = _empty(M, 3, device=dev) if cfg.use_rgb else None
         x0, h, e = _empty(M, X0, device=dev), _empty(D, M, W, device=dev), _empty(M, W, device=dev)
-        hmask = torch.empty(D * ((M + _lib.TILE_ROWS - 1) // _lib.TILE_ROWS) * 256, device=dev, dtype=torch.int64)
+        hmask = torch.empty((D + 1) * ((M + _lib.TILE_ROWS - 1) // _lib.TILE_ROWS) * 256, device=dev,
+                            dtype=torch.int64)
         amax = torch.zeros(16, device=dev)  # running max|.| of the activations (scales of the f16x3 weight gradients)
         g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
         g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
@@ -102,9 +119,10 @@ class _FieldPass(torch.autograd.Function):
         fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
-                          rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1))
-        check(TIMER.run("field_fwd", lambda: lib.upnerf_field_fwd(C.byref(L), C.byref(fa), st), units=M),
-              "upnerf_field_fwd")
+                          rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1),
+                          P16=ptr(P16), wexp=ptr(wexp))
+        fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
+        check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
         w_all = _empty(R, S, device=dev) if joint else None
         w_sj = _empty(R, S, device=dev) if joint else None
@@ -128,7 +146,8 @@ class _FieldPass(torch.autograd.Function):
         ctx.cfg, ctx.dims = cfg, (R, S)
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, hmask=hmask, amax=amax, e=e, g1=g1, g2=g2, r1=r1, w_all=w_all, w_sj=w_sj,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, hmask=hmask, amax=amax, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp,
+                         w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s)
         z0 = torch.zeros(0, device=dev)
         outs = (E_s, G_c, sum_sfeat, t_weight, c_depth, s_depth, rgb_map, w_all, w_s)
@@ -166,7 +185,8 @@ class _FieldPass(torch.autograd.Function):
 
         need_dxyz = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         P = sv["P"]
-        PT = pk.frag_t_hip(P)
+        use16 = sv["PT16"] is not None
+        PT = None if use16 else pk.frag_t_hip(P)
         gz_h, gz_e = _empty(D, M, W, device=dev), _empty(M, W, device=dev)
         gz_g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
         gz_g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
@@ -184,9 +204,9 @@ class _FieldPass(torch.autograd.Function):
                           g_G_c=ptr(gG), x0=ptr(sv["x0"]), h=ptr(sv["h"]), g1=ptr(sv["g1"]), g2=ptr(sv["g2"]),
                           r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
-                          dxyz=ptr(dxyz))
-        check(TIMER.run("field_bwd", lambda: lib.upnerf_field_bwd(C.byref(L), C.byref(fb), st), units=M),
-              "upnerf_field_bwd")
+                          dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]))
+        bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
+        check(TIMER.run("field_bwd", lambda: bwd_fn(C.byref(L), C.byref(fb), st), units=M), "upnerf_field_bwd")
 
         if _DEBUG_SINK is not None:
             _DEBUG_SINK.update(d_sigma_s=d_sigma_s, d_sigma_c=d_sigma_c, d_rgb=d_rgb, gz_h=gz_h, gz_e=gz_e, gz_g1=gz_g1,
