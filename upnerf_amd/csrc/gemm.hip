@@ -358,14 +358,33 @@ __global__ void frag16_amax_kernel(const float* __restrict__ src, Frag16Descs D,
     v = fabsf(frag16_src(src, q, r, c));
     id = q.exp_id;
   }
-  // descriptors are long runs: a wave almost always holds a single id; fall back to per-lane atomics otherwise
-  const int id0 = __shfl(id, 0);
-  if (__all(id == id0)) {
+  // one atomic per workgroup when the whole group sits inside one matrix id (the common case: descriptors are long runs)
+  __shared__ float wmax[4];
+  __shared__ int wid[4];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)&amax[id0], __float_as_uint(v));
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float ov = __shfl_xor(v, d);
+    const int oid = __shfl_xor(id, d);
+    if (oid != id) id = -1;  // mixed ids inside the wave (spreads to every lane by the end of the butterfly)
+    v = fmaxf(v, ov);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    wmax[wave] = v;
+    wid[wave] = id;
+  }
+  __syncthreads();
+  const bool uniform = wid[0] >= 0 && wid[0] == wid[1] && wid[1] == wid[2] && wid[2] == wid[3];
+  if (uniform) {
+    if (threadIdx.x == 0)
+      atomicMax((unsigned int*)&amax[wid[0]], __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
   } else if (idx < D.start[D.n]) {
-    atomicMax((unsigned int*)&amax[id], __float_as_uint(v));
+    int j = 0;
+    while (idx >= D.start[j + 1]) ++j;
+    const upnerf_frag16_desc q = D.d[j];
+    const int e = idx - D.start[j];
+    const int r = e / q.cols, c = e - r * q.cols;
+    atomicMax((unsigned int*)&amax[q.exp_id], __float_as_uint(fabsf(frag16_src(src, q, r, c))));
   }
 }
 __global__ void frag16_write_kernel(const float* __restrict__ src, char* __restrict__ dst, Frag16Descs D,

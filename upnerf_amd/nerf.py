@@ -26,6 +26,9 @@ class NeRF(nn.Module):
         self.encode_candidate = candidate_dim > 0
         self.c2f = c2f
         self.progress = nn.Parameter(torch.tensor(0.0))  # written through .data only
+        # Host mirror of `progress`: render_rays needs the value on the host (band weights are kernel arguments) and
+        # reading the device parameter would drain the HIP queue twice per step.  None = unknown (read the parameter).
+        self.host_progress = None
         if not encode_feat:
             raise NotImplementedError("nerf.feat_dim = 0 is not implemented on the HIP path")
         for i in range(D):
@@ -44,6 +47,15 @@ class NeRF(nn.Module):
             self.feat_candidate_layer = nn.Linear(W // 2, feat_dim)
         self.packer = NerfPacker(W, D, self.skips, self.in_channels_xyz, self.in_channels_dir, feat_dim,
                                  appearance_dim, candidate_dim)
+
+    def set_progress(self, progress: float):
+        """Write `progress` (device parameter, as the reference does through .data) and its host mirror."""
+        self.progress.data.fill_(float(progress))
+        self.host_progress = float(progress)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.host_progress = None  # a checkpoint may carry another progress value
 
     def packed(self) -> torch.Tensor:
         """Flat kernel-layout parameter buffer, differentiable w.r.t. the parameters."""

@@ -191,9 +191,9 @@ class NeRFSystem(_Base):
     def set_progress(self, progress: float):
         """Host-side copy of NeRF.progress (avoids the reference's per-step .item() sync)."""
         self._host_progress = float(progress)
-        self.nerf_coarse.progress.data.fill_(progress)
+        self.nerf_coarse.set_progress(progress)
         if self.fine:
-            self.nerf_fine.progress.data.fill_(progress)
+            self.nerf_fine.set_progress(progress)
 
     def training_step(self, batch, batch_nb=0, u_list=None):
         hp = self.hparams

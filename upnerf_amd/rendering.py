@@ -337,7 +337,10 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
         typ = model.typ
         a_rows = embeddings[f"{typ}_a"](img_idx) if model.encode_appearance else None
         c_rows = embeddings[f"{typ}_c"](img_idx) if model.encode_candidate else None
-        progress = float(model.progress.data)
+        # host mirror kept by NeRF.set_progress; code that writes model.progress.data directly (the reference's way)
+        # leaves it None and pays a device read here
+        hp = getattr(model, "host_progress", None)
+        progress = float(model.progress.data) if hp is None else float(torch.tensor(hp, dtype=torch.float32))
         use_cand = bool(sched_mult < 1 and model.encode_candidate)
         use_rgb = bool(sched_mult > 0)
         mode = (1 if use_rgb else 0) if use_cand else (3 if sched_mult < 1 else 2)
