@@ -54,7 +54,9 @@ def _worker(rank, world, port, q):
     sync = parallel.GradSync(m.parameters(), check=True)
     n = sync()
     out = {n_: p.grad.clone() for n_, p in m.named_parameters() if p.grad is not None}
-    q.put((rank, n, local, out, m.unused.grad is None))
+    # numpy arrays travel by value; torch tensors would travel as shared-memory handles that die with this process
+    q.put((rank, n, {k: v.numpy().copy() for k, v in local.items()}, {k: v.numpy().copy() for k, v in out.items()},
+           m.unused.grad is None))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,6 +84,8 @@ def test_flat_allreduce_world2_gloo():
         res = _run_world2()
     except Exception:  # a rendezvous port can be taken between _free_port() and bind: one retry on a new port
         res = _run_world2()
+    res = [(r, n, {k: torch.from_numpy(v) for k, v in a.items()}, {k: torch.from_numpy(v) for k, v in b.items()}, u)
+           for r, n, a, b, u in res]
     (_, n0, loc0, out0, un0), (_, n1, loc1, out1, un1) = res
     assert n0 == n1 == sum(v.numel() for v in loc0.values())
     assert un0 and un1                                   # unused parameter still has no gradient
