@@ -170,6 +170,15 @@ def test_linear_fwd_bwd(hip, M, N, K, relu):
     assert rel_err(cpu(bg.grad), br.grad) < TOL_GRAD
 
 
+@pytest.mark.parametrize("M,K,N,ld,off", [(300, 128, 48, 336, 283), (4096, 128, 16, 272, 256), (65, 64, 70, 77, 3)])
+def test_linear_on_a_strided_kn_view(hip, M, K, N, ld, off):
+    """y = x . Wv with Wv[k][n] = base[off + k*ld + n] read in place (column block of a packed matrix, odd strides)."""
+    x, base = gen((M, K), 24), gen((off + K * ld + N,), 25)
+    y = hip["ops"].linear_kn_view(x.cuda(), base.cuda(), off, ld, N)
+    Wv = torch.as_strided(base, (K, N), (ld, 1), off)
+    assert rel_err(cpu(y), x.double() @ Wv.double()) < TOL_ACT
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (333, 128, 256), (5000, 256, 64), (64, 32, 16), (777, 64, 80),
                                    (40000, 256, 256)])
 def test_wgrad_and_bias(hip, M, N, K):
@@ -435,8 +444,11 @@ def test_frag16_layout_and_exponents(hip):
 
     def unpack(buf, off, n, kp):
         raw = cpu(buf)[off:off + n * kp].view(torch.float16).view(n // 32, kp // 16, 2, 2, 32, 8)
-        # [ntile][t][plane][khalf][n%32][k%8] -> [plane][n][k]
-        return raw.permute(2, 0, 4, 1, 3, 5).reshape(2, n, kp).float()
+        # [ntile][t][plane][khalf][lane][k%8] -> [plane][ntile*32 + lane][k]
+        out = raw.permute(2, 0, 4, 1, 3, 5).reshape(2, n, kp).float()
+        if n == 256:  # pair_cols: tile 2g + b, lane i holds row 64g + 2i + b
+            out = out.view(2, 4, 2, 32, kp).permute(0, 1, 3, 2, 4).reshape(2, n, kp)
+        return out
 
     W, W2 = 256, 128
     checks = [(P16, L.w[0], W, 64, Pc[L.w[0]:L.w[0] + W * 64].view(W, 64), 0),

@@ -1,0 +1,34 @@
+"""Per-phase shader-clock breakdown of the f16x3 forward trunk loop (diagnostic build: make -C upnerf_amd/csrc stamps).
+
+    UPNERF_LIB=upnerf_amd/libupnerf_hip_stamps.so python tools/stamps_field16.py
+"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("UPNERF_LIB", os.path.join(ROOT, "upnerf_amd", "libupnerf_hip_stamps.so"))
+import torch
+import bench
+from upnerf_amd import _lib
+
+dev = torch.device("cuda", 0)
+sysm = bench.build_system(dev, 0.3)
+batches = bench.make_batches(dev, 2, 100)
+for i in range(3):
+    sysm.training_step(batches[i % 2], i)
+rd = _lib.lib.upnerf_stamps_read
+rd.argtypes = [C.c_void_p, C.c_int]
+buf = (C.c_ulonglong * 16)()
+rd(buf, 1)
+N = 5
+for i in range(N):
+    sysm.training_step(batches[i % 2], i)
+rd(buf, 1)
+names = ["loop top", "K loop (issue)", "epilogue: fma/relu/pack/max", "barrier 1", "planes write (split16 + ds_write)",
+         "barrier 2", "activation store (fp32 global)"]
+tiles = N * (4096 * 64 + 4096 * 192) // 64
+waves = tiles * 4 / 16  # one workgroup in 16 reports
+tot = sum(buf[:7])
+print(f"{tiles} tiles x 8 layers, 4 waves each; cycles per wave per layer:")
+for i, n in enumerate(names):
+    print(f"  {n:40s} {buf[i] / waves / 8:9.0f}   {100 * buf[i] / tot:5.1f} %")
+print(f"  {'sum':40s} {tot / waves / 8:9.0f}")

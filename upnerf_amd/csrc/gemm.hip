@@ -244,70 +244,81 @@ __global__ void vec_wgrad_reduce_kernel(int nvec, int K, int nsplit, const float
   else if (dbv) dbv[c] = s;
 }
 
-// ---- generic linear: C = act(A B^T + bias); A tile staged in LDS in K-chunks of 128
-#define LIN_KC 128
-#define TILE 128  // rows per workgroup of the generic linear kernel
-__global__ __launch_bounds__(NTHREADS, 1) void linear_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+// ---- generic linear: C = act(A B^T + bias) for the per-ray layers (M = rays: a few thousand rows).
+// 64 x 64 output tile per workgroup (one 32 x 32 MFMA tile per wave), A and B staged in LDS in K-chunks of 64 with
+// coalesced 16-byte loads: 16 x (N/64) x ... = several hundred workgroups even at M = 4096, four or five per CU, so
+// the chip is full and the workgroups hide each other's load phases.  (128 x 256 tiles left 3/4 of the CUs idle.)
+// act bit 0: ReLU;  act bit 1: B is given transposed, [K][N] with row stride ldb (no host-side transpose copy).
+#define LIN_T 64
+#define LIN_KC 64
+__global__ __launch_bounds__(NTHREADS, 4) void linear_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                              const float* __restrict__ B, int ldb,
                                                              const float* __restrict__ bias, float* __restrict__ C,
                                                              int ldc, int act) {
-  __shared__ __attribute__((aligned(16))) float As[TILE * LIN_KC];
-  using TW = WaveTile<256, TILE>;
+  __shared__ __attribute__((aligned(16))) float As[LIN_T * LIN_KC];
+  __shared__ __attribute__((aligned(16))) float Bs[LIN_T * LIN_KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * TILE, nb = blockIdx.y * 256;
-  const int n0 = TW::n0(wave), row0 = TW::row0(wave);
-  f32x16 acc[TW::MT][TW::NT];
-  acc_zero(acc);
-  // B rows beyond N are clamped (their columns are never stored)
+  const int m0 = blockIdx.x * LIN_T, nb = blockIdx.y * LIN_T;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;  // this wave's 32 x 32 piece of the tile
   const int li = lane & 31, hh = lane >> 5;
+  const bool transb = (act & 2) != 0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   for (int kc = 0; kc < K; kc += LIN_KC) {
-    const int kk = (K - kc) < LIN_KC ? (K - kc) : LIN_KC;
-    const int gpr = kk >> 2;
+    const int kk = (K - kc) < LIN_KC ? (K - kc) : LIN_KC;  // multiple of 8
     __syncthreads();
-    for (int idx = tid; idx < TILE * gpr; idx += NTHREADS) {
-      const int row = idx / gpr, g = idx - row * gpr;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m0 + row < M) v = *(const f32x4*)&A[(size_t)(m0 + row) * lda + kc + 4 * g];
-      *(f32x4*)&As[swz4(row, 4 * g, LIN_KC)] = v;
+    // stage A[m0.., kc..] and B[nb.., kc..] (zero fill outside M / N / K)
+    for (int idx = tid; idx < LIN_T * (LIN_KC / 4); idx += NTHREADS) {
+      const int row = idx >> 4, g = idx & 15;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      if (4 * g < kk) {
+        if (m0 + row < M) va = *(const f32x4*)&A[(size_t)(m0 + row) * lda + kc + 4 * g];
+        if (!transb && nb + row < N) vb = *(const f32x4*)&B[(size_t)(nb + row) * ldb + kc + 4 * g];
+      }
+      *(f32x4*)&As[swz4(row, 4 * g, LIN_KC)] = va;
+      if (!transb) *(f32x4*)&Bs[swz4(row, 4 * g, LIN_KC)] = vb;
+    }
+    if (transb) {  // B^T tile: rows are k, 64 consecutive n per row; scattered into the [n][k] image
+      for (int idx = tid; idx < LIN_KC * (LIN_T / 4); idx += NTHREADS) {
+        const int k = idx >> 4, g = idx & 15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kk) {
+          const float* src = &B[(size_t)(kc + k) * ldb + nb + 4 * g];
+          if (nb + 4 * g + 3 < N && (ldb & 3) == 0) {
+            v = *(const f32x4*)src;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (nb + 4 * g + j < N) v[j] = src[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[swz(4 * g + j, k, LIN_KC)] = v[j];
+      }
     }
     __syncthreads();
-    const int T = kk >> 3;
-    for (int t = 0; t < T; ++t) {
-      f32x4 a[TW::MT], b[TW::NT];
+#pragma unroll 2
+    for (int t = 0; t < (kk >> 3); ++t) {
+      const f32x4 a = *(const f32x4*)&As[swz4(wr + li, 8 * t + 4 * hh, LIN_KC)];
+      const f32x4 b = *(const f32x4*)&Bs[swz4(wc + li, 8 * t + 4 * hh, LIN_KC)];
 #pragma unroll
-      for (int nt = 0; nt < TW::NT; ++nt) {
-        int n = nb + n0 + 32 * nt + li;
-        n = n < N ? n : N - 1;
-        b[nt] = *(const f32x4*)&B[(size_t)n * ldb + kc + 8 * t + 4 * hh];
-      }
-#pragma unroll
-      for (int mt = 0; mt < TW::MT; ++mt) {
-        const int row = row0 + 32 * mt + li;
-        a[mt] = *(const f32x4*)&As[swz4(row, 8 * t + 4 * hh, LIN_KC)];
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int mt = 0; mt < TW::MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < TW::NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
     }
   }
+  const int col = nb + wc + li;
+  if (col < N) {
+    const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-  for (int mt = 0; mt < TW::MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < TW::NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int col = nb + n0 + 32 * nt + li;
-        if (row < M && col < N) {
-          float v = acc[mt][nt][r] + (bias ? bias[col] : 0.f);
-          if (act == 1) v = fmaxf(v, 0.f);
-          C[(size_t)row * ldc + col] = v;
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (row < M) {
+        float v = acc[r] + bv;
+        if (act & 1) v = fmaxf(v, 0.f);
+        C[(size_t)row * ldc + col] = v;
       }
+    }
+  }
 }
 
 // ---- per-step re-layout of the weight matrices into MFMA fragment order (see common.cuh:mma_lds)
@@ -400,8 +411,10 @@ __global__ void frag16_write_kernel(const float* __restrict__ src, char* __restr
   const float x = ldexpf(frag16_src(src, q, r, c), frag16_exp(amax[q.exp_id]));
   const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
   const int k = q.dst_k0 + c;
-  const size_t base = (size_t)q.dst_off * 4 + ((size_t)(r >> 5) * (q.dst_kp >> 4) + (k >> 4)) * 2048 +
-                      ((((k >> 3) & 1) << 5) + (r & 31)) * 16 + (k & 7) * 2;
+  const int tile = q.pair_cols ? (((r >> 6) << 1) | (r & 1)) : (r >> 5);
+  const int ln = q.pair_cols ? ((r & 63) >> 1) : (r & 31);
+  const size_t base = (size_t)q.dst_off * 4 + ((size_t)tile * (q.dst_kp >> 4) + (k >> 4)) * 2048 +
+                      ((((k >> 3) & 1) << 5) + ln) * 16 + (k & 7) * 2;
   *(_Float16*)(dst + base) = hi;
   *(_Float16*)(dst + base + 1024) = lo;
 }
@@ -520,8 +533,9 @@ extern "C" int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const 
 
 extern "C" int upnerf_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
                              float* C, int ldc, int act, void* stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 3) || (ldb & 3) || !A || !B || !C) return UPNERF_EINVAL;
-  dim3 grid((M + TILE - 1) / TILE, (N + 255) / 256);
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 3) || (!(act & 2) && (ldb & 3)) || !A || !B || !C || (act & ~3))
+    return UPNERF_EINVAL;
+  dim3 grid((M + LIN_T - 1) / LIN_T, (N + LIN_T - 1) / LIN_T);
   hipLaunchKernelGGL(linear_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, M, N, K, A, lda, B, ldb, bias, C, ldc,
                      act);
   return (int)hipGetLastError();
@@ -550,7 +564,7 @@ static int frag16_build(const upnerf_frag16_desc* descs, int n, Frag16Descs* D) 
   for (int j = 0; j < n; ++j) {
     const upnerf_frag16_desc& q = descs[j];
     if (q.rows <= 0 || q.cols <= 0 || (q.rows & 31) || (q.dst_kp & 15) || q.dst_k0 + q.cols > q.dst_kp || q.exp_id < 0 ||
-        q.exp_id >= 16)
+        q.exp_id >= 16 || (q.pair_cols && (q.rows & 63)))
       return UPNERF_EINVAL;
     D->d[j] = q;
     D->start[j + 1] = D->start[j] + q.rows * q.cols;

@@ -112,9 +112,19 @@ def vec_wgrad_into(M: int, v: torch.Tensor, ldv: int, nvec: int, X: torch.Tensor
           "upnerf_vec_wgrad")
 
 
-def linear_raw(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int) -> torch.Tensor:
-    """y = act(x w^T + b) with x [M][K], w [N][K]; K is padded to a multiple of 8 when needed."""
+def linear_raw(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int, w_is_kn: bool = False) -> torch.Tensor:
+    """y = act(x w^T + b) with x [M][K], w [N][K]; K is padded to a multiple of 8 when needed.
+    w_is_kn: w is given as [K][N] (y = act(x w + b)): the kernel reads it in place, no transposed copy."""
     M, K = x.shape
+    if w_is_kn:
+        if K % 8 == 0 and w.is_contiguous():
+            x = x.contiguous()
+            N = w.shape[1]
+            b = b.contiguous() if b is not None else None
+            y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+            check(lib.upnerf_linear(M, N, K, ptr(x), K, ptr(w), N, ptr(b), ptr(y), N, act | 2, stream()), "upnerf_linear")
+            return y
+        w = w.t()
     N = w.shape[0]
     if K % 8:
         pad = 8 - K % 8
@@ -124,6 +134,18 @@ def linear_raw(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act:
     b = b.contiguous() if b is not None else None  # (named: must outlive the launch call)
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
     check(lib.upnerf_linear(M, N, K, ptr(x), K, ptr(w), K, ptr(b), ptr(y), N, act, stream()), "upnerf_linear")
+    return y
+
+
+def linear_kn_view(x: torch.Tensor, w_base: torch.Tensor, w_off: int, ldw: int, N: int) -> torch.Tensor:
+    """y[M][N] = x[M][K] . Wv[K][N] where Wv is the strided view  w_base[w_off + k*ldw + n]  (a column block of a packed
+    row-major matrix), read in place by the kernel."""
+    M, K = x.shape
+    assert K % 8 == 0
+    x = x.contiguous()
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    check(lib.upnerf_linear(M, N, K, ptr(x), K, w_base.data_ptr() + 4 * w_off, ldw, None, ptr(y), N, 2, stream()),
+          "upnerf_linear")
     return y
 
 
@@ -148,7 +170,7 @@ class HipLinear(torch.autograd.Function):
         N = w.shape[0]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = linear_raw(gy, w.t(), None, 0)
+            gx = linear_raw(gy, w, None, 0, w_is_kn=True)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             xc = x.contiguous()
             gw = torch.empty(N, K, device=x.device, dtype=torch.float32)

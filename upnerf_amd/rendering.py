@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, X0, check, lib, ptr,
                    stream)
-from .ops import TIMER, hip_linear, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16x3_into, wgrad_into
+from .ops import TIMER, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16x3_into, wgrad_into
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
@@ -250,8 +250,7 @@ class _FieldPass(torch.autograd.Function):
                 wg(gz_g2, W2, W2, sv["g1"], W2, W2, L.wc2, W2, L.bc2, D + 2, D + 1)
                 vec_wgrad_into(M, dpre_c, 1, 1, sv["g2"], W2, W2, at(L.wcsig), at(L.bcsig), dev)
             if ctx.needs_input_grad[3]:
-                wc = P[L.wc1:L.wc1 + W2 * (W + CK)].view(W2, W + CK)[:, W:]
-                d_c_rows = linear_raw(rs, wc.t(), None, 0)
+                d_c_rows = linear_kn_view(rs, P, L.wc1 + W, W + CK, CK)  # rs . wc1[:, W:]
         if cfg.use_rgb:
             rs = _empty(R, W2, device=dev)
             check(lib.upnerf_ray_sum(R, S, ptr(gz_r1), W2, ptr(rs), st), "upnerf_ray_sum")
@@ -260,8 +259,7 @@ class _FieldPass(torch.autograd.Function):
                 wgrad_into(R, rs, W2, W2, sv["aux"], AUXK, AUXK, at(L.wr1 + W), W + AUXK, None, dev)
                 vec_wgrad_into(M, dpre_rgb, 4, 3, sv["r1"], W2, W2, at(L.wr2), at(L.br2), dev)
             if ctx.has_a and ctx.needs_input_grad[4]:
-                wa = P[L.wr1:L.wr1 + W2 * (W + AUXK)].view(W2, W + AUXK)[:, W + 27:W + 75]
-                d_a_rows = linear_raw(rs, wa.t(), None, 0)
+                d_a_rows = linear_kn_view(rs, P, L.wr1 + W + 27, W + AUXK, 48)  # rs . wr1[:, W+27 : W+75]
         d_o = d_d = None
         if need_dxyz:
             d_o, d_d = _empty(R, 3, device=dev), _empty(R, 3, device=dev)
