@@ -251,6 +251,11 @@ int upnerf_ray_sum(int R, int S, const float* X, int C, float* out, void* stream
 /* (d_o, d_d)[r] = (sum_i dxyz_i, sum_i z_i dxyz_i)    */
 int upnerf_ray_geom_bwd(int R, int S, const float* dxyz, const float* z, float* d_o, float* d_d, void* stream);
 
+/* ---- dense gradient of an embedding table (autograd of nn.Embedding(img_idx): the per-image appearance / candidate /
+ * transient rows, se3_refine and depth_scale of models/nerf_system.py:79-91): out[n][:] = sum_{r: idx[r]==n} g[r][:],
+ * rows without a hit are written as zeros; summation in increasing r (bitwise reproducible).  dim <= 256. */
+int upnerf_embed_bwd(int R, int N, int dim, const int64_t* idx, const float* g, float* out, void* stream);
+
 /* ---- generic fp32 MFMA linear layer: C[M][N] = act(A[M][K] . B[N][K]^T + bias) --------------------
  * (TransientNet, models/transient_net.py:27-38, and the per-ray feature projection.)  K multiple of 8,
  * act bit 0: ReLU; act bit 1: B is given as [K][N] (row stride ldb), i.e. C = act(A . B + bias) -- the data-gradient

@@ -151,6 +151,32 @@ def test_sort_rows(hip, S):
     assert np.array_equal(cpu(zd).numpy(), torch.sort(z, -1)[0].numpy())
 
 
+@pytest.mark.parametrize("R,N,dim", [(4096, 763, 48), (100, 7, 6), (5000, 1200, 128), (64, 3, 2), (300, 10, 200)])
+def test_embedding_gradient_kernel(hip, R, N, dim):
+    """Dense embedding gradient (one HIP kernel) against ATen's nn.Embedding backward; also bitwise run-to-run."""
+    table = gen((N, dim), 26)
+    idx = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(R))
+    if N > 5:
+        idx[idx == 2] = 3  # one table row never referenced: its gradient must come out as exact zeros
+    up = gen((R, dim), 27)
+    ref = torch.nn.Embedding(N, dim)
+    ref.weight.data.copy_(table)
+    (ref(idx).double() * up.double()).sum().backward()
+    emb = torch.nn.Embedding(N, dim).cuda()
+    emb.weight.data.copy_(table.cuda())
+    grads = []
+    for _ in range(2):
+        emb.weight.grad = None
+        rows = hip["ops"].embed_rows(emb, idx.cuda())
+        assert torch.equal(cpu(rows), table[idx])
+        (rows * up.cuda()).sum().backward()
+        grads.append(cpu(emb.weight.grad).clone())
+    assert torch.equal(grads[0], grads[1])
+    assert rel_err(grads[0], ref.weight.grad) < 1e-6
+    if N > 5:
+        assert float(grads[0][2].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------ generic GEMMs
 @pytest.mark.parametrize("M,N,K,relu", [(300, 256, 384, True), (129, 384, 256, False), (64, 1, 256, False),
                                         (500, 3, 128, False), (77, 128, 384, True), (4096, 16, 128, False)])

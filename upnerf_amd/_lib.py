@@ -115,6 +115,7 @@ _SIGNATURES = {
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],
+    "upnerf_embed_bwd": [_i, _i, _i, _p, _p, _p, _p],
     "upnerf_linear": [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p],
     "upnerf_loss_fwd": [C.POINTER(LossArgs), _p, _p, _p, _p],
     "upnerf_loss_bwd": [C.POINTER(LossArgs), _p, C.POINTER(LossGrads), _p],

@@ -298,7 +298,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_kernel(int M, int N, int K
       }
     }
     __syncthreads();
-#pragma unroll 2
     for (int t = 0; t < (kk >> 3); ++t) {
       const f32x4 a = *(const f32x4*)&As[swz4(wr + li, 8 * t + 4 * hh, LIN_KC)];
       const f32x4 b = *(const f32x4*)&Bs[swz4(wc + li, 8 * t + 4 * hh, LIN_KC)];

@@ -370,6 +370,33 @@ __global__ __launch_bounds__(NTHREADS) void ray_geom_bwd_kernel(int R, int S, co
   }
 }
 
+
+// Dense gradient of an embedding table from the gradients of the gathered rows (autograd of nn.Embedding(idx),
+// models/nerf_system.py:79-91 tables and models/transient_net.py): out[n] = sum over r with idx[r] == n of g[r], summed
+// in increasing r (deterministic, no atomics, no sort).  One wave per table row scans idx 64 entries at a time.
+__global__ void embed_bwd_kernel(int R, int N, int dim, const long long* __restrict__ idx, const float* __restrict__ g,
+                                 float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // dim <= 256
+  for (int base = 0; base < R; base += 64) {
+    const int r = base + lane;
+    const bool hit = r < R && idx[r] == (long long)n;
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int j = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const float* __restrict__ row = g + (size_t)(base + j) * dim;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lane + 64 * q < dim) acc[q] += row[lane + 64 * q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (lane + 64 * q < dim) out[(size_t)n * dim + lane + 64 * q] = acc[q];
+}
 }  // namespace
 
 extern "C" int upnerf_abi_version(void) { return UPNERF_ABI_VERSION; }
@@ -437,5 +464,12 @@ extern "C" int upnerf_ray_geom_bwd(int R, int S, const float* dxyz, const float*
   if (R <= 0 || S <= 0 || !dxyz || !z || !d_o || !d_d) return UPNERF_EINVAL;
   hipLaunchKernelGGL(ray_geom_bwd_kernel, dim3((R + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, S, dxyz, z, d_o,
                      d_d);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_embed_bwd(int R, int N, int dim, const int64_t* idx, const float* g, float* out, void* stream) {
+  if (R <= 0 || N <= 0 || dim <= 0 || dim > 256 || !idx || !g || !out) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((N + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, N, dim,
+                     (const long long*)idx, g, out);
   return (int)hipGetLastError();
 }

@@ -20,6 +20,7 @@ from torch import nn
 from .camera import refine_and_get_rays
 from .losses import UPNeRFLoss
 from .nerf import NeRF
+from .ops import embed_rows
 from .optim import get_learning_rate, get_optimizer, get_scheduler
 from .parallel import GradSync
 from .rendering import render_rays
@@ -166,14 +167,14 @@ class NeRFSystem(_Base):
     # ---- pieces of training_step, exposed for tests and the benchmark ------------------------------------
     def rays_from_batch(self, batch):
         idx = batch["img_idx"]
-        se3 = self.se3_refine(idx) if self.hparams["pose.optimize"] else None
+        se3 = embed_rows(self.se3_refine, idx) if self.hparams["pose.optimize"] else None
         rays_o, rays_d = refine_and_get_rays(se3, batch["c2w"], batch["directions"])
         return torch.cat([rays_o, rays_d, batch["ray_infos"]], 1)
 
     def depth_targets(self, batch):
         """Affine-corrected mono-depth prior (nerf_system.py:169-177)."""
         near, far = self.hparams["nerf.near"], self.hparams["nerf.far"]
-        scale, shift = torch.unbind(self.depth_scale(batch["img_idx"]), 1)
+        scale, shift = torch.unbind(embed_rows(self.depth_scale, batch["img_idx"]), 1)
         p = batch["inv_depths"] * torch.exp(scale) + shift
         p = torch.where(p < 1 / far, torch.full_like(p, 1 / far), p)
         d = 1.0 / p
@@ -185,7 +186,7 @@ class NeRFSystem(_Base):
         sched_mult = self.get_schedule_mult(self._host_progress)
         results = self(rays, batch["feats"], batch["img_idx"], sched_mult, u_list=u_list, keep=keep)
         loss_d, _depth = self.loss.forward_with_prior(results, batch["rgbs"], batch["feats"], batch["inv_depths"],
-                                                      self.depth_scale(batch["img_idx"]), sched_mult)
+                                                      embed_rows(self.depth_scale, batch["img_idx"]), sched_mult)
         return sum(l for l in loss_d.values()), loss_d, results
 
     def set_progress(self, progress: float):

@@ -205,6 +205,37 @@ def hip_linear(x, w, b=None, relu: bool = False):
     return HipLinear.apply(x, w, b, 1 if relu else 0)
 
 
+class _EmbedRows(torch.autograd.Function):
+    """table[idx] whose backward is one HIP kernel (dense, deterministic) instead of ATen's sort-based embedding
+    backward (14 small launches per table and step)."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(table.shape)
+        return table.detach().index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        N, dim = ctx.shape
+        g = g.contiguous()
+        out = torch.empty(N, dim, device=g.device, dtype=torch.float32)
+        check(lib.upnerf_embed_bwd(idx.numel(), N, dim, ptr(idx), ptr(g), ptr(out), stream()), "upnerf_embed_bwd")
+        return out, None
+
+
+def embed_rows(emb, idx: torch.Tensor) -> torch.Tensor:
+    """emb(idx) for an nn.Embedding with a float32 CUDA table of width <= 256 and a 1-D int64 index; anything else is
+    handed to the module itself."""
+    w = getattr(emb, "weight", None)
+    if (w is None or not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or w.shape[1] > 256 or idx.dim() != 1
+            or idx.dtype != torch.int64 or getattr(emb, "padding_idx", None) is not None
+            or getattr(emb, "max_norm", None) is not None):
+        return emb(idx)
+    return _EmbedRows.apply(w, idx.contiguous())
+
+
 def adam_flat_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
     """In-place Adam update of a flat fp32 buffer (utils/optim.py:20-33 -> torch.optim.Adam semantics)."""

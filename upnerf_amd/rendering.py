@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, X0, check, lib, ptr,
                    stream)
-from .ops import TIMER, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16x3_into, wgrad_into
+from .ops import TIMER, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16x3_into, wgrad_into
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
@@ -333,8 +333,8 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
 
     def inference(model, zz):
         typ = model.typ
-        a_rows = embeddings[f"{typ}_a"](img_idx) if model.encode_appearance else None
-        c_rows = embeddings[f"{typ}_c"](img_idx) if model.encode_candidate else None
+        a_rows = embed_rows(embeddings[f"{typ}_a"], img_idx) if model.encode_appearance else None
+        c_rows = embed_rows(embeddings[f"{typ}_c"], img_idx) if model.encode_candidate else None
         # host mirror kept by NeRF.set_progress; code that writes model.progress.data directly (the reference's way)
         # leaves it None and pays a device read here
         hp = getattr(model, "host_progress", None)
