@@ -34,8 +34,12 @@ __device__ __forceinline__ h4 tr_read(const char* base, int byteoff) {
   return __builtin_bit_cast(h4, v);
 }
 
+// 512 threads = 8 waves per workgroup, one workgroup per CU, two waves per SIMD: the fp32 -> (hi, lo) conversion of one
+// wave overlaps the MFMAs of the other, each thread stages half as many rows (two register sets fit: the loads of chunk
+// c+2 are in flight while chunk c is contracted), and each wave keeps at most 128 accumulator registers.
+#define FX_THREADS 512
 template <int MTW, int NTW>
-__global__ __launch_bounds__(NTHREADS, 1) void wgrad_f16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                                   const float* __restrict__ B, int ldb,
                                                                   const int* __restrict__ expo_a, const int* __restrict__ expo_b,
                                                                   float* __restrict__ slabs, float* __restrict__ bslabs,
@@ -43,12 +47,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_f16x3_kernel(int M, int N, 
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   constexpr int PN = (TN + 127) / 128, PK = (TK + 127) / 128;           // 128-column panels per plane
   constexpr int SZA = PN * FX_CHUNK * 256, SZB = PK * FX_CHUNK * 256;  // bytes per plane
-  constexpr int A4 = FX_CHUNK * TN / 4 / NTHREADS, B4 = FX_CHUNK * TK / 4 / NTHREADS;
+  constexpr int A4 = FX_CHUNK * TN / 4 / FX_THREADS, B4 = FX_CHUNK * TK / 4 / FX_THREADS;
+  static_assert(A4 >= 1 && B4 >= 1, "tile too small for 512 threads");
+  constexpr int WK = (TK >= 128) ? 4 : 2, WN = 8 / WK;                  // waves along k / along n
+  constexpr int MT = (TN / WN >= 32) ? TN / WN / 32 : 1, NT = TK / WK / 32;  // 32x32 tiles per wave
+  constexpr bool HALF = TN / WN < 32;                                   // 64x64 block: only 4 of the 8 waves contract
   // [buffer][A hi | A lo | B hi | B lo]
   __shared__ __attribute__((aligned(16))) char lds[2 * (2 * SZA + 2 * SZB)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
-  const int n0 = (wave >> 1) * 32 * MTW, k0 = (wave & 1) * 32 * NTW;
+  const bool active = !HALF || wave < 4;
+  const int wn = HALF ? ((wave & 3) >> 1) : wave / WK, wk = HALF ? (wave & 1) : wave % WK;
+  const int n0 = wn * 32 * MT, k0 = wk * 32 * NT;
   const int split = blockIdx.x;
   const int nblk = blockIdx.y * TN, kblk = blockIdx.z * TK;
   const int mbeg = split * rows_per_split;
@@ -56,21 +66,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_f16x3_kernel(int M, int N, 
   const int ea = expo_a[0], eb = expo_b[0];
   const float sa = ldexpf(1.0f, ea), sb = ldexpf(1.0f, eb);
 
-  f32x16 acc[MTW][NTW];
+  f32x16 acc[MT][NT];
   acc_zero(acc);
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // this thread's 4 columns of A, summed over its rows (fp32, unscaled)
 
-  f32x4 ra[A4], rb[B4];
-  auto gload = [&](int mc) {
+  f32x4 ra0[A4], rb0[B4], ra1[A4], rb1[B4];
+  auto gload = [&](f32x4 (&ra)[A4], f32x4 (&rb)[B4], int mc) {
 #pragma unroll
     for (int q = 0; q < A4; ++q) {
-      const int idx = tid + q * NTHREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
+      const int idx = tid + q * FX_THREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
       const int m = mc + row;
       ra[q] = (m < mend && nblk + 4 * c4 < N) ? *(const f32x4*)&A[(size_t)m * lda + nblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int q = 0; q < B4; ++q) {
-      const int idx = tid + q * NTHREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
+      const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
       const int m = mc + row;
       rb[q] = (m < mend && kblk + 4 * c4 < K) ? *(const f32x4*)&B[(size_t)m * ldb + kblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -87,17 +97,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_f16x3_kernel(int M, int N, 
     *(h4*)(hi + off) = vh;
     *(h4*)(lo + off) = vl;
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](const f32x4 (&ra)[A4], const f32x4 (&rb)[B4], int buf) {
     char* base = lds + buf * (2 * SZA + 2 * SZB);
 #pragma unroll
     for (int q = 0; q < A4; ++q) {
-      const int idx = tid + q * NTHREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
+      const int idx = tid + q * FX_THREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
       bsum += ra[q];
       split_store(base, base + SZA, ra[q], sa, row, 4 * c4);
     }
 #pragma unroll
     for (int q = 0; q < B4; ++q) {
-      const int idx = tid + q * NTHREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
+      const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
       split_store(base + 2 * SZA, base + 2 * SZA + SZB, rb[q], sb, row, 4 * c4);
     }
   };
@@ -105,18 +115,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_f16x3_kernel(int M, int N, 
   const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
   const int trow = 8 * (g >> 1) + tq, tcol = 16 * (g & 1) + 4 * tp;
 
-  int buf = 0;
-  if (mbeg < mend) gload(mbeg);
-  for (int mc = mbeg; mc < mend; mc += FX_CHUNK) {
-    lstore(buf);
-    __syncthreads();
-    if (mc + FX_CHUNK < mend) gload(mc + FX_CHUNK);
+  auto contract = [&](int buf) {
+    if (!active) return;
     const char* base = lds + buf * (2 * SZA + 2 * SZB);
 #pragma unroll
     for (int kk = 0; kk < FX_CHUNK / 16; ++kk) {
-      h8 ah[MTW], al[MTW];
+      h8 ah[MT], al[MT];
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         const int o0 = himg(16 * kk + trow, n0 + 32 * mt + tcol), o1 = himg(16 * kk + trow + 4, n0 + 32 * mt + tcol);
         const h4 x0 = tr_read(base, o0), x1 = tr_read(base, o1);
         const h4 y0 = tr_read(base + SZA, o0), y1 = tr_read(base + SZA, o1);
@@ -124,42 +130,73 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_f16x3_kernel(int M, int N, 
         al[mt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         const int o0 = himg(16 * kk + trow, k0 + 32 * nt + tcol), o1 = himg(16 * kk + trow + 4, k0 + 32 * nt + tcol);
         const h4 x0 = tr_read(base + 2 * SZA, o0), x1 = tr_read(base + 2 * SZA, o1);
         const h4 y0 = tr_read(base + 2 * SZA + SZB, o0), y1 = tr_read(base + 2 * SZA + SZB, o1);
         const h8 bh = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
         const h8 bl = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
         }
       }
     }
-    buf ^= 1;
+  };
+  // Two register sets (loads of chunk c+2 in flight while chunk c is contracted) where the accumulators leave room for
+  // them; the 256x256 block (128 accumulator registers per wave) keeps one set.
+  constexpr bool TWO_SETS = MT * NT * 16 <= 64;
+  if constexpr (TWO_SETS) {
+    // rows beyond mend load as zeros, so an odd number of chunks simply contracts one all-zero chunk
+    gload(ra0, rb0, mbeg);
+    gload(ra1, rb1, mbeg + FX_CHUNK);
+#pragma unroll 1
+    for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
+      lstore(ra0, rb0, 0);
+      __syncthreads();
+      gload(ra0, rb0, mc + 2 * FX_CHUNK);
+      contract(0);
+      lstore(ra1, rb1, 1);
+      __syncthreads();
+      gload(ra1, rb1, mc + 3 * FX_CHUNK);
+      contract(1);
+    }
+  } else {
+    int buf = 0;
+    gload(ra0, rb0, mbeg);
+#pragma unroll 1
+    for (int mc = mbeg; mc < mend; mc += FX_CHUNK) {
+      lstore(ra0, rb0, buf);
+      __syncthreads();
+      gload(ra0, rb0, mc + FX_CHUNK);
+      contract(buf);
+      buf ^= 1;
+    }
   }
   // partial slab [split][by][bz][TN][TK], unscaled
   const float unscale = ldexpf(1.0f, -(ea + eb));
   const size_t blk = ((size_t)split * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
   float* slab = slabs + blk * TN * TK;
+  if (active) {
 #pragma unroll
-  for (int mt = 0; mt < MTW; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        slab[n * TK + k0 + 32 * nt + li] = acc[mt][nt][r] * unscale;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          slab[n * TK + k0 + 32 * nt + li] = acc[mt][nt][r] * unscale;
+        }
+  }
   if (bslabs && blockIdx.z == 0) {
     // column sums: thread t owns columns 4*(t % (TN/4)) ..+3; the NTHREADS/(TN/4) threads sharing them meet in LDS
     __syncthreads();
     f32x4* red = (f32x4*)lds;
     red[tid] = bsum;
     __syncthreads();
-    constexpr int Q = TN / 4, G = NTHREADS / Q;
+    constexpr int Q = TN / 4, G = FX_THREADS / Q;
     if (tid < Q) {
       f32x4 s = red[tid];
 #pragma unroll
@@ -174,7 +211,7 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
            float* bslabs, int nsplit, int rows, hipStream_t st) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   dim3 grid(nsplit, (N + TN - 1) / TN, (K + TK - 1) / TK);
-  hipLaunchKernelGGL((wgrad_f16x3_kernel<MTW, NTW>), grid, dim3(NTHREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs,
+  hipLaunchKernelGGL((wgrad_f16x3_kernel<MTW, NTW>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs,
                      bslabs, rows);
   return (int)hipGetLastError();
 }
