@@ -86,16 +86,16 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     }
   };
   auto split_store = [&](char* hi, char* lo, f32x4 v, float s, int row, int col) {
-    h4 vh, vl;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float x = v[j] * s;
-      vh[j] = (_Float16)x;
-      vl[j] = (_Float16)(x - (float)vh[j]);
-    }
+    // packed forms: v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_fma_f32 -- 6 vector instructions per two elements
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+    const f2 x0 = f2{v[0], v[1]} * s, x1 = f2{v[2], v[3]} * s;
+    const hh2 h0 = __builtin_convertvector(x0, hh2), h1 = __builtin_convertvector(x1, hh2);
+    const hh2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f2), hh2);
+    const hh2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f2), hh2);
     const int off = himg(row, col);
-    *(h4*)(hi + off) = vh;
-    *(h4*)(lo + off) = vl;
+    *(h4*)(hi + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+    *(h4*)(lo + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
   };
   auto lstore = [&](const f32x4 (&ra)[A4], const f32x4 (&rb)[B4], int buf) {
     char* base = lds + buf * (2 * SZA + 2 * SZB);
