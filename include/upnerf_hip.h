@@ -251,6 +251,30 @@ int upnerf_ray_sum(int R, int S, const float* X, int C, float* out, void* stream
 /* (d_o, d_d)[r] = (sum_i dxyz_i, sum_i z_i dxyz_i)    */
 int upnerf_ray_geom_bwd(int R, int S, const float* dxyz, const float* z, float* d_o, float* d_d, void* stream);
 
+/* ---- f1: train-split ray sampler (datasets/phototourism.py:420-454, PhototourismDataset.__getitem__ + default
+ * collate): gathers a batch of rays from the flat per-ray buffers, resident in HBM, and interpolates each ray's
+ * feature bilinearly from its image's [h][h][C] map with the reference's weights (incl. its vanishing weights on the
+ * last row / column).  Bit-exact with the reference.  inv_depths / feats may be NULL (depth / feature supervision off). */
+typedef struct {
+  int32_t R, h, C;                 /* rays in the batch, feature-map side, channels */
+  const int64_t* idx;              /* [R] indices into the flat ray buffers */
+  const float* all_ray_infos;      /* [N][3] near, far, image index */
+  const float* all_directions;     /* [N][3] */
+  const float* all_rgbs;           /* [N][3] */
+  const float* all_pxl_coords;     /* [N][2] (row, column) in [0, 1] */
+  const float* all_inv_depths;     /* [N] or NULL */
+  const float* feat_maps;          /* [I][h][h][C] or NULL */
+  const float* poses;              /* [I][3][4] camera-to-world per image index */
+  float* ray_infos;                /* [R][2] */
+  float* directions;               /* [R][3] */
+  int64_t* img_idx;                /* [R] */
+  float* c2w;                      /* [R][3][4] */
+  float* rgbs;                     /* [R][3] */
+  float* feats;                    /* [R][C] or NULL */
+  float* inv_depths;               /* [R] or NULL */
+} upnerf_gather_rays_args;
+int upnerf_gather_rays(const upnerf_gather_rays_args* a, void* stream);
+
 /* ---- dense gradient of an embedding table (autograd of nn.Embedding(img_idx): the per-image appearance / candidate /
  * transient rows, se3_refine and depth_scale of models/nerf_system.py:79-91): out[n][:] = sum_{r: idx[r]==n} g[r][:],
  * rows without a hit are written as zeros; summation in increasing r (bitwise reproducible).  dim <= 256. */

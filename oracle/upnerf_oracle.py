@@ -430,6 +430,35 @@ def training_forward(state: Dict[str, Params], cfgs: Dict[str, NerfCfg], batch: 
 
 
 # a18: Adam (torch.optim.Adam defaults, eps=1e-8: utils/optim.py:20-33) + ExponentialLR (optim.py:36-45)
+def sample_train_rays(buf: Dict[str, Tensor], idx: Tensor) -> Dict[str, Tensor]:
+    """Train-split ray sampler: PhototourismDataset.__getitem__ (datasets/phototourism.py:420-454) for every index of
+    `idx`, stacked like torch's default collate.  buf: all_ray_infos [N,3] (near, far, image index), all_directions
+    [N,3], all_rgbs [N,3], all_pxl_coords [N,2] (row, column in [0,1]), all_inv_depths [N], feat_maps [I,h,h,C],
+    poses [I,3,4] (poses_dict in image-index order).
+    Quirk kept (phototourism.py:433-449): x2 = min(h-1, x1+1), so on the last row / column of a feature map BOTH
+    interpolation weights of that axis are zero and the sampled feature is the zero vector."""
+    out: Dict[str, List[Tensor]] = {k: [] for k in ("ray_infos", "directions", "img_idx", "c2w", "rgbs", "feats",
+                                                      "inv_depths")}
+    fm = buf["feat_maps"]
+    h = fm.shape[1]
+    for i in idx.tolist():
+        img = buf["all_ray_infos"][i, 2].long()
+        out["ray_infos"].append(buf["all_ray_infos"][i, :2])
+        out["directions"].append(buf["all_directions"][i])
+        out["img_idx"].append(img)
+        out["c2w"].append(buf["poses"][img])
+        out["rgbs"].append(buf["all_rgbs"][i])
+        pm = buf["all_pxl_coords"][i] * (h - 1)
+        y, x = pm
+        y1, x1 = torch.floor(pm).long()
+        y2, x2 = min(h - 1, int(y1) + 1), min(h - 1, int(x1) + 1)
+        w11, w12 = (y2 - y) * (x2 - x), (y2 - y) * (x - x1)
+        w21, w22 = (y - y1) * (x2 - x), (y - y1) * (x - x1)
+        out["feats"].append(w11 * fm[img, y1, x1] + w12 * fm[img, y1, x2] + w21 * fm[img, y2, x1] + w22 * fm[img, y2, x2])
+        out["inv_depths"].append(buf["all_inv_depths"][i])
+    return {k: torch.stack(v) for k, v in out.items()}
+
+
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, b1=0.9, b2=0.999, eps=1e-8):
     """One in-place Adam update, bias-corrected exactly like torch.optim.Adam (no amsgrad/weight decay)."""
     m.mul_(b1).add_(g, alpha=1 - b1)

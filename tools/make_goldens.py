@@ -245,12 +245,62 @@ def leaf_fixtures():
     print("leaf fixtures written")
 
 
+def sampler_fixture():
+    """Train-split ray sampler (datasets/phototourism.py:420-454): the REAL PhototourismDataset.__getitem__ run on small
+    synthetic buffers (three images of different sizes, one 6x6x384 feature map each), default-collated.  The dataset
+    module imports cv2 and torchvision at module level (absent here, used only by __init__'s file loading): empty
+    stand-ins are registered for the import; the object is created without __init__ and given the buffers directly."""
+    for name in ("cv2", "torchvision"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].transforms = types.ModuleType("torchvision.transforms")
+    sys.modules["torchvision.transforms"] = sys.modules["torchvision"].transforms
+    import datasets.phototourism as ref_ds
+    from torch.utils.data.dataloader import default_collate
+    wh = [(5, 7), (8, 6), (4, 4)]
+    n_img, fh, C = len(wh), 6, 384
+    ds = object.__new__(ref_ds.PhototourismDataset)
+    ds.split, ds.feat_map_dir = "train", "synthetic"
+    ds.img_ids_train = [11, 12, 13]
+    poses = synth.uniform("smp_pose", (n_img, 3, 4), 9)
+    ds.poses_dict = {id_: poses[i].numpy() for i, id_ in enumerate(ds.img_ids_train)}
+    infos, dirs, rgbs, pxl, invd = [], [], [], [], []
+    for i, (w, h) in enumerate(wh):
+        n = w * h
+        infos.append(torch.cat([torch.full((n, 1), 0.1 + 0.01 * i), torch.full((n, 1), 5.0 - 0.1 * i), torch.full((n, 1), float(i))], 1))
+        dirs.append(synth.uniform(f"smp_dir{i}", (n, 3), 9))
+        rgbs.append(synth.uniform(f"smp_rgb{i}", (n, 3), 9, 0.0, 1.0))
+        invd.append(synth.uniform(f"smp_inv{i}", (n,), 9, 0.2, 10.0))
+        h_pxl = torch.linspace(0, h - 1, h) / (h - 1)  # phototourism.py:296-305
+        w_pxl = torch.linspace(0, w - 1, w) / (w - 1)
+        hh, ww = torch.meshgrid(h_pxl, w_pxl, indexing="ij")
+        pxl.append(torch.stack((hh, ww), -1).view(-1, 2))
+    ds.all_ray_infos, ds.all_directions, ds.all_rgbs = torch.cat(infos), torch.cat(dirs), torch.cat(rgbs)
+    ds.all_pxl_coords, ds.all_inv_depths = torch.cat(pxl), torch.cat(invd)
+    fm = synth.uniform("smp_feat", (n_img, fh, fh, C), 9)
+    ds.feat_maps = fm / torch.norm(fm, dim=-1, keepdim=True)
+    N = len(ds.all_ray_infos)
+    # every ray once (covers first/last rows and columns of every image, where the reference's weights vanish), then repeats
+    idx = torch.cat([torch.arange(N), torch.tensor([0, N - 1, 34, 34, 35, 7])])
+    batch = default_collate([ds[int(i)] for i in idx])
+    out = {"idx": idx.numpy(), "poses": poses.numpy(), "all_ray_infos": ds.all_ray_infos.numpy(),
+           "all_directions": ds.all_directions.numpy(), "all_rgbs": ds.all_rgbs.numpy(),
+           "all_pxl_coords": ds.all_pxl_coords.numpy(), "all_inv_depths": ds.all_inv_depths.numpy(),
+           "feat_maps": ds.feat_maps.numpy().astype(np.float32)}
+    for k, v in batch.items():
+        out["out_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
+    print("sampler fixture written:", {k: tuple(v.shape) for k, v in batch.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
     os.makedirs(OUT, exist_ok=True)
     if not only or "leaf" in only:
         leaf_fixtures()
+    if not only or "sampler" in only:
+        sampler_fixture()
     for n, c in CASES.items():
         if not only or n in only:
             run_case(n, c)

@@ -90,6 +90,14 @@ class FragDesc(C.Structure):
                 ("cols", C.c_int32), ("dst_off", C.c_int32), ("dst_kp", C.c_int32), ("dst_k0", C.c_int32)]
 
 
+class GatherRaysArgs(C.Structure):
+    _fields_ = [("R", C.c_int32), ("h", C.c_int32), ("C", C.c_int32), ("idx", _fp),
+                ("all_ray_infos", _fp), ("all_directions", _fp), ("all_rgbs", _fp), ("all_pxl_coords", _fp),
+                ("all_inv_depths", _fp), ("feat_maps", _fp), ("poses", _fp),
+                ("ray_infos", _fp), ("directions", _fp), ("img_idx", _fp), ("c2w", _fp), ("rgbs", _fp), ("feats", _fp),
+                ("inv_depths", _fp)]
+
+
 class Frag16Desc(C.Structure):
     _fields_ = FragDesc._fields_ + [("exp_id", C.c_int32), ("pair_cols", C.c_int32)]
 
@@ -115,6 +123,7 @@ _SIGNATURES = {
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],
+    "upnerf_gather_rays": [C.POINTER(GatherRaysArgs), _p],
     "upnerf_embed_bwd": [_i, _i, _i, _p, _p, _p, _p],
     "upnerf_linear": [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p],
     "upnerf_loss_fwd": [C.POINTER(LossArgs), _p, _p, _p, _p],

@@ -397,6 +397,47 @@ __global__ void embed_bwd_kernel(int R, int N, int dim, const long long* __restr
   for (int q = 0; q < 4; ++q)
     if (lane + 64 * q < dim) out[(size_t)n * dim + lane + 64 * q] = acc[q];
 }
+
+// Train-split ray sampler (datasets/phototourism.py:420-454 + default collate): one wave per ray gathers the per-ray
+// scalars and interpolates the image's feature map bilinearly -- same operand order and roundings as the reference's
+// scalar code (w11 p11 + w12 p12 + w21 p21 + w22 p22, no fma), including its zero weights on the last row / column.
+__global__ void gather_rays_kernel(upnerf_gather_rays_args a) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= a.R) return;
+  const long long i = a.idx[r];
+  const int img = (int)a.all_ray_infos[i * 3 + 2];
+  if (lane < 2) a.ray_infos[r * 2 + lane] = a.all_ray_infos[i * 3 + lane];
+  if (lane < 3) {
+    a.directions[r * 3 + lane] = a.all_directions[i * 3 + lane];
+    a.rgbs[r * 3 + lane] = a.all_rgbs[i * 3 + lane];
+  }
+  if (lane < 12) a.c2w[r * 12 + lane] = a.poses[img * 12 + lane];
+  if (lane == 0) {
+    a.img_idx[r] = img;
+    if (a.inv_depths) a.inv_depths[r] = a.all_inv_depths[i];
+  }
+  if (!a.feats) return;
+  const int h = a.h, C = a.C;
+  const float y = a.all_pxl_coords[i * 2 + 0] * (float)(h - 1), x = a.all_pxl_coords[i * 2 + 1] * (float)(h - 1);
+  const int y1 = (int)floorf(y), x1 = (int)floorf(x);
+  const int y2 = y1 + 1 < h - 1 ? y1 + 1 : h - 1, x2 = x1 + 1 < h - 1 ? x1 + 1 : h - 1;
+  const float wy2 = (float)y2 - y, wy1 = y - (float)y1, wx2 = (float)x2 - x, wx1 = x - (float)x1;
+  const float w11 = wy2 * wx2, w12 = wy2 * wx1, w21 = wy1 * wx2, w22 = wy1 * wx1;
+  const float* __restrict__ fm = a.feat_maps + (size_t)img * h * h * C;
+  const float* __restrict__ p11 = fm + ((size_t)y1 * h + x1) * C;
+  const float* __restrict__ p12 = fm + ((size_t)y1 * h + x2) * C;
+  const float* __restrict__ p21 = fm + ((size_t)y2 * h + x1) * C;
+  const float* __restrict__ p22 = fm + ((size_t)y2 * h + x2) * C;
+  for (int c = lane; c < C; c += 64) {
+    float v = w11 * p11[c];
+    v = v + w12 * p12[c];
+    v = v + w21 * p21[c];
+    v = v + w22 * p22[c];
+    a.feats[(size_t)r * C + c] = v;
+  }
+}
 }  // namespace
 
 extern "C" int upnerf_abi_version(void) { return UPNERF_ABI_VERSION; }
@@ -471,5 +512,15 @@ extern "C" int upnerf_embed_bwd(int R, int N, int dim, const int64_t* idx, const
   if (R <= 0 || N <= 0 || dim <= 0 || dim > 256 || !idx || !g || !out) return UPNERF_EINVAL;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((N + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, N, dim,
                      (const long long*)idx, g, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_gather_rays(const upnerf_gather_rays_args* a, void* stream) {
+  if (!a || a->R <= 0 || !a->idx || !a->all_ray_infos || !a->all_directions || !a->all_rgbs || !a->poses || !a->ray_infos ||
+      !a->directions || !a->img_idx || !a->c2w || !a->rgbs)
+    return UPNERF_EINVAL;
+  if (a->feats && (!a->feat_maps || !a->all_pxl_coords || a->h < 2 || a->C <= 0)) return UPNERF_EINVAL;
+  if (a->inv_depths && !a->all_inv_depths) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(gather_rays_kernel, dim3((a->R + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, *a);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,80 @@
+"""GPU-resident train-split ray sampler: replaces the reference's per-ray Python
+`PhototourismDataset.__getitem__` + DataLoader workers (datasets/phototourism.py:420-454, models/nerf_system.py:75-82).
+
+All per-ray buffers (`all_ray_infos`, `all_directions`, `all_rgbs`, `all_pxl_coords`, `all_inv_depths`), the per-image
+feature maps and the poses live in HBM (Brandenburg Gate at img_downscale 2: ~30 M rays x 48 B + 763 x 64 x 64 x 384 x 4 B
+= 1.4 GB + 4.8 GB, a fraction of the 288 GB); one HIP launch (`upnerf_gather_rays`) produces a batch with exactly the keys,
+shapes and values the reference's collated batch has -- including the bilinear feature interpolation and its quirk on
+the last row / column.  The shuffle is a device-side `torch.randperm` per epoch (the reference: DataLoader(shuffle=True)).
+
+With world_size > 1 every rank draws the same permutation (same seed) and takes its own contiguous slice of every
+global batch, which is what DistributedSampler gives the reference (train.py:70-72)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterator, Optional
+
+import torch
+
+from ._lib import GatherRaysArgs, check, lib, ptr, stream
+
+
+class GpuRaySampler:
+    def __init__(self, all_ray_infos, all_directions, all_rgbs, poses, all_pxl_coords=None, feat_maps=None,
+                 all_inv_depths=None, device="cuda"):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("GpuRaySampler keeps its buffers in HBM (no CPU path)")
+        f = lambda t: None if t is None else torch.as_tensor(t, dtype=torch.float32).to(dev).contiguous()
+        self.ray_infos, self.directions, self.rgbs = f(all_ray_infos), f(all_directions), f(all_rgbs)
+        self.poses, self.pxl, self.feat_maps, self.inv_depths = f(poses), f(all_pxl_coords), f(feat_maps), f(all_inv_depths)
+        self.N = self.ray_infos.shape[0]
+        if self.ray_infos.shape != (self.N, 3) or self.directions.shape != (self.N, 3) or self.rgbs.shape != (self.N, 3):
+            raise ValueError("all_ray_infos / all_directions / all_rgbs must be [N,3]")
+        if self.poses.dim() != 3 or tuple(self.poses.shape[1:]) != (3, 4):
+            raise ValueError("poses must be [N_images,3,4]")
+        if self.feat_maps is not None:
+            if self.feat_maps.dim() != 4 or self.feat_maps.shape[1] != self.feat_maps.shape[2]:
+                raise ValueError("feat_maps must be [N_images,h,h,C] (the reference asserts h == w)")
+            if self.pxl is None or tuple(self.pxl.shape) != (self.N, 2):
+                raise ValueError("all_pxl_coords [N,2] is required with feat_maps")
+        self.device = dev
+
+    def __len__(self) -> int:
+        return self.N
+
+    def sample(self, idx: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Batch for the ray indices `idx` (int64, on the device): the reference's collated `__getitem__` results."""
+        idx = idx.to(self.device, torch.int64).contiguous()
+        R = idx.numel()
+        dev = self.device
+        e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        out = {"ray_infos": e(R, 2), "directions": e(R, 3), "img_idx": torch.empty(R, device=dev, dtype=torch.int64),
+               "c2w": e(R, 3, 4), "rgbs": e(R, 3)}
+        h = Cc = 0
+        if self.feat_maps is not None:
+            h, Cc = self.feat_maps.shape[1], self.feat_maps.shape[3]
+            out["feats"] = e(R, Cc)
+            if self.inv_depths is not None:  # the reference reads inv_depths inside the feature branch (phototourism.py:452)
+                out["inv_depths"] = e(R)
+        a = GatherRaysArgs(R=R, h=h, C=Cc, idx=ptr(idx), all_ray_infos=ptr(self.ray_infos),
+                           all_directions=ptr(self.directions), all_rgbs=ptr(self.rgbs), all_pxl_coords=ptr(self.pxl),
+                           all_inv_depths=ptr(self.inv_depths), feat_maps=ptr(self.feat_maps), poses=ptr(self.poses),
+                           ray_infos=ptr(out["ray_infos"]), directions=ptr(out["directions"]), img_idx=ptr(out["img_idx"]),
+                           c2w=ptr(out["c2w"]), rgbs=ptr(out["rgbs"]), feats=ptr(out.get("feats")),
+                           inv_depths=ptr(out.get("inv_depths")))
+        check(lib.upnerf_gather_rays(C.byref(a), stream()), "upnerf_gather_rays")
+        return out
+
+    def batches(self, batch_size: int, seed: int = 0, epoch: int = 0, rank: int = 0, world_size: int = 1,
+                drop_last: bool = False) -> Iterator[Dict[str, torch.Tensor]]:
+        """One shuffled epoch of batches of `batch_size` rays PER RANK (Lightning semantics: batch_size is per rank)."""
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed + epoch)
+        perm = torch.randperm(self.N, device=self.device, generator=g)
+        step = batch_size * world_size
+        for lo in range(0, self.N, step):
+            sl = perm[lo + rank * batch_size: lo + (rank + 1) * batch_size]
+            if sl.numel() == 0 or (drop_last and sl.numel() < batch_size):
+                return
+            yield self.sample(sl)
