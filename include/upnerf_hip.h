@@ -332,13 +332,10 @@ int upnerf_frag_copy(const float* src, float* dst, const upnerf_frag_desc* descs
  * Same descriptors as upnerf_frag_copy plus `exp_id`: matrices sharing an id share one power-of-two exponent
  * (2^14 / max|.| over all their elements), written to wexp[exp_id].  Destination element (r, k) of a [rows][dst_kp]
  * matrix at float offset dst_off:  byte dst_off*4 + (((r/32)*(dst_kp/16) + k/16)*2 + plane)*1024
- *                                       + (((k/8)%2)*32 + r%32)*16 + (k%8)*2,   plane 0 = hi, 1 = lo
- * (with pair_cols: r/32 and r%32 replaced by the tile and lane given below).
+ *                                       + (((k/8)%2)*32 + r%32)*16 + (k%8)*2,   plane 0 = hi, 1 = lo.
  * `amax_scratch` [16] floats is zeroed and used inside. */
 typedef struct {
   int32_t src_off, src_ld, transpose, rows, cols, dst_off, dst_kp, dst_k0, exp_id;
-  int32_t pair_cols;             /* 1 for the 256-row matrices: row r sits in 32-row tile 2*(r/64) + r%2, lane (r%64)/2, so
-                                    that one lane of the kernels' 2-tile accumulators owns two ADJACENT output columns */
 } upnerf_frag16_desc;
 int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, const upnerf_frag16_desc* fwd, int nfwd,
                   const upnerf_frag16_desc* bwd, int nbwd, float* amax_scratch /*[16]*/, int32_t* wexp /*[16]*/,

@@ -471,10 +471,7 @@ def test_frag16_layout_and_exponents(hip):
     def unpack(buf, off, n, kp):
         raw = cpu(buf)[off:off + n * kp].view(torch.float16).view(n // 32, kp // 16, 2, 2, 32, 8)
         # [ntile][t][plane][khalf][lane][k%8] -> [plane][ntile*32 + lane][k]
-        out = raw.permute(2, 0, 4, 1, 3, 5).reshape(2, n, kp).float()
-        if n == 256:  # pair_cols: tile 2g + b, lane i holds row 64g + 2i + b
-            out = out.view(2, 4, 2, 32, kp).permute(0, 1, 3, 2, 4).reshape(2, n, kp)
-        return out
+        return raw.permute(2, 0, 4, 1, 3, 5).reshape(2, n, kp).float()
 
     W, W2 = 256, 128
     checks = [(P16, L.w[0], W, 64, Pc[L.w[0]:L.w[0] + W * 64].view(W, 64), 0),

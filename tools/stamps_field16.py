@@ -24,7 +24,7 @@ for i in range(N):
     sysm.training_step(batches[i % 2], i)
 rd(buf, 1)
 names = ["loop top", "K loop (issue)", "epilogue: fma/relu/pack/max", "barrier 1", "planes write (split16 + ds_write)",
-         "barrier 2", "activation store (fp32 global)"]
+         "barrier 2", "tile store (planes -> fp32 global)"]
 tiles = N * (4096 * 64 + 4096 * 192) // 64
 waves = tiles * 4 / 16  # one workgroup in 16 reports
 tot = sum(buf[:7])

@@ -99,7 +99,7 @@ class GatherRaysArgs(C.Structure):
 
 
 class Frag16Desc(C.Structure):
-    _fields_ = FragDesc._fields_ + [("exp_id", C.c_int32), ("pair_cols", C.c_int32)]
+    _fields_ = FragDesc._fields_ + [("exp_id", C.c_int32)]
 
 
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p

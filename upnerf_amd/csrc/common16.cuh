@@ -85,9 +85,6 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
   const int T = K >> 4;
   h8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
   auto fetch = [&](h8 (&ah)[MT], h8 (&al)[MT], h8 (&bh)[NT], h8 (&bl)[NT], int t) {
-#ifdef UPNERF_EXP_NOWLOAD  // timing experiment only: weights fetched for the first two k-blocks, then reused (wrong results)
-    if (t < 2)
-#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       bh[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048);
@@ -144,97 +141,41 @@ __device__ __forceinline__ void mma16_glb(f32x16 (&acc)[MT][NT], const float* co
   }
 }
 
-// Output column of accumulator tile nt, lane i.  The 2-tile-per-wave tiling (256-wide layers) gives a lane two ADJACENT
-// columns (weights are packed accordingly, upnerf_frag16 pair_cols): plane writes are 32-bit, global stores 64-bit.
-template <int NT>
-__device__ __forceinline__ int acc_col(int n0, int nt, int i) {
-  return NT == 2 ? n0 + 2 * i + nt : n0 + 32 * nt + i;
-}
-
-// Visit every accumulator element of this lane: v = f(v, row_in_tile, col).
-template <int MT, int NT, class F>
-__device__ __forceinline__ void acc_map16(f32x16 (&acc)[MT][NT], int row0, int n0, int lane, F f) {
+// Write accumulator values (already in natural units) into the hi/lo planes at column offset c0 with scale 2^e.
+template <int W, int MT, int NT>
+__device__ __forceinline__ void acc_to_planes(const f32x16 (&acc)[MT][NT], char* Ph, char* Pl, int row0, int n0, int c0,
+                                              float sc, int lane) {
   const int i = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        acc[mt][nt][r] = f(acc[mt][nt][r], row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh, acc_col<NT>(n0, nt, i));
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Write accumulator values (natural units) into the hi/lo planes at column offset c0 with scale sc = 2^e.  Pb = hi
-// plane, lo plane at Pb + TILE*W*2.  All per-element addressing is folded into 8 per-lane bases (one per value of the
-// swizzle bits a register index can change) plus compile-time offsets.
-template <int W, int TILE, int MT, int NT>
-__device__ __forceinline__ void acc_to_planes(const f32x16 (&acc)[MT][NT], char* Pb, int row0, int n0, int c0, float sc,
-                                              int lane) {
-  static_assert(NT == 1 || NT == 2, "tilings of this library");
-  constexpr int PLANE = TILE * W * 2, ROWB = W * 2;
-  const int i = lane & 31, hh = lane >> 5;
-  const int col = c0 + acc_col<NT>(n0, 0, i);
-  const int chunk = col >> 3, within = (col & 7) * 2;
-  char* base[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int rowlow = (c & 3) | (hh << 2) | ((c >> 2) << 3);
-    base[c] = Pb + (row0 + 4 * hh) * ROWB + ((chunk ^ rowlow) << 4) + within;
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      char* p = base[(r & 3) | (((r >> 2) & 1) << 2)] + (32 * mt + (r & 3) + 8 * (r >> 2)) * ROWB;
-      if constexpr (NT == 2) {
-        const f32x2 v = {acc[mt][0][r] * sc, acc[mt][1][r] * sc};
-        const h2 h = __builtin_convertvector(v, h2);
-        const f32x2 res = v - __builtin_convertvector(h, f32x2);
-        *(h2*)p = h;
-        *(h2*)(p + PLANE) = __builtin_convertvector(res, h2);
-      } else {
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int o = poff<W>(row, c0 + n0 + 32 * nt + i);
         _Float16 h, l;
-        split16(acc[mt][0][r] * sc, h, l);
-        *(_Float16*)p = h;
-        *(_Float16*)(p + PLANE) = l;
+        split16(acc[mt][nt][r] * sc, h, l);
+        *(_Float16*)(Ph + o) = h;
+        *(_Float16*)(Pl + o) = l;
       }
-    }
 }
 
-// Store accumulator values (natural units, exact fp32) straight to a row-major global tensor: one instruction covers
-// two rows x 256 (or 128) contiguous bytes.  Tiles that lie fully inside M (all but the last one) take a path without
-// per-row predicates (32 exec-mask branches otherwise).
-template <int MT, int NT, bool CHECK>
-__device__ __forceinline__ void acc_to_global_impl(const f32x16 (&acc)[MT][NT], float* __restrict__ p, int ldg, int rows_left) {
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ro = 32 * mt + (r & 3) + 8 * (r >> 2);
-      if (!CHECK || ro < rows_left) {
-        if constexpr (NT == 2) {
-          const f32x2 v = {acc[mt][0][r], acc[mt][1][r]};
-          *(f32x2*)(p + (size_t)ro * ldg) = v;
-        } else {
-          p[(size_t)ro * ldg] = acc[mt][0][r];
-        }
-      }
-    }
-}
-template <int TILE, int MT, int NT>
+// Store accumulator values (natural units, exact fp32) straight to a row-major global tensor: every register of a
+// lane group covers two full 128-byte row segments.
+template <int MT, int NT>
 __device__ __forceinline__ void acc_to_global(const f32x16 (&acc)[MT][NT], float* __restrict__ dst, int ldg, int row0,
                                               int n0, int m0, int M, int lane) {
-  static_assert(NT == 1 || NT == 2, "tilings of this library");
   const int i = lane & 31, hh = lane >> 5;
-  const int mb = m0 + row0 + 4 * hh;
-  float* p = dst + (size_t)mb * ldg + acc_col<NT>(n0, 0, i);
-#ifdef UPNERF_EXP_NOSTORE  // timing experiment only
-  if (M < 0)
-#endif
-  if (m0 + TILE <= M) acc_to_global_impl<MT, NT, false>(acc, p, ldg, 0);
-  else acc_to_global_impl<MT, NT, true>(acc, p, ldg, M - mb);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m < M) __builtin_nontemporal_store(acc[mt][nt][r], &dst[(size_t)m * ldg + n0 + 32 * nt + i]);
+      }
 }
 
 // fp32 value of plane element (row, k)

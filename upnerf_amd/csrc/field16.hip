@@ -14,11 +14,12 @@
 
 #define F16_TILE 64
 
-// Diagnostic build only (-DUPNERF_STAMPS): per-phase shader-clock stamps of the forward trunk loop, accumulated per
-// wave into a global table [phase] (tools/stamps_field16.py).  Never compiled into the shipped library.
+// Diagnostic build only (make -C upnerf_amd/csrc stamps, -DUPNERF_STAMPS): per-phase shader-clock stamps of the forward
+// trunk loop, accumulated in registers and flushed once per workgroup (tools/stamps_field16.py).  Never compiled into
+// the shipped library.
 #ifdef UPNERF_STAMPS
 __device__ unsigned long long upnerf_stamp_acc[16];
-#define STAMP_DECL                                   \
+#define STAMP_DECL                                         \
   unsigned long long _t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
   unsigned long long _t_prev = __builtin_amdgcn_s_memtime()
 #define STAMP(i)                                                \
@@ -27,10 +28,10 @@ __device__ unsigned long long upnerf_stamp_acc[16];
     _t_acc[i] += _t - _t_prev;                                  \
     _t_prev = _t;                                               \
   } while (0)
-#define STAMP_FLUSH                                                                   \
-  do {                                                                                \
-    if (lane == 0 && (blockIdx.x & 15) == 0)                                          \
-      for (int _i = 0; _i < 8; ++_i) atomicAdd(&upnerf_stamp_acc[_i], _t_acc[_i]);     \
+#define STAMP_FLUSH                                                               \
+  do {                                                                            \
+    if (lane == 0 && (blockIdx.x & 15) == 0)                                      \
+      for (int _i = 0; _i < 8; ++_i) atomicAdd(&upnerf_stamp_acc[_i], _t_acc[_i]); \
   } while (0)
 #else
 #define STAMP_DECL
@@ -76,7 +77,7 @@ __device__ __forceinline__ unsigned long long acc_fma_relu_pack(f32x16 (&acc)[MT
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const float b = bias[acc_col<NT>(n0, nt, i)];
+      const float b = bias[n0 + 32 * nt + i];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int e = (mt * NT + nt) * 16 + r;
@@ -222,18 +223,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     if (lane == 0) smax[wave] = wm;
     ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
     STAMP(2);
-    acc_to_global<TILE>(acc, a.h + (size_t)l * M * W, W, row0, n0, m0, M, lane);  // exact fp32, issued early
-    STAMP(6);
     __syncthreads();
     STAMP(3);
     float mx = wg_max4(smax);
     track(a.amax ? a.amax + l : nullptr, mx, tid);
     if (l + 1 == L.skip) mx = fmaxf(mx, x0max);  // the skip layer feeds x0 rows through the same accumulators
     ecur = scale_exp(mx);
-    acc_to_planes<W, TILE>(acc, Ph, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     STAMP(4);
     __syncthreads();
     STAMP(5);
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.h + (size_t)l * M * W, W, m0, M, tid);
+    STAMP(6);
   }
 
   STAMP_FLUSH;
@@ -250,16 +251,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, W, lane);
     const float* __restrict__ bias = P + L.be;
     const float un = pow2f(-(ecur + wexp[8]));
-    acc_map16(acc, row0, n0, lane, [&](float v, int, int col) { return fmaf(v, un, bias[col]); });
+    acc_map(acc, row0, n0, lane, [&](float v, int, int col) { return fmaf(v, un, bias[col]); });
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
     const float mx = wg_max4(smax);
     track(a.amax ? a.amax + D : nullptr, mx, tid);
     ecur = scale_exp(fmaxf(mx, sidemax));  // the heads feed per-ray rows through the same accumulators
-    acc_to_global<TILE>(acc, a.e, W, row0, n0, m0, M, lane);
-    acc_to_planes<W, TILE>(acc, Ph, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.e, W, m0, M, tid);
   }
   if (!a.use_rgb && !a.use_cand) return;
 
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     mma16_glb(accr, ap, pow2f(ecur), P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, W, UPNERF_AUXK, lane);
     const float* __restrict__ bias = P + L.br1;
     const float un = pow2f(-(ecur + wexp[11]));
-    acc_map16(accr, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(fmaf(v, un, bias[col]), 0.0f); });
+    acc_map(accr, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(fmaf(v, un, bias[col]), 0.0f); });
     mr = acc_absmax(accr);
   }
   if (a.use_cand) {
@@ -307,16 +308,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     track(a.amax && a.use_cand ? a.amax + D + 1 : nullptr, mxc, tid);
     ecur = scale_exp(fmaxf(mxr, mxc));
   }
-  if (a.use_rgb) {
-    acc_to_global<TILE>(accr, a.r1, W2, hrow0, hn0, m0, M, lane);
-    acc_to_planes<W, TILE>(accr, Ph, hrow0, hn0, 0, pow2f(ecur), lane);
-  }
-  if (a.use_cand) {
-    acc_to_global<TILE>(accc, a.g1, W2, hrow0, hn0, m0, M, lane);
-    acc_to_planes<W, TILE>(accc, Ph, hrow0, hn0, W2, pow2f(ecur), lane);
-  }
+  if (a.use_rgb) acc_to_planes<W>(accr, Ph, Pl, hrow0, hn0, 0, pow2f(ecur), lane);
+  if (a.use_cand) acc_to_planes<W>(accc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
   __syncthreads();
   if (a.use_rgb) {
+    tile_store16<W, TILE>(Ph, Pl, 0, W2, pow2f(-ecur), a.r1, W2, m0, M, tid);
     // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -325,19 +321,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     }
   }
   if (a.use_cand) {
+    tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
     f32x16 acc[TH::MT][TH::NT];
     acc_zero(acc);
     mma16_lds<W>(acc, Ph, Pl, hrow0, W2, P16 + 4 * (size_t)L.wc2, W2 / 16, hn0, 0, W2, lane);
     const float* __restrict__ bias = P + L.bc2;
     const float un = pow2f(-(ecur + wexp[10]));
-    acc_map16(acc, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(fmaf(v, un, bias[col]), 0.0f); });
+    acc_map(acc, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(fmaf(v, un, bias[col]), 0.0f); });
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
     ecur = scale_exp(wg_max4(smax));
-    acc_to_global<TILE>(acc, a.g2, W2, hrow0, hn0, m0, M, lane);
-    acc_to_planes<W, TILE>(acc, Ph, hrow0, hn0, W2, pow2f(ecur), lane);
+    acc_to_planes<W>(acc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
     __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
     const float pre = rowdot16<W, TPR>(Ph, Pl, prow, phalf, W2, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
     if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
   }
@@ -497,10 +494,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
       erg = scale_exp(fmaxf(mxg, mxr));
     }
     const float sc = pow2f(erg);
-    if (a.use_cand) {
-      acc_to_global<TILE>(accg, a.gz_g1, W2, hrow0, hn0, m0, M, lane);
-      acc_to_planes<W, TILE>(accg, Ph, hrow0, hn0, W2, sc, lane);
-    }
+    if (a.use_cand) acc_to_planes<W>(accg, Ph, Pl, hrow0, hn0, W2, sc, lane);
     if (a.use_rgb) {
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
@@ -520,6 +514,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
       }
     }
     __syncthreads();
+    if (a.use_cand) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
   }
 
   int ecur;
@@ -539,7 +534,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
         if (j < nr) {
           float gv[TW::NT];
 #pragma unroll
-          for (int nt = 0; nt < TW::NT; ++nt) gv[nt] = a.g_E_s[(size_t)(ray0 + j) * W + acc_col<TW::NT>(n0, nt, li)];
+          for (int nt = 0; nt < TW::NT; ++nt) gv[nt] = a.g_E_s[(size_t)(ray0 + j) * W + n0 + 32 * nt + li];
 #pragma unroll
           for (int mt = 0; mt < TW::MT; ++mt)
 #pragma unroll
@@ -559,9 +554,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     const float mx = wg_max4(smax);
     track(a.gmax ? a.gmax + D : nullptr, mx, tid);
     ecur = scale_exp(mx);
-    acc_to_global<TILE>(acc, a.gz_e, W, row0, n0, m0, M, lane);
-    acc_to_planes<W, TILE>(acc, Ph, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_e, W, m0, M, tid);
   }
   // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu (sign bits from the forward, in this lane's layout)
   {
@@ -571,7 +566,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     mma16_lds<W>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_we, W / 16, n0, 0, W, lane);
     const float* __restrict__ ws = P + L.wsig;
     const float un = pow2f(-(ecur + wexp[8]));
-    acc_map16(acc, row0, n0, lane, [&](float v, int row, int col) { return fmaf(v, un, ws[col] * pre_s[row]); });
+    acc_map(acc, row0, n0, lane, [&](float v, int row, int col) { return fmaf(v, un, ws[col] * pre_s[row]); });
     acc_apply_mask(acc, bits);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
@@ -579,9 +574,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     const float mx = wg_max4(smax);
     track(a.gmax ? a.gmax + (D - 1) : nullptr, mx, tid);
     ecur = scale_exp(mx);
-    acc_to_global<TILE>(acc, a.gz_h + (size_t)(D - 1) * M * W, W, row0, n0, m0, M, lane);
-    acc_to_planes<W, TILE>(acc, Ph, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, tid);
   }
   // ---- trunk, last layer to first
   f32x16 accx[TX::MT][TX::NT];
@@ -603,9 +598,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     const float mx = wg_max4(smax);
     track(a.gmax ? a.gmax + (l - 1) : nullptr, mx, tid);
     ecur = scale_exp(mx);
-    acc_to_global<TILE>(acc, a.gz_h + (size_t)(l - 1) * M * W, W, row0, n0, m0, M, lane);
-    acc_to_planes<W, TILE>(acc, Ph, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     __syncthreads();
+    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, tid);
   }
   if (!a.need_dxyz) return;
   // ---- d x0 (first layer + skip) -> d xyz through the encoding

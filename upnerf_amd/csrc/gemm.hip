@@ -410,10 +410,8 @@ __global__ void frag16_write_kernel(const float* __restrict__ src, char* __restr
   const float x = ldexpf(frag16_src(src, q, r, c), frag16_exp(amax[q.exp_id]));
   const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
   const int k = q.dst_k0 + c;
-  const int tile = q.pair_cols ? (((r >> 6) << 1) | (r & 1)) : (r >> 5);
-  const int ln = q.pair_cols ? ((r & 63) >> 1) : (r & 31);
-  const size_t base = (size_t)q.dst_off * 4 + ((size_t)tile * (q.dst_kp >> 4) + (k >> 4)) * 2048 +
-                      ((((k >> 3) & 1) << 5) + ln) * 16 + (k & 7) * 2;
+  const size_t base = (size_t)q.dst_off * 4 + ((size_t)(r >> 5) * (q.dst_kp >> 4) + (k >> 4)) * 2048 +
+                      ((((k >> 3) & 1) << 5) + (r & 31)) * 16 + (k & 7) * 2;
   *(_Float16*)(dst + base) = hi;
   *(_Float16*)(dst + base + 1024) = lo;
 }
@@ -563,7 +561,7 @@ static int frag16_build(const upnerf_frag16_desc* descs, int n, Frag16Descs* D) 
   for (int j = 0; j < n; ++j) {
     const upnerf_frag16_desc& q = descs[j];
     if (q.rows <= 0 || q.cols <= 0 || (q.rows & 31) || (q.dst_kp & 15) || q.dst_k0 + q.cols > q.dst_kp || q.exp_id < 0 ||
-        q.exp_id >= 16 || (q.pair_cols && (q.rows & 63)))
+        q.exp_id >= 16)
       return UPNERF_EINVAL;
     D->d[j] = q;
     D->start[j + 1] = D->start[j] + q.rows * q.cols;

@@ -190,10 +190,7 @@ class NerfPacker:
 
             def mk(src, n, ids):
                 fields = [f for f, _ in FragDesc._fields_]
-                # matrices with 256 output rows are consumed by the 2-tile-per-wave tiling: adjacent columns per lane
-                return (Frag16Desc * n)(*[Frag16Desc(*[getattr(src[i], f) for f in fields], ids[i],
-                                                     int(src[i].rows == 256))
-                                          for i in range(n)])
+                return (Frag16Desc * n)(*[Frag16Desc(*[getattr(src[i], f) for f in fields], ids[i]) for i in range(n)])
 
             self._desc16_cache = (mk(fd, nf, fid), nf, mk(bd, nb, bid), nb)
         return self._desc16_cache
