@@ -115,7 +115,9 @@ typedef struct {
   float* sigma_s;                /* [M] softplus output */
   float* sigma_c;                /* [M] (use_cand) */
   float* rgb;                    /* [M][3] sigmoid output (use_rgb) */
-  /* activations kept for compositing and for the backward pass */
+  /* activations kept for compositing and for the backward pass.  Inference (no gradient wanted): h, hmask, g1, r1 may be
+   * NULL = not stored; e and g2 may be NULL when the compositing mode does not build a feature map (mode 2).  x0 is
+   * always required (the skip layer re-reads it). */
   float* x0;                     /* [M][64] */
   float* h;                      /* [D][M][W] post-ReLU trunk activations */
   uint64_t* hmask;               /* [D][ceil(M/64)][256] ReLU sign bits of h in the kernels' accumulator layout */

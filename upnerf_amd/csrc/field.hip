@@ -105,11 +105,11 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
     }
     const unsigned long long bits = acc_bias_relu_pack(acc, P + L.b[l], n0, lane);
     acc_track_max(acc, a.amax ? a.amax + l : nullptr, lane);
-    ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
+    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
     __syncthreads();
     acc_to_lds(acc, Hs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_store<TILE>(Hs, W, 0, W, a.h + (size_t)l * M * W, W, m0, M, tid);
+    if (a.h) tile_store<TILE>(Hs, W, 0, W, a.h + (size_t)l * M * W, W, m0, M, tid);
   }
 
   const int prow = tid / TPR, phalf = tid % TPR, pm = m0 + prow;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
     __syncthreads();
     acc_to_lds(acc, Hs, W, row0, n0, 0, lane);
     __syncthreads();
-    tile_store<TILE>(Hs, W, 0, W, a.e, W, m0, M, tid);
+    if (a.e) tile_store<TILE>(Hs, W, 0, W, a.e, W, m0, M, tid);
   }
   if (!a.use_rgb && !a.use_cand) return;
 
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
   }
   __syncthreads();
   if (a.use_rgb) {
-    tile_store<TILE>(Hs, W, 0, W2, a.r1, W2, m0, M, tid);
+    if (a.r1) tile_store<TILE>(Hs, W, 0, W2, a.r1, W2, m0, M, tid);
     // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
     }
   }
   if (a.use_cand) {
-    tile_store<TILE>(Hs, W, W2, W2, a.g1, W2, m0, M, tid);
+    if (a.g1) tile_store<TILE>(Hs, W, W2, W2, a.g1, W2, m0, M, tid);
     f32x16 acc[TH::MT][TH::NT];
     acc_zero(acc);
     mma_lds(acc, Hs, W, hrow0, W2, P + L.wc2, W2, hn0, 0, W2, lane);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
     __syncthreads();
     acc_to_lds(acc, Hs, W, hrow0, hn0, W2, lane);
     __syncthreads();
-    tile_store<TILE>(Hs, W, W2, W2, a.g2, W2, m0, M, tid);
+    if (a.g2) tile_store<TILE>(Hs, W, W2, W2, a.g2, W2, m0, M, tid);
     const float pre = rowdot<TPR>(Hs, W, prow, phalf, W2, W2, P + L.wcsig) + P[L.bcsig];
     if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
   }
@@ -383,11 +383,10 @@ int check_layout(const upnerf_layout* L) {
 extern "C" int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream) {
   int rc = check_layout(L);
   if (rc) return rc;
-  if (!a || a->R <= 0 || a->S <= 0 || !a->rays_o || !a->rays_d || !a->z || !a->P || !a->x0 || !a->h || !a->e ||
-      !a->sigma_s || !a->hmask)
+  if (!a || a->R <= 0 || a->S <= 0 || !a->rays_o || !a->rays_d || !a->z || !a->P || !a->x0 || !a->sigma_s)
     return UPNERF_EINVAL;
-  if (a->use_cand && (!a->c_rows || !a->g1 || !a->g2 || !a->sigma_c)) return UPNERF_EINVAL;
-  if (a->use_rgb && (!a->aux || !a->r1 || !a->rgb)) return UPNERF_EINVAL;
+  if (a->use_cand && (!a->c_rows || !a->sigma_c)) return UPNERF_EINVAL;
+  if (a->use_rgb && (!a->aux || !a->rgb)) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int grid = (int)((M + FIELD_TILE - 1) / FIELD_TILE);

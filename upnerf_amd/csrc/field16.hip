@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wexp[l])), P + L.b[l], n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
-    ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
+    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
     STAMP(2);
     __syncthreads();
     STAMP(3);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     STAMP(4);
     __syncthreads();
     STAMP(5);
-    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.h + (size_t)l * M * W, W, m0, M, tid);
+    if (a.h) tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.h + (size_t)l * M * W, W, m0, M, tid);
     STAMP(6);
   }
 
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     ecur = scale_exp(fmaxf(mx, sidemax));  // the heads feed per-ray rows through the same accumulators
     acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     __syncthreads();
-    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.e, W, m0, M, tid);
+    if (a.e) tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.e, W, m0, M, tid);
   }
   if (!a.use_rgb && !a.use_cand) return;
 
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.c_rows + (size_t)rayrow[mt] * UPNERF_CK + 8 * hh;
     mma16_glb(accc, ap, pow2f(ecur), P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, UPNERF_CK, lane);
     const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), P + L.bc1, hn0, lane);
-    ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
+    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
     mc = acc_absmax(accc);
   }
   if (lane == 0) {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
   if (a.use_cand) acc_to_planes<W>(accc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
   __syncthreads();
   if (a.use_rgb) {
-    tile_store16<W, TILE>(Ph, Pl, 0, W2, pow2f(-ecur), a.r1, W2, m0, M, tid);
+    if (a.r1) tile_store16<W, TILE>(Ph, Pl, 0, W2, pow2f(-ecur), a.r1, W2, m0, M, tid);
     // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     }
   }
   if (a.use_cand) {
-    tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
+    if (a.g1) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
     f32x16 acc[TH::MT][TH::NT];
     acc_zero(acc);
     mma16_lds<W>(acc, Ph, Pl, hrow0, W2, P16 + 4 * (size_t)L.wc2, W2 / 16, hn0, 0, W2, lane);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     ecur = scale_exp(wg_max4(smax));
     acc_to_planes<W>(acc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
     __syncthreads();
-    tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
+    if (a.g2) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
     const float pre = rowdot16<W, TPR>(Ph, Pl, prow, phalf, W2, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
     if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
   }
@@ -658,10 +658,10 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
   int rc = check_layout16(L);
   if (rc) return rc;
   if (!a || a->R <= 0 || a->S <= 0 || !a->rays_o || !a->rays_d || !a->z || !a->P || !a->P16 || !a->wexp || !a->x0 ||
-      !a->h || !a->e || !a->sigma_s || !a->hmask)
+      !a->sigma_s)
     return UPNERF_EINVAL;
-  if (a->use_cand && (!a->c_rows || !a->g1 || !a->g2 || !a->sigma_c)) return UPNERF_EINVAL;
-  if (a->use_rgb && (!a->aux || !a->r1 || !a->rgb)) return UPNERF_EINVAL;
+  if (a->use_cand && (!a->c_rows || !a->sigma_c)) return UPNERF_EINVAL;
+  if (a->use_rgb && (!a->aux || !a->rgb)) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);

@@ -221,6 +221,39 @@ class NeRFSystem(_Base):
             self.set_progress(self.global_step / (hp["max_steps"] * 2))
         return loss
 
+    # ---- validation (nerf_system.py:231-269 without the image logging; 318-324) -------------------------------------
+    @torch.no_grad()
+    def validation_step(self, batch, batch_nb=0):
+        """One full validation image (DataLoader batch_size 1: every tensor has a leading 1): chunked render with
+        perturb = 0 and no gradient (the field kernels then skip all stores the backward would need), the loss terms
+        of the current phase and the PSNR of the blended colour, both on device."""
+        b = {k: (v[0] if torch.is_tensor(v) else v) for k, v in batch.items()}
+        if b["c2w"].dim() == 2:
+            b["c2w"] = b["c2w"][None].expand(b["directions"].shape[0], 3, 4)
+        rays = self.rays_from_batch(b)
+        sched_mult = self.get_schedule_mult(self._host_progress)
+        results = self(rays, b["feats"], b["img_idx"], sched_mult, train=False)
+        row = embed_rows(self.depth_scale, b["img_idx"][:1])  # the reference uses the first ray's image (nerf_system.py:249)
+        loss_d, _ = self.loss.forward_with_prior(results, b["rgbs"], b["feats"], b["inv_depths"],
+                                                 row.expand(b["img_idx"].shape[0], 2).contiguous(), sched_mult)
+        log = {"val_loss": sum(l for l in loss_d.values())}
+        typ = "fine" if "rgb_fine" in results else "coarse"
+        if f"rgb_{typ}" in results:
+            log["val_psnr"] = -10.0 * torch.log10(((results[f"rgb_{typ}"] - b["rgbs"]) ** 2).mean())  # utils/metric.py:9-20
+        else:
+            log["val_psnr"] = torch.zeros(1, device=rays.device)
+        log["results"] = results
+        return log
+
+    def validation_epoch_end(self, outputs):
+        if not outputs:
+            return None
+        out = {"val/loss": torch.stack([x["val_loss"] for x in outputs]).mean(),
+               "val/psnr": torch.stack([x["val_psnr"].reshape(()) for x in outputs]).mean()}
+        for k, v in out.items():
+            self.log(k, v)
+        return out
+
     def enable_data_parallel(self, check=False):
         """Average gradients over torch.distributed ranks after every backward (one flat all-reduce)."""
         self.grad_sync = GradSync([p for p in self.parameters()], check=check)

@@ -109,13 +109,18 @@ class _FieldPass(torch.autograd.Function):
         sigma_s = _empty(M, device=dev)
         sigma_c = _empty(M, device=dev) if cfg.use_cand else None
         rgb = _empty(M, 3, device=dev) if cfg.use_rgb else None
-        x0, h, e = _empty(M, X0, device=dev), _empty(D, M, W, device=dev), _empty(M, W, device=dev)
+        # No gradient wanted (validation / test renders under torch.no_grad()): the kernels skip every store that only
+        # the backward pass reads -- 8 of the 11 KB per sample -- and keep what compositing needs (e, g2) plus x0.
+        train = any(ctx.needs_input_grad)
+        x0 = _empty(M, X0, device=dev)
+        h = _empty(D, M, W, device=dev) if train else None
+        e = _empty(M, W, device=dev) if (train or want_feat) else None
         hmask = torch.empty((D + 1) * ((M + _lib.TILE_ROWS - 1) // _lib.TILE_ROWS) * 256, device=dev,
-                            dtype=torch.int64)
-        amax = torch.zeros(16, device=dev)  # running max|.| of the activations (scales of the f16x3 weight gradients)
-        g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
-        g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
-        r1 = _empty(M, W2, device=dev) if cfg.use_rgb else None
+                            dtype=torch.int64) if train else None
+        amax = torch.zeros(16, device=dev) if train else None  # running max|.| (scales of the f16x3 weight gradients)
+        g1 = _empty(M, W2, device=dev) if (cfg.use_cand and train) else None
+        g2 = _empty(M, W2, device=dev) if (cfg.use_cand and (train or joint)) else None
+        r1 = _empty(M, W2, device=dev) if (cfg.use_rgb and train) else None
         fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
