@@ -330,6 +330,20 @@ typedef struct {
 #define UPNERF_MAX_FRAG_DESC 32
 int upnerf_frag_copy(const float* src, float* dst, const upnerf_frag_desc* descs /*host*/, int ndesc, void* stream);
 
+/* ---- packed parameter buffer P <-> the network's named parameters (one launch instead of ~40 cat / pad / copy launches) ----
+ * pack   (unpack = 0): P[dst_off + r*dst_ld + c] = ptr[r*src_ld + c] for c < cols (padding columns are left alone: start
+ *                      from a zeroed P); with `accumulate` the value is added to what P holds (bias of the folded layer).
+ * unpack (unpack = 1): ((float*)ptr)[r*src_ld + c] = P[dst_off + r*dst_ld + c]   -- the backward of pack on dP.
+ * Descriptors are host memory, `ptr` are device pointers; at most UPNERF_MAX_PACK_DESC per call. */
+#define UPNERF_MAX_PACK_DESC 48
+typedef struct {
+  const float* ptr;              /* device pointer of the parameter (pack: source, unpack: destination) */
+  int32_t rows, cols, src_ld;    /* logical shape and row stride of the parameter */
+  int32_t dst_off, dst_ld;       /* float offset and row stride inside P (dst_ld >= cols) */
+  int32_t accumulate;            /* pack only */
+} upnerf_pack_desc;
+int upnerf_pack(float* P, const upnerf_pack_desc* descs, int ndesc, int unpack, void* stream);
+
 /* ---- f16x3 weight re-layout: every matrix of `src` -> scaled fp16 (hi, lo) pairs in MFMA fragment order ------------
  * Same descriptors as upnerf_frag_copy plus `exp_id`: matrices sharing an id share one power-of-two exponent
  * (2^14 / max|.| over all their elements), written to wexp[exp_id].  Destination element (r, k) of a [rows][dst_kp]

@@ -492,6 +492,31 @@ def test_frag16_layout_and_exponents(hip):
         assert 2 ** 13 <= mx * 2.0 ** int(wexp[eid]) < 2 ** 14
 
 
+@pytest.mark.parametrize("W,D,cand", [(256, 8, 16), (64, 4, 16), (256, 8, 0)])
+def test_hip_pack_matches_torch_pack_forward_and_backward(hip, W, D, cand):
+    """NerfPacker.pack_hip (upnerf_pack + upnerf_linear, hand-written backward) against the torch restatement pack()."""
+    from upnerf_amd import synth
+    from upnerf_amd.nerf import NeRF
+    kw = dict(D=D, W=W, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=cand)
+    m = NeRF("coarse", c2f=None, **kw)
+    m.load_state_dict(synth.nerf_state("coarse", seed=4, **kw))
+    pk = m.packer
+    ref_p = {n: t.detach().clone().requires_grad_(True) for n, t in m.named_parameters()}
+    P_ref = pk.pack(ref_p)
+    up = gen((pk.L.total,), 33)
+    (P_ref * up).sum().backward()
+    mg = m.cuda()
+    gp = dict(mg.named_parameters())
+    P = pk.pack_hip(gp)
+    assert rel_err(cpu(P), P_ref.detach()) < 1e-6
+    assert float((cpu(P) - P_ref.detach()).abs().max()) < 1e-5 * float(P_ref.detach().abs().max())
+    (P * up.cuda()).sum().backward()
+    for n in pk.pack_names():
+        assert rel_err(cpu(gp[n].grad), ref_p[n].grad) < 2e-6, n
+    if cand:  # not part of P: feat_candidate_layer (projected per ray by the caller)
+        assert gp["feat_candidate_layer.weight"].grad is None
+
+
 # ------------------------------------------------------------------------------------------ parameter re-layout
 @pytest.mark.parametrize("W,D", [(256, 8), (64, 4)])
 def test_frag_copy_matches_torch_packing(hip, W, D):

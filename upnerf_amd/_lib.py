@@ -90,6 +90,11 @@ class FragDesc(C.Structure):
                 ("cols", C.c_int32), ("dst_off", C.c_int32), ("dst_kp", C.c_int32), ("dst_k0", C.c_int32)]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [("ptr", _fp), ("rows", C.c_int32), ("cols", C.c_int32), ("src_ld", C.c_int32), ("dst_off", C.c_int32),
+                ("dst_ld", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class GatherRaysArgs(C.Structure):
     _fields_ = [("R", C.c_int32), ("h", C.c_int32), ("C", C.c_int32), ("idx", _fp),
                 ("all_ray_infos", _fp), ("all_directions", _fp), ("all_rgbs", _fp), ("all_pxl_coords", _fp),
@@ -123,6 +128,7 @@ _SIGNATURES = {
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],
+    "upnerf_pack": [_p, C.POINTER(PackDesc), _i, _i, _p],
     "upnerf_gather_rays": [C.POINTER(GatherRaysArgs), _p],
     "upnerf_embed_bwd": [_i, _i, _i, _p, _p, _p, _p],
     "upnerf_linear": [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p],

@@ -339,6 +339,38 @@ __global__ void frag_copy_kernel(const float* __restrict__ src, float* __restric
   dst[q.dst_off + ((size_t)(r >> 5) * (q.dst_kp >> 3) + (k >> 3)) * 256 + ((((k >> 2) & 1) << 5) + (r & 31)) * 4 + (k & 3)] = v;
 }
 
+// ---- packed parameter buffer <-> named parameters (upnerf_amd/packing.py:NerfPacker.pack and its backward)
+struct PackDescs {
+  upnerf_pack_desc d[UPNERF_MAX_PACK_DESC];
+  int start[UPNERF_MAX_PACK_DESC + 1];  // prefix sums of rows * cols
+  int n;
+};
+// P[dst_off + r*dst_ld + c] (=|+=) src[r*src_ld + c]   (padding columns are not touched: P starts zeroed)
+__global__ void pack_kernel(float* __restrict__ P, PackDescs D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.start[D.n]) return;
+  int j = 0;
+  while (idx >= D.start[j + 1]) ++j;
+  const upnerf_pack_desc q = D.d[j];
+  const int e = idx - D.start[j];
+  const int r = e / q.cols, c = e - r * q.cols;
+  const float v = q.ptr[(size_t)r * q.src_ld + c];
+  float* dst = &P[q.dst_off + (size_t)r * q.dst_ld + c];
+  if (q.accumulate) *dst += v;
+  else *dst = v;
+}
+// param_grad[r*src_ld + c] = dP[dst_off + r*dst_ld + c]
+__global__ void unpack_kernel(const float* __restrict__ dP, PackDescs D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.start[D.n]) return;
+  int j = 0;
+  while (idx >= D.start[j + 1]) ++j;
+  const upnerf_pack_desc q = D.d[j];
+  const int e = idx - D.start[j];
+  const int r = e / q.cols, c = e - r * q.cols;
+  ((float*)q.ptr)[(size_t)r * q.src_ld + c] = dP[q.dst_off + (size_t)r * q.dst_ld + c];
+}
+
 // ---- f16x3 weight re-layout (hi/lo fp16, fragment order, one power-of-two exponent per matrix id)
 struct Frag16Descs {
   upnerf_frag16_desc d[UPNERF_MAX_FRAG_DESC];
@@ -551,6 +583,25 @@ extern "C" int upnerf_frag_copy(const float* src, float* dst, const upnerf_frag_
   }
   const int total = D.start[ndesc];
   hipLaunchKernelGGL(frag_copy_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, D);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_pack(float* P, const upnerf_pack_desc* descs, int ndesc, int unpack, void* stream) {
+  if (!P || !descs || ndesc <= 0 || ndesc > UPNERF_MAX_PACK_DESC) return UPNERF_EINVAL;
+  PackDescs D;
+  D.n = ndesc;
+  D.start[0] = 0;
+  for (int j = 0; j < ndesc; ++j) {
+    const upnerf_pack_desc& q = descs[j];
+    if (!q.ptr || q.rows <= 0 || q.cols <= 0 || q.src_ld < q.cols || q.dst_ld < q.cols || q.dst_off < 0) return UPNERF_EINVAL;
+    D.d[j] = q;
+    D.start[j + 1] = D.start[j] + q.rows * q.cols;
+  }
+  const int total = D.start[ndesc];
+  if (unpack)
+    hipLaunchKernelGGL(unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)P, D);
+  else
+    hipLaunchKernelGGL(pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D);
   return (int)hipGetLastError();
 }
 
