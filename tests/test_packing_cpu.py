@@ -86,3 +86,18 @@ def test_pack_is_differentiable_to_reference_named_parameters():
         if n in ("progress", "feat_candidate_layer.weight", "feat_candidate_layer.bias"):
             continue  # not part of the packed buffer (projected per ray on the host side)
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_state_dict_keys_and_shapes_match_the_reference_modules():
+    """Checkpoint interchange: the modules expose exactly the reference's state_dict keys and shapes
+    (fixture recorded from the real models/nerf.py and models/transient_net.py by tools/make_goldens.py)."""
+    import json
+    import os
+    from golden_util import GOLDEN
+    from upnerf_amd.nerf import NeRF
+    from upnerf_amd.transient_net import TransientNet
+    fx = json.load(open(os.path.join(GOLDEN, "state_keys.json")))
+    for tag, item in fx.items():
+        m = TransientNet(**item["kwargs"]) if tag.startswith("transient") else NeRF("coarse", c2f=(0.1, 0.5), **item["kwargs"])
+        mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+        assert mine == item["state"], (tag, set(mine) ^ set(item["state"]))

@@ -293,6 +293,25 @@ def sampler_fixture():
     print("sampler fixture written:", {k: tuple(v.shape) for k, v in batch.items()})
 
 
+def state_key_fixture():
+    """state_dict keys and shapes of the REAL reference modules (models/nerf.py:39-78, models/transient_net.py:11-25)
+    for the configurations the path uses -- pins checkpoint interchange: only names and shapes, no values."""
+    import json
+    out = {}
+    for tag, kw in {"nerf_d8_w256": dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16),
+                    "nerf_d4_w64": dict(D=4, W=64, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16),
+                    "nerf_d8_w256_nocand": dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48,
+                                                candidate_dim=0)}.items():
+        m = ref_nerf.NeRF("coarse", c2f=(0.1, 0.5), **kw)
+        out[tag] = {"kwargs": kw, "state": {k: list(v.shape) for k, v in m.state_dict().items()}}
+    t = ref_tnet.TransientNet(763, beta_min=0.1, trasient_dim=128, feat_dim=384)
+    out["transient_763"] = {"kwargs": dict(N_images=763, beta_min=0.1, trasient_dim=128, feat_dim=384),
+                            "state": {k: list(v.shape) for k, v in t.state_dict().items()}}
+    with open(os.path.join(OUT, "state_keys.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("state-key fixture written:", {k: len(v["state"]) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
@@ -301,6 +320,8 @@ if __name__ == "__main__":
         leaf_fixtures()
     if not only or "sampler" in only:
         sampler_fixture()
+    if not only or "state_keys" in only:
+        state_key_fixture()
     for n, c in CASES.items():
         if not only or n in only:
             run_case(n, c)
