@@ -1,3 +1,5 @@
+"""Run-to-run reproducibility of one field pass (forward + backward) on 65 536 samples: lists the backward buffers that
+differ between identical runs, where, and compares against the fp32-kernel result.  UPNERF_LIB selects a diagnostic build."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

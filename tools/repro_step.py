@@ -1,3 +1,5 @@
+"""Run-to-run reproducibility of a whole training step, per gradient tensor, in both field modes (diagnostic companion of
+tests/test_hip_fullsize.py::test_training_step_is_bitwise_reproducible)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
