@@ -21,9 +21,14 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef short s4 __attribute__((ext_vector_type(4)));
 
-#define FX_CHUNK 32  // rows per staged chunk = two 16-deep MFMA steps
+// Rows per staged chunk: two 16-deep MFMA steps, or one for the 256x256 block, whose 128 accumulator registers per wave
+// leave room for two register sets only at half the chunk size (same bytes in flight, but continuously).
+#ifndef FX_CHUNK_BIG
+#define FX_CHUNK_BIG 16
+#endif
 
 // byte offset of fp16 element (row, col) inside one plane; col % 4 == 0 for 8-byte accesses
+template <int FX_CHUNK>
 __device__ __forceinline__ int himg(int row, int col) {
   const int panel = col >> 7, c = col & 127;
   return panel * (FX_CHUNK * 256) + 256 * row + 16 * ((c >> 3) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 2 * (c & 7);
@@ -45,6 +50,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
                                                                   float* __restrict__ slabs, float* __restrict__ bslabs,
                                                                   int rows_per_split) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
+  constexpr int FX_CHUNK = (MTW * NTW == 16) ? FX_CHUNK_BIG : 32;
   constexpr int PN = (TN + 127) / 128, PK = (TK + 127) / 128;           // 128-column panels per plane
   constexpr int SZA = PN * FX_CHUNK * 256, SZB = PK * FX_CHUNK * 256;  // bytes per plane
   constexpr int A4 = FX_CHUNK * TN / 4 / FX_THREADS, B4 = FX_CHUNK * TK / 4 / FX_THREADS;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     const hh2 h0 = __builtin_convertvector(x0, hh2), h1 = __builtin_convertvector(x1, hh2);
     const hh2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f2), hh2);
     const hh2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f2), hh2);
-    const int off = himg(row, col);
+    const int off = himg<FX_CHUNK>(row, col);
     *(h4*)(hi + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
     *(h4*)(lo + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
   };
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       h8 ah[MT], al[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int o0 = himg(16 * kk + trow, n0 + 32 * mt + tcol), o1 = himg(16 * kk + trow + 4, n0 + 32 * mt + tcol);
+        const int o0 = himg<FX_CHUNK>(16 * kk + trow, n0 + 32 * mt + tcol), o1 = himg<FX_CHUNK>(16 * kk + trow + 4, n0 + 32 * mt + tcol);
         const h4 x0 = tr_read(base, o0), x1 = tr_read(base, o1);
         const h4 y0 = tr_read(base + SZA, o0), y1 = tr_read(base + SZA, o1);
         ah[mt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int o0 = himg(16 * kk + trow, k0 + 32 * nt + tcol), o1 = himg(16 * kk + trow + 4, k0 + 32 * nt + tcol);
+        const int o0 = himg<FX_CHUNK>(16 * kk + trow, k0 + 32 * nt + tcol), o1 = himg<FX_CHUNK>(16 * kk + trow + 4, k0 + 32 * nt + tcol);
         const h4 x0 = tr_read(base + 2 * SZA, o0), x1 = tr_read(base + 2 * SZA, o1);
         const h4 y0 = tr_read(base + 2 * SZA + SZB, o0), y1 = tr_read(base + 2 * SZA + SZB, o1);
         const h8 bh = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
   };
   // Two register sets (loads of chunk c+2 in flight while chunk c is contracted) where the accumulators leave room for
   // them; the 256x256 block (128 accumulator registers per wave) keeps one set.
-  constexpr bool TWO_SETS = MT * NT * 16 <= 64;
+  constexpr bool TWO_SETS = MT * NT * 16 <= 64 || FX_CHUNK == 16;
   if constexpr (TWO_SETS) {
     // rows beyond mend load as zeros, so an odd number of chunks simply contracts one all-zero chunk
     gload(ra0, rb0, mbeg);
