@@ -43,22 +43,38 @@ namespace {
 
 __device__ __forceinline__ float pow2f(int n) { return ldexpf(1.0f, n); }
 
+// hi + lo of one fp16 pair of planes as fp32, in ONE vector instruction: v_fma_mix_f32 reads both fp16 operands straight
+// from the halves of their registers (hi * 1.0 + lo; the sum of a hi/lo pair is exact in fp32).  HALF selects the half.
+template <int HALF>
+__device__ __forceinline__ float mix_sum(unsigned int wh, unsigned int wl) {
+  float r;
+  if constexpr (HALF == 0)
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(wh), "v"(wl));
+  else
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(wh), "v"(wl));
+  return r;
+}
+
 // LDS planes -> row-major fp32 global tensor, coalesced (8 columns = 32 bytes per thread, whole rows per wave).
 template <int W, int TILE>
 __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, int ncols, float unscale,
                                              float* __restrict__ dst, int ldg, int m0, int M, int tid) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int gpr = ncols >> 3;
   for (int idx = tid; idx < TILE * gpr; idx += NTHREADS) {
     const int row = idx / gpr, g = idx - row * gpr;
     if (m0 + row < M) {
       const int o = poff<W>(row, c0 + 8 * g);
-      const h8 vh = *(const h8*)(Ph + o), vl = *(const h8*)(Pl + o);
+      const u32x4 wh = *(const u32x4*)(Ph + o), wl = *(const u32x4*)(Pl + o);
       f32x4 o0, o1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o0[j] = ((float)vh[j] + (float)vl[j]) * unscale;
-        o1[j] = ((float)vh[4 + j] + (float)vl[4 + j]) * unscale;
-      }
+      o0[0] = mix_sum<0>(wh[0], wl[0]) * unscale;
+      o0[1] = mix_sum<1>(wh[0], wl[0]) * unscale;
+      o0[2] = mix_sum<0>(wh[1], wl[1]) * unscale;
+      o0[3] = mix_sum<1>(wh[1], wl[1]) * unscale;
+      o1[0] = mix_sum<0>(wh[2], wl[2]) * unscale;
+      o1[1] = mix_sum<1>(wh[2], wl[2]) * unscale;
+      o1[2] = mix_sum<0>(wh[3], wl[3]) * unscale;
+      o1[3] = mix_sum<1>(wh[3], wl[3]) * unscale;
       float* p = &dst[(size_t)(m0 + row) * ldg + 8 * g];
       *(f32x4*)p = o0;
       *(f32x4*)(p + 4) = o1;
