@@ -32,3 +32,11 @@ print(f"{tiles} tiles x 8 layers, 4 waves each; cycles per wave per layer:")
 for i, n in enumerate(names):
     print(f"  {n:40s} {buf[i] / waves / 8:9.0f}   {100 * buf[i] / tot:5.1f} %")
 print(f"  {'sum':40s} {tot / waves / 8:9.0f}")
+
+bnames = ["head stages (d g2, d r1, 128-wide contraction)", "d e (256-wide + rank-1 feature term)", "d h_{D-1}",
+          "trunk, 7 layers", "d x0 -> d xyz"]
+btot = sum(buf[8:13])
+print("backward kernel, cycles per wave per tile:")
+for i, n in enumerate(bnames):
+    print(f"  {n:48s} {buf[8 + i] / waves:9.0f}   {100 * buf[8 + i] / btot:5.1f} %")
+print(f"  {'sum':48s} {btot / waves:9.0f}")

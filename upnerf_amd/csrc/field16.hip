@@ -18,7 +18,7 @@
 // trunk loop, accumulated in registers and flushed once per workgroup (tools/stamps_field16.py).  Never compiled into
 // the shipped library.
 #ifdef UPNERF_STAMPS
-__device__ unsigned long long upnerf_stamp_acc[16];
+__device__ unsigned long long upnerf_stamp_acc[16];  // [0..7] forward trunk phases, [8..15] backward stages
 #define STAMP_DECL                                         \
   unsigned long long _t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
   unsigned long long _t_prev = __builtin_amdgcn_s_memtime()
@@ -28,15 +28,17 @@ __device__ unsigned long long upnerf_stamp_acc[16];
     _t_acc[i] += _t - _t_prev;                                  \
     _t_prev = _t;                                               \
   } while (0)
-#define STAMP_FLUSH                                                               \
-  do {                                                                            \
-    if (lane == 0 && (blockIdx.x & 15) == 0)                                      \
-      for (int _i = 0; _i < 8; ++_i) atomicAdd(&upnerf_stamp_acc[_i], _t_acc[_i]); \
+#define STAMP_FLUSH_AT(base)                                                               \
+  do {                                                                                     \
+    if (lane == 0 && (blockIdx.x & 15) == 0)                                               \
+      for (int _i = 0; _i < 8; ++_i) atomicAdd(&upnerf_stamp_acc[(base) + _i], _t_acc[_i]); \
   } while (0)
+#define STAMP_FLUSH STAMP_FLUSH_AT(0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_FLUSH
+#define STAMP_FLUSH_AT(base)
 #endif
 
 namespace {
@@ -368,6 +370,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
   __shared__ float smax[4], smaxb[4];
   __shared__ float pre_s[TILE];
   __shared__ __attribute__((aligned(16))) float wfj[MAXRAYS][TILE];  // w_feat[row] on the row's ray slot, else 0
+  // per-row scalars of the head stages, computed once per row (not once per 16-byte column group): d pre-activation of
+  // the candidate density, its compositing weight, the three d pre-activations of the colour output
+  __shared__ float dpc_s[TILE], cwj_s[TILE];
+  __shared__ __attribute__((aligned(16))) float dprgb_s[TILE][4];
   char* Ph = planes;
   char* Pl = planes + TILE * W * 2;
   using TW = WaveTile<W, TILE>;
@@ -386,22 +392,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
   const unsigned long long* __restrict__ hm = (const unsigned long long*)a.hmask + (size_t)blockIdx.x * NTHREADS + tid;
   const size_t hm_stride = (size_t)gridDim.x * NTHREADS;
 
-  // softplus'(x) = 1 - exp(-softplus(x)); per-row feature weight on its ray slot
+  // softplus'(x) = 1 - exp(-softplus(x)); per-row feature weight on its ray slot; per-row scalars of the head stages
   if (tid < TILE) {
     const int m = m0 + tid;
-    float v = 0.0f, wf = 0.0f;
+    float v = 0.0f, wf = 0.0f, dpc = 0.0f, cwj = 0.0f;
+    f32x4 dprgb = {0.f, 0.f, 0.f, 0.f};
     int j = 0;
     if (m < M) {
       v = a.d_sigma_s[m] * (1.0f - expf(-a.sigma_s[m]));
       a.dpre_sig_s[m] = v;
       if (a.g_E_s) wf = a.w_feat_s[m];
       j = m / S - ray0;
+      if (a.use_cand) {
+        dpc = a.d_sigma_c[m] * (1.0f - expf(-a.sigma_c[m]));
+        a.dpre_sig_c[m] = dpc;
+        if (a.g_G_c) cwj = a.w_cj[m];
+      }
+      if (a.use_rgb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float y = a.rgb[(size_t)m * 3 + c];
+          dprgb[c] = a.d_rgb[(size_t)m * 3 + c] * (y * (1.0f - y));
+        }
+        *(f32x4*)&a.dpre_rgb[(size_t)m * 4] = dprgb;
+      }
     }
     pre_s[tid] = v;
+    dpc_s[tid] = dpc;
+    cwj_s[tid] = cwj;
+    *(f32x4*)&dprgb_s[tid][0] = dprgb;
 #pragma unroll
     for (int q = 0; q < MAXRAYS; ++q) wfj[q][tid] = (q == j) ? wf : 0.0f;
   }
+  __syncthreads();
+  // column group and first row of this thread in the elementwise head stages (row advances by NTHREADS / GPR per step)
+  const int eg = tid % GPR, er0 = tid / GPR;
+  constexpr int ERS = NTHREADS / GPR;
 
+  STAMP_DECL;
   int erg = 0;  // exponent of the [gz_r1 | gz_g1] planes
   {
     f32x16 accg[TH::MT][TH::NT];
@@ -411,28 +439,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
       // d g2 = w_csig * dpre_c + w_cj * g_G_c[ray]   (candidate_sigma / feat_candidate_layer, nerf.py:99-100)
       f32x4 vals[EPT];
       float lmax = 0.0f;
+      {
+        // all loads first, unconditionally (rows past M are clamped and masked afterwards): a branch around each load
+        // makes hipcc wait for every one of them in turn
+        const f32x4 wv = *(const f32x4*)&P[L.wcsig + 4 * eg];
+        f32x4 gv[EPT], gg[EPT];
 #pragma unroll
-      for (int q = 0; q < EPT; ++q) {
-        const int idx = tid + q * NTHREADS;
-        const int row = idx / GPR, g = idx - row * GPR, m = m0 + row;
-        f32x4 out = {0.f, 0.f, 0.f, 0.f};
-        if (m < M) {
-          const float dp = a.d_sigma_c[m] * (1.0f - expf(-a.sigma_c[m]));
-          if (g == 0) a.dpre_sig_c[m] = dp;
-          const f32x4 gv = *(const f32x4*)&a.g2[(size_t)m * W2 + 4 * g];
-          const f32x4 wv = *(const f32x4*)&P[L.wcsig + 4 * g];
-          f32x4 gg = {0.f, 0.f, 0.f, 0.f};
-          float cw = 0.0f;
-          if (a.g_G_c) {
-            gg = *(const f32x4*)&a.g_G_c[(size_t)(m / S) * W2 + 4 * g];
-            cw = a.w_cj[m];
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) out[c] = gv[c] > 0.f ? wv[c] * dp + cw * gg[c] : 0.f;
-          *(f32x4*)&a.gz_g2[(size_t)m * W2 + 4 * g] = out;
+        for (int q = 0; q < EPT; ++q) {
+          int m = m0 + er0 + ERS * q;
+          m = m < M ? m : M - 1;
+          gv[q] = *(const f32x4*)&a.g2[(size_t)m * W2 + 4 * eg];
+          gg[q] = a.g_G_c ? *(const f32x4*)&a.g_G_c[(size_t)(m / S) * W2 + 4 * eg] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        vals[q] = out;
-        lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+          const int row = er0 + ERS * q, m = m0 + row;
+          const float dp = dpc_s[row], cw = cwj_s[row];
+          f32x4 out;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) out[c] = (m < M && gv[q][c] > 0.f) ? wv[c] * dp + cw * gg[q][c] : 0.f;
+          if (m < M) *(f32x4*)&a.gz_g2[(size_t)m * W2 + 4 * eg] = out;
+          vals[q] = out;
+          lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
+        }
       }
       lmax = wave_max(lmax);
       if (lane == 0) smax[wave] = lmax;
@@ -443,8 +472,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
       const float sc = pow2f(eg2);
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
-        const int idx = tid + q * NTHREADS;
-        const int row = idx / GPR, g = idx - row * GPR;
+        const int row = er0 + ERS * q, g = eg;
         h4 vh, vl;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -466,33 +494,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     f32x4 valr[EPT];
     float mr1 = 0.0f;
     if (a.use_rgb) {
-      // d r1 = W_r2^T (d rgb * rgb (1-rgb))   (rgb_share_layer.2 + sigmoid)
+      // d r1 = W_r2^T (d rgb * rgb (1-rgb))   (rgb_share_layer.2 + sigmoid); loads first, as above
+      f32x4 wr[3], rv[EPT];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) wr[c] = *(const f32x4*)&P[L.wr2 + c * W2 + 4 * eg];
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
-        const int idx = tid + q * NTHREADS;
-        const int row = idx / GPR, g = idx - row * GPR, m = m0 + row;
-        f32x4 out = {0.f, 0.f, 0.f, 0.f};
-        if (m < M) {
-          float dp[3];
+        int m = m0 + er0 + ERS * q;
+        m = m < M ? m : M - 1;
+        rv[q] = *(const f32x4*)&a.r1[(size_t)m * W2 + 4 * eg];
+      }
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float y = a.rgb[(size_t)m * 3 + c];
-            dp[c] = a.d_rgb[(size_t)m * 3 + c] * (y * (1.0f - y));
-            if (g == 0) a.dpre_rgb[(size_t)m * 4 + c] = dp[c];
-          }
-          if (g == 0) a.dpre_rgb[(size_t)m * 4 + 3] = 0.0f;
-          const f32x4 rv = *(const f32x4*)&a.r1[(size_t)m * W2 + 4 * g];
-          f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < EPT; ++q) {
+        const int row = er0 + ERS * q, m = m0 + row;
+        const f32x4 dp = *(const f32x4*)&dprgb_s[row][0];
+        f32x4 out;
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const f32x4 wv = *(const f32x4*)&P[L.wr2 + c * W2 + 4 * g];
+        for (int u = 0; u < 4; ++u) {
+          float t = 0.0f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc4[u] += wv[u] * dp[c];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) out[u] = rv[u] > 0.f ? acc4[u] : 0.f;
-          *(f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * g] = out;
+          for (int c = 0; c < 3; ++c) t += wr[c][u] * dp[c];
+          out[u] = (m < M && rv[q][u] > 0.f) ? t : 0.f;
         }
+        if (m < M) *(f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * eg] = out;
         valr[q] = out;
         mr1 = fmaxf(mr1, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
       }
@@ -514,8 +538,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     if (a.use_rgb) {
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
-        const int idx = tid + q * NTHREADS;
-        const int row = idx / GPR, g = idx - row * GPR;
+        const int row = er0 + ERS * q, g = eg;
         h4 vh, vl;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -533,6 +556,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     if (a.use_cand) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
   }
 
+  STAMP(0);  // head stages (elementwise d g2 / d r1, 128-wide contraction, plane writes)
   int ecur;
   // ---- d e = [gz_r1 | gz_g1] . [W_fold | W_c1e] + w_feat * g_E_s[ray]   (e has no activation)
   {
@@ -574,6 +598,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     __syncthreads();
     tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_e, W, m0, M, tid);
   }
+  STAMP(1);  // d e
   // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu (sign bits from the forward, in this lane's layout)
   {
     const unsigned long long bits = hm[(size_t)(D - 1) * hm_stride];
@@ -594,6 +619,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     __syncthreads();
     tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, tid);
   }
+  STAMP(2);  // d h_{D-1}
   // ---- trunk, last layer to first
   f32x16 accx[TX::MT][TX::NT];
   acc_zero(accx);
@@ -618,7 +644,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     __syncthreads();
     tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, tid);
   }
-  if (!a.need_dxyz) return;
+  STAMP(3);  // D-1 trunk layers
+  if (!a.need_dxyz) {
+    STAMP_FLUSH_AT(8);
+    return;
+  }
   // ---- d x0 (first layer + skip) -> d xyz through the encoding
   {
     f32x16 acc0[TX::MT][TX::NT];
@@ -646,6 +676,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     }
     a.dxyz[(size_t)m * 3 + n] = g;
   }
+  STAMP(4);  // d x0 -> d xyz
+  STAMP_FLUSH_AT(8);
 }
 
 int check_layout16(const upnerf_layout* L) {
