@@ -33,6 +33,8 @@ for i, n in enumerate(names):
     print(f"  {n:40s} {buf[i] / waves / 8:9.0f}   {100 * buf[i] / tot:5.1f} %")
 print(f"  {'sum':40s} {tot / waves / 8:9.0f}")
 
+print(f"forward kernel outside the trunk, cycles per wave per tile: prologue + encoding {buf[7] / waves:.0f}, "
+      f"density head + final layer {buf[13] / waves:.0f}, colour / candidate heads {buf[14] / waves:.0f}")
 bnames = ["head stages (d g2, d r1, 128-wide contraction)", "d e (256-wide + rank-1 feature term)", "d h_{D-1}",
           "trunk, 7 layers", "d x0 -> d xyz"]
 btot = sum(buf[8:13])

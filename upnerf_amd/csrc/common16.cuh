@@ -185,20 +185,28 @@ __device__ __forceinline__ float plane_at(const char* Ph, const char* Pl, int ro
   return ((float)*(const _Float16*)(Ph + o) + (float)*(const _Float16*)(Pl + o)) * unscale;
 }
 
-// dot of plane row segment [c0, c0+K) with w[0..K), split over the TPR adjacent threads that share a row
-template <int W, int TPR>
-__device__ __forceinline__ float rowdot16(const char* Ph, const char* Pl, int row, int part, int c0, int K,
+// dot of plane row segment [c0, c0+K) with w[0..K), split over the TPR adjacent threads that share a row; K is a
+// compile-time constant and the weight loads are issued before anything consumes them.
+template <int W, int TPR, int K>
+__device__ __forceinline__ float rowdot16(const char* Ph, const char* Pl, int row, int part, int c0,
                                           const float* __restrict__ w, float unscale) {
-  float s = 0.0f;
+  constexpr int N8 = K / TPR / 8;
   const int kb = part * (K / TPR);
-  for (int k = 0; k < K / TPR; k += 8) {
-    const int o = poff<W>(row, c0 + kb + k);
+  f32x4 w0[N8], w1[N8];
+#pragma unroll
+  for (int q = 0; q < N8; ++q) {
+    w0[q] = *(const f32x4*)&w[kb + 8 * q];
+    w1[q] = *(const f32x4*)&w[kb + 8 * q + 4];
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int q = 0; q < N8; ++q) {
+    const int o = poff<W>(row, c0 + kb + 8 * q);
     const h8 vh = *(const h8*)(Ph + o), vl = *(const h8*)(Pl + o);
-    const f32x4 w0 = *(const f32x4*)&w[kb + k], w1 = *(const f32x4*)&w[kb + k + 4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      s += ((float)vh[j] + (float)vl[j]) * w0[j];
-      s += ((float)vh[4 + j] + (float)vl[4 + j]) * w1[j];
+      s += ((float)vh[j] + (float)vl[j]) * w0[q][j];
+      s += ((float)vh[4 + j] + (float)vl[4 + j]) * w1[q][j];
     }
   }
 #pragma unroll

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
   const int n0 = TW::n0(wave), row0 = TW::row0(wave);
   const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
   const int D = L.D;
+  STAMP_DECL;
 
   // ---- sample positions (rendering.py:251 / 308) and the maxima that bound the side inputs of this tile
   {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
   tile_store16<W, TILE>(Ph, Pl, 0, UPNERF_X0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
 
   // ---- trunk (nerf.py:84-87)
-  STAMP_DECL;
+  STAMP(7);  // sample positions + encoding + x0 store
   for (int l = 0; l < D; ++l) {
     STAMP(0);
     f32x16 acc[TW::MT][TW::NT];
@@ -256,10 +257,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
   }
 
   STAMP_FLUSH;
+#ifdef UPNERF_STAMPS
+  for (int _i = 0; _i < 8; ++_i) _t_acc[_i] = 0;
+  _t_prev = __builtin_amdgcn_s_memtime();
+#endif
   const int prow = tid / TPR, phalf = tid % TPR, pm = m0 + prow;
   // ---- shared density head (nerf.py:89): softplus(w . h + b)
   {
-    const float pre = rowdot16<W, TPR>(Ph, Pl, prow, phalf, 0, W, P + L.wsig, pow2f(-ecur)) + P[L.bsig];
+    const float pre = rowdot16<W, TPR, W>(Ph, Pl, prow, phalf, 0, P + L.wsig, pow2f(-ecur)) + P[L.bsig];
     if (phalf == 0 && pm < M) a.sigma_s[pm] = softplus_f(pre);
   }
   // ---- xyz_encoding_final (nerf.py:93), no activation
@@ -280,7 +285,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     __syncthreads();
     if (a.e) tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.e, W, m0, M, tid);
   }
-  if (!a.use_rgb && !a.use_cand) return;
+  STAMP(5);  // density head + xyz_encoding_final
+  if (!a.use_rgb && !a.use_cand) {
+    STAMP_FLUSH_AT(8);
+    return;
+  }
 
   // ---- first layer of the colour head (folded, nerf.py:95+102-109) and of the candidate head (nerf.py:97-98)
   f32x16 accr[TH::MT][TH::NT], accc[TH::MT][TH::NT];
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float pre = rowdot16<W, TPR>(Ph, Pl, prow, phalf, 0, W2, P + L.wr2 + c * W2, pow2f(-ecur)) + P[L.br2 + c];
+      const float pre = rowdot16<W, TPR, W2>(Ph, Pl, prow, phalf, 0, P + L.wr2 + c * W2, pow2f(-ecur)) + P[L.br2 + c];
       if (phalf == 0 && pm < M) a.rgb[(size_t)pm * 3 + c] = sigmoid_f(pre);
     }
   }
@@ -353,9 +362,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     acc_to_planes<W>(acc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
     __syncthreads();
     if (a.g2) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
-    const float pre = rowdot16<W, TPR>(Ph, Pl, prow, phalf, W2, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
+    const float pre = rowdot16<W, TPR, W2>(Ph, Pl, prow, phalf, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
     if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
   }
+  STAMP(6);  // colour / candidate heads
+  STAMP_FLUSH_AT(8);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -666,13 +677,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
   for (int it = tid; it < TILE * 3; it += NTHREADS) {
     const int row = it / 3, n = it - row * 3, m = m0 + row;
     if (m >= M) continue;
-    const float* __restrict__ x0 = a.x0 + (size_t)m * UPNERF_X0;
+    const float* __restrict__ x0 = a.x0 + (size_t)m * UPNERF_X0 + 3 + 20 * n;
+    float xs[10], xc[10];  // all 20 loads in flight at once (two per trip left ten dependent L2 round trips)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      xs[k] = x0[k];
+      xc[k] = x0[10 + k];
+    }
     float g = Gs[swz(row, n, UPNERF_X0)];
-#pragma unroll 2
+#pragma unroll
     for (int k = 0; k < 10; ++k) {
       const float f = ldexpf(PI_F, k);
-      g += f * (x0[3 + 20 * n + 10 + k] * Gs[swz(row, 3 + 20 * n + k, UPNERF_X0)] -
-                x0[3 + 20 * n + k] * Gs[swz(row, 3 + 20 * n + 10 + k, UPNERF_X0)]);
+      g += f * (xc[k] * Gs[swz(row, 3 + 20 * n + k, UPNERF_X0)] - xs[k] * Gs[swz(row, 3 + 20 * n + 10 + k, UPNERF_X0)]);
     }
     a.dxyz[(size_t)m * 3 + n] = g;
   }
