@@ -204,6 +204,9 @@ template <int W, int TILE>
 __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W * 4 <= 65536) ? 2 : 1)) void field_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
   __shared__ __attribute__((aligned(16))) float Gs[TILE * W];
   __shared__ float pre_s[TILE];
+  // per-row scalars of the head stages, computed once per row instead of once per 16-byte column group
+  __shared__ float dpc_s[TILE], cwj_s[TILE];
+  __shared__ __attribute__((aligned(16))) float dprgb_s[TILE][4];
   constexpr int W2 = W / 2;
   using TW = WaveTile<W, TILE>;
   using TH = WaveTile<W2, TILE>;
@@ -216,43 +219,63 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
   const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
   const int xn0 = TX::n0(wave), xrow0 = TX::row0(wave);
 
-  // softplus'(x) = 1 - exp(-softplus(x))
+  // softplus'(x) = 1 - exp(-softplus(x)); per-row scalars of the head stages
   if (tid < TILE) {
     const int m = m0 + tid;
-    float v = 0.0f;
+    float v = 0.0f, dpc = 0.0f, cwj = 0.0f;
+    f32x4 dprgb = {0.f, 0.f, 0.f, 0.f};
     if (m < M) {
       v = a.d_sigma_s[m] * (1.0f - expf(-a.sigma_s[m]));
       a.dpre_sig_s[m] = v;
+      if (a.use_cand) {
+        dpc = a.d_sigma_c[m] * (1.0f - expf(-a.sigma_c[m]));
+        a.dpre_sig_c[m] = dpc;
+        if (a.g_G_c) cwj = a.w_cj[m];
+      }
+      if (a.use_rgb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float y = a.rgb[(size_t)m * 3 + c];
+          dprgb[c] = a.d_rgb[(size_t)m * 3 + c] * (y * (1.0f - y));
+        }
+        *(f32x4*)&a.dpre_rgb[(size_t)m * 4] = dprgb;
+      }
     }
     pre_s[tid] = v;
+    dpc_s[tid] = dpc;
+    cwj_s[tid] = cwj;
+    *(f32x4*)&dprgb_s[tid][0] = dprgb;
   }
+  __syncthreads();
+  // column group / first row of this thread in the element-wise head stages; all loads of a stage are issued before
+  // anything consumes them (a branch around each load made hipcc wait for every one in turn)
+  constexpr int GPR = W2 / 4, ERS = NTHREADS / GPR, EPT = (TILE * GPR + NTHREADS - 1) / NTHREADS;
+  const int eg = tid % GPR, er0 = tid / GPR;
 
   if (a.use_cand) {
     // d g2 = w_csig * dpre_c + w_cj * g_G_c[ray]   (candidate_sigma / feat_candidate_layer, nerf.py:99-100)
-    constexpr int GPR = W2 / 4;
     float lmax = 0.0f;
-    for (int idx = tid; idx < TILE * GPR; idx += NTHREADS) {
-      const int row = idx / GPR, g = idx - row * GPR, m = m0 + row;
-      f32x4 out = {0.f, 0.f, 0.f, 0.f};
-      if (m < M) {
-        const float dp = a.d_sigma_c[m] * (1.0f - expf(-a.sigma_c[m]));
-        if (g == 0) a.dpre_sig_c[m] = dp;
-        const f32x4 gv = *(const f32x4*)&a.g2[(size_t)m * W2 + 4 * g];
-        const f32x4 wv = *(const f32x4*)&P[L.wcsig + 4 * g];
-        f32x4 gg = {0.f, 0.f, 0.f, 0.f};
-        float cw = 0.0f;
-        if (a.g_G_c) {
-          gg = *(const f32x4*)&a.g_G_c[(size_t)(m / S) * W2 + 4 * g];
-          cw = a.w_cj[m];
-        }
-        out.x = gv.x > 0.f ? wv.x * dp + cw * gg.x : 0.f;
-        out.y = gv.y > 0.f ? wv.y * dp + cw * gg.y : 0.f;
-        out.z = gv.z > 0.f ? wv.z * dp + cw * gg.z : 0.f;
-        out.w = gv.w > 0.f ? wv.w * dp + cw * gg.w : 0.f;
-        *(f32x4*)&a.gz_g2[(size_t)m * W2 + 4 * g] = out;
+    const f32x4 wv = *(const f32x4*)&P[L.wcsig + 4 * eg];
+    f32x4 gv[EPT], gg[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      int m = m0 + er0 + ERS * q;
+      m = m < M ? m : M - 1;
+      gv[q] = *(const f32x4*)&a.g2[(size_t)m * W2 + 4 * eg];
+      gg[q] = a.g_G_c ? *(const f32x4*)&a.g_G_c[(size_t)(m / S) * W2 + 4 * eg] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int row = er0 + ERS * q, m = m0 + row;
+      if (row < TILE) {
+        const float dp = dpc_s[row], cw = cwj_s[row];
+        f32x4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = (m < M && gv[q][c] > 0.f) ? wv[c] * dp + cw * gg[q][c] : 0.f;
+        if (m < M) *(f32x4*)&a.gz_g2[(size_t)m * W2 + 4 * eg] = out;
+        *(f32x4*)&Gs[swz4(row, W2 + 4 * eg, W)] = out;
+        lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out.x), fabsf(out.y)), fmaxf(fabsf(out.z), fabsf(out.w))));
       }
-      *(f32x4*)&Gs[swz4(row, W2 + 4 * g, W)] = out;
-      lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out.x), fabsf(out.y)), fmaxf(fabsf(out.z), fabsf(out.w))));
     }
     wave_track_max(lmax, a.gmax ? a.gmax + D + 2 : nullptr, lane);
     __syncthreads();
@@ -267,35 +290,33 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
   }
   if (a.use_rgb) {
     // d r1 = W_r2^T (d rgb * rgb (1-rgb))   (rgb_share_layer.2 + sigmoid)
-    constexpr int GPR = W2 / 4;
     float lmax = 0.0f;
-    for (int idx = tid; idx < TILE * GPR; idx += NTHREADS) {
-      const int row = idx / GPR, g = idx - row * GPR, m = m0 + row;
-      f32x4 out = {0.f, 0.f, 0.f, 0.f};
-      if (m < M) {
-        float dp[3];
+    f32x4 wr[3], rv[EPT];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float y = a.rgb[(size_t)m * 3 + c];
-          dp[c] = a.d_rgb[(size_t)m * 3 + c] * (y * (1.0f - y));
-          if (g == 0) a.dpre_rgb[(size_t)m * 4 + c] = dp[c];
-        }
-        if (g == 0) a.dpre_rgb[(size_t)m * 4 + 3] = 0.0f;
-        const f32x4 rv = *(const f32x4*)&a.r1[(size_t)m * W2 + 4 * g];
-        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 3; ++c) wr[c] = *(const f32x4*)&P[L.wr2 + c * W2 + 4 * eg];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const f32x4 wv = *(const f32x4*)&P[L.wr2 + c * W2 + 4 * g];
-          acc4.x += wv.x * dp[c]; acc4.y += wv.y * dp[c]; acc4.z += wv.z * dp[c]; acc4.w += wv.w * dp[c];
+    for (int q = 0; q < EPT; ++q) {
+      int m = m0 + er0 + ERS * q;
+      m = m < M ? m : M - 1;
+      rv[q] = *(const f32x4*)&a.r1[(size_t)m * W2 + 4 * eg];
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int row = er0 + ERS * q, m = m0 + row;
+      if (row < TILE) {
+        const f32x4 dp = *(const f32x4*)&dprgb_s[row][0];
+        f32x4 out;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float t = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) t += wr[c][u] * dp[c];
+          out[u] = (m < M && rv[q][u] > 0.f) ? t : 0.f;
         }
-        out.x = rv.x > 0.f ? acc4.x : 0.f;
-        out.y = rv.y > 0.f ? acc4.y : 0.f;
-        out.z = rv.z > 0.f ? acc4.z : 0.f;
-        out.w = rv.w > 0.f ? acc4.w : 0.f;
-        *(f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * g] = out;
+        if (m < M) *(f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * eg] = out;
+        *(f32x4*)&Gs[swz4(row, 4 * eg, W)] = out;
+        lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out.x), fabsf(out.y)), fmaxf(fabsf(out.z), fabsf(out.w))));
       }
-      *(f32x4*)&Gs[swz4(row, 4 * g, W)] = out;
-      lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out.x), fabsf(out.y)), fmaxf(fabsf(out.z), fabsf(out.w))));
     }
     wave_track_max(lmax, a.gmax ? a.gmax + D + 3 : nullptr, lane);
   }
@@ -358,13 +379,18 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
   for (int it = tid; it < TILE * 3; it += NTHREADS) {
     const int row = it / 3, n = it - row * 3, m = m0 + row;
     if (m >= M) continue;
-    const float* __restrict__ x0 = a.x0 + (size_t)m * UPNERF_X0;
+    const float* __restrict__ x0 = a.x0 + (size_t)m * UPNERF_X0 + 3 + 20 * n;
+    float xs[10], xc[10];  // all 20 loads in flight at once
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      xs[k] = x0[k];
+      xc[k] = x0[10 + k];
+    }
     float g = Gs[swz(row, n, W)];
-#pragma unroll 2
+#pragma unroll
     for (int k = 0; k < 10; ++k) {
       const float f = ldexpf(PI_F, k);
-      g += f * (x0[3 + 20 * n + 10 + k] * Gs[swz(row, 3 + 20 * n + k, W)] -
-                x0[3 + 20 * n + k] * Gs[swz(row, 3 + 20 * n + 10 + k, W)]);
+      g += f * (xc[k] * Gs[swz(row, 3 + 20 * n + k, W)] - xs[k] * Gs[swz(row, 3 + 20 * n + 10 + k, W)]);
     }
     a.dxyz[(size_t)m * 3 + n] = g;
   }
