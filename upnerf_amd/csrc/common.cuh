@@ -5,8 +5,8 @@
 //   * dense contractions run on the matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32 in / fp32 accumulate,
 //     64 FLOP/clk/SIMD): lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31], and holds
 //     D[row = (reg&3) + 8*(reg>>2) + 4*(l>>5)][col = l&31] in its 16 accumulator registers;
-//   * a workgroup owns a tile of TILE = 128 rows (samples); the tile's activations live in LDS as
-//     [128][W] fp32 with a 16-byte-granule XOR swizzle (granule ^= row & 15), which makes both the
+//   * a workgroup owns a tile of TILE = 64 rows (samples); the tile's activations live in LDS as
+//     [TILE][W] fp32 with a 16-byte-granule XOR swizzle (granule ^= row & 15), which makes both the
 //     ds_read_b128 operand reads (16 distinct rows per lane group) and the ds_write_b32 accumulator
 //     write-back (32 consecutive columns of one row) bank-conflict free;
 //   * weights are streamed from L2 straight into registers, pre-packed per step in MFMA fragment order so that

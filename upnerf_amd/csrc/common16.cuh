@@ -161,30 +161,6 @@ __device__ __forceinline__ void acc_to_planes(const f32x16 (&acc)[MT][NT], char*
       }
 }
 
-// Store accumulator values (natural units, exact fp32) straight to a row-major global tensor: every register of a
-// lane group covers two full 128-byte row segments.
-template <int MT, int NT>
-__device__ __forceinline__ void acc_to_global(const f32x16 (&acc)[MT][NT], float* __restrict__ dst, int ldg, int row0,
-                                              int n0, int m0, int M, int lane) {
-  const int i = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m < M) __builtin_nontemporal_store(acc[mt][nt][r], &dst[(size_t)m * ldg + n0 + 32 * nt + i]);
-      }
-}
-
-// fp32 value of plane element (row, k)
-template <int W>
-__device__ __forceinline__ float plane_at(const char* Ph, const char* Pl, int row, int k, float unscale) {
-  const int o = poff<W>(row, k);
-  return ((float)*(const _Float16*)(Ph + o) + (float)*(const _Float16*)(Pl + o)) * unscale;
-}
-
 // dot of plane row segment [c0, c0+K) with w[0..K), split over the TPR adjacent threads that share a row; K is a
 // compile-time constant and the weight loads are issued before anything consumes them.
 template <int W, int TPR, int K>

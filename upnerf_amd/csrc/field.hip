@@ -1,5 +1,6 @@
 // Fused NeRF field for gfx950: positional encoding -> D x W trunk (skip connection) -> density / feature /
-// candidate / colour heads, forward and data-gradient backward, one 128-sample tile per workgroup.
+// candidate / colour heads, forward and data-gradient backward, one 64-sample tile per workgroup (fp32 MFMA variant;
+// csrc/field16.hip is the f16x3 variant used for 256-wide fields).
 //
 // Reference behaviour: models/nerf.py:80-124 (NeRF.forward) and 126-147 (positional_encoding), evaluated by
 // models/rendering.py:102-122 on xyz = o + d*z.  What is different by design (not by arithmetic):
