@@ -25,12 +25,16 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # UPNERF_DIST_BACKEND: diagnostic override (e.g. "gloo" to exercise the multi-rank path of bench.py on a
+        # single-GPU box, together with UPNERF_SHARE_DEVICE=1); the product path is "nccl" = RCCL
+        backend = backend or os.environ.get("UPNERF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if os.environ.get("UPNERF_SHARE_DEVICE"):
+        local = 0  # diagnostic: every rank on cuda:0
     return rank, local, world
 
 
