@@ -13,6 +13,17 @@
 #include "common16.cuh"
 
 #define F16_TILE 64
+// Waves per workgroup: 4 (one 64 x 64 output block per wave; what ships) or 8 (64 x 32 blocks: half the accumulators and
+// half the epilogue per wave, four waves per SIMD instead of two -- measured 14-20 % SLOWER: twice the LDS operand
+// traffic, twice the weight bytes per MFMA and ~30 spilled registers under the 128-VGPR cap; needs 512 mask words
+// per tile and layer from the caller).
+#ifndef F16_WAVES
+#define F16_WAVES 4
+#endif
+#define F16_THREADS (64 * F16_WAVES)
+// two workgroups per CU = 2 or 4 waves per SIMD (the latter caps a wave at 128 VGPRs); hipcc takes the second
+// __launch_bounds__ argument as the minimum number of waves per SIMD
+#define F16_WAVES_PER_EU (F16_WAVES / 2)
 
 // Diagnostic build only (make -C upnerf_amd/csrc stamps, -DUPNERF_STAMPS): per-phase shader-clock stamps of the forward
 // trunk loop, accumulated in registers and flushed once per workgroup (tools/stamps_field16.py).  Never compiled into
@@ -43,6 +54,28 @@ __device__ unsigned long long upnerf_stamp_acc[16];  // [0..7] forward trunk pha
 
 namespace {
 
+// How the F16_WAVES waves of a workgroup share a [TILE x N] output tile (32 x 32 MFMA tiles); same rules as WaveTile in
+// common.cuh: surplus waves of a narrow layer recompute a piece another wave owns.
+template <int N, int TILE>
+struct WaveTile16 {
+  static constexpr int NW = F16_WAVES;
+  static constexpr int NT = (N >= 256 && NW == 4) ? 2 : 1;
+  static constexpr int NG = N / 32 / NT;
+  static constexpr int MG = TILE / 32;
+  static constexpr int WN = NG >= NW ? NW : NG;
+  static constexpr int WM = (NW / WN) < MG ? (NW / WN) : MG;
+  static constexpr int MT = MG / WM;
+  __device__ static __forceinline__ int n0(int wave) { return (wave % WN) * 32 * NT; }
+  __device__ static __forceinline__ int row0(int wave) { return ((wave / WN) % WM) * 32 * MT; }
+};
+
+__device__ __forceinline__ float wg_max(const float* smax) {
+  float m = smax[0];
+#pragma unroll
+  for (int w = 1; w < F16_WAVES; ++w) m = fmaxf(m, smax[w]);
+  return m;
+}
+
 __device__ __forceinline__ float pow2f(int n) { return ldexpf(1.0f, n); }
 
 // hi + lo of one fp16 pair of planes as fp32, in ONE vector instruction: v_fma_mix_f32 reads both fp16 operands straight
@@ -63,7 +96,7 @@ __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int
                                              float* __restrict__ dst, int ldg, int m0, int M, int tid) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int gpr = ncols >> 3;
-  for (int idx = tid; idx < TILE * gpr; idx += NTHREADS) {
+  for (int idx = tid; idx < TILE * gpr; idx += F16_THREADS) {
     const int row = idx / gpr, g = idx - row * gpr;
     if (m0 + row < M) {
       const int o = poff<W>(row, c0 + 8 * g);
@@ -130,16 +163,16 @@ __device__ __forceinline__ void track(float* __restrict__ slot, float mx, int ti
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int TILE>
-__global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
+__global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
   constexpr int W = 256, W2 = 128;
-  constexpr int TPR = NTHREADS / TILE;
+  constexpr int TPR = F16_THREADS / TILE;
   __shared__ __attribute__((aligned(16))) char planes[2 * TILE * W * 2];
-  __shared__ float smax[4], smaxb[4];
+  __shared__ float smax[F16_WAVES], smaxb[F16_WAVES];
   __shared__ float xyz_s[TILE * 3];
   char* Ph = planes;
   char* Pl = planes + TILE * W * 2;
-  using TW = WaveTile<W, TILE>;
-  using TH = WaveTile<W2, TILE>;
+  using TW = WaveTile16<W, TILE>;
+  using TH = WaveTile16<W2, TILE>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE;
@@ -173,9 +206,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     const int mlast = (m0 + TILE < M ? m0 + TILE : M) - 1;
     const int ray0 = m0 / S, nr = mlast / S - ray0 + 1;
     if (a.use_rgb)
-      for (int idx = tid; idx < nr * UPNERF_AUXK; idx += NTHREADS) sm = fmaxf(sm, fabsf(a.aux[(size_t)ray0 * UPNERF_AUXK + idx]));
+      for (int idx = tid; idx < nr * UPNERF_AUXK; idx += F16_THREADS) sm = fmaxf(sm, fabsf(a.aux[(size_t)ray0 * UPNERF_AUXK + idx]));
     if (a.use_cand)
-      for (int idx = tid; idx < nr * UPNERF_CK; idx += NTHREADS) sm = fmaxf(sm, fabsf(a.c_rows[(size_t)ray0 * UPNERF_CK + idx]));
+      for (int idx = tid; idx < nr * UPNERF_CK; idx += F16_THREADS) sm = fmaxf(sm, fabsf(a.c_rows[(size_t)ray0 * UPNERF_CK + idx]));
     xm = wave_max(xm);
     sm = wave_max(sm);
     if (lane == 0) {
@@ -184,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     }
   }
   __syncthreads();
-  const float x0max = wg_max4(smax), sidemax = wg_max4(smaxb);
+  const float x0max = wg_max(smax), sidemax = wg_max(smaxb);
   track(a.amax ? a.amax + D + 4 : nullptr, x0max, tid);
   int ecur = scale_exp(x0max);
   // ---- BARF-masked encoding (nerf.py:126-147) straight into the planes
@@ -197,7 +230,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
       *(_Float16*)(Ph + o) = h;
       *(_Float16*)(Pl + o) = l;
     };
-    for (int it = tid; it < TILE * 3; it += NTHREADS) {
+    for (int it = tid; it < TILE * 3; it += F16_THREADS) {
       const int row = it / 3, n = it - row * 3;
       const float xv = xyz_s[row * 3 + n];
       put(row, n, xv);
@@ -240,11 +273,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wexp[l])), P + L.b[l], n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
-    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
+    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * F16_THREADS + tid] = bits;
     STAMP(2);
     __syncthreads();
     STAMP(3);
-    float mx = wg_max4(smax);
+    float mx = wg_max(smax);
     track(a.amax ? a.amax + l : nullptr, mx, tid);
     if (l + 1 == L.skip) mx = fmaxf(mx, x0max);  // the skip layer feeds x0 rows through the same accumulators
     ecur = scale_exp(mx);
@@ -278,7 +311,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    const float mx = wg_max4(smax);
+    const float mx = wg_max(smax);
     track(a.amax ? a.amax + D : nullptr, mx, tid);
     ecur = scale_exp(fmaxf(mx, sidemax));  // the heads feed per-ray rows through the same accumulators
     acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
@@ -321,7 +354,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.c_rows + (size_t)rayrow[mt] * UPNERF_CK + 8 * hh;
     mma16_glb(accc, ap, pow2f(ecur), P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, UPNERF_CK, lane);
     const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), P + L.bc1, hn0, lane);
-    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * NTHREADS + tid] = bits;
+    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * F16_THREADS + tid] = bits;
     mc = acc_absmax(accc);
   }
   if (lane == 0) {
@@ -330,7 +363,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
   }
   __syncthreads();
   {
-    const float mxr = wg_max4(smax), mxc = wg_max4(smaxb);
+    const float mxr = wg_max(smax), mxc = wg_max(smaxb);
     track(a.amax && a.use_rgb ? a.amax + D + 3 : nullptr, mxr, tid);
     track(a.amax && a.use_cand ? a.amax + D + 1 : nullptr, mxc, tid);
     ecur = scale_exp(fmaxf(mxr, mxc));
@@ -358,7 +391,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    ecur = scale_exp(wg_max4(smax));
+    ecur = scale_exp(wg_max(smax));
     acc_to_planes<W>(acc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
     __syncthreads();
     if (a.g2) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
@@ -372,13 +405,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_fwd_kernel(upnerf_layout 
 // ------------------------------------------------------------------------------------------------------------------
 // Backward data-gradient chain (autograd of nerf.py:80-124), stage for stage as field.hip:field_bwd_kernel.
 template <int TILE>
-__global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
+__global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
   constexpr int W = 256, W2 = 128;
   constexpr int MAXRAYS = 3;            // rays a 64-sample tile can touch when S >= 32
   constexpr int GPR = W2 / 4;           // 16-byte groups per half-width row
-  constexpr int EPT = TILE * GPR / NTHREADS;  // groups per thread in the elementwise stages
+  constexpr int EPT = TILE * GPR / F16_THREADS;  // groups per thread in the elementwise stages
   __shared__ __attribute__((aligned(16))) char planes[2 * TILE * W * 2];
-  __shared__ float smax[4], smaxb[4];
+  __shared__ float smax[F16_WAVES], smaxb[F16_WAVES];
   __shared__ float pre_s[TILE];
   __shared__ __attribute__((aligned(16))) float wfj[MAXRAYS][TILE];  // w_feat[row] on the row's ray slot, else 0
   // per-row scalars of the head stages, computed once per row (not once per 16-byte column group): d pre-activation of
@@ -387,9 +420,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
   __shared__ __attribute__((aligned(16))) float dprgb_s[TILE][4];
   char* Ph = planes;
   char* Pl = planes + TILE * W * 2;
-  using TW = WaveTile<W, TILE>;
-  using TH = WaveTile<W2, TILE>;
-  using TX = WaveTile<UPNERF_X0, TILE>;
+  using TW = WaveTile16<W, TILE>;
+  using TH = WaveTile16<W2, TILE>;
+  using TX = WaveTile16<UPNERF_X0, TILE>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE, D = L.D;
@@ -400,8 +433,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
   const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
   const int xn0 = TX::n0(wave), xrow0 = TX::row0(wave);
   const int ray0 = m0 / S;
-  const unsigned long long* __restrict__ hm = (const unsigned long long*)a.hmask + (size_t)blockIdx.x * NTHREADS + tid;
-  const size_t hm_stride = (size_t)gridDim.x * NTHREADS;
+  const unsigned long long* __restrict__ hm = (const unsigned long long*)a.hmask + (size_t)blockIdx.x * F16_THREADS + tid;
+  const size_t hm_stride = (size_t)gridDim.x * F16_THREADS;
 
   // softplus'(x) = 1 - exp(-softplus(x)); per-row feature weight on its ray slot; per-row scalars of the head stages
   if (tid < TILE) {
@@ -436,9 +469,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     for (int q = 0; q < MAXRAYS; ++q) wfj[q][tid] = (q == j) ? wf : 0.0f;
   }
   __syncthreads();
-  // column group and first row of this thread in the elementwise head stages (row advances by NTHREADS / GPR per step)
+  // column group and first row of this thread in the elementwise head stages (row advances by F16_THREADS / GPR per step)
   const int eg = tid % GPR, er0 = tid / GPR;
-  constexpr int ERS = NTHREADS / GPR;
+  constexpr int ERS = F16_THREADS / GPR;
 
   STAMP_DECL;
   int erg = 0;  // exponent of the [gz_r1 | gz_g1] planes
@@ -477,7 +510,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
       lmax = wave_max(lmax);
       if (lane == 0) smax[wave] = lmax;
       __syncthreads();
-      const float mx = wg_max4(smax);
+      const float mx = wg_max(smax);
       track(a.gmax ? a.gmax + D + 2 : nullptr, mx, tid);
       const int eg2 = scale_exp(mx);
       const float sc = pow2f(eg2);
@@ -539,7 +572,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     }
     __syncthreads();  // also: every wave is done reading the gz_g2 planes
     {
-      const float mxg = wg_max4(smax), mxr = wg_max4(smaxb);
+      const float mxg = wg_max(smax), mxr = wg_max(smaxb);
       track(a.gmax && a.use_cand ? a.gmax + D + 1 : nullptr, mxg, tid);
       track(a.gmax && a.use_rgb ? a.gmax + D + 3 : nullptr, mxr, tid);
       erg = scale_exp(fmaxf(mxg, mxr));
@@ -602,7 +635,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    const float mx = wg_max4(smax);
+    const float mx = wg_max(smax);
     track(a.gmax ? a.gmax + D : nullptr, mx, tid);
     ecur = scale_exp(mx);
     acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
@@ -623,7 +656,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    const float mx = wg_max4(smax);
+    const float mx = wg_max(smax);
     track(a.gmax ? a.gmax + (D - 1) : nullptr, mx, tid);
     ecur = scale_exp(mx);
     acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
@@ -648,7 +681,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    const float mx = wg_max4(smax);
+    const float mx = wg_max(smax);
     track(a.gmax ? a.gmax + (l - 1) : nullptr, mx, tid);
     ecur = scale_exp(mx);
     acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
@@ -674,7 +707,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void field16_bwd_kernel(upnerf_layout 
   float* Gs = (float*)planes;  // fp32 [TILE][64] scratch over the (now dead) hi plane
   acc_to_lds(accx, Gs, UPNERF_X0, xrow0, xn0, 0, lane);
   __syncthreads();
-  for (int it = tid; it < TILE * 3; it += NTHREADS) {
+  for (int it = tid; it < TILE * 3; it += F16_THREADS) {
     const int row = it / 3, n = it - row * 3, m = m0 + row;
     if (m >= M) continue;
     const float* __restrict__ x0 = a.x0 + (size_t)m * UPNERF_X0 + 3 + 20 * n;
@@ -729,7 +762,7 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
-  hipLaunchKernelGGL((field16_fwd_kernel<F16_TILE>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, *L, *a);
+  hipLaunchKernelGGL((field16_fwd_kernel<F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
   return (int)hipGetLastError();
 }
 
@@ -749,6 +782,6 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
-  hipLaunchKernelGGL((field16_bwd_kernel<F16_TILE>), dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, *L, *a);
+  hipLaunchKernelGGL((field16_bwd_kernel<F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
   return (int)hipGetLastError();
 }
