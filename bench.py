@@ -76,6 +76,10 @@ def build_system(dev, progress):
     return sysm
 
 
+CPU_BASELINE_THREADS = 32  # fastest of 16 / 32 / 64 / 128 on the GPU box's 256-thread host (tools/cpu_baseline_threads.py:
+#                            186 / 219 / 127 / 64 rays/s -- the oracle's ATen kernels stop scaling past one socket's worth)
+
+
 def cpu_baseline(progress, rays=768, iters=3):
     """Oracle forward+backward (no optimiser) on a bounded sample of the same workload; returns rays/s."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -215,12 +219,16 @@ def main():
                                      "executes 3x the algorithmic FLOPs); for scale: fp32 MFMA peak is 157.3 TF"
                                      if f16 else "peak = fp32 MFMA")}
     if world == 1 and not args.no_cpu_baseline:
-        nthreads = torch.get_num_threads()
+        nthreads = min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
+        prev = torch.get_num_threads()
+        torch.set_num_threads(nthreads)
         v, sec = cpu_baseline(args.progress)
+        torch.set_num_threads(prev)
         line["cpu_baseline"] = {"value": v, "unit": "rays/s", "cores": nthreads, "kind": "port",
                                 "sample": f"oracle forward+backward (no optimiser step) on 768 rays of the same "
                                           f"configuration (64+128 samples, 8x256 fields, pose opt ON), mean of 3 warm "
-                                          f"iterations ({sec:.1f} s each) after 1 warm-up"}
+                                          f"iterations ({sec:.1f} s each) after 1 warm-up, torch threads = {nthreads} of "
+                                          f"{os.cpu_count()} host threads (the fastest setting measured)"}
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
