@@ -165,7 +165,7 @@ class HipLinear(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         gy = gy.contiguous()
         if ctx.act == 1:
-            gy = gy * (y > 0)
+            gy = torch.ops.aten.threshold_backward(gy, y, 0.0)  # ReLU backward in one launch
         M, K = x.shape
         N = w.shape[0]
         gx = gw = gb = None
