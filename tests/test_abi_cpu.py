@@ -62,3 +62,25 @@ def test_argument_errors_are_reported_not_crashed():
     L = _lib.Layout()
     L.W, L.D, L.skip = 100, 8, 4
     assert _lib.lib.upnerf_field_fwd(ctypes.byref(L), ctypes.byref(_lib.FieldFwdArgs()), None) == -2
+
+
+def test_host_wrappers_refuse_or_fall_back_cleanly_without_a_gpu():
+    """Host-side guards of the newer entry points: the sampler has no CPU path (raises), the embedding helper hands CPU
+    tables to the module itself, the optimiser factory keeps torch.optim.Adam for CPU parameters."""
+    import torch
+    from upnerf_amd.ops import embed_rows
+    from upnerf_amd.optim import FlatAdam, get_optimizer
+    from upnerf_amd.ray_sampler import GpuRaySampler
+    with pytest.raises(RuntimeError):
+        GpuRaySampler(torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(1, 3, 4), device="cpu")
+    emb = torch.nn.Embedding(5, 3)
+    idx = torch.tensor([4, 0, 4])
+    rows = embed_rows(emb, idx)
+    assert torch.equal(rows, emb(idx))
+    rows.sum().backward()
+    assert emb.weight.grad is not None and float(emb.weight.grad[4].sum()) == 6.0
+    lin = torch.nn.Linear(3, 2)
+    opt = get_optimizer("adam", 1e-3, [lin])
+    assert isinstance(opt, torch.optim.Adam) and not isinstance(opt, FlatAdam)
+    with pytest.raises(ValueError):
+        FlatAdam(lin.parameters())
