@@ -265,22 +265,31 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_kernel(int M, int N, int K
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  for (int kc = 0; kc < K; kc += LIN_KC) {
+  // Register-staged software pipeline: the global loads of chunk c+1 are in flight while chunk c is contracted out of
+  // LDS (each chunk used to wait out its own HBM / L2 round trip between two barriers).
+  constexpr int LPT = LIN_T * (LIN_KC / 4) / NTHREADS;  // 16-byte loads per thread and operand: 4
+  f32x4 ra[LPT], rb[LPT];
+  auto gload = [&](int kc) {
     const int kk = (K - kc) < LIN_KC ? (K - kc) : LIN_KC;  // multiple of 8
-    __syncthreads();
-    // stage A[m0.., kc..] and B[nb.., kc..] (zero fill outside M / N / K)
-    for (int idx = tid; idx < LIN_T * (LIN_KC / 4); idx += NTHREADS) {
-      const int row = idx >> 4, g = idx & 15;
-      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-      if (4 * g < kk) {
-        if (m0 + row < M) va = *(const f32x4*)&A[(size_t)(m0 + row) * lda + kc + 4 * g];
-        if (!transb && nb + row < N) vb = *(const f32x4*)&B[(size_t)(nb + row) * ldb + kc + 4 * g];
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+      const int idx = tid + q * NTHREADS;
+      {
+        const int row = idx >> 4, g = idx & 15;
+        const bool kin = 4 * g < kk;
+        int ma = m0 + row, nbr = nb + row;
+        const bool ina = kin && ma < M, inb = kin && !transb && nbr < N;
+        ma = ma < M ? ma : M - 1;
+        nbr = nbr < N ? nbr : N - 1;
+        const int kg = kin ? kc + 4 * g : 0;
+        ra[q] = *(const f32x4*)&A[(size_t)ma * lda + kg];
+        if (!ina) ra[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!transb) {
+          rb[q] = *(const f32x4*)&B[(size_t)nbr * ldb + kg];
+          if (!inb) rb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
-      *(f32x4*)&As[swz4(row, 4 * g, LIN_KC)] = va;
-      if (!transb) *(f32x4*)&Bs[swz4(row, 4 * g, LIN_KC)] = vb;
-    }
-    if (transb) {  // B^T tile: rows are k, 64 consecutive n per row; scattered into the [n][k] image
-      for (int idx = tid; idx < LIN_KC * (LIN_T / 4); idx += NTHREADS) {
+      if (transb) {  // B^T tile: rows are k, 64 consecutive n per row
         const int k = idx >> 4, g = idx & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (k < kk) {
@@ -293,11 +302,31 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_kernel(int M, int N, int K
               if (nb + 4 * g + j < N) v[j] = src[j];
           }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Bs[swz(4 * g + j, k, LIN_KC)] = v[j];
+        rb[q] = v;
       }
     }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+      const int idx = tid + q * NTHREADS;
+      const int row = idx >> 4, g = idx & 15;
+      *(f32x4*)&As[swz4(row, 4 * g, LIN_KC)] = ra[q];
+      if (!transb) {
+        *(f32x4*)&Bs[swz4(row, 4 * g, LIN_KC)] = rb[q];
+      } else {  // scattered into the [n][k] image (row = k here)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[swz(4 * g + j, row, LIN_KC)] = rb[q][j];
+      }
+    }
+  };
+  gload(0);
+  for (int kc = 0; kc < K; kc += LIN_KC) {
+    const int kk = (K - kc) < LIN_KC ? (K - kc) : LIN_KC;
+    __syncthreads();  // everyone is done reading the previous chunk
+    lstore();
     __syncthreads();
+    if (kc + LIN_KC < K) gload(kc + LIN_KC);
     for (int t = 0; t < (kk >> 3); ++t) {
       const f32x4 a = *(const f32x4*)&As[swz4(wr + li, 8 * t + 4 * hh, LIN_KC)];
       const f32x4 b = *(const f32x4*)&Bs[swz4(wc + li, 8 * t + 4 * hh, LIN_KC)];
