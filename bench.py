@@ -174,13 +174,17 @@ def main():
         "metric": "training rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.field == "f32" else "f32 (contractions as 3-term f16 split on f16 MFMA, fp32 accumulate)",
-        "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: Brandenburg Gate shape, 4096 rays/GPU/step, 64 coarse + 128 "
                                "fine samples, two 8x256 fields + candidate/colour heads + TransientNet + appearance/"
                                "candidate embeddings (763 images), pose optimisation ON, full step incl. both Adam updates",
                    "rays_per_gpu": RAYS, "N_samples": NC, "N_importance": NF, "progress": args.progress,
-                   "sched_mult": sched, "parallelism": f"dp{world}"},
+                   "sched_mult": sched, "parallelism": f"dp{world}",
+                   "contraction": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.field == "f32" else
+                                   "fp32 operands and results; products formed as a 3-term fp16 hi/lo split on "
+                                   "v_mfma_f32_32x32x16_f16 with fp32 accumulation (<= 1e-6 of the fp32-MFMA kernels on "
+                                   "every activation, tests/test_hip_kernels.py, tests/test_hip_fullsize.py; "
+                                   "--field f32 selects the fp32-MFMA kernels)")},
         "algorithmic_tflop_per_step": 3 * 2 * mac * RAYS * (NC + NC + NF) / 1e12,
     }
     if not args.no_kernel_timing:
