@@ -295,7 +295,9 @@ def sampler_fixture():
 
 def state_key_fixture():
     """state_dict keys and shapes of the REAL reference modules (models/nerf.py:39-78, models/transient_net.py:11-25)
-    for the configurations the path uses -- pins checkpoint interchange: only names and shapes, no values."""
+    for the configurations the path uses -- pins checkpoint interchange: only names and shapes, no values.
+    `param_order` is the registration order of the parameters: torch.optim state dicts index parameters by it, so
+    resuming a reference checkpoint's optimiser needs the same order."""
     import json
     out = {}
     for tag, kw in {"nerf_d8_w256": dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16),
@@ -303,10 +305,12 @@ def state_key_fixture():
                     "nerf_d8_w256_nocand": dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48,
                                                 candidate_dim=0)}.items():
         m = ref_nerf.NeRF("coarse", c2f=(0.1, 0.5), **kw)
-        out[tag] = {"kwargs": kw, "state": {k: list(v.shape) for k, v in m.state_dict().items()}}
+        out[tag] = {"kwargs": kw, "state": {k: list(v.shape) for k, v in m.state_dict().items()},
+                    "param_order": [k for k, _ in m.named_parameters()]}
     t = ref_tnet.TransientNet(763, beta_min=0.1, trasient_dim=128, feat_dim=384)
     out["transient_763"] = {"kwargs": dict(N_images=763, beta_min=0.1, trasient_dim=128, feat_dim=384),
-                            "state": {k: list(v.shape) for k, v in t.state_dict().items()}}
+                            "state": {k: list(v.shape) for k, v in t.state_dict().items()},
+                            "param_order": [k for k, _ in t.named_parameters()]}
     with open(os.path.join(OUT, "state_keys.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("state-key fixture written:", {k: len(v["state"]) for k, v in out.items()})

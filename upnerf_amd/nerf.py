@@ -6,11 +6,17 @@ parameter buffer (`packed()`); `forward()` keeps the reference's per-sample call
 (nerf.py:80-124) and runs layer by layer on the HIP linear kernel."""
 from __future__ import annotations
 
+import struct
+
 import torch
 from torch import nn
 
 from .ops import hip_linear
 from .packing import NerfPacker
+
+
+def fp32_round(x: float) -> float:
+    return struct.unpack("f", struct.pack("f", float(x)))[0]
 
 
 class NeRF(nn.Module):
@@ -49,9 +55,11 @@ class NeRF(nn.Module):
                                  appearance_dim, candidate_dim)
 
     def set_progress(self, progress: float):
-        """Write `progress` (device parameter, as the reference does through .data) and its host mirror."""
+        """Write `progress` (device parameter, as the reference does through .data) and its host mirror.  The mirror
+        holds the fp32-rounded value -- what the reference reads back with `progress.data.item()` (nerf.py:94,
+        nerf_system.py:180) and what a checkpoint restores."""
         self.progress.data.fill_(float(progress))
-        self.host_progress = float(progress)
+        self.host_progress = fp32_round(progress)
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)

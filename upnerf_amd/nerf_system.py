@@ -19,7 +19,7 @@ from torch import nn
 
 from .camera import refine_and_get_rays
 from .losses import UPNeRFLoss
-from .nerf import NeRF
+from .nerf import NeRF, fp32_round
 from .ops import embed_rows
 from .optim import get_learning_rate, get_optimizer, get_scheduler
 from .parallel import GradSync
@@ -191,7 +191,7 @@ class NeRFSystem(_Base):
 
     def set_progress(self, progress: float):
         """Host-side copy of NeRF.progress (avoids the reference's per-step .item() sync)."""
-        self._host_progress = float(progress)
+        self._host_progress = fp32_round(progress)  # the value `.item()` on the fp32 parameter would give
         self.nerf_coarse.set_progress(progress)
         if self.fine:
             self.nerf_fine.set_progress(progress)
