@@ -173,3 +173,27 @@ def test_validation_render_is_chunk_invariant_matches_the_training_forward_and_s
     log = sysm.validation_step(vb)
     psnr = -10.0 * torch.log10(((outs[4096]["rgb_fine"] - b["rgbs"]) ** 2).mean())
     assert torch.isfinite(log["val_loss"]) and abs(float(log["val_psnr"]) - float(psnr)) < 1e-4
+
+
+def test_density_only_coarse_pass_at_full_size():
+    """Test-time-optimisation shape at configs[1] sizes on the f16x3 kernels: the density-only coarse pass changes neither
+    the fine colour map nor any gradient, bit for bit."""
+    from upnerf_amd.rendering import render_rays
+    sysm, b = _system(1.0), _batch()
+    for m in (sysm.nerf_coarse, sysm.nerf_fine):
+        m.encode_candidate = False
+    outs = []
+    for flag in (False, True):
+        for p in sysm.parameters():
+            p.grad = None
+        res = render_rays(sysm.models, sysm.embeddings, sysm.rays_from_batch(b), b["img_idx"], 1.0, N_samples=NC,
+                          perturb=0, N_importance=NF, coarse_sigma_only=flag)
+        ((res["s_rgb_fine"] - b["rgbs"]) ** 2).mean().backward()
+        outs.append((res, _grads(sysm)))
+    (full, g_full), (lean, g_lean) = outs
+    assert "s_rgb_coarse" in full and "s_rgb_coarse" not in lean
+    for k in lean:
+        assert torch.equal(lean[k], full[k]), k
+    assert g_full.keys() == g_lean.keys() and len(g_lean) > 20
+    for k in g_full:
+        assert torch.equal(g_full[k], g_lean[k]), k

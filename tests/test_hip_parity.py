@@ -210,3 +210,36 @@ def test_tto_step_frozen_field_matches_oracle_and_skips_weight_gradients():
     out = tto.validation_step(batch)
     assert out["s_rgb_fine"].shape == (c.R, 3) and torch.isfinite(out["val_psnr"])
     assert rel_err(out["s_rgb_fine"].cpu().numpy(), ref["s_rgb_fine"].detach().numpy()) < 1e-4
+
+
+def test_coarse_sigma_only_leaves_the_fine_pass_untouched():
+    """render_rays(coarse_sigma_only=True) (nerf.py:90-91): same fine maps and same gradients bit for
+    bit, only the coarse maps nobody reads are gone; refused where the resampling needs the candidate head."""
+    from upnerf_amd.rendering import render_rays
+    c = Case("small_tto")
+    sysm = build_system(c).cuda()
+    for m in (sysm.nerf_coarse, sysm.nerf_fine):
+        m.encode_candidate = False
+    sysm.set_progress(1.0)
+    b = {k: v.cuda() for k, v in c.batch().items()}
+    outs = []
+    for flag in (False, True):
+        for p in sysm.parameters():
+            p.grad = None
+        rays = sysm.rays_from_batch(b)
+        res = render_rays(sysm.models, sysm.embeddings, rays, b["img_idx"], 1.0, N_samples=c.Nc, perturb=0,
+                          N_importance=c.Nf, coarse_sigma_only=flag)
+        ((res["s_rgb_fine"] - b["rgbs"]) ** 2).mean().backward()
+        outs.append((res, {n: p.grad.clone() for n, p in sysm.named_parameters() if p.grad is not None}))
+    (full, g_full), (lean, g_lean) = outs
+    assert set(lean) == {k for k in full if k.endswith("_fine")} | {"s_weights_coarse", "s_depth_coarse"}
+    for k in lean:
+        assert torch.equal(lean[k], full[k]), k
+    assert g_full.keys() == g_lean.keys() and any(k.startswith("nerf_fine") for k in g_lean)
+    for k in g_full:
+        assert torch.equal(g_full[k], g_lean[k]), k
+    assert not any(k.startswith("nerf_coarse") for k in g_lean)  # the coarse field never had a gradient in this phase
+    sysm.nerf_fine.encode_candidate = sysm.nerf_coarse.encode_candidate = True
+    with pytest.raises(ValueError, match="coarse_sigma_only"):
+        render_rays(sysm.models, sysm.embeddings, sysm.rays_from_batch(b), b["img_idx"], 0.3, N_samples=c.Nc,
+                    perturb=0, N_importance=c.Nf, coarse_sigma_only=True)

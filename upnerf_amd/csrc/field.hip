@@ -119,6 +119,8 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
     const float pre = rowdot<TPR>(Hs, W, prow, phalf, 0, W, P + L.wsig) + P[L.bsig];
     if (phalf == 0 && pm < M) a.sigma_s[pm] = softplus_f(pre);
   }
+  // density-only pass (nerf.py:90-91 `sigma_only`): nobody consumes e, so the pass ends here
+  if (!a.e && !a.use_rgb && !a.use_cand) return;
   // ---- xyz_encoding_final (nerf.py:93), no activation
   {
     f32x16 acc[TW::MT][TW::NT];

@@ -300,6 +300,11 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     const float pre = rowdot16<W, TPR, W>(Ph, Pl, prow, phalf, 0, P + L.wsig, pow2f(-ecur)) + P[L.bsig];
     if (phalf == 0 && pm < M) a.sigma_s[pm] = softplus_f(pre);
   }
+  // density-only pass (nerf.py:90-91 `sigma_only`): nobody consumes e, so the pass ends here
+  if (!a.e && !a.use_rgb && !a.use_cand) {
+    STAMP_FLUSH_AT(8);
+    return;
+  }
   // ---- xyz_encoding_final (nerf.py:93), no activation
   {
     f32x16 acc[TW::MT][TW::NT];

@@ -22,6 +22,9 @@ class NeRFSystemOptimize(NeRFSystem):
     def __init__(self, hparams, train_dataset=None, val_dataset=None, pose_optimize=True):
         super().__init__(hparams, train_dataset, val_dataset)
         self.pose_optimize = pose_optimize
+        # only s_rgb_fine is ever read here, so the coarse field stops at its density head (set False to get the
+        # reference's full set of coarse maps back)
+        self.coarse_sigma_only = True
 
     def model_setup(self, trained_state=None, n_test_images: int = 1):
         super().model_setup()
@@ -59,7 +62,8 @@ class NeRFSystemOptimize(NeRFSystem):
             outs.append(render_rays(models=self.models, embeddings=self.embeddings, rays=rays[i:i + chunk],
                                     img_idx=img_idx[i:i + chunk], sched_mult=1.0, N_samples=hp["nerf.N_samples"],
                                     use_disp=hp["nerf.use_disp"], perturb=hp["nerf.perturb"] if train else 0,
-                                    N_importance=hp["nerf.N_importance"], encode_feat=True, u_list=u_list))
+                                    N_importance=hp["nerf.N_importance"], encode_feat=True, u_list=u_list,
+                                    coarse_sigma_only=self.coarse_sigma_only))
         return {k: (outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], 0)) for k in outs[0]}
 
     def rays_from_batch(self, batch):

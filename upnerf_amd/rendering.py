@@ -311,7 +311,12 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
 
     Extensions used by the parity tests: kwargs["u_list"] = explicit uniform draws consumed in the reference's RNG
     call order (coarse jitter [R,Nc], then the sample_pdf draws); kwargs["keep"] = dict that receives the sampled
-    depths (z_coarse, z_fine)."""
+    depths (z_coarse, z_fine).
+
+    Extension for the eval / test-time-optimisation callers (nerf_system_optmize.py:84-111 read `s_rgb_fine` only):
+    kwargs["coarse_sigma_only"] = True evaluates the coarse field up to its density head only, without gradient (the
+    resampling weights are detached in the reference too, rendering.py:271-306), and returns just `s_weights_coarse` /
+    `s_depth_coarse` for it; the fine pass is unchanged, bit for bit."""
     if not rays.is_cuda:
         raise RuntimeError("upnerf_amd.render_rays runs on the GPU only (no CPU fallback)")
     if not encode_feat:
@@ -336,8 +341,17 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
                                    float(perturb), int(bool(use_disp)), ptr(z), st), "upnerf_sample_coarse")
     results = {}
 
-    def inference(model, zz):
+    def inference(model, zz, sigma_only=False):
         typ = model.typ
+        if sigma_only:  # nerf.py:90-91: trunk + density head, composited into resampling weights and a depth
+            hp = getattr(model, "host_progress", None)
+            progress = float(model.progress.data) if hp is None else float(torch.tensor(hp, dtype=torch.float32))
+            cfg = _PassCfg(model.packer, 2, False, False, band_weights(model.xyz_L, progress, model.c2f),
+                           band_weights(model.dir_L, progress, model.c2f))
+            with torch.no_grad():
+                outs = _FieldPass.apply(rays_o, rays_d, zz, None, None, model.packed(), cfg)
+            results[f"s_weights_{typ}"], results[f"s_depth_{typ}"] = outs[8], outs[5]
+            return
         a_rows = embed_rows(embeddings[f"{typ}_a"], img_idx) if model.encode_appearance else None
         c_rows = embed_rows(embeddings[f"{typ}_c"], img_idx) if model.encode_candidate else None
         # host mirror kept by NeRF.set_progress; code that writes model.progress.data directly (the reference's way)
@@ -368,7 +382,11 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
     keep = kwargs.get("keep")
     if keep is not None:
         keep["z_coarse"] = z
-    inference(models["nerf_coarse"], z)
+    coarse_sigma_only = bool(kwargs.get("coarse_sigma_only")) and N_importance > 0
+    if coarse_sigma_only and models["nerf_fine"].encode_candidate and sched_mult < 1:
+        raise ValueError("coarse_sigma_only needs a schedule phase that resamples from the shared weights only "
+                         "(sched_mult == 1 or no candidate head): c_weights_coarse come from the candidate head")
+    inference(models["nerf_coarse"], z, sigma_only=coarse_sigma_only)
     if N_importance > 0:
         model = models["nerf_fine"]
         det = perturb == 0
