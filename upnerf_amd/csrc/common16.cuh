@@ -87,8 +87,16 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
   auto fetch = [&](h8 (&ah)[MT], h8 (&al)[MT], h8 (&bh)[NT], h8 (&bl)[NT], int t) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+#ifdef UPNERF_EXP_SAMEB  // timing experiment only (wrong results): every k-block re-reads block 0 -> L1 hits
+      bh[nt] = *(const h8*)(bp[nt] + (size_t)(t & 0) * 2048);
+      bl[nt] = *(const h8*)(bp[nt] + (size_t)(t & 0) * 2048 + 1024);
+#elif defined(UPNERF_EXP_SAMEA)
       bh[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048);
       bl[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048 + 1024);
+#else
+      bh[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048);
+      bl[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048 + 1024);
+#endif
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {

@@ -90,31 +90,82 @@ __device__ __forceinline__ float mix_sum(unsigned int wh, unsigned int wl) {
   return r;
 }
 
-// LDS planes -> row-major fp32 global tensor, coalesced (8 columns = 32 bytes per thread, whole rows per wave).
-template <int W, int TILE>
-__device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, int ncols, float unscale,
+// LDS planes -> row-major fp32 global tensor, coalesced (8 columns = 32 bytes per thread, whole rows per wave).  The
+// LDS reads of BATCH row groups are issued before the first conversion, so their latency is paid once per batch
+// (BATCH = 0: the whole tile at once, 64 registers for a 256-wide tile -- used where the accumulators are dead).
+template <int W, int TILE, int NCOLS, int BATCH = 1>
+__device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, float unscale,
                                              float* __restrict__ dst, int ldg, int m0, int M, int tid) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const int gpr = ncols >> 3;
-  for (int idx = tid; idx < TILE * gpr; idx += F16_THREADS) {
-    const int row = idx / gpr, g = idx - row * gpr;
-    if (m0 + row < M) {
+  constexpr int GPR = NCOLS >> 3, ITER = TILE * GPR / F16_THREADS;
+  static_assert(TILE * GPR % F16_THREADS == 0, "whole passes of the workgroup");
+  constexpr int B = (BATCH == 0 || BATCH > ITER) ? ITER : BATCH;
+  static_assert(ITER % B == 0, "whole batches");
+  const bool whole = m0 + TILE <= M;
+#pragma unroll 1
+  for (int it0 = 0; it0 < ITER; it0 += B) {
+    u32x4 wh[B], wl[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int idx = tid + (it0 + j) * F16_THREADS, row = idx / GPR, g = idx % GPR;
       const int o = poff<W>(row, c0 + 8 * g);
-      const u32x4 wh = *(const u32x4*)(Ph + o), wl = *(const u32x4*)(Pl + o);
+      wh[j] = *(const u32x4*)(Ph + o);
+      wl[j] = *(const u32x4*)(Pl + o);
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int idx = tid + (it0 + j) * F16_THREADS, row = idx / GPR, g = idx % GPR;
       f32x4 o0, o1;
-      o0[0] = mix_sum<0>(wh[0], wl[0]) * unscale;
-      o0[1] = mix_sum<1>(wh[0], wl[0]) * unscale;
-      o0[2] = mix_sum<0>(wh[1], wl[1]) * unscale;
-      o0[3] = mix_sum<1>(wh[1], wl[1]) * unscale;
-      o1[0] = mix_sum<0>(wh[2], wl[2]) * unscale;
-      o1[1] = mix_sum<1>(wh[2], wl[2]) * unscale;
-      o1[2] = mix_sum<0>(wh[3], wl[3]) * unscale;
-      o1[3] = mix_sum<1>(wh[3], wl[3]) * unscale;
-      float* p = &dst[(size_t)(m0 + row) * ldg + 8 * g];
-      *(f32x4*)p = o0;
-      *(f32x4*)(p + 4) = o1;
+      o0[0] = mix_sum<0>(wh[j][0], wl[j][0]) * unscale;
+      o0[1] = mix_sum<1>(wh[j][0], wl[j][0]) * unscale;
+      o0[2] = mix_sum<0>(wh[j][1], wl[j][1]) * unscale;
+      o0[3] = mix_sum<1>(wh[j][1], wl[j][1]) * unscale;
+      o1[0] = mix_sum<0>(wh[j][2], wl[j][2]) * unscale;
+      o1[1] = mix_sum<1>(wh[j][2], wl[j][2]) * unscale;
+      o1[2] = mix_sum<0>(wh[j][3], wl[j][3]) * unscale;
+      o1[3] = mix_sum<1>(wh[j][3], wl[j][3]) * unscale;
+#ifdef UPNERF_EXP_NOSTORE  // timing experiment only: everything but the global stores (kept alive by an impossible branch)
+      if (o0[0] + o0[1] + o0[2] + o0[3] + o1[0] + o1[1] + o1[2] + o1[3] == 123.456f) {
+#else
+      if (whole || m0 + row < M) {
+#endif
+        float* p = &dst[(size_t)(m0 + row) * ldg + 8 * g];
+        *(f32x4*)p = o0;
+        *(f32x4*)(p + 4) = o1;
+      }
     }
   }
+}
+
+// Accumulators (natural units) -> row-major fp32 global tile, straight from the registers: for one register index the 64
+// lanes cover 32 consecutive columns of two rows, i.e. two full 128-byte lines per store instruction; no LDS round
+// trip.  (The planes keep (hi + lo) 2^-e of the same values: they differ from what is stored here by the 2^-22 split
+// residue only.)
+template <int MT, int NT>
+__device__ __forceinline__ void acc_store_global(const f32x16 (&acc)[MT][NT], float* __restrict__ dst, int ldg, int m0,
+                                                 int M, int row0, int n0, int lane) {
+  const int i = lane & 31, hh = lane >> 5;
+  float* __restrict__ base = dst + (size_t)m0 * ldg + (size_t)(row0 + 4 * hh) * ldg + n0 + i;
+  if (m0 + F16_TILE <= M) {  // whole tile (all but the last workgroup): no per-row predicate
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          base[(size_t)(32 * mt + (r & 3) + 8 * (r >> 2)) * ldg + 32 * nt] = acc[mt][nt][r];
+    return;
+  }
+  const int rows_left = M - m0 - row0 - 4 * hh;  // rows of this lane's group that exist
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = 32 * mt + (r & 3) + 8 * (r >> 2);
+        if (dr < rows_left) base[(size_t)dr * ldg + 32 * nt] = acc[mt][nt][r];
+      }
 }
 
 // v = relu(fma(acc, un, bias[col])) with the sign bits packed in the accumulator layout (common.cuh)
@@ -246,7 +297,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     }
   }
   __syncthreads();
-  tile_store16<W, TILE>(Ph, Pl, 0, UPNERF_X0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
+  tile_store16<W, TILE, UPNERF_X0>(Ph, Pl, 0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
 
   // ---- trunk (nerf.py:84-87)
   STAMP(7);  // sample positions + encoding + x0 store
@@ -274,6 +325,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * F16_THREADS + tid] = bits;
+    if (a.h) acc_store_global(acc, a.h + (size_t)l * M * W, W, m0, M, row0, n0, lane);
     STAMP(2);
     __syncthreads();
     STAMP(3);
@@ -285,7 +337,6 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     STAMP(4);
     __syncthreads();
     STAMP(5);
-    if (a.h) tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.h + (size_t)l * M * W, W, m0, M, tid);
     STAMP(6);
   }
 
@@ -313,6 +364,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     const float* __restrict__ bias = P + L.be;
     const float un = pow2f(-(ecur + wexp[8]));
     acc_map(acc, row0, n0, lane, [&](float v, int, int col) { return fmaf(v, un, bias[col]); });
+    if (a.e) acc_store_global(acc, a.e, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
@@ -321,7 +373,6 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     ecur = scale_exp(fmaxf(mx, sidemax));  // the heads feed per-ray rows through the same accumulators
     acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     __syncthreads();
-    if (a.e) tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.e, W, m0, M, tid);
   }
   STAMP(5);  // density head + xyz_encoding_final
   if (!a.use_rgb && !a.use_cand) {
@@ -377,7 +428,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
   if (a.use_cand) acc_to_planes<W>(accc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
   __syncthreads();
   if (a.use_rgb) {
-    if (a.r1) tile_store16<W, TILE>(Ph, Pl, 0, W2, pow2f(-ecur), a.r1, W2, m0, M, tid);
+    if (a.r1) tile_store16<W, TILE, W2>(Ph, Pl, 0, pow2f(-ecur), a.r1, W2, m0, M, tid);
     // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -386,7 +437,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     }
   }
   if (a.use_cand) {
-    if (a.g1) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
+    if (a.g1) tile_store16<W, TILE, W2>(Ph, Pl, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
     f32x16 acc[TH::MT][TH::NT];
     acc_zero(acc);
     mma16_lds<W>(acc, Ph, Pl, hrow0, W2, P16 + 4 * (size_t)L.wc2, W2 / 16, hn0, 0, W2, lane);
@@ -399,7 +450,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     ecur = scale_exp(wg_max(smax));
     acc_to_planes<W>(acc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
     __syncthreads();
-    if (a.g2) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
+    if (a.g2) tile_store16<W, TILE, W2>(Ph, Pl, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
     const float pre = rowdot16<W, TPR, W2>(Ph, Pl, prow, phalf, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
     if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
   }
@@ -602,7 +653,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
       }
     }
     __syncthreads();
-    if (a.use_cand) tile_store16<W, TILE>(Ph, Pl, W2, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
+    if (a.use_cand) tile_store16<W, TILE, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
   }
 
   STAMP(0);  // head stages (elementwise d g2 / d r1, 128-wide contraction, plane writes)
@@ -637,6 +688,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
         }
       }
     }
+    acc_store_global(acc, a.gz_e, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
@@ -645,7 +697,6 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     ecur = scale_exp(mx);
     acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     __syncthreads();
-    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_e, W, m0, M, tid);
   }
   STAMP(1);  // d e
   // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu (sign bits from the forward, in this lane's layout)
@@ -658,6 +709,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     const float un = pow2f(-(ecur + wexp[8]));
     acc_map(acc, row0, n0, lane, [&](float v, int row, int col) { return fmaf(v, un, ws[col] * pre_s[row]); });
     acc_apply_mask(acc, bits);
+    acc_store_global(acc, a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
@@ -666,7 +718,6 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     ecur = scale_exp(mx);
     acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     __syncthreads();
-    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, tid);
   }
   STAMP(2);  // d h_{D-1}
   // ---- trunk, last layer to first
@@ -683,6 +734,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     mma16_lds<W>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_w[l], W / 16, n0, 0, W, lane);
     acc_scale(acc, pow2f(-(ecur + wexp[l])));
     acc_apply_mask(acc, bits);
+    acc_store_global(acc, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
@@ -691,7 +743,6 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     ecur = scale_exp(mx);
     acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
     __syncthreads();
-    tile_store16<W, TILE>(Ph, Pl, 0, W, pow2f(-ecur), a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, tid);
   }
   STAMP(3);  // D-1 trunk layers
   if (!a.need_dxyz) {

@@ -70,6 +70,9 @@ class _PassCfg:
     def __init__(self, packer, mode: int, use_cand: bool, use_rgb: bool, wk_xyz, wk_dir):
         self.packer, self.mode, self.use_cand, self.use_rgb = packer, mode, use_cand, use_rgb
         self.wk_xyz, self.wk_dir = wk_xyz, wk_dir
+        # ctx.needs_input_grad reports requires_grad of the inputs even under torch.no_grad(); whether a backward pass
+        # can follow is decided where the pass is configured (Function.forward itself always runs with grad disabled)
+        self.grad = torch.is_grad_enabled()
 
 
 class _FieldPass(torch.autograd.Function):
@@ -111,7 +114,7 @@ class _FieldPass(torch.autograd.Function):
         rgb = _empty(M, 3, device=dev) if cfg.use_rgb else None
         # No gradient wanted (validation / test renders under torch.no_grad()): the kernels skip every store that only
         # the backward pass reads -- 8 of the 11 KB per sample -- and keep what compositing needs (e, g2) plus x0.
-        train = any(ctx.needs_input_grad)
+        train = cfg.grad and any(ctx.needs_input_grad)
         x0 = _empty(M, X0, device=dev)
         h = _empty(D, M, W, device=dev) if train else None
         e = _empty(M, W, device=dev) if (train or want_feat) else None
@@ -346,9 +349,9 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
         if sigma_only:  # nerf.py:90-91: trunk + density head, composited into resampling weights and a depth
             hp = getattr(model, "host_progress", None)
             progress = float(model.progress.data) if hp is None else float(torch.tensor(hp, dtype=torch.float32))
-            cfg = _PassCfg(model.packer, 2, False, False, band_weights(model.xyz_L, progress, model.c2f),
-                           band_weights(model.dir_L, progress, model.c2f))
             with torch.no_grad():
+                cfg = _PassCfg(model.packer, 2, False, False, band_weights(model.xyz_L, progress, model.c2f),
+                               band_weights(model.dir_L, progress, model.c2f))
                 outs = _FieldPass.apply(rays_o, rays_d, zz, None, None, model.packed(), cfg)
             results[f"s_weights_{typ}"], results[f"s_depth_{typ}"] = outs[8], outs[5]
             return
