@@ -90,9 +90,6 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
 #ifdef UPNERF_EXP_SAMEB  // timing experiment only (wrong results): every k-block re-reads block 0 -> L1 hits
       bh[nt] = *(const h8*)(bp[nt] + (size_t)(t & 0) * 2048);
       bl[nt] = *(const h8*)(bp[nt] + (size_t)(t & 0) * 2048 + 1024);
-#elif defined(UPNERF_EXP_SAMEA)
-      bh[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048);
-      bl[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048 + 1024);
 #else
       bh[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048);
       bl[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048 + 1024);
