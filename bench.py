@@ -204,7 +204,7 @@ def main():
         dom = max((n for n in kern if n in per_sample), key=lambda n: kern[n]["ms_per_step"])
         ach = kern[dom]["tflops_algorithmic"]
         traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected live)
-        pmc = os.path.join(ROOT, "profiles", "r01_c_pmc.json")  # tools/pmc_collect.sh on the same command
+        pmc = os.path.join(ROOT, "profiles", "r01_d_pmc.json")  # tools/pmc_collect.sh on the same command
         pmc_name = {"field_fwd": "field16_fwd_kernel<64>" if args.field == "f16x3" else "field_fwd_kernel<256, 64>",
                     "field_bwd": "field16_bwd_kernel<64>" if args.field == "f16x3" else "field_bwd_kernel<256, 64>",
                     "wgrad16_256x256": "wgrad_f16x3_kernel<4, 4>", "wgrad_256x256": "wgrad_kernel<4, 4>"}.get(dom)
