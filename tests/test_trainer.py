@@ -1,0 +1,155 @@
+"""Training loop with the reference's Trainer configuration (train.py:43-79).
+
+CPU: ModelCheckpoint(save_top_k=2, save_last, monitor val/psnr, mode max) bookkeeping, validation cadence arithmetic.
+GPU: sampler -> training_step -> validation -> checkpoints; an interrupted run resumed from last.ckpt (found in the
+checkpoint directory, as train.py:37-40 does) ends bit-identical to an uninterrupted one."""
+import os
+
+import pytest
+import torch
+
+from upnerf_amd.trainer import TopKCheckpoints, Trainer
+
+
+def test_top_k_keeps_the_two_best_and_always_refreshes_last(tmp_path):
+    written = []
+    save = lambda p: (written.append(os.path.basename(p)), open(p, "w").write("x"))
+    ck = TopKCheckpoints(str(tmp_path / "ckpts"), k=2, mode="max")
+    assert ck.best_path() is None
+    names = lambda: sorted(os.listdir(tmp_path / "ckpts"))
+    assert ck.update(10.0, 0, 100, save).endswith("epoch=0-step=100.ckpt")
+    assert ck.update(12.0, 0, 200, save).endswith("epoch=0-step=200.ckpt")
+    assert names() == ["epoch=0-step=100.ckpt", "epoch=0-step=200.ckpt", "last.ckpt"]
+    assert ck.update(9.0, 0, 300, save) is None  # not among the best two: only last.ckpt is rewritten
+    assert names() == ["epoch=0-step=100.ckpt", "epoch=0-step=200.ckpt", "last.ckpt"] and written[-1] == "last.ckpt"
+    assert ck.update(11.0, 1, 400, save).endswith("epoch=1-step=400.ckpt")  # pushes the 10.0 out
+    assert names() == ["epoch=0-step=200.ckpt", "epoch=1-step=400.ckpt", "last.ckpt"]
+    assert ck.update(float("nan"), 1, 500, save) is None
+    assert ck.best_path().endswith("epoch=0-step=200.ckpt")
+    assert written.count("last.ckpt") == 5
+    # state survives a restart; entries whose file is gone are forgotten
+    ck2 = TopKCheckpoints(str(tmp_path / "ckpts"), k=2, mode="max")
+    os.unlink(tmp_path / "ckpts" / "epoch=1-step=400.ckpt")
+    ck2.load_state_dict(ck.state_dict())
+    assert list(ck2.best) == [str(tmp_path / "ckpts" / "epoch=0-step=200.ckpt")]
+    lo = TopKCheckpoints(str(tmp_path / "lo"), k=1, mode="min")
+    lo.update(3.0, 0, 1, save), lo.update(2.0, 0, 2, save), lo.update(5.0, 0, 3, save)
+    assert sorted(os.listdir(tmp_path / "lo")) == ["epoch=0-step=2.ckpt", "last.ckpt"]
+
+
+def test_validation_cadence_follows_lightning():
+    t = Trainer(max_steps=10)
+    assert t._val_every(1000) == 250 and t._val_every(3) == 1  # int(n * 0.25), at least one batch
+    assert Trainer(10, val_check_interval=1.0)._val_every(40) == 40
+    assert Trainer(10, val_check_interval=7)._val_every(40) == 7
+    with pytest.raises(ValueError):
+        Trainer(10, val_check_interval=1.5)._val_every(40)
+
+
+def _scene(seed=5, I=4, h=8, N=1536):
+    gen = torch.Generator().manual_seed(seed)
+    d = torch.randn(N, 3, generator=gen) * 0.3
+    d[:, 2] = -1.0
+    return {"all_ray_infos": torch.cat([torch.full((N, 1), 0.1), torch.full((N, 1), 5.0),
+                                        torch.randint(0, I, (N, 1), generator=gen).float()], 1),
+            "all_directions": d, "all_rgbs": torch.rand(N, 3, generator=gen),
+            "all_pxl_coords": torch.rand(N, 2, generator=gen), "all_inv_depths": torch.rand(N, generator=gen) * 2 + 0.3,
+            "feat_maps": torch.nn.functional.normalize(torch.randn(I, h, h, 384, generator=gen), dim=-1),
+            "poses": torch.eye(3, 4).repeat(I, 1, 1)}, I
+
+
+def _system(I):
+    from upnerf_amd.nerf_system import NeRFSystem, SyntheticDataset, default_hparams
+    hp = default_hparams(**{"nerf.N_samples": 32, "nerf.N_importance": 32, "train.batch_size": 128, "max_steps": 40,
+                            "val.chunk_size": 96})
+    torch.manual_seed(0)
+    s = NeRFSystem(hp, SyntheticDataset(I))
+    s.setup()
+    return s.cuda()
+
+
+@pytest.mark.gpu
+def test_fit_validates_checkpoints_and_resumes_bitwise(tmp_path):
+    from test_sampler import _sampler
+    bufs, I = _scene()
+    smp = _sampler(bufs)
+    n_batches = (len(smp) + 127) // 128  # 12
+    batches = lambda epoch: smp.batches(128, seed=3, epoch=epoch)
+    # two "validation images" of 160 rays each, in the DataLoader's batch-of-one layout
+    val = [{k: v[None] for k, v in smp.sample(torch.arange(i * 160, (i + 1) * 160)).items()} for i in range(2)]
+    MAX = 2 * 20  # 20 iterations, two optimiser steps each (pose optimisation on): 12 in epoch 0, 8 in epoch 1
+
+    torch.manual_seed(11)
+    a = _system(I)
+    ta = Trainer(MAX, val_check_interval=0.25, dirpath=str(tmp_path / "a"), seed=3).fit(a, batches, n_batches, val)
+    assert a.global_step == MAX and ta.epoch == 1 and ta.batch_in_epoch == 8
+    steps = [h["step"] for h in ta.history]
+    assert steps == [6, 12, 18, 24, 30, 36, 40]  # every int(12 * 0.25) = 3 batches, and once more at the end
+    assert all("val/psnr" in h and "val/loss" in h for h in ta.history)
+    files = sorted(os.listdir(tmp_path / "a"))
+    assert "last.ckpt" in files and len(files) == 3
+    top2 = sorted(ta.history, key=lambda h: -h["val/psnr"])[:2]
+    assert {f"epoch={h['epoch']}-step={h['step']}.ckpt" for h in top2} == set(files) - {"last.ckpt"}
+
+    # the same run, stopped after 6 iterations (mid-epoch, right after the validation at step 12)
+    torch.manual_seed(11)
+    b = _system(I)
+    Trainer(2 * 6, val_check_interval=0.25, dirpath=str(tmp_path / "b"), seed=3).fit(b, batches, n_batches, val)
+    c = _system(I)  # a fresh process would build the system the same way; everything else comes from last.ckpt
+    with torch.no_grad():
+        for p in c.parameters():
+            p.add_(0.05)
+    tc = Trainer(MAX, val_check_interval=0.25, dirpath=str(tmp_path / "b"), seed=3).fit(c, batches, n_batches, val)
+    assert c.global_step == MAX and tc.epoch == 1 and tc.batch_in_epoch == 8
+    sa, sc = a.state_dict(), c.state_dict()
+    assert sa.keys() == sc.keys()
+    for k in sa:
+        assert torch.equal(sa[k], sc[k]), k
+    assert [h["val/psnr"] for h in tc.history] == [h["val/psnr"] for h in ta.history if h["step"] > 12]
+
+
+@pytest.mark.gpu
+def test_fit_from_config_wires_yaml_to_run_directory(tmp_path):
+    """A scene file in the reference's format + command-line overrides -> system, sampler, loop, run directory."""
+    from types import SimpleNamespace
+    from upnerf_amd import config as cfg
+    from upnerf_amd.trainer import fit_from_config
+    bufs, I = _scene(seed=9, N=1024)
+    scene = tmp_path / "scene.yaml"
+    scene.write_text("""\
+scene_name: 'toy_gate'
+exp_name: 'unit'
+max_steps: 8
+train:
+  batch_size: 128
+val:
+  log_interval: 0.5
+  chunk_size: 64
+pose:
+  optimize: True
+  c2f: [0.1,0.5]
+  noise: -1
+candidate_schedule: [0.1,0.5]
+""")
+    hp = cfg.get_from_path(str(scene))
+    cfg.merge_from_list(hp, ["out_dir", str(tmp_path / "out"), "nerf.N_samples", "32", "nerf.N_importance", "32"])
+    img_ids = [10, 11, 12, 13]
+    train = SimpleNamespace(N_images_train=I, white_back=False, img_ids_train=img_ids,
+                            poses_dict={i: bufs["poses"][k].numpy() for k, i in enumerate(img_ids)},
+                            **{k: v for k, v in bufs.items() if k != "poses"})
+    from test_sampler import _sampler
+    smp = _sampler(bufs)
+    val = [{k: v.cpu() for k, v in smp.sample(torch.arange(0, 96)).items()}]
+    seen = []
+    system, tr = fit_from_config(hp, train, val, log=seen.append)
+    assert system.global_step == 16 and tr.epoch == 0 and tr.batch_in_epoch == 8  # 8 iterations = exactly one epoch
+    run = tmp_path / "out" / "toy_gate" / "unit"
+    assert sorted(os.listdir(run)) == ["ckpts", "config.yaml"] and "last.ckpt" in os.listdir(run / "ckpts")
+    assert [m["step"] for m in seen] == [8, 16]
+    back = cfg.load(str(run / "config.yaml"))
+    assert back["pose.c2f"] == (0.1, 0.5) and back["nerf.N_samples"] == 32 and back["scene_name"] == "toy_gate"
+    # calling it again finds ckpts/last.ckpt, resumes at the budget and does nothing more
+    system2, tr2 = fit_from_config(hp, train, val)
+    assert system2.global_step == 16 and not tr2.history
+    with pytest.raises(AssertionError):
+        fit_from_config({**hp, "pose.optimize": False}, train, val)

@@ -316,6 +316,73 @@ def state_key_fixture():
     print("state-key fixture written:", {k: len(v["state"]) for k, v in out.items()})
 
 
+CONFIG_CASES = {  # YAML texts written for this test suite (not the reference's files) + command-line override lists
+    "nested_and_literals": ("""\
+exp: 'run A'
+n: 7
+lr: 1e-3
+none_word: None
+flag: False
+path: data/x
+lst: [0.1,0.5]
+quoted_list: '[1, 2, 3]'
+quoted_tuple: '(4, 5)'
+nest:
+  a: 1
+  b:
+    c: 2.5
+    d: ['x', 'y']
+    e: {}
+  f: 1_000
+empty:
+""", []),
+    "overrides": ("""\
+nerf:
+  N_samples: 64
+pose:
+  optimize: True
+  c2f: [0.1,0.5]
+""", ["nerf.N_importance", "0", "pose.c2f", "None", "exp_name", "my run", "val.img_idx", "[0,11]", "x.y.z", "1e-4",
+        "nerf.N_samples", "32"]),
+    "empty_file": ("", ["a", "b"]),
+}
+
+
+def _enc(v):
+    if isinstance(v, tuple):
+        return {"__tuple__": [_enc(x) for x in v]}
+    if isinstance(v, list):
+        return [_enc(x) for x in v]
+    if isinstance(v, dict):
+        return {"__dict__": {k: _enc(x) for k, x in v.items()}}
+    return v
+
+
+def config_fixture():
+    """What the REAL configs/config.py (lines 12-99) makes of the reference's default.yaml and of the YAML texts /
+    override lists above: flat dicts with type-tagged values (tuples vs lists).  Pins upnerf_amd/config.py."""
+    import json
+    import tempfile
+    import configs.config as ref_config
+    out = {"default": {k: _enc(v) for k, v in ref_config.default().items()}, "cases": {}}
+    for name, (text, opts) in CONFIG_CASES.items():
+        with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+            f.write(text)
+        cfg = ref_config.get_from_path(f.name)
+        ref_config.merge_from_list(cfg, opts)
+        os.unlink(f.name)
+        with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+            pass
+        ref_config.save_yaml(cfg, f.name)  # round trip through the reference's writer and reader
+        back = ref_config.load(f.name)
+        os.unlink(f.name)
+        out["cases"][name] = {"yaml": text, "opts": opts, "config": {k: _enc(v) for k, v in cfg.items()},
+                              "after_save_and_load": {k: _enc(v) for k, v in back.items()}}
+    with open(os.path.join(OUT, "config_cases.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("config fixture written:", {k: len(v["config"]) for k, v in out["cases"].items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
@@ -326,6 +393,8 @@ if __name__ == "__main__":
         sampler_fixture()
     if not only or "state_keys" in only:
         state_key_fixture()
+    if not only or "config" in only:
+        config_fixture()
     for n, c in CASES.items():
         if not only or n in only:
             run_case(n, c)

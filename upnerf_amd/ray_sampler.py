@@ -40,6 +40,20 @@ class GpuRaySampler:
                 raise ValueError("all_pxl_coords [N,2] is required with feat_maps")
         self.device = dev
 
+    @classmethod
+    def from_dataset(cls, ds, device="cuda") -> "GpuRaySampler":
+        """From a train-split dataset object with the reference's buffer attributes (datasets/phototourism.py:213-323:
+        all_ray_infos, all_directions, all_rgbs, all_pxl_coords, all_inv_depths, feat_maps; the per-image poses are
+        `poses_dict[img_ids_train[i]]`, or a ready `poses` array of N_images_train rows)."""
+        import numpy as np
+        if hasattr(ds, "poses_dict") and hasattr(ds, "img_ids_train"):
+            poses = np.stack([np.asarray(ds.poses_dict[i], dtype=np.float32) for i in ds.img_ids_train])
+        else:
+            poses = ds.poses
+        g = lambda name: getattr(ds, name, None)
+        return cls(ds.all_ray_infos, ds.all_directions, ds.all_rgbs, poses, all_pxl_coords=g("all_pxl_coords"),
+                   feat_maps=g("feat_maps"), all_inv_depths=g("all_inv_depths"), device=device)
+
     def __len__(self) -> int:
         return self.N
 
