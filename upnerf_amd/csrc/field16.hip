@@ -168,18 +168,18 @@ __device__ __forceinline__ void acc_store_global(const f32x16 (&acc)[MT][NT], fl
       }
 }
 
-// v = relu(fma(acc, un, bias[col])) with the sign bits packed in the accumulator layout (common.cuh)
+// v = relu(fma(acc, un, bias)) with the sign bits packed in the accumulator layout (common.cuh); bias[nt] = this lane's
+// column of tile nt, loaded by the caller BEFORE the contraction (an L2 round trip otherwise sits in front of the epilogue)
 template <int MT, int NT>
 __device__ __forceinline__ unsigned long long acc_fma_relu_pack(f32x16 (&acc)[MT][NT], float un,
-                                                                const float* __restrict__ bias, int n0, int lane) {
+                                                                const float (&bias)[NT]) {
   static_assert(MT * NT * 16 <= 64, "mask word is 64 bits");
-  const int i = lane & 31;
   unsigned int lo = 0u, hi = 0u;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const float b = bias[n0 + 32 * nt + i];
+      const float b = bias[nt];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int e = (mt * NT + nt) * 16 + r;
@@ -305,6 +305,10 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     STAMP(0);
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
+    float bl[TW::NT];
+#pragma unroll
+    for (int nt = 0; nt < TW::NT; ++nt) bl[nt] = P[L.b[l] + n0 + 32 * nt + li];
+    const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);  // wave-uniform; asked for before the contraction
     if (l == 0) {
       mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[0], UPNERF_X0 / 16, n0, 0, UPNERF_X0, lane);
     } else if (l == L.skip) {
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
       mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[l], W / 16, n0, 0, W, lane);
     }
     STAMP(1);
-    const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wexp[l])), P + L.b[l], n0, lane);
+    const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wel)), bl);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * F16_THREADS + tid] = bits;
@@ -409,7 +413,10 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
 #pragma unroll
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.c_rows + (size_t)rayrow[mt] * UPNERF_CK + 8 * hh;
     mma16_glb(accc, ap, pow2f(ecur), P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, UPNERF_CK, lane);
-    const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), P + L.bc1, hn0, lane);
+    float bc[TH::NT];
+#pragma unroll
+    for (int nt = 0; nt < TH::NT; ++nt) bc[nt] = P[L.bc1 + hn0 + 32 * nt + li];
+    const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), bc);
     if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * F16_THREADS + tid] = bits;
     mc = acc_absmax(accc);
   }
@@ -731,8 +738,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     }
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
+    const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);  // wave-uniform; asked for before the contraction
     mma16_lds<W>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_w[l], W / 16, n0, 0, W, lane);
-    acc_scale(acc, pow2f(-(ecur + wexp[l])));
+    acc_scale(acc, pow2f(-(ecur + wel)));
     acc_apply_mask(acc, bits);
     acc_store_global(acc, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
