@@ -94,3 +94,23 @@ class NeRFSystemOptimize(NeRFSystem):
         res = self(self.rays_from_batch(batch), batch["img_idx"], train=False)
         mse = ((res["s_rgb_fine"] - batch["rgbs"]) ** 2).mean()
         return {"val_psnr": -10.0 * torch.log10(mse), "s_rgb_fine": res["s_rgb_fine"], "s_depth_fine": res["s_depth_fine"]}
+
+    def validation_epoch_end(self, outputs):
+        """Mean PSNR over the validation images (nerf_system_optmize.py:190-196)."""
+        if not outputs:
+            return None
+        out = {"val/psnr": torch.stack([x["val_psnr"].reshape(()) for x in outputs]).mean()}
+        self.log("val/psnr", out["val/psnr"])
+        return out
+
+
+def run_stage(system: NeRFSystemOptimize, train_batches, n_batches_per_epoch: int, max_epochs: int, val_batches=()):
+    """One test-time-optimisation stage the way tto.py:56-91 runs it: `max_epochs` passes over the held-out image's rays
+    (50 for the pose stage, 20 for the appearance stage), a validation render after every epoch, no checkpoints.
+    Returns the Trainer (its `history` holds val/psnr per epoch)."""
+    from .trainer import Trainer
+    opts = system.optimizers()
+    n_opt = len(opts) if isinstance(opts, (list, tuple)) else 1
+    budget = int(system.global_step) + max_epochs * n_batches_per_epoch * n_opt
+    return Trainer(budget, val_check_interval=1.0, dirpath=None).fit(system, train_batches, n_batches_per_epoch,
+                                                                      val_batches)
