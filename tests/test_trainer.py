@@ -74,7 +74,7 @@ def test_fit_validates_checkpoints_and_resumes_bitwise(tmp_path):
     bufs, I = _scene()
     smp = _sampler(bufs)
     n_batches = (len(smp) + 127) // 128  # 12
-    batches = lambda epoch: smp.batches(128, seed=3, epoch=epoch)
+    batches = lambda epoch, start=0: smp.batches(128, seed=3, epoch=epoch, start=start)  # fast-forwards on resume
     # two "validation images" of 160 rays each, in the DataLoader's batch-of-one layout
     val = [{k: v[None] for k, v in smp.sample(torch.arange(i * 160, (i + 1) * 160)).items()} for i in range(2)]
     MAX = 2 * 20  # 20 iterations, two optimiser steps each (pose optimisation on): 12 in epoch 0, 8 in epoch 1

@@ -81,13 +81,15 @@ class GpuRaySampler:
         return out
 
     def batches(self, batch_size: int, seed: int = 0, epoch: int = 0, rank: int = 0, world_size: int = 1,
-                drop_last: bool = False) -> Iterator[Dict[str, torch.Tensor]]:
-        """One shuffled epoch of batches of `batch_size` rays PER RANK (Lightning semantics: batch_size is per rank)."""
+                drop_last: bool = False, start: int = 0) -> Iterator[Dict[str, torch.Tensor]]:
+        """One shuffled epoch of batches of `batch_size` rays PER RANK (Lightning semantics: batch_size is per rank).
+        `start` = number of leading batches to leave out (a run resumed inside the epoch: same permutation, nothing
+        gathered for the batches already consumed)."""
         g = torch.Generator(device=self.device)
         g.manual_seed(seed + epoch)
         perm = torch.randperm(self.N, device=self.device, generator=g)
         step = batch_size * world_size
-        for lo in range(0, self.N, step):
+        for lo in range(start * step, self.N, step):
             sl = perm[lo + rank * batch_size: lo + (rank + 1) * batch_size]
             if sl.numel() == 0 or (drop_last and sl.numel() < batch_size):
                 return

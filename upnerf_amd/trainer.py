@@ -12,10 +12,11 @@
     scheduler state, global step, and the position inside the epoch -- the batches already consumed are skipped, so a
     resumed run sees the same batches as an uninterrupted one.
 
-Batches come from any `batches(epoch) -> iterable of dicts` (GpuRaySampler.batches bound to its arguments); the loop
+Batches come from any `batches(epoch[, start]) -> iterable of dicts` (GpuRaySampler.batches bound to its arguments); the loop
 itself never touches the host side of a batch and never synchronises with the device outside validation."""
 from __future__ import annotations
 
+import inspect
 import math
 import os
 from typing import Callable, Dict, Iterable, List, Optional, Sequence
@@ -145,7 +146,11 @@ class Trainer:
         every = self._val_every(n_batches_per_epoch)
         while system.global_step < self.max_steps:
             skip = self.batch_in_epoch
-            for i, batch in enumerate(train_batches(self.epoch)):
+            if skip and len(inspect.signature(train_batches).parameters) >= 2:
+                it = enumerate(train_batches(self.epoch, skip), skip)  # provider fast-forwards: nothing gathered twice
+            else:
+                it = enumerate(train_batches(self.epoch))
+            for i, batch in it:
                 if i < skip:
                     continue  # consumed before the checkpoint this run resumed from
                 system.training_step(batch, i)
@@ -202,7 +207,8 @@ def fit_from_config(hparams: dict, train_dataset, val_dataset=None, device="cuda
     sampler = GpuRaySampler.from_dataset(train_dataset, device)
     bs = int(hparams["train.batch_size"])
     n_batches = -(-len(sampler) // (bs * world_size))
-    batches = lambda epoch: sampler.batches(bs, seed=int(hparams["seed"]), epoch=epoch, rank=rank, world_size=world_size)
+    batches = lambda epoch, start=0: sampler.batches(bs, seed=int(hparams["seed"]), epoch=epoch, rank=rank,
+                                                     world_size=world_size, start=start)
     val = []
     for i in range(len(val_dataset) if val_dataset is not None else 0):
         item = val_dataset[i]
