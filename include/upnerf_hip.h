@@ -236,6 +236,21 @@ int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field_bwd_args* 
 int upnerf_wgrad(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
                  float* dW, int ldo, float* db, float* slabs, int nsplit, void* stream);
 
+/* Many small weight gradients in one launch + one fixed-order reduction (the per-ray layers of TransientNet and the
+ * feature projections, M = rays: separately each is a 25 us launch that fills a quarter of the GPU).  Same arithmetic
+ * as upnerf_wgrad (fp32 MFMA); N, K, lda, ldb, ldo multiples of 4, any N and K (cut into 128 x 128 blocks).
+ * scratch: upnerf_wgrad_grouped_scratch(...) floats (a negative return is an error code). */
+#define UPNERF_MAX_WGRAD_GROUPS 32
+typedef struct {
+  const float* A;                /* [M][lda], N columns used */
+  const float* B;                /* [M][ldb], K columns used */
+  float* dW;                     /* [N][ldo] */
+  float* db;                     /* [N] or NULL */
+  int32_t M, N, K, lda, ldb, ldo;
+} upnerf_wgrad_group;
+int upnerf_wgrad_grouped_scratch(const upnerf_wgrad_group* groups, int ngroups, int nsplit);
+int upnerf_wgrad_grouped(const upnerf_wgrad_group* groups, int ngroups, float* scratch, int nsplit, void* stream);
+
 /* Same contract, contraction on the f16 matrix cores with fp32-level accuracy: A and B are scaled by 2^*expo_a,
  * 2^*expo_b (DEVICE ints, chosen so that the scaled maxima are ~2^14), split into fp16 hi + lo parts, and
  * Ah Bh + Ah Bl + Al Bh is accumulated in fp32 (5.3x fewer matrix cycles than the fp32 MFMA; HBM-bound). */

@@ -221,6 +221,58 @@ def test_wgrad_and_bias(hip, M, N, K):
     assert torch.equal(dW, dW2)
 
 
+def test_grouped_wgrad_matches_the_per_layer_kernel_and_autograd_defers_to_it(hip):
+    """upnerf_wgrad_grouped: mixed shapes (blocks cut at 128, ragged N / K / M, strided operands, with and without bias)
+    in one launch; and HipLinear's backward hands its small weight gradients to it through the engine callback."""
+    import ctypes as C
+    from upnerf_amd import _lib
+    ops = hip["ops"]
+    dev = torch.device("cuda", 0)
+    shapes = [(4096, 256, 384, True), (4096, 128, 384, True), (1000, 384, 128, False), (777, 132, 20, True),
+              (4096, 256, 256, True), (64, 8, 392, False)]
+    groups, keep, outs = [], [], []
+    for j, (M, N, K, bias) in enumerate(shapes):
+        lda, ldb = N + 4 * (j % 2), K + 8 * (j % 3)  # strided operands: only the first N / K columns are used
+        a, b = gen((M, lda), 300 + j).cuda(), gen((M, ldb), 320 + j).cuda()
+        dW = torch.full((N, K), float("nan"), device=dev)
+        db = torch.full((N,), float("nan"), device=dev) if bias else None
+        groups.append(_lib.WgradGroup(A=a.data_ptr(), B=b.data_ptr(), dW=dW.data_ptr(),
+                                      db=None if db is None else db.data_ptr(), M=M, N=N, K=K, lda=lda, ldb=ldb, ldo=K))
+        keep.append((a, b))
+        outs.append((dW, db))
+    arr = (_lib.WgradGroup * len(groups))(*groups)
+    n = _lib.lib.upnerf_wgrad_grouped_scratch(arr, len(groups), 64)
+    assert n > 0
+    for rep in range(2):
+        ws = torch.empty(n, device=dev)
+        assert _lib.lib.upnerf_wgrad_grouped(arr, len(groups), ws.data_ptr(), 64, _lib.stream()) == 0
+        if rep == 0:
+            first = [(w.clone(), None if b_ is None else b_.clone()) for w, b_ in outs]
+    for (M, N, K, bias), (a, b), (dW, db), (w0, b0) in zip(shapes, keep, outs, first):
+        ref = a[:, :N].double().cpu().t() @ b[:, :K].double().cpu()
+        assert rel_err(cpu(dW), ref) < TOL_ACT, (M, N, K)
+        assert torch.equal(dW, w0)  # fixed-order reduction: bitwise reproducible
+        if bias:
+            assert rel_err(cpu(db), a[:, :N].double().cpu().sum(0)) < TOL_ACT and torch.equal(db, b0)
+    assert _lib.lib.upnerf_wgrad_grouped(arr, 0, ws.data_ptr(), 64, None) == -1
+    # autograd: a small MLP on hip_linear, gradients with the deferral on and off
+    x = gen((512, 384), 340).cuda()
+    ws_ = [gen((256, 384), 341).cuda().requires_grad_(True), gen((128, 256), 342).cuda().requires_grad_(True)]
+    bs_ = [gen((256,), 343).cuda().requires_grad_(True), None]
+    res = {}
+    for on in (True, False):
+        ops.DEFERRED_WGRADS.enabled = on
+        try:
+            h = ops.hip_linear(x, ws_[0], bs_[0], True, defer_wgrad=True)
+            y = ops.hip_linear(h, ws_[1], bs_[1], defer_wgrad=True)
+            res[on] = torch.autograd.grad((y * y).sum(), [ws_[0], bs_[0], ws_[1]])
+        finally:
+            ops.DEFERRED_WGRADS.enabled = True
+    assert not ops.DEFERRED_WGRADS.groups and not ops.DEFERRED_WGRADS.keep
+    for g_on, g_off in zip(res[True], res[False]):
+        assert torch.isfinite(g_on).all() and rel_err(cpu(g_on), cpu(g_off).double()) < 1e-5
+
+
 def test_vec_wgrad(hip):
     M, K = 3001, 128
     v, x = gen((M, 4), 32), gen((M, K), 33)

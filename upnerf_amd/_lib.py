@@ -95,6 +95,14 @@ class PackDesc(C.Structure):
                 ("dst_ld", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class WgradGroup(C.Structure):
+    _fields_ = [("A", _fp), ("B", _fp), ("dW", _fp), ("db", _fp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldo", C.c_int32)]
+
+
+MAX_WGRAD_GROUPS = 32
+
+
 class GatherRaysArgs(C.Structure):
     _fields_ = [("R", C.c_int32), ("h", C.c_int32), ("C", C.c_int32), ("idx", _fp),
                 ("all_ray_infos", _fp), ("all_directions", _fp), ("all_rgbs", _fp), ("all_pxl_coords", _fp),
@@ -125,6 +133,8 @@ _SIGNATURES = {
     "upnerf_frag16": [_p, _p, _p, C.POINTER(Frag16Desc), _i, C.POINTER(Frag16Desc), _i, _p, _p, _p],
     "upnerf_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p],
+    "upnerf_wgrad_grouped_scratch": [C.POINTER(WgradGroup), _i, _i],
+    "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],

@@ -15,11 +15,12 @@ namespace {
 
 #define WG_CHUNK 32
 
+// One [64 MTW x 64 NTW] block of  sum_{m in [mbeg, mend)} A[m][nblk + n] B[m][kblk + k]  -> slab (row-major [TN][TK]);
+// column sums of A -> bslab [TN] when given.  The whole workgroup works on the block.
 template <int MTW, int NTW>
-__global__ __launch_bounds__(NTHREADS, 1) void wgrad_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                            const float* __restrict__ B, int ldb,
-                                                            float* __restrict__ slabs, float* __restrict__ bslabs,
-                                                            int rows_per_split) {
+__device__ __forceinline__ void wgrad_tile(int N, int K, const float* __restrict__ A, int lda,
+                                           const float* __restrict__ B, int ldb, float* __restrict__ slab,
+                                           float* __restrict__ bslab, int mbeg, int mend, int nblk, int kblk) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   constexpr int A4 = WG_CHUNK * TN / 4 / NTHREADS, B4 = WG_CHUNK * TK / 4 / NTHREADS;  // float4 per thread per chunk
   __shared__ __attribute__((aligned(16))) float As[2][WG_CHUNK * TN];
@@ -27,10 +28,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_kernel(int M, int N, int K,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int n0 = (wave >> 1) * 32 * MTW, k0 = (wave & 1) * 32 * NTW;
-  const int split = blockIdx.x;
-  const int nblk = blockIdx.y * TN, kblk = blockIdx.z * TK;  // output block origin (N, K larger than one block)
-  const int mbeg = split * rows_per_split;
-  const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
   f32x16 acc[MTW][NTW];
   acc_zero(acc);
   float bsum[MTW];
@@ -100,9 +97,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_kernel(int M, int N, int K,
     }
     buf ^= 1;
   }
-  // partial slab [split][by][bz][TN][TK]
-  const size_t blk = ((size_t)split * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
-  float* slab = slabs + blk * TN * TK;
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -112,12 +106,95 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgrad_kernel(int M, int N, int K,
         const int n = n0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
         slab[n * TK + k0 + 32 * nt + li] = acc[mt][nt][r];
       }
-  if (bslabs && blockIdx.z == 0 && (wave & 1) == 0) {
+  if (bslab && (wave & 1) == 0) {
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
       const float s = bsum[mt] + __shfl_xor(bsum[mt], 32);
-      if (hh == 0) bslabs[((size_t)split * gridDim.y + blockIdx.y) * TN + n0 + 32 * mt + li] = s;
+      if (hh == 0) bslab[n0 + 32 * mt + li] = s;
     }
+  }
+}
+
+template <int MTW, int NTW>
+__global__ __launch_bounds__(NTHREADS, 1) void wgrad_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                            const float* __restrict__ B, int ldb,
+                                                            float* __restrict__ slabs, float* __restrict__ bslabs,
+                                                            int rows_per_split) {
+  constexpr int TN = 64 * MTW, TK = 64 * NTW;
+  const int split = blockIdx.x;
+  const int mbeg = split * rows_per_split;
+  const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  // partial slab [split][by][bz][TN][TK]
+  const size_t blk = ((size_t)split * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+  wgrad_tile<MTW, NTW>(N, K, A, lda, B, ldb, slabs + blk * TN * TK,
+                       (bslabs && blockIdx.z == 0) ? bslabs + ((size_t)split * gridDim.y + blockIdx.y) * TN : nullptr, mbeg,
+                       mend, blockIdx.y * TN, blockIdx.z * TK);
+}
+
+// ---- grouped variant: many small weight gradients (the per-ray layers: M = rays) in ONE launch + ONE reduction.
+// Every group is cut into 128 x 128 output blocks and `nsplit` row ranges; blockIdx.y walks the blocks of all groups.
+struct WgradGroups {
+  upnerf_wgrad_group g[UPNERF_MAX_WGRAD_GROUPS];
+  int tile_start[UPNERF_MAX_WGRAD_GROUPS + 1];  // first output block of each group
+  int red_start[UPNERF_MAX_WGRAD_GROUPS + 1];   // first reduction workgroup of each group
+  int n;
+};
+#define GT 128  // block edge of the grouped kernels
+
+__device__ __forceinline__ int find_group(const int* start, int n, int idx) {
+  int g = 0;
+  while (g + 1 < n && idx >= start[g + 1]) ++g;
+  return g;
+}
+
+__global__ __launch_bounds__(NTHREADS, 1) void wgrad_grouped_kernel(WgradGroups T, float* __restrict__ slabs,
+                                                                    float* __restrict__ bslabs, int nsplit) {
+  const int tile = blockIdx.y, split = blockIdx.x;
+  const int gi = find_group(T.tile_start, T.n, tile);
+  const upnerf_wgrad_group& G = T.g[gi];
+  const int gz = (G.K + GT - 1) / GT, local = tile - T.tile_start[gi], by = local / gz, bz = local - by * gz;
+  const int rows = (((G.M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  const int mbeg = split * rows;
+  const int mend = (mbeg + rows < G.M) ? mbeg + rows : G.M;
+  const size_t blk = (size_t)tile * nsplit + split;
+  wgrad_tile<2, 2>(G.N, G.K, G.A, G.lda, G.B, G.ldb, slabs + blk * GT * GT,
+                   (G.db && bz == 0) ? bslabs + blk * GT : nullptr, mbeg < mend ? mbeg : mend, mend, by * GT, bz * GT);
+}
+
+// fixed-order sum over the splits, one thread per 4 consecutive k of one group's dW (and per row for db)
+__global__ __launch_bounds__(NTHREADS) void wgrad_grouped_reduce_kernel(WgradGroups T, const float* __restrict__ slabs,
+                                                                       const float* __restrict__ bslabs, int nsplit) {
+  const int gi = find_group(T.red_start, T.n, blockIdx.x);
+  const upnerf_wgrad_group& G = T.g[gi];
+  const int b = blockIdx.x - T.red_start[gi];
+  const int K4 = G.K >> 2, gz = (G.K + GT - 1) / GT;
+  const int q = b * NTHREADS + threadIdx.x;
+  if (q < G.N * K4) {
+    const int n = q / K4, k = (q - n * K4) * 4;
+    const int by = n / GT, bz = k / GT;
+    const float* src = slabs + ((size_t)(T.tile_start[gi] + by * gz + bz) * nsplit) * GT * GT + (size_t)(n - by * GT) * GT +
+                       (k - bz * GT);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int sp = 0;
+    for (; sp + 4 <= nsplit; sp += 4) {
+      const f32x4 a = *(const f32x4*)&src[(size_t)sp * GT * GT], c = *(const f32x4*)&src[(size_t)(sp + 1) * GT * GT];
+      const f32x4 d = *(const f32x4*)&src[(size_t)(sp + 2) * GT * GT], e = *(const f32x4*)&src[(size_t)(sp + 3) * GT * GT];
+      s0 += a; s1 += c; s2 += d; s3 += e;
+    }
+    for (; sp < nsplit; ++sp) s0 += *(const f32x4*)&src[(size_t)sp * GT * GT];
+    *(f32x4*)&G.dW[(size_t)n * G.ldo + k] = (s0 + s1) + (s2 + s3);
+  }
+  if (G.db && q < G.N) {
+    const int by = q / GT;
+    const float* src = bslabs + ((size_t)(T.tile_start[gi] + by * gz) * nsplit) * GT + (q - by * GT);
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= nsplit; sp += 4) {
+      p0 += src[(size_t)sp * GT]; p1 += src[(size_t)(sp + 1) * GT];
+      p2 += src[(size_t)(sp + 2) * GT]; p3 += src[(size_t)(sp + 3) * GT];
+    }
+    for (; sp < nsplit; ++sp) p0 += src[(size_t)sp * GT];
+    G.db[q] = (p0 + p1) + (p2 + p3);
   }
 }
 
@@ -566,6 +643,43 @@ extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const f
   if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(NTHREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
                      ldo, db);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_wgrad_grouped_scratch(const upnerf_wgrad_group* groups, int ngroups, int nsplit) {
+  if (!groups || ngroups <= 0 || ngroups > UPNERF_MAX_WGRAD_GROUPS || nsplit <= 0) return UPNERF_EINVAL;
+  long long tiles = 0;
+  for (int j = 0; j < ngroups; ++j)
+    tiles += (long long)((groups[j].N + GT - 1) / GT) * ((groups[j].K + GT - 1) / GT);
+  const long long n = tiles * nsplit * (GT * GT + GT);
+  return n > 0x7fffffffLL ? UPNERF_EUNSUP : (int)n;
+}
+
+extern "C" int upnerf_wgrad_grouped(const upnerf_wgrad_group* groups, int ngroups, float* scratch, int nsplit,
+                                    void* stream) {
+  if (!groups || ngroups <= 0 || ngroups > UPNERF_MAX_WGRAD_GROUPS || !scratch || nsplit <= 0) return UPNERF_EINVAL;
+  WgradGroups T;
+  T.n = ngroups;
+  T.tile_start[0] = T.red_start[0] = 0;
+  for (int j = 0; j < ngroups; ++j) {
+    const upnerf_wgrad_group& q = groups[j];
+    if (!q.A || !q.B || !q.dW || q.M <= 0 || q.N <= 0 || q.K <= 0 || (q.N & 3) || (q.K & 3) || (q.lda & 3) || (q.ldb & 3) ||
+        (q.ldo & 3))
+      return UPNERF_EINVAL;
+    T.g[j] = q;
+    T.tile_start[j + 1] = T.tile_start[j] + ((q.N + GT - 1) / GT) * ((q.K + GT - 1) / GT);
+    int rb = (q.N * (q.K / 4) + NTHREADS - 1) / NTHREADS;
+    if (rb * NTHREADS < q.N) rb = (q.N + NTHREADS - 1) / NTHREADS;  // the bias sum needs one thread per row
+    T.red_start[j + 1] = T.red_start[j] + rb;
+  }
+  const int tiles = T.tile_start[ngroups];
+  float* bslabs = scratch + (size_t)tiles * nsplit * GT * GT;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(nsplit, tiles), dim3(NTHREADS), 0, st, T, scratch, bslabs, nsplit);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(T.red_start[ngroups]), dim3(NTHREADS), 0, st, T, scratch, bslabs,
+                     nsplit);
   return (int)hipGetLastError();
 }
 

@@ -80,6 +80,56 @@ def wgrad_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor, ldb: 
     check(rc, "upnerf_wgrad")
 
 
+class _DeferredWgrads:
+    """Small (per-ray, M = rays) weight gradients of HipLinear, collected during a backward pass and computed by ONE
+    grouped launch + ONE reduction when the autograd engine finishes that pass (`queue_callback`, the hook DDP's reducer
+    uses), instead of a 25 us launch pair per layer.  The gradient tensors are handed to autograd right away and filled
+    at the flush, so nothing may read them earlier: only call sites whose weight has NO other consumer in the graph ask
+    for it (`hip_linear(..., defer_wgrad=True)`: TransientNet, the candidate feature projection) -- autograd would sum a
+    second contribution into the still empty tensor (feat_share_layer.weight also feeds the packed colour weights and
+    therefore stays on the immediate path) -- and their AccumulateGrad only adopts the tensor (gradients are reset to
+    None every step).  `enabled = False` restores one launch per layer everywhere."""
+
+    enabled = __import__("os").environ.get("UPNERF_DEFER_WGRADS", "1") != "0"  # diagnostic switch for A/B runs
+    MAX_M = 16384  # larger problems go to upnerf_wgrad directly (they fill the GPU on their own)
+    NSPLIT = 64
+
+    def __init__(self):
+        self.groups, self.keep = [], []
+
+    def add(self, M, gy, lda, N, x, ldb, K, gw, gb):
+        # one callback per entry: the first to run launches everything pending, the others find nothing (no state that
+        # an exception inside a backward pass could leave behind; `keep` holds every tensor a pending group points at)
+        torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+        self.groups.append(_lib.WgradGroup(A=gy.data_ptr(), B=x.data_ptr(), dW=gw.data_ptr(),
+                                           db=None if gb is None else gb.data_ptr(), M=M, N=N, K=K, lda=lda, ldb=ldb,
+                                           ldo=K))
+        # alive until the grouped kernels have been enqueued.  For the outputs only the STORAGE is held: a second
+        # reference to the tensor itself would make AccumulateGrad copy it (before it is filled) instead of adopting it
+        self.keep.append((gy, x, gw.untyped_storage(), None if gb is None else gb.untyped_storage()))
+        if len(self.groups) == _lib.MAX_WGRAD_GROUPS:
+            self._launch()
+
+    def _launch(self):
+        groups, self.groups = self.groups, []
+        keep, self.keep = self.keep, []
+        if not groups:
+            return
+        arr = (_lib.WgradGroup * len(groups))(*groups)
+        n = lib.upnerf_wgrad_grouped_scratch(arr, len(groups), self.NSPLIT)
+        if n < 0:
+            check(n, "upnerf_wgrad_grouped_scratch")
+        ws = workspace("wgrad_grouped", n, keep[0][0].device)
+        check(TIMER.run("wgrad_grouped", lambda: lib.upnerf_wgrad_grouped(arr, len(groups), ptr(ws), self.NSPLIT,
+                                                                          stream())), "upnerf_wgrad_grouped")
+
+    def flush(self):
+        self._launch()
+
+
+DEFERRED_WGRADS = _DeferredWgrads()
+
+
 def scale_exponents(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """Device int32 [2]: power-of-two exponents that bring max|A|, max|B| to ~2^14 (no host sync)."""
     amax = torch.stack([A.abs().amax(), B.abs().amax()]).clamp_min(1e-30)
@@ -154,10 +204,10 @@ class HipLinear(torch.autograd.Function):
     per-ray feature projection)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act: int):
+    def forward(ctx, x, w, b, act: int, defer_wgrad: bool = False):
         y = linear_raw(x.detach(), w.detach(), None if b is None else b.detach(), act)
         ctx.save_for_backward(x, w, y if act == 1 else None)
-        ctx.has_bias, ctx.act = b is not None, act
+        ctx.has_bias, ctx.act, ctx.defer = b is not None, act, defer_wgrad
         return y
 
     @staticmethod
@@ -181,6 +231,9 @@ class HipLinear(torch.autograd.Function):
             else:
                 Kp, Np = (K + 3) // 4 * 4, (N + 3) // 4 * 4
                 assert Kp == K and Np == N, "HipLinear needs in/out features that are multiples of 4 (or out <= 4)"
+                if ctx.defer and DEFERRED_WGRADS.enabled and M <= DEFERRED_WGRADS.MAX_M and not torch.is_grad_enabled():
+                    DEFERRED_WGRADS.add(M, gy, N, N, xc, K, K, gw, gb if ctx.has_bias else None)
+                    return gx, gw, gb if ctx.has_bias else None, None, None
                 for n0 in range(0, N, 256):
                     nn_ = min(256, N - n0)
                     for k0 in range(0, K, 256):
@@ -189,7 +242,7 @@ class HipLinear(torch.autograd.Function):
                                    gb.data_ptr() + 4 * n0 if k0 == 0 else None, x.device, a_off=n0, b_off=k0)
             if not ctx.has_bias:
                 gb = None
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def _vec_wgrad_wide(M, gy, N, xc, K, gw, gb):
@@ -201,8 +254,10 @@ def _vec_wgrad_wide(M, gy, N, xc, K, gw, gb):
         gw[:, k0:k0 + kk] = part
 
 
-def hip_linear(x, w, b=None, relu: bool = False):
-    return HipLinear.apply(x, w, b, 1 if relu else 0)
+def hip_linear(x, w, b=None, relu: bool = False, defer_wgrad: bool = False):
+    """defer_wgrad: the weight gradient may be computed at the end of the backward pass, grouped with the other small
+    ones -- only for a weight (and bias) that nothing else in the graph consumes (see _DeferredWgrads)."""
+    return HipLinear.apply(x, w, b, 1 if relu else 0, defer_wgrad)
 
 
 class _EmbedRows(torch.autograd.Function):

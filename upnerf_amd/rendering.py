@@ -301,7 +301,7 @@ def _project_feat(model, E_s, sum_sfeat, G_c=None, t_weight=None):
     rendering.py:166-177)."""
     feat = hip_linear(E_s, model.feat_share_layer.weight) + sum_sfeat[:, None] * model.feat_share_layer.bias
     if G_c is not None:
-        feat = feat + hip_linear(G_c, model.feat_candidate_layer.weight) \
+        feat = feat + hip_linear(G_c, model.feat_candidate_layer.weight, defer_wgrad=True) \
             + t_weight[:, None] * model.feat_candidate_layer.bias
     return feat
 

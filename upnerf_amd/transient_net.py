@@ -23,7 +23,7 @@ class TransientNet(nn.Module):
         self.rgb_layer = nn.Sequential(nn.Linear(128, 3), nn.Sigmoid())
 
     def forward(self, feat, ts):
-        lin = lambda m, x, relu=False: hip_linear(x, m.weight, m.bias, relu)
+        lin = lambda m, x, relu=False: hip_linear(x, m.weight, m.bias, relu, defer_wgrad=True)  # sole consumers
         h = feat
         for i in (0, 2, 4, 6):
             h = lin(self.feat_encoder[i], h, True)
