@@ -296,6 +296,16 @@ int upnerf_gather_rays(const upnerf_gather_rays_args* a, void* stream);
  * transient rows, se3_refine and depth_scale of models/nerf_system.py:79-91): out[n][:] = sum_{r: idx[r]==n} g[r][:],
  * rows without a hit are written as zeros; summation in increasing r (bitwise reproducible).  dim <= 256. */
 int upnerf_embed_bwd(int R, int N, int dim, const int64_t* idx, const float* g, float* out, void* stream);
+/* The same for up to UPNERF_MAX_EMBED_GROUPS tables of N rows gathered with the SAME idx (every per-image table of a
+ * training step): one scan of idx serves all of them. */
+#define UPNERF_MAX_EMBED_GROUPS 8
+typedef struct {
+  const float* g;                /* [R][dim] gradient of the gathered rows */
+  float* out;                    /* [N][dim] dense table gradient */
+  int32_t dim;                   /* <= 256 */
+} upnerf_embed_group;
+int upnerf_embed_bwd_grouped(int R, int N, const int64_t* idx, const upnerf_embed_group* groups, int ngroups, void* stream);
+
 
 /* ---- generic fp32 MFMA linear layer: C[M][N] = act(A[M][K] . B[N][K]^T + bias) --------------------
  * (TransientNet, models/transient_net.py:27-38, and the per-ray feature projection.)  K multiple of 8,

@@ -177,6 +177,29 @@ def test_embedding_gradient_kernel(hip, R, N, dim):
         assert float(grads[0][2].abs().max()) == 0.0
 
 
+def test_deferred_embedding_gradients_share_one_launch_and_equal_the_immediate_ones(hip):
+    """Seven tables gathered with the same indices (a training step's per-image tables) + one with other indices:
+    gradients through the end-of-pass grouped kernel are bit-identical to the per-table kernel's."""
+    ops = hip["ops"]
+    R, N = 3000, 97
+    dims = (48, 48, 16, 16, 128, 6, 2, 256, 33)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, N, (R,), generator=g).cuda()
+    idx2 = torch.randint(0, N, (R // 2,), generator=g).cuda()
+    embs = [torch.nn.Embedding(N, d).cuda() for d in dims]
+    ups = [gen((R if i else R // 2, d), 400 + i).cuda() for i, d in enumerate(dims)]
+    res = {}
+    for defer in (False, True):
+        for e in embs:
+            e.weight.grad = None
+        loss = sum((ops.embed_rows(e, idx if i else idx2, defer_grad=defer) * u).sum() for i, (e, u) in enumerate(zip(embs, ups)))
+        loss.backward()
+        assert not ops.DEFERRED_EMBEDS.items
+        res[defer] = [e.weight.grad.clone() for e in embs]
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------ generic GEMMs
 @pytest.mark.parametrize("M,N,K,relu", [(300, 256, 384, True), (129, 384, 256, False), (64, 1, 256, False),
                                         (500, 3, 128, False), (77, 128, 384, True), (4096, 16, 128, False)])

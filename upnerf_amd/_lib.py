@@ -103,6 +103,13 @@ class WgradGroup(C.Structure):
 MAX_WGRAD_GROUPS = 32
 
 
+class EmbedGroup(C.Structure):
+    _fields_ = [("g", _fp), ("out", _fp), ("dim", C.c_int32)]
+
+
+MAX_EMBED_GROUPS = 8
+
+
 class GatherRaysArgs(C.Structure):
     _fields_ = [("R", C.c_int32), ("h", C.c_int32), ("C", C.c_int32), ("idx", _fp),
                 ("all_ray_infos", _fp), ("all_directions", _fp), ("all_rgbs", _fp), ("all_pxl_coords", _fp),
@@ -141,6 +148,7 @@ _SIGNATURES = {
     "upnerf_pack": [_p, C.POINTER(PackDesc), _i, _i, _p],
     "upnerf_gather_rays": [C.POINTER(GatherRaysArgs), _p],
     "upnerf_embed_bwd": [_i, _i, _i, _p, _p, _p, _p],
+    "upnerf_embed_bwd_grouped": [_i, _i, _p, C.POINTER(EmbedGroup), _i, _p],
     "upnerf_linear": [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p],
     "upnerf_loss_fwd": [C.POINTER(LossArgs), _p, _p, _p, _p],
     "upnerf_loss_bwd": [C.POINTER(LossArgs), _p, C.POINTER(LossGrads), _p],

@@ -268,19 +268,26 @@ __global__ __launch_bounds__(NTHREADS) void vec_wgrad_kernel(int M, const float*
   float bacc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int m = mbeg + rg; m < mend; m += 4 * RG) {
-    f32x4 x[4];
-    float vv[4][3];
+  constexpr int U = 8;  // rows in flight per lane: the stream is latency-bound at one workgroup per CU
+  for (int m = mbeg + rg; m < mend; m += U * RG) {
+    f32x4 x[U];
+    float vv[U][3];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int mm = m + u * RG;
       const bool ok = mm < mend;
-      x[u] = ok ? *(const f32x4*)&X[(size_t)mm * ldx + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int mc = ok ? mm : mend - 1;  // loads first (clamped), masks after: no branch around a load
+      x[u] = *(const f32x4*)&X[(size_t)mc * ldx + 4 * c4];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) vv[u][c] = (ok && c < nvec) ? v[(size_t)mm * ldv + c] : 0.f;
+      for (int c = 0; c < 3; ++c) vv[u][c] = (c < nvec) ? v[(size_t)mc * ldv + c] : 0.f;
+      if (!ok) {
+        x[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vv[u][c] = 0.f;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         acc[c].x += vv[u][c] * x[u].x; acc[c].y += vv[u][c] * x[u].y;

@@ -398,6 +398,54 @@ __global__ void embed_bwd_kernel(int R, int N, int dim, const long long* __restr
     if (lane + 64 * q < dim) out[(size_t)n * dim + lane + 64 * q] = acc[q];
 }
 
+// Several tables indexed by the SAME idx (the per-image tables of a training step all are): one scan of idx per table
+// row serves every table, one launch instead of one per table.
+struct EmbedGroups {
+  const float* g[UPNERF_MAX_EMBED_GROUPS];
+  float* out[UPNERF_MAX_EMBED_GROUPS];
+  int dim[UPNERF_MAX_EMBED_GROUPS];
+  int n;
+};
+
+__global__ void embed_bwd_grouped_kernel(int R, int N, const long long* __restrict__ idx, EmbedGroups T) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[UPNERF_MAX_EMBED_GROUPS][4];
+#pragma unroll
+  for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[t][q] = 0.f;
+  for (int base = 0; base < R; base += 64) {
+    const int r = base + lane;
+    const bool hit = r < R && idx[r] == (long long)n;
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int j = __ffsll((long long)m) - 1;
+      m &= m - 1;
+#pragma unroll
+      for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t) {
+        if (t < T.n) {
+          const int dim = T.dim[t];
+          const float* __restrict__ row = T.g[t] + (size_t)(base + j) * dim;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (lane + 64 * q < dim) acc[t][q] += row[lane + 64 * q];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t) {
+    if (t < T.n) {
+      const int dim = T.dim[t];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lane + 64 * q < dim) T.out[t][(size_t)n * dim + lane + 64 * q] = acc[t][q];
+    }
+  }
+}
+
 // Train-split ray sampler (datasets/phototourism.py:420-454 + default collate): one wave per ray gathers the per-ray
 // scalars and interpolates the image's feature map bilinearly -- same operand order and roundings as the reference's
 // scalar code (w11 p11 + w12 p12 + w21 p21 + w22 p22, no fma), including its zero weights on the last row / column.
@@ -512,6 +560,23 @@ extern "C" int upnerf_embed_bwd(int R, int N, int dim, const int64_t* idx, const
   if (R <= 0 || N <= 0 || dim <= 0 || dim > 256 || !idx || !g || !out) return UPNERF_EINVAL;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((N + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, N, dim,
                      (const long long*)idx, g, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_embed_bwd_grouped(int R, int N, const int64_t* idx, const upnerf_embed_group* groups, int ngroups,
+                                        void* stream) {
+  if (R <= 0 || N <= 0 || !idx || !groups || ngroups <= 0 || ngroups > UPNERF_MAX_EMBED_GROUPS) return UPNERF_EINVAL;
+  EmbedGroups T;
+  T.n = ngroups;
+  for (int j = 0; j < UPNERF_MAX_EMBED_GROUPS; ++j) {
+    const bool live = j < ngroups;
+    if (live && (!groups[j].g || !groups[j].out || groups[j].dim <= 0 || groups[j].dim > 256)) return UPNERF_EINVAL;
+    T.g[j] = live ? groups[j].g : nullptr;
+    T.out[j] = live ? groups[j].out : nullptr;
+    T.dim[j] = live ? groups[j].dim : 0;
+  }
+  hipLaunchKernelGGL(embed_bwd_grouped_kernel, dim3((N + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, N,
+                     (const long long*)idx, T);
   return (int)hipGetLastError();
 }
 

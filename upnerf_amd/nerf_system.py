@@ -167,7 +167,7 @@ class NeRFSystem(_Base):
     # ---- pieces of training_step, exposed for tests and the benchmark ------------------------------------
     def rays_from_batch(self, batch):
         idx = batch["img_idx"]
-        se3 = embed_rows(self.se3_refine, idx) if self.hparams["pose.optimize"] else None
+        se3 = embed_rows(self.se3_refine, idx, defer_grad=True) if self.hparams["pose.optimize"] else None
         rays_o, rays_d = refine_and_get_rays(se3, batch["c2w"], batch["directions"])
         return torch.cat([rays_o, rays_d, batch["ray_infos"]], 1)
 
@@ -186,7 +186,7 @@ class NeRFSystem(_Base):
         sched_mult = self.get_schedule_mult(self._host_progress)
         results = self(rays, batch["feats"], batch["img_idx"], sched_mult, u_list=u_list, keep=keep)
         loss_d, _depth = self.loss.forward_with_prior(results, batch["rgbs"], batch["feats"], batch["inv_depths"],
-                                                      embed_rows(self.depth_scale, batch["img_idx"]), sched_mult)
+                                                      embed_rows(self.depth_scale, batch["img_idx"], defer_grad=True), sched_mult)
         return sum(l for l in loss_d.values()), loss_d, results
 
     def set_progress(self, progress: float):

@@ -67,7 +67,7 @@ class NeRFSystemOptimize(NeRFSystem):
         return {k: (outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], 0)) for k in outs[0]}
 
     def rays_from_batch(self, batch):
-        se3 = embed_rows(self.se3_refine, batch["img_idx"]) if self.pose_optimize else None
+        se3 = embed_rows(self.se3_refine, batch["img_idx"], defer_grad=True) if self.pose_optimize else None
         o, d = refine_and_get_rays(se3, batch["c2w"], batch["directions"])
         return torch.cat([o, d, batch["ray_infos"]], 1)
 

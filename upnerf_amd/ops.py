@@ -260,14 +260,42 @@ def hip_linear(x, w, b=None, relu: bool = False, defer_wgrad: bool = False):
     return HipLinear.apply(x, w, b, 1 if relu else 0, defer_wgrad)
 
 
+class _DeferredEmbeds:
+    """Table gradients of `embed_rows(..., defer_grad=True)`, collected during a backward pass and computed at its end
+    (same mechanism and same single-consumer rule as _DeferredWgrads): tables gathered with the same index tensor share
+    ONE launch and one scan of the indices (seven per-image tables per training step)."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, idx, N, dim, g, out):
+        torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+        self.items.append((idx, N, dim, g, out.data_ptr(), out.untyped_storage()))  # storage only: see _DeferredWgrads
+
+    def flush(self):
+        items, self.items = self.items, []
+        buckets = {}
+        for it in items:
+            buckets.setdefault((it[0].data_ptr(), it[0].numel(), it[1]), []).append(it)
+        for (_, R, N), its in buckets.items():
+            for lo in range(0, len(its), _lib.MAX_EMBED_GROUPS):
+                part = its[lo:lo + _lib.MAX_EMBED_GROUPS]
+                arr = (_lib.EmbedGroup * len(part))(*[_lib.EmbedGroup(g=i[3].data_ptr(), out=i[4], dim=i[2]) for i in part])
+                check(lib.upnerf_embed_bwd_grouped(R, N, ptr(part[0][0]), arr, len(part), stream()),
+                      "upnerf_embed_bwd_grouped")
+
+
+DEFERRED_EMBEDS = _DeferredEmbeds()
+
+
 class _EmbedRows(torch.autograd.Function):
     """table[idx] whose backward is one HIP kernel (dense, deterministic) instead of ATen's sort-based embedding
     backward (14 small launches per table and step)."""
 
     @staticmethod
-    def forward(ctx, table, idx):
+    def forward(ctx, table, idx, defer: bool = False):
         ctx.save_for_backward(idx)
-        ctx.shape = tuple(table.shape)
+        ctx.shape, ctx.defer = tuple(table.shape), defer
         return table.detach().index_select(0, idx)
 
     @staticmethod
@@ -276,19 +304,23 @@ class _EmbedRows(torch.autograd.Function):
         N, dim = ctx.shape
         g = g.contiguous()
         out = torch.empty(N, dim, device=g.device, dtype=torch.float32)
-        check(lib.upnerf_embed_bwd(idx.numel(), N, dim, ptr(idx), ptr(g), ptr(out), stream()), "upnerf_embed_bwd")
-        return out, None
+        if ctx.defer and DEFERRED_WGRADS.enabled and not torch.is_grad_enabled():
+            DEFERRED_EMBEDS.add(idx, N, dim, g, out)
+        else:
+            check(lib.upnerf_embed_bwd(idx.numel(), N, dim, ptr(idx), ptr(g), ptr(out), stream()), "upnerf_embed_bwd")
+        return out, None, None
 
 
-def embed_rows(emb, idx: torch.Tensor) -> torch.Tensor:
+def embed_rows(emb, idx: torch.Tensor, defer_grad: bool = False) -> torch.Tensor:
     """emb(idx) for an nn.Embedding with a float32 CUDA table of width <= 256 and a 1-D int64 index; anything else is
-    handed to the module itself."""
+    handed to the module itself.  defer_grad: the table gradient may be computed at the end of the backward pass together
+    with the other tables' -- only when nothing else in the graph consumes the table (see _DeferredEmbeds)."""
     w = getattr(emb, "weight", None)
     if (w is None or not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or w.shape[1] > 256 or idx.dim() != 1
             or idx.dtype != torch.int64 or getattr(emb, "padding_idx", None) is not None
             or getattr(emb, "max_norm", None) is not None):
         return emb(idx)
-    return _EmbedRows.apply(w, idx.contiguous())
+    return _EmbedRows.apply(w, idx.contiguous(), defer_grad)
 
 
 def adam_flat_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,

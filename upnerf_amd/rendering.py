@@ -355,8 +355,8 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
                 outs = _FieldPass.apply(rays_o, rays_d, zz, None, None, model.packed(), cfg)
             results[f"s_weights_{typ}"], results[f"s_depth_{typ}"] = outs[8], outs[5]
             return
-        a_rows = embed_rows(embeddings[f"{typ}_a"], img_idx) if model.encode_appearance else None
-        c_rows = embed_rows(embeddings[f"{typ}_c"], img_idx) if model.encode_candidate else None
+        a_rows = embed_rows(embeddings[f"{typ}_a"], img_idx, defer_grad=True) if model.encode_appearance else None
+        c_rows = embed_rows(embeddings[f"{typ}_c"], img_idx, defer_grad=True) if model.encode_candidate else None
         # host mirror kept by NeRF.set_progress; code that writes model.progress.data directly (the reference's way)
         # leaves it None and pays a device read here
         hp = getattr(model, "host_progress", None)

@@ -28,7 +28,7 @@ class TransientNet(nn.Module):
         for i in (0, 2, 4, 6):
             h = lin(self.feat_encoder[i], h, True)
         e = lin(self.final_encoder, h)
-        t = lin(self.t_encoder[0], torch.cat([e, embed_rows(self.embedding_t, ts)], -1), True)
+        t = lin(self.t_encoder[0], torch.cat([e, embed_rows(self.embedding_t, ts, defer_grad=True)], -1), True)
         alpha = torch.sigmoid(lin(self.alpha_layer[0], h))
         rgb = torch.sigmoid(lin(self.rgb_layer[0], t))
         beta = F.softplus(lin(self.beta_layer[0], t)) * alpha + self.beta_min
