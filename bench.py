@@ -121,6 +121,10 @@ def main():
                          "(fp32-level accuracy, default); f32 = fp32 MFMA kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-timing", choices=["field", "all"], default="field",
+                    help="HIP-event timing inside the timed region: the two field kernels only (what the roofline object "
+                         "needs; 4 event pairs per step) or every instrumented kernel class (≈45 pairs per step, costs "
+                         "≈1.5 %% of the step)")
     args = ap.parse_args()
 
     from upnerf_amd import parallel
@@ -151,6 +155,7 @@ def main():
         sysm.training_step(batches[i % len(batches)], i)
     TIMER.reset()
     TIMER.enabled = not args.no_kernel_timing
+    TIMER.only = {"field_fwd", "field_bwd"} if args.kernel_timing == "field" else None
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -23,10 +23,11 @@ class KernelTimer:
 
     def __init__(self):
         self.enabled = False
+        self.only = None  # None = every instrumented kernel class; else the set of names to record
         self.records = {}
 
     def run(self, name: str, fn, units: int = 0):
-        if not self.enabled:
+        if not self.enabled or (self.only is not None and name not in self.only):
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
