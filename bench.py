@@ -1,46 +1,66 @@
 #!/usr/bin/env python3
 """Benchmark of the UP-NeRF training hot path on MI355X (BASELINE.json: "training rays/sec").
 
-One step = one full optimisation step of the Brandenburg-Gate configuration (BASELINE.json configs[1]) on a batch
-of synthetic rays already resident in HBM:  se(3) refine -> rays -> render_rays coarse (64) + resample + fine (192)
-on two 8x256 fields -> TransientNet -> UPNeRFLoss -> backward (data + weight gradients, pose gradients) ->
-[gradient all-reduce when --gpus > 1] -> Adam + ExponentialLR on both optimisers.  fp32 end to end.
+One step = one full optimisation step on a batch of synthetic rays already resident in HBM:  se(3) refine -> rays ->
+render_rays coarse (64) + resample + fine (192) on two 8x256 fields -> TransientNet -> UPNeRFLoss -> backward (data +
+weight gradients, pose gradients) -> [gradient all-reduce when --gpus > 1] -> Adam + ExponentialLR on both optimisers.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py [--gpus 1] [--steps 20] [--warmup 5]
+    python bench.py --gpus N           # no torchrun environment: spawns the N ranks itself (fresh processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `value` is whole-job rays/s (N ranks x 4096 rays per step, weak scaling: every rank
-renders its own 4096-ray shard; model state is replicated and gradients are averaged by one flat all-reduce).
+Rank 0 prints ONE JSON line.  `value` is whole-job rays/s (N ranks x rays per step, weak scaling: every rank renders its
+own shard; model state is replicated and gradients are averaged by one flat all-reduce over RCCL).
+
+Workloads (--config):
+  brandenburg   BASELINE.json configs[1]/[2]: 4096 rays per GPU, 763 images, fp32-accurate contractions (default)
+  trevi         BASELINE.json configs[3]: 8192 rays per GPU, 1689 images, fp16 MLP weights/activations on MFMA (fp32 accumulate)
 
 Extra objects on the line:
-  roofline      dominant kernel of the step (largest summed device time) against the fp32 MFMA peak; `achieved` =
-                algorithmic FLOPs per launch (SURVEY.md 8d per-sample figure x samples per launch) / average
-                launch duration measured with HIP events on the launch stream over the timed steps.
-  cpu_baseline  the CPU oracle (oracle/upnerf_oracle.py, a port of the reference's arithmetic) timed on this box's
-                host cores on a bounded sample of the same workload (rank 0, N == 1 only).
+  roofline      dominant kernel of the step against the matrix peak of its arithmetic; `achieved` = algorithmic FLOPs per
+                launch (SURVEY.md 8d per-sample figure x samples per launch) / average launch duration from HIP
+                events on the launch stream.  The timed region replays captured HIP graphs (no place for event records
+                between graph nodes), so the events bracket the same kernels in eager steps run right after it.
+  phases        the three schedule phases BASELINE configs[1] asks for (progress 0.05 / 0.3 / 0.8), same K and W each
+  strict_f32    the same step with every contraction on the fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of the f16x3 split
+  cpu_baseline  the CPU oracle (oracle/upnerf_oracle.py, a port of the reference's arithmetic) timed on this box's host
+                cores on a bounded sample of the same workload incl. the Adam update (rank 0, N == 1 only).
 """
 import argparse
+import gc
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 # f16 dense MFMA: 1024 FLOP/clk/SIMD (v_mfma_f32_32x32x16_f16 = 32 cycles) x 1024 SIMDs x 2.4 GHz (same guide, "~2.5 PF")
 PEAK_F16_MFMA_TFLOPS = 2516.6
 # the f16x3 kernels issue three f16 MFMAs (hi*hi + hi*lo + lo*hi) per fp32-accurate multiply-accumulate
-PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3
-N_IMAGES = 763                 # Brandenburg Gate train split
-RAYS, NC, NF = 4096, 64, 128
-
+PEAK = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3, "f16": PEAK_F16_MFMA_TFLOPS}
+DTYPE = {"f32": "f32", "f16x3": "f32 (f16x3 emulated: 3 fp16 MFMAs per product, fp32 accumulate)",
+         "f16": "f16 (fp32 accumulate)"}
+NC, NF = 64, 128
+CONFIGS = {
+    "brandenburg": dict(rays=4096, n_images=763, field="f16x3",
+                        workload="BASELINE.json configs[1]: Brandenburg Gate shape, 4096 rays/GPU/step, 64 coarse + 128 fine "
+                                 "samples, two 8x256 fields + candidate/colour heads + TransientNet + appearance/candidate "
+                                 "embeddings (763 images), pose optimisation ON, full step incl. both Adam updates"),
+    "trevi": dict(rays=8192, n_images=1689, field="f16",
+                  workload="BASELINE.json configs[3]: Trevi Fountain shape, 8192 rays/GPU/step, 1689 images, 64 coarse + 128 "
+                           "fine samples, two 8x256 fields with fp16 weights and activations on MFMA (fp32 accumulate, fp32 "
+                           "encoding / compositing / loss / Adam), pose optimisation ON, full step incl. both Adam updates"),
+}
 # per-sample forward MACs of the reference network, D=8 W=256
 MAC = {"trunk": 491008, "sigma": 256, "final": 65536, "feat": 98304, "cand": 100480, "rgb": 59136}
+CPU_BASELINE_THREADS = 32  # fastest of 16 / 32 / 64 / 128 on the GPU box's 256-thread host (tools/cpu_baseline_threads.py)
 
 
 def algorithmic_fwd_mac(sched):
@@ -52,20 +72,41 @@ def algorithmic_fwd_mac(sched):
     return m
 
 
-def make_batches(dev, n, seed0):
+def source_sha16():
+    """Hash of the HIP sources + C header: identifies the build a committed PMC profile belongs to."""
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "include", "upnerf_hip.h")]
+    d = os.path.join(ROOT, "upnerf_amd", "csrc")
+    files += sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".cuh")))
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n):
+    """--gpus N without a torchrun environment: start the N ranks as fresh processes (this process has not touched the GPU
+    and never will) and pass their output and exit code through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def make_batches(dev, n, seed0, rays=4096, n_images=763):
     from upnerf_amd import synth
-    out = []
-    for i in range(n):
-        b = synth.batch(RAYS, N_IMAGES, seed=seed0 + i)
-        out.append({k: v.to(dev) for k, v in b.items()})
-    return out
+    return [{k: v.to(dev) for k, v in synth.batch(rays, n_images, seed=seed0 + i).items()} for i in range(n)]
 
 
-def build_system(dev, progress):
+def build_system(dev, progress, rays=4096, n_images=763):
+    import torch
     from upnerf_amd.nerf_system import NeRFSystem, SyntheticDataset, default_hparams
-    hp = default_hparams(**{"nerf.N_samples": NC, "nerf.N_importance": NF, "train.batch_size": RAYS})
+    hp = default_hparams(**{"nerf.N_samples": NC, "nerf.N_importance": NF, "train.batch_size": rays})
     torch.manual_seed(0)
-    sysm = NeRFSystem(hp, SyntheticDataset(N_IMAGES))
+    sysm = NeRFSystem(hp, SyntheticDataset(n_images))
     sysm.setup()
     with torch.no_grad():  # small non-zero pose/depth tables so that every gradient path does real work
         sysm.se3_refine.weight.normal_(0, 1e-2)
@@ -76,12 +117,9 @@ def build_system(dev, progress):
     return sysm
 
 
-CPU_BASELINE_THREADS = 32  # fastest of 16 / 32 / 64 / 128 on the GPU box's 256-thread host (tools/cpu_baseline_threads.py:
-#                            186 / 219 / 127 / 64 rays/s -- the oracle's ATen kernels stop scaling past one socket's worth)
-
-
-def cpu_baseline(progress, rays=768, iters=3):
-    """Oracle forward+backward (no optimiser) on a bounded sample of the same workload; returns rays/s."""
+def cpu_baseline(progress, n_images, rays=768, iters=3):
+    """Oracle forward + backward + Adam update on a bounded sample of the same workload; returns rays/s."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import upnerf_oracle as orc
     from upnerf_amd import synth
@@ -91,21 +129,88 @@ def cpu_baseline(progress, rays=768, iters=3):
         sd = synth.nerf_state(typ, seed=0, **kw)
         sd.pop("progress")
         st[f"nerf_{typ}"] = {k: v.requires_grad_(True) for k, v in sd.items()}
-    st["transient_net"] = {k: v.requires_grad_(True) for k, v in synth.transient_state(N_IMAGES, seed=0).items()}
-    for k, v in synth.tables(N_IMAGES, seed=0).items():
+    st["transient_net"] = {k: v.requires_grad_(True) for k, v in synth.transient_state(n_images, seed=0).items()}
+    for k, v in synth.tables(n_images, seed=0).items():
         st[k] = v.requires_grad_(True)
+    leaves = [v for x in st.values() for v in (x.values() if isinstance(x, dict) else [x])]
+    pose = [st["depth_scale"], st["se3_refine"]]
+    opts = [torch.optim.Adam([v for v in leaves if all(v is not p for p in pose)], lr=5e-4, eps=1e-8),
+            torch.optim.Adam(pose, lr=2e-3, eps=1e-8)]  # utils/optim.py:20-33, nerf_system.py:41-73
     cfgs = {f"nerf_{t}": orc.NerfCfg(typ=t, c2f=(0.1, 0.5), **kw) for t in ("coarse", "fine")}
     hp = {"pose.optimize": True, "nerf.near": 0.1, "nerf.far": 5.0, "candidate_schedule": (0.1, 0.5),
           "nerf.N_samples": NC, "nerf.N_importance": NF, "nerf.perturb": 1.0}
-    b = synth.batch(rays, N_IMAGES, seed=5)
+    b = synth.batch(rays, n_images, seed=5)
     times = []
     for it in range(iters + 1):
         t0 = time.perf_counter()
+        for o in opts:
+            o.zero_grad()
         losses, _ = orc.training_forward(st, cfgs, b, hp, progress)
         sum(losses.values()).backward()
+        for o in opts:
+            o.step()
         times.append(time.perf_counter() - t0)
     dt = sum(times[1:]) / iters
     return rays / dt, dt
+
+
+class Bench:
+    def __init__(self, args, rank, world, dev):
+        self.args, self.rank, self.world, self.dev = args, rank, world, dev
+        self.cfg = CONFIGS[args.config]
+        self.rays, self.n_images = self.cfg["rays"], self.cfg["n_images"]
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def leg(self, progress, field, graph, timer_only=None, steps=None, warmup=None):
+        """Build a fresh system, warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks)."""
+        import torch
+        import torch.distributed as dist
+        from upnerf_amd import _lib, rendering
+        from upnerf_amd.graph_step import GraphedTrainingStep
+        from upnerf_amd.ops import TIMER
+        steps = self.args.steps if steps is None else steps
+        warmup = self.args.warmup if warmup is None else warmup
+        rendering.FIELD_MODE = field
+        sysm = build_system(self.dev, progress, self.rays, self.n_images)
+        if self.world > 1:
+            sysm.enable_data_parallel()
+        batches = make_batches(self.dev, 4, 100 + 10 * self.rank, self.rays, self.n_images)
+        step = GraphedTrainingStep(sysm) if graph else sysm.training_step
+        for i in range(2 if graph else 0):  # first step of a shape signature runs eagerly, the second one is captured
+            step(batches[i % 4], i)
+        for i in range(warmup):
+            step(batches[i % 4], i)
+        TIMER.reset()
+        TIMER.enabled, TIMER.only = timer_only is not None, timer_only or None
+        calls0 = _lib.CALLS[0]
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(batches[i % 4], i)
+        host = time.perf_counter() - t0
+        self.barrier()
+        dt = time.perf_counter() - t0
+        TIMER.enabled = False
+        if self.world > 1:
+            t = torch.tensor([dt, host], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, host = float(t[0]), float(t[1])
+        out = {"value": self.world * self.rays * steps / dt, "ms_per_step": dt / steps * 1e3,
+               "host_issue_ms_per_step": host / steps * 1e3, "c_abi_calls_per_step": (_lib.CALLS[0] - calls0) / steps,
+               "sched_mult": sysm.get_schedule_mult(progress), "graph": bool(graph)}
+        if graph:
+            out["graph_stats"] = dict(step.stats)
+        summ = TIMER.summary() if timer_only is not None else None
+        del step, sysm, batches
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out, summ
 
 
 def main():
@@ -113,128 +218,150 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="brandenburg")
     ap.add_argument("--progress", type=float, default=0.3,
                     help="training progress in [0,1]: 0.05 -> sched 0 (candidate only), 0.3 -> sched 0.5 (all heads, "
                          "the heaviest phase; default), 0.8 -> sched 1 (colour only)")
-    ap.add_argument("--field", choices=["f16x3", "f32"], default="f16x3",
+    ap.add_argument("--field", choices=["f16x3", "f32", "f16"], default=None,
                     help="arithmetic of the field contractions: f16x3 = 3-term fp16 split on the f16 matrix cores "
-                         "(fp32-level accuracy, default); f32 = fp32 MFMA kernels")
+                         "(fp32-level accuracy; default of --config brandenburg); f32 = fp32 MFMA kernels; f16 = fp16 weights "
+                         "and activations, one MFMA per product (default of --config trevi)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `phases` and `strict_f32` legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-timing", choices=["field", "all"], default="field",
-                    help="HIP-event timing inside the timed region: the two field kernels only (what the roofline object "
-                         "needs; 4 event pairs per step) or every instrumented kernel class (≈45 pairs per step, costs "
-                         "≈1.5 %% of the step)")
+                    help="HIP-event leg: the two field kernels only (what `roofline` needs) or every instrumented class")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise launcher, rendezvous, barriers and the output contract without touching a GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # before anything initialises a GPU in this process
+
+    import torch
+    import torch.distributed as dist
     from upnerf_amd import parallel
     rank, local, world = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    observed = dist.get_world_size() if dist.is_initialized() else 1
+    backend = dist.get_backend() if dist.is_initialized() else None
+    cfg = CONFIGS[args.config]
+    field = args.field or cfg["field"]
+
+    if args.dry_run:  # plumbing only: same barriers / max-over-ranks / one line from rank 0
+        t = torch.zeros(1)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            t += 1
+        if world > 1:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "training rays/sec", "value": 0.0, "unit": "rays/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(dt) / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[field],
+                              "data": "synthetic", "dry_run": True, "world_size_observed": observed, "backend": backend,
+                              "config": {"workload": cfg["workload"], "parallelism": f"dp{world}"}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    import torch.distributed as dist
-    from upnerf_amd.ops import TIMER
+    B = Bench(args, rank, world, dev)
+    graph = not args.no_graph
 
-    from upnerf_amd import rendering
-    rendering.FIELD_MODE = args.field
-    sysm = build_system(dev, args.progress)
-    if world > 1:
-        sysm.enable_data_parallel()
-    batches = make_batches(dev, 4, seed0=100 + 10 * rank)
-    sched = sysm.get_schedule_mult(args.progress)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        sysm.training_step(batches[i % len(batches)], i)
-    TIMER.reset()
-    TIMER.enabled = not args.no_kernel_timing
-    TIMER.only = {"field_fwd", "field_bwd"} if args.kernel_timing == "field" else None
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        sysm.training_step(batches[i % len(batches)], i)
-    barrier()
-    dt = time.perf_counter() - t0
-    TIMER.enabled = False
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    main_leg, _ = B.leg(args.progress, field, graph)
+    extras = {}
+    if not args.no_extras:
+        phases = {}
+        for p in (0.05, 0.3, 0.8):
+            phases[str(p)] = main_leg if abs(p - args.progress) < 1e-9 else B.leg(p, field, graph)[0]
+        extras["phases"] = {k: {x: v[x] for x in ("value", "ms_per_step", "sched_mult")} for k, v in phases.items()}
+        if field != "f32":
+            f32, _ = B.leg(args.progress, "f32", graph)
+            extras["strict_f32"] = {"value": f32["value"], "ms_per_step": f32["ms_per_step"], "dtype": "f32",
+                                    "contraction": "fp32 MFMA (v_mfma_f32_32x32x2_f32) in every field contraction"}
+    summ = None
+    if not args.no_kernel_timing:
+        only = {"field_fwd", "field_bwd"} if args.kernel_timing == "field" else set()
+        _, summ = B.leg(args.progress, field, False, timer_only=only if only else set(),
+                        steps=min(args.steps, 10), warmup=2)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    ms_per_step = dt / args.steps * 1e3
-    value = world * RAYS * args.steps / dt
+    sched = main_leg["sched_mult"]
     mac = algorithmic_fwd_mac(sched)
+    rays = B.rays
     line = {
-        "metric": "training rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: Brandenburg Gate shape, 4096 rays/GPU/step, 64 coarse + 128 "
-                               "fine samples, two 8x256 fields + candidate/colour heads + TransientNet + appearance/"
-                               "candidate embeddings (763 images), pose optimisation ON, full step incl. both Adam updates",
-                   "rays_per_gpu": RAYS, "N_samples": NC, "N_importance": NF, "progress": args.progress,
-                   "sched_mult": sched, "parallelism": f"dp{world}",
-                   "contraction": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.field == "f32" else
-                                   "fp32 operands and results; products formed as a 3-term fp16 hi/lo split on "
-                                   "v_mfma_f32_32x32x16_f16 with fp32 accumulation (<= 1e-6 of the fp32-MFMA kernels on "
-                                   "every activation, tests/test_hip_kernels.py, tests/test_hip_fullsize.py; "
-                                   "--field f32 selects the fp32-MFMA kernels)")},
-        "algorithmic_tflop_per_step": 3 * 2 * mac * RAYS * (NC + NC + NF) / 1e12,
+        "metric": "training rays/sec", "value": main_leg["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE[field], "data": "synthetic",
+        "config": {"workload": cfg["workload"], "rays_per_gpu": rays, "n_images": B.n_images, "N_samples": NC,
+                   "N_importance": NF, "progress": args.progress, "sched_mult": sched, "parallelism": f"dp{world}",
+                   "field": field,
+                   "launch": "HIP graph replay (one graph per shape signature, per-step scalars in device memory)"
+                             if graph else "eager launches"},
+        "world_size_observed": observed, "backend": backend,
+        "host_issue_ms_per_step": main_leg["host_issue_ms_per_step"],
+        "c_abi_calls_per_step": main_leg["c_abi_calls_per_step"],
+        "algorithmic_tflop_per_step": 3 * 2 * mac * rays * (NC + NC + NF) / 1e12,
     }
-    if not args.no_kernel_timing:
-        summ = TIMER.summary()
-        # algorithmic FLOPs per sample of each kernel class: forward, data-gradient and weight-gradient passes each
-        # contract every layer once ("training step = fwd + dgrad + wgrad ~ 3x fwd")
+    if "graph_stats" in main_leg:
+        line["graph_stats"] = main_leg["graph_stats"]
+    line.update(extras)
+    if summ:
         per_sample = {"field_fwd": 2 * mac, "field_bwd": 2 * mac, "wgrad_256x256": 2 * 256 * 256,
                       "wgrad16_256x256": 2 * 256 * 256}
+        nk = min(args.steps, 10)
         kern = {}
         for name, s in summ.items():
-            k = dict(launches_per_step=s["launches"] / args.steps, avg_ms=s["avg_ms"],
-                     ms_per_step=s["total_ms"] / args.steps)
+            k = dict(launches_per_step=s["launches"] / nk, avg_ms=s["avg_ms"], ms_per_step=s["total_ms"] / nk)
             if name in per_sample:
                 k["tflops_algorithmic"] = per_sample[name] * s["units_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
             kern[name] = k
         line["kernels"] = kern
         dom = max((n for n in kern if n in per_sample), key=lambda n: kern[n]["ms_per_step"])
         ach = kern[dom]["tflops_algorithmic"]
-        traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected live)
-        pmc = os.path.join(ROOT, "profiles", "r01_d_pmc.json")  # tools/pmc_collect.sh on the same command
-        pmc_name = {"field_fwd": "field16_fwd_kernel<64>" if args.field == "f16x3" else "field_fwd_kernel<256, 64>",
-                    "field_bwd": "field16_bwd_kernel<64>" if args.field == "f16x3" else "field_bwd_kernel<256, 64>",
-                    "wgrad16_256x256": "wgrad_f16x3_kernel<4, 4>", "wgrad_256x256": "wgrad_kernel<4, 4>"}.get(dom)
-        if os.path.exists(pmc) and pmc_name:
-            t = json.load(open(pmc)).get(pmc_name)
-            if t and "fetch_bytes_per_launch" in t:
-                traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
-        f16 = dom.startswith("wgrad16") or (dom.startswith("field") and args.field == "f16x3")
-        peak = PEAK_F16X3_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
-        line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak,
-                            "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+        # HBM bytes per launch come from rocprofv3 PMC passes (tools/pmc_collect.sh; they cannot be collected live): used
+        # only when the committed profile was taken from THIS build on THIS workload, otherwise null
+        traffic, source = None, None
+        meta_p = os.path.join(ROOT, "profiles", "pmc_current.json")
+        if os.path.exists(meta_p):
+            meta = json.load(open(meta_p))
+            if (meta.get("src_sha16") == source_sha16() and meta.get("field") == field and meta.get("config") == args.config
+                    and abs(meta.get("progress", -1) - args.progress) < 1e-9):
+                t = meta.get("kernels", {}).get(dom)
+                if t:
+                    traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                    source = f"profiles/{meta.get('file')} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same sources)"
+        peak = PEAK[field] if dom.startswith("field") else (PEAK["f16"] if field == "f16" else PEAK["f16x3"])
+        line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                            "frac": ach / peak, "traffic": traffic, "traffic_source": source,
                             "avg_launch_ms": kern[dom]["avg_ms"],
-                            "note": "achieved = algorithmic (fp32-equivalent) FLOPs / HIP-event launch time, averaged "
-                                    "over the coarse (262144-sample) and fine (786432-sample) launches; " +
-                                    ("peak = f16 dense MFMA 2516.6 TF / 3 MFMAs per fp32-accurate MAC (the hardware "
-                                     "executes 3x the algorithmic FLOPs); for scale: fp32 MFMA peak is 157.3 TF"
-                                     if f16 else "peak = fp32 MFMA")}
+                            "note": "achieved = algorithmic (fp32-equivalent) FLOPs / HIP-event launch time, averaged over "
+                                    "the coarse and fine launches of eager steps run right after the timed region; peak = "
+                                    + {"f16x3": "f16 dense MFMA 2516.6 TF / 3 MFMAs per fp32-accurate product (the hardware "
+                                                "executes 3x the algorithmic FLOPs); for scale: fp32 MFMA peak is 157.3 TF",
+                                       "f16": "f16 dense MFMA 2516.6 TF", "f32": "fp32 MFMA 157.3 TF"}[field]}
     if world == 1 and not args.no_cpu_baseline:
         nthreads = min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
         prev = torch.get_num_threads()
         torch.set_num_threads(nthreads)
-        v, sec = cpu_baseline(args.progress)
+        v, sec = cpu_baseline(args.progress, B.n_images)
         torch.set_num_threads(prev)
         line["cpu_baseline"] = {"value": v, "unit": "rays/s", "cores": nthreads, "kind": "port",
-                                "sample": f"oracle forward+backward (no optimiser step) on 768 rays of the same "
+                                "sample": f"oracle forward + backward + both Adam updates on 768 rays of the same "
                                           f"configuration (64+128 samples, 8x256 fields, pose opt ON), mean of 3 warm "
                                           f"iterations ({sec:.1f} s each) after 1 warm-up, torch threads = {nthreads} of "
                                           f"{os.cpu_count()} host threads (the fastest setting measured)"}

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UPNERF_ABI_VERSION 1
+#define UPNERF_ABI_VERSION 2
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
@@ -68,7 +68,9 @@ int upnerf_sort_rows(int R, int S, float* z, void* stream);
 /* ---- per-ray rgb-head side input: [PE(rays_d, L=4, masked) | appearance row | 0]  (nerf.py:102-107;
  *      the reference repeats it per sample, rendering.py:104-109) ---------------------------------- */
 int upnerf_ray_aux(int R, const float* rays_d, const float* a_rows /*[R][48] or NULL*/,
-                   const float* wk_dir /*[4]*/, float* aux /*[R][UPNERF_AUXK]*/, void* stream);
+                   const float* wk_dir /*[4] HOST*/, const float* wk_dir_dev /*[4] DEVICE or NULL: overrides wk_dir (graph
+                   replay: per-step scalars live in device memory, see upnerf_set_scalars)*/,
+                   float* aux /*[R][UPNERF_AUXK]*/, void* stream);
 
 /* ---- a6-a9: fused NeRF field, forward (models/nerf.py:80-124 + 126-147) --------------------------
  * Layout of the packed parameter buffers (floats): offsets below; a matrix is [N][Kp] with Kp a multiple
@@ -130,6 +132,8 @@ typedef struct {
   /* f16x3 variant only (upnerf_field_fwd_f16x3): */
   const void* P16;               /* matrices of P as scaled fp16 (hi, lo) fragments, from upnerf_frag16 (forward set) */
   const int32_t* wexp;           /* [16] per-matrix exponents from upnerf_frag16 */
+  const float* wk_xyz_dev;       /* [10] DEVICE or NULL: overrides wk_xyz (read at execution time, so a captured HIP graph
+                                    follows the schedule from one replay to the next) */
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -330,6 +334,8 @@ typedef struct {
   const float* feat_c; const float* feat_f; const float* feat_gt;   /* [R][F] */
   const float* rgb_c; const float* rgb_f; const float* rgb_gt;      /* [R][3] */
   const float* beta; const float* alpha;                             /* [R] */
+  const float* sched_dev;                /* [1] DEVICE or NULL: the multiplier m of the terms is read from here at execution
+                                            time (graph replay); `sched` then only selects the phase (== 0, in (0,1), == 1) */
 } upnerf_loss_args;
 int upnerf_loss_fwd(const upnerf_loss_args* a, float* depth_out /*[R]*/, float* terms /*[8]*/,
                     float* scratch /*[64*8]*/, void* stream);
@@ -382,9 +388,25 @@ int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, const upnerf_f
                   const upnerf_frag16_desc* bwd, int nbwd, float* amax_scratch /*[16]*/, int32_t* wexp /*[16]*/,
                   void* stream);
 
-/* ---- a18: fused Adam on a flat fp32 buffer (torch.optim.Adam semantics, utils/optim.py:20-33) ---- */
-int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
-                float eps, float bias_corr1, float bias_corr2, void* stream);
+/* ---- a18: fused Adam on a flat fp32 buffer (torch.optim.Adam semantics, utils/optim.py:20-33) ----
+ * step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t), both formed by the host in double precision and rounded
+ * to fp32 (as torch forms them).  dyn2 (DEVICE [step_size, bc2_sqrt], or NULL) overrides the by-value pair at execution
+ * time: a captured graph follows the step count and the learning-rate schedule from one replay to the next. */
+int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float beta1, float beta2, float eps,
+                float step_size, float bc2_sqrt, const float* dyn2, void* stream);
+
+/* ---- per-step scalars for captured HIP graphs: dst[i] = vals[i], i < n <= UPNERF_MAX_SCALARS --------------------------
+ * `vals` is HOST memory, copied into the kernel arguments at call time (no staging buffer whose lifetime the caller would
+ * have to manage, no host-device synchronisation): one small launch in front of every graph replay carries the learning
+ * rates, Adam bias corrections, BARF band weights and the schedule multiplier of that step. */
+#define UPNERF_MAX_SCALARS 96
+int upnerf_set_scalars(float* dst, int n, const float* vals, void* stream);
+
+#ifdef UPNERF_STAMPS
+/* Diagnostic build only (make -C upnerf_amd/csrc stamps -> libupnerf_hip_stamps.so, never the shipped library): per-phase
+ * shader-clock sums accumulated by the f16x3 field kernels; out16[0..7] forward trunk phases, [8..15] backward stages. */
+int upnerf_stamps_read(unsigned long long* out16, int reset);
+#endif
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,12 @@ def test_default_shape_bench_line():
     assert d["metric"] == "training rays/sec" and d["unit"] == "rays/s" and d["higher_is_better"] is True
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["dtype"].startswith("f32 (f16x3") and d["world_size_observed"] == 1
+    assert d["config"]["launch"].startswith("HIP graph replay") and d["graph_stats"]["replays"] >= 4 + 2
+    assert d["host_issue_ms_per_step"] < 6.0  # the host no longer paces the step
+    assert set(d["phases"]) == {"0.05", "0.3", "0.8"} and all(v["value"] > 50_000 for v in d["phases"].values())
+    assert d["phases"]["0.3"]["value"] == d["value"]
+    assert d["strict_f32"]["dtype"] == "f32" and 50_000 < d["strict_f32"]["value"] < d["value"]
     rays = d["config"]["rays_per_gpu"]
     assert rays == 4096 and d["config"]["N_samples"] == 64 and d["config"]["N_importance"] == 128
     assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
@@ -32,8 +38,50 @@ def test_default_shape_bench_line():
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and r["unit"] in ("TFLOP/s", "GB/s") and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
-    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["traffic"] is None or (r["traffic"] > 0 and r["traffic_source"])
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0
     assert isinstance(c["sample"], str) and c["sample"]
     assert d["value"] / c["value"] > 10  # north_star: >= 10x the CPU path
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=timeout, cwd=ROOT, env=e)
+
+
+def test_gpus_n_without_torchrun_spawns_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (fresh processes) -- never run
+    one rank silently; checked on the plumbing-only path (gloo, no GPU needed)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["UPNERF_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--dry-run"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_observed"] == 2 and d["backend"] == "gloo" and d["dry_run"] is True
+    assert d["config"]["parallelism"] == "dp2" and d["steps"] == 3
+
+
+def test_world_size_mismatch_is_an_error():
+    """A launcher environment that disagrees with --gpus must fail, not measure something else."""
+    out = _run(["--gpus", "2", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_two_ranks_spawned_on_one_device_run_the_real_step():
+    """The spawn path with the real workload: two ranks share cuda:0 through gloo (diagnostic switches of parallel.py),
+    graph replay with the all-reduce between the two graphs of a step."""
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--no-kernel-timing"],
+               env={"UPNERF_DIST_BACKEND": "gloo", "UPNERF_SHARE_DEVICE": "1"}, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_observed"] == 2 and d["graph_stats"]["replays"] >= 4
+    assert abs(d["value"] - 2 * 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -1,0 +1,92 @@
+"""Training steps replayed from captured HIP graphs (upnerf_amd/graph_step.py) against the eager steps they replace
+(models/nerf_system.py:150-228 is the step both perform).
+
+GPU: two systems with identical initial state train on the same batches, one eagerly, one through GraphedTrainingStep,
+while the schedule crosses phase 0 -> 1 (new shape signatures: eager, capture, replay all occur) -- every parameter, both
+Adam states and every logged loss term must come out BITWISE identical: the per-step scalars (band weights, schedule
+multiplier, Adam step sizes, learning rates) reach the kernels through device memory under replay and by value in the
+eager step, with the same fp32 values.
+CPU: the scalar table's slot bookkeeping."""
+import pytest
+import torch
+
+
+def test_step_scalars_slots_and_values():
+    pytest.importorskip("upnerf_amd._lib")
+    from upnerf_amd import step_scalars
+    from upnerf_amd.step_scalars import StepScalars
+    if not torch.cuda.is_available():
+        # the table lives in device memory; without a GPU only the host-side bookkeeping can run
+        class _Host(StepScalars):
+            def __init__(self, providers):
+                self.buf = torch.zeros(96)
+                self.providers, self.named, self.slots, self.used = dict(providers), {}, [], 0
+        t = _Host({"a": lambda: [1.0, 2.0], "b": lambda: [3.0]})
+    else:
+        t = StepScalars(torch.device("cuda", 0), {"a": lambda: [1.0, 2.0], "b": lambda: [3.0]})
+    assert step_scalars.current() is None
+    with t:
+        assert step_scalars.current() is t
+        pa = t.ptr_named("a", 2)
+        assert t.ptr_named("a", 2) == pa  # allocated once
+        pb = t.ptr_named("b", 1)
+        pf = t.ptr_fn(3, lambda: (7.0, 8.0, 9.0))
+        assert (pb - pa, pf - pb) == (8, 4)
+        with pytest.raises(ValueError):
+            t.ptr_named("a", 3)
+        with pytest.raises(KeyError):
+            t.ptr_named("zzz", 1)
+    assert step_scalars.current() is None
+    assert t.values() == [1.0, 2.0, 3.0, 7.0, 8.0, 9.0]
+
+
+def _system(perturb, steps):
+    from upnerf_amd.nerf_system import NeRFSystem, SyntheticDataset, default_hparams
+    hp = default_hparams(**{"nerf.N_samples": 32, "nerf.N_importance": 32, "train.batch_size": 192, "max_steps": steps,
+                            "nerf.perturb": perturb})
+    torch.manual_seed(0)
+    s = NeRFSystem(hp, SyntheticDataset(7))
+    s.setup()
+    with torch.no_grad():
+        s.se3_refine.weight.normal_(0, 1e-2)
+        s.depth_scale.weight.normal_(0, 1e-2)
+    return s.cuda()
+
+
+def _state(s):
+    out = {k: v.detach().clone() for k, v in s.state_dict().items()}
+    for i, o in enumerate(s._opts_scheds()[0]):
+        out[f"opt{i}.m"], out[f"opt{i}.v"] = o.flat_m.clone(), o.flat_v.clone()
+        out[f"opt{i}.steps"] = torch.tensor(o._steps)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("perturb", [0.0, 1.0])
+def test_replayed_steps_are_bitwise_the_eager_steps(perturb):
+    from upnerf_amd import synth
+    from upnerf_amd.graph_step import GraphedTrainingStep
+    STEPS = 120  # progress advances by 1/120 per iteration: phase 0 until 0.1, then n_s = 0, 0, 1, 1, 1, 2, ... (repeats)
+    batches = [{k: v.cuda() for k, v in synth.batch(192, 7, seed=40 + i).items()} for i in range(3)]
+    runs = {}
+    for mode in ("eager", "graph"):
+        s = _system(perturb, STEPS)
+        s.global_step = 12  # progress 0.05: eight iterations of phase 0, then the candidate schedule starts
+        s.set_progress(s.global_step / (2 * STEPS))
+        step = GraphedTrainingStep(s) if mode == "graph" else s.training_step
+        torch.manual_seed(123)
+        torch.cuda.manual_seed(123)
+        losses = []
+        for i in range(26):
+            loss = step(batches[i % 3], i)
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        runs[mode] = (_state(s), losses, dict(s.logged), step.stats if mode == "graph" else None)
+    st = runs["graph"][3]
+    assert st["replays"] >= 8 and st["captures"] >= 3 and st["eager"] >= 3, st
+    assert runs["eager"][1] == runs["graph"][1], (runs["eager"][1], runs["graph"][1])
+    for k, v in runs["eager"][0].items():
+        assert torch.equal(v, runs["graph"][0][k]), k
+    for k, v in runs["eager"][2].items():
+        w = runs["graph"][2][k]
+        assert (torch.equal(v, w) if torch.is_tensor(v) else v == w), k

@@ -66,7 +66,7 @@ def test_gpu_sampler_matches_oracle_on_a_larger_random_set_and_shards_like_a_dis
         assert all(r.shape[0] <= 256 for r in rows)
         seen.append(torch.cat(rows))
     allrows = torch.cat(seen)
-    assert allrows.shape[0] == N
+    assert seen[0].shape[0] == seen[1].shape[0] == -(-N // 2) and allrows.shape[0] == N  # N is even: no padding
     assert torch.equal(torch.sort(allrows[:, 0])[0], torch.sort(bufs["all_directions"][:, 0])[0])
 
 
@@ -93,3 +93,21 @@ def test_gpu_sampler_feeds_the_training_step():
     batch = next(iter(smp.batches(128, seed=1)))
     loss = sysm.training_step(batch, 0)
     assert torch.isfinite(loss)
+
+
+def test_every_rank_gets_the_same_number_of_batches():
+    """DistributedSampler semantics (train.py:70-72 via Lightning): for every remainder position of the last global batch
+    all ranks run the same number of batches, the union of their indices is the whole split, and the padding is the
+    wrapped head of the permutation."""
+    from upnerf_amd.ray_sampler import epoch_indices
+    bs, world = 256, 8
+    for N in (3000, 2048 * 3 + 5, 2048 * 3 + 255, 2048 * 3 + 257, 2048 * 3 + 1800, 7):
+        per = [epoch_indices(N, seed=3, epoch=2, rank=r, world_size=world, device="cpu") for r in range(world)]
+        assert len({p.numel() for p in per}) == 1 and per[0].numel() == -(-N // world)
+        counts = {-(-p.numel() // bs) for p in per}
+        assert len(counts) == 1
+        allidx = torch.stack(per, 1).reshape(-1)  # interleaved = the padded permutation
+        full = epoch_indices(N, seed=3, epoch=2, device="cpu")
+        assert torch.equal(allidx[:N], full)
+        assert torch.equal(allidx[N:], full[:allidx.numel() - N])
+        assert torch.equal(torch.sort(torch.unique(allidx))[0], torch.arange(N))

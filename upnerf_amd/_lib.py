@@ -35,7 +35,7 @@ class FieldFwdArgs(C.Structure):
                 ("wk_xyz", C.c_float * 10), ("P", _fp),
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
                 ("x0", _fp), ("h", _fp), ("hmask", _fp), ("amax", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp),
-                ("P16", _fp), ("wexp", _fp)]
+                ("P16", _fp), ("wexp", _fp), ("wk_xyz_dev", _fp)]
 
 
 class CompositeFwdArgs(C.Structure):
@@ -76,7 +76,7 @@ class LossArgs(C.Structure):
                 ("depth_direct", _fp), ("inv_depth", _fp), ("depth_scale_rows", _fp),
                 ("s_depth_c", _fp), ("s_depth_f", _fp), ("t_weight_c", _fp), ("t_weight_f", _fp),
                 ("feat_c", _fp), ("feat_f", _fp), ("feat_gt", _fp),
-                ("rgb_c", _fp), ("rgb_f", _fp), ("rgb_gt", _fp), ("beta", _fp), ("alpha", _fp)]
+                ("rgb_c", _fp), ("rgb_f", _fp), ("rgb_gt", _fp), ("beta", _fp), ("alpha", _fp), ("sched_dev", _fp)]
 
 
 class LossGrads(C.Structure):
@@ -130,7 +130,7 @@ _SIGNATURES = {
     "upnerf_sample_coarse": [_i, _i, _p, _p, _p, _f, _i, _p, _p],
     "upnerf_sample_pdf": [_i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     "upnerf_sort_rows": [_i, _i, _p, _p],
-    "upnerf_ray_aux": [_i, _p, _p, C.POINTER(C.c_float), _p, _p],
+    "upnerf_ray_aux": [_i, _p, _p, C.POINTER(C.c_float), _p, _p, _p],
     "upnerf_field_fwd": [C.POINTER(Layout), C.POINTER(FieldFwdArgs), _p],
     "upnerf_composite_fwd": [C.POINTER(CompositeFwdArgs), _p],
     "upnerf_composite_bwd": [C.POINTER(CompositeBwdArgs), _p],
@@ -153,8 +153,10 @@ _SIGNATURES = {
     "upnerf_loss_fwd": [C.POINTER(LossArgs), _p, _p, _p, _p],
     "upnerf_loss_bwd": [C.POINTER(LossArgs), _p, C.POINTER(LossGrads), _p],
     "upnerf_frag_copy": [_p, _p, C.POINTER(FragDesc), _i, _p],
-    "upnerf_adam": [C.c_int64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p],
+    "upnerf_adam": [C.c_int64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p],
+    "upnerf_set_scalars": [_p, _i, C.POINTER(C.c_float), _p],
 }
+MAX_SCALARS = 96
 EXPORTS = tuple(_SIGNATURES)
 
 
@@ -174,16 +176,25 @@ def _load():
 
 
 lib = _load()
-if lib.upnerf_abi_version() != 1:
+ABI_VERSION = 2
+if lib.upnerf_abi_version() != ABI_VERSION:
     raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
+
+
+_PTR_DTYPES = (torch.float32, torch.int64, torch.int32, torch.float16, torch.uint8)
 
 
 def ptr(t):
     """Device pointer of a contiguous fp32/int64 CUDA tensor (None -> NULL)."""
     if t is None:
         return None
-    assert t.is_cuda, "libupnerf_hip operates on device memory only"
-    assert t.is_contiguous(), "non-contiguous tensor handed to the HIP path"
+    # explicit raises, not asserts: this is the only guard between Python and raw device pointers (python -O keeps it)
+    if not t.is_cuda:
+        raise RuntimeError("libupnerf_hip operates on device memory only (got a CPU tensor)")
+    if not t.is_contiguous():
+        raise RuntimeError("non-contiguous tensor handed to the HIP path")
+    if t.dtype not in _PTR_DTYPES:
+        raise TypeError(f"unsupported dtype {t.dtype} handed to the HIP path")
     return t.data_ptr()
 
 
@@ -191,7 +202,11 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+CALLS = [0]  # C-ABI calls checked so far (bench.py reports calls per step)
+
+
 def check(rc: int, what: str):
+    CALLS[0] += 1
     if rc != 0:
         kind = {-1: "invalid argument", -2: "unsupported shape"}.get(rc, f"hipError_t {rc}")
         raise RuntimeError(f"{what} failed: {kind}")

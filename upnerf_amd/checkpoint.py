@@ -9,7 +9,11 @@ nerf_system_optmize.py:257-264, utils/__init__.py:4-26).  The file is a pickled 
 
 with `state_dict` keyed by the module tree (`nerf_coarse.xyz_encoding_1.0.weight`, `se3_refine.weight`, ...; pinned by
 tests/golden/state_keys.json) and `optimizer_states` in torch.optim's per-parameter shape (FlatAdam.state_dict emits
-that shape and accepts it back).  A file written here loads in the reference and vice versa.
+that shape and accepts it back).  Interchange with the reference: its `torch.load(...)["state_dict"]` consumers (eval,
+test-time optimisation, `load_ckpt`) read a file written here as they read their own, and a file written by the reference
+loads here (weights, optimiser moments, schedulers, step counters).  Resuming one of OUR files with Lightning's
+`trainer.fit(ckpt_path=...)` is not claimed: Lightning additionally wants its own `loops` / `callbacks` entries, which this
+package does not emit (trainer.py keeps its private resume state under `upnerf_*` keys that Lightning ignores).
 
 Everything is written from CPU copies, so a checkpoint saved on an MI355X opens anywhere."""
 from __future__ import annotations

@@ -78,8 +78,9 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
       const float arg = xv * ldexpf(PI_F, k);
       float sv, cv;
       sincos_f32_via_f64(arg, sv, cv);
-      Hs[swz(row, 3 + 20 * n + k, W)] = sv * a.wk_xyz[k];
-      Hs[swz(row, 3 + 20 * n + 10 + k, W)] = cv * a.wk_xyz[k];
+      const float wk = a.wk_xyz_dev ? a.wk_xyz_dev[k] : a.wk_xyz[k];  // device copy: graph replay
+      Hs[swz(row, 3 + 20 * n + k, W)] = sv * wk;
+      Hs[swz(row, 3 + 20 * n + 10 + k, W)] = cv * wk;
     }
   }
   __syncthreads();

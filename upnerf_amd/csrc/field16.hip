@@ -281,6 +281,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
       *(_Float16*)(Ph + o) = h;
       *(_Float16*)(Pl + o) = l;
     };
+    const float* __restrict__ wkd = a.wk_xyz_dev;  // per-step band weights from device memory under graph replay
     for (int it = tid; it < TILE * 3; it += F16_THREADS) {
       const int row = it / 3, n = it - row * 3;
       const float xv = xyz_s[row * 3 + n];
@@ -291,8 +292,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
         const float arg = xv * ldexpf(PI_F, k);
         float sv, cv;
         sincos_f32_via_f64(arg, sv, cv);
-        put(row, 3 + 20 * n + k, sv * a.wk_xyz[k]);
-        put(row, 3 + 20 * n + 10 + k, cv * a.wk_xyz[k]);
+        const float wk = wkd ? wkd[k] : a.wk_xyz[k];
+        put(row, 3 + 20 * n + k, sv * wk);
+        put(row, 3 + 20 * n + 10 + k, cv * wk);
       }
     }
   }

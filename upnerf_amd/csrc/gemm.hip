@@ -561,18 +561,33 @@ __global__ void frag16_write_kernel(const float* __restrict__ src, char* __restr
   *(_Float16*)(dst + base + 1024) = lo;
 }
 
-// ---- Adam (torch.optim.Adam, no weight decay / amsgrad): same op order as torch's single-tensor path
+// ---- Adam (torch.optim.Adam, no weight decay / amsgrad): same op order as torch's single-tensor path.  step_size =
+// lr / bias_corr1 and bc2_sqrt = sqrt(bias_corr2) are formed by the host in double precision and rounded to fp32, as
+// torch forms its Python scalars; dyn2 (device, [step_size, bc2_sqrt]) overrides the by-value pair under graph replay.
 __global__ void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                            float* __restrict__ v, float b1, float b2, float eps, float step_size, float bc2_sqrt,
+                            const float* __restrict__ dyn2) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (dyn2) {
+    step_size = dyn2[0];
+    bc2_sqrt = dyn2[1];
+  }
   const float gi = g[i];
   const float mi = m[i] + (gi - m[i]) * (1.f - b1);       // exp_avg.lerp_(grad, 1-beta1)
   const float vi = v[i] * b2 + (1.f - b2) * gi * gi;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
   m[i] = mi;
   v[i] = vi;
   const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  p[i] = p[i] - (lr / bc1) * (mi / denom);
+  p[i] = p[i] - step_size * (mi / denom);
+}
+
+struct ScalarPack {
+  float v[UPNERF_MAX_SCALARS];
+};
+__global__ void set_scalars_kernel(float* __restrict__ dst, int n, ScalarPack s) {
+  const int i = threadIdx.x;
+  if (i < n) dst[i] = s.v[i];
 }
 
 template <int MTW, int NTW>
@@ -790,10 +805,18 @@ extern "C" int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, con
   return (int)hipGetLastError();
 }
 
-extern "C" int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
-                           float eps, float bias_corr1, float bias_corr2, void* stream) {
+extern "C" int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float beta1, float beta2, float eps,
+                           float step_size, float bc2_sqrt, const float* dyn2, void* stream) {
   if (n <= 0 || !p || !g || !m || !v) return UPNERF_EINVAL;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n, p,
-                     g, m, v, lr, beta1, beta2, eps, bias_corr1, sqrtf(bias_corr2));
+                     g, m, v, beta1, beta2, eps, step_size, bc2_sqrt, dyn2);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_set_scalars(float* dst, int n, const float* vals, void* stream) {
+  if (!dst || !vals || n <= 0 || n > UPNERF_MAX_SCALARS) return UPNERF_EINVAL;
+  ScalarPack s;
+  for (int i = 0; i < UPNERF_MAX_SCALARS; ++i) s.v[i] = i < n ? vals[i] : 0.0f;
+  hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(UPNERF_MAX_SCALARS < 64 ? 64 : 128), 0, (hipStream_t)stream, dst, n, s);
   return (int)hipGetLastError();
 }

@@ -98,7 +98,7 @@ __global__ void loss_finish_kernel(upnerf_loss_args a, const float* __restrict__
   if (k >= T_N) return;
   float s = 0.f;
   for (int b = 0; b < LOSS_BLOCKS; ++b) s += part[b * T_N + k];
-  const float m = a.sched, R = (float)a.R;
+  const float m = a.sched_dev ? *a.sched_dev : a.sched, R = (float)a.R;
   float scale = 0.f;
   switch (k) {
     case T_DEPTH_C: case T_DEPTH_F: scale = a.depth_mult * (1.f - m) / R; break;
@@ -114,8 +114,8 @@ __global__ void loss_finish_kernel(upnerf_loss_args a, const float* __restrict__
 __global__ __launch_bounds__(NTHREADS) void loss_bwd_kernel(upnerf_loss_args a, const float* __restrict__ gt,
                                                            upnerf_loss_grads g) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const float m = a.sched, R = (float)a.R;
-  const bool p0 = m < 1.0f, p1 = m > 0.0f;
+  const float m = a.sched_dev ? *a.sched_dev : a.sched, R = (float)a.R;
+  const bool p0 = a.sched < 1.0f, p1 = a.sched > 0.0f;  // the phase is static; only the multiplier follows the step
   if (idx < a.R) {
     const int r = idx;
     float dsc, dsh;

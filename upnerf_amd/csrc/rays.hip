@@ -305,11 +305,16 @@ __global__ __launch_bounds__(NTHREADS) void sort_rows_kernel(int R, int S, float
 
 // ---- per-ray side input of the colour head: [PE(dir, L=4) | a | 0]
 __global__ void ray_aux_kernel(int R, const float* __restrict__ rays_d, const float* __restrict__ a_rows,
-                               float w0, float w1, float w2, float w3, float* __restrict__ aux) {
+                               float w0, float w1, float w2, float w3, const float* __restrict__ wk_dev,
+                               float* __restrict__ aux) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   float* o = aux + (size_t)r * UPNERF_AUXK;
-  const float wk[4] = {w0, w1, w2, w3};
+  float wk[4] = {w0, w1, w2, w3};
+  if (wk_dev) {  // per-step scalars from device memory (graph replay)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wk[k] = wk_dev[k];
+  }
 #pragma unroll
   for (int n = 0; n < 3; ++n) {
     const float x = rays_d[r * 3 + n];
@@ -532,12 +537,13 @@ extern "C" int upnerf_sort_rows(int R, int S, float* z, void* stream) {
   return (int)hipGetLastError();
 }
 
-extern "C" int upnerf_ray_aux(int R, const float* rays_d, const float* a_rows, const float* wk_dir, float* aux,
-                              void* stream) {
+extern "C" int upnerf_ray_aux(int R, const float* rays_d, const float* a_rows, const float* wk_dir,
+                              const float* wk_dir_dev, float* aux, void* stream) {
   if (R <= 0 || !rays_d || !wk_dir || !aux) return UPNERF_EINVAL;
-  // wk_dir is a HOST pointer to 4 floats (band weights are host scalars derived from the step counter)
+  // wk_dir is a HOST pointer to 4 floats (band weights are host scalars derived from the step counter); wk_dir_dev, when
+  // given, is read by the kernel instead (same values, but live across replays of a captured graph)
   hipLaunchKernelGGL(ray_aux_kernel, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, R, rays_d, a_rows,
-                     wk_dir[0], wk_dir[1], wk_dir[2], wk_dir[3], aux);
+                     wk_dir[0], wk_dir[1], wk_dir[2], wk_dir[3], wk_dir_dev, aux);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,146 @@
+"""NeRFSystem.training_step replayed from captured HIP graphs.
+
+An eager step issues ~370 kernel launches through ctypes, torch's allocator and the autograd engine: 16-17 ms of host
+time for ~19 ms of device time (round 1), i.e. any kernel improvement beyond ~2 ms per step would have been invisible.
+Here the device work of a step -- pose refine -> rays -> render_rays coarse + fine -> TransientNet -> loss -> backward ->
+both Adam updates (models/nerf_system.py:150-228) -- is captured ONCE per shape signature into a HIP graph and replayed:
+~0.2 ms of host time per step (copy the batch into the graph's static input tensors, one `upnerf_set_scalars` launch with
+the step's scalars, one graph launch), the host bookkeeping (step counts, LR schedulers, progress) runs beside it.
+
+Shape signature = (rays in the batch, schedule phase, n_s): the fine-sample split n_s = round(sched * N_importance)
+(models/rendering.py:283) is the only shape that moves during training, and it takes 129 values over the whole candidate
+schedule -- a new graph every ~1 900 steps in that window, none outside it.  The first step with a new signature runs
+eagerly (it also warms caches and workspaces), the second one is captured, every later one is replayed.  All graphs share
+one memory pool (they never run concurrently), and only the most recent few are kept.
+
+Per-step scalars (band weights, schedule multiplier, Adam step sizes) are read by the kernels from device memory
+(step_scalars.py), so a replayed step is bitwise identical to the eager step it replaces -- tests/test_graph_step.py.
+
+Data parallel (world_size > 1): the gradient all-reduce stays OUTSIDE the graphs -- graph 1 = forward + backward + pack of
+the flat gradient buffer, RCCL all-reduce issued eagerly, graph 2 = unpack + Adam -- so nothing depends on collective
+capture support in the communication library."""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+from .rendering import band_weights
+from .step_scalars import StepScalars
+
+__all__ = ["GraphedTrainingStep"]
+
+_BATCH_KEYS = ("ray_infos", "directions", "c2w", "feats", "img_idx", "rgbs", "inv_depths")
+
+
+class _Entry:
+    __slots__ = ("g1", "g2", "scalars", "loss", "loss_d", "done", "grads", "replays", "n_sync")
+
+
+class GraphedTrainingStep:
+    def __init__(self, system, max_graphs: int = 3, eager_steps: int = 1):
+        self.system = system
+        p = next(system.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("GraphedTrainingStep needs the system on the GPU")
+        self.device = p.device
+        self.stream = torch.cuda.Stream(self.device)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.graphs: "OrderedDict[tuple, _Entry]" = OrderedDict()
+        self.static: Dict[int, Dict[str, torch.Tensor]] = {}
+        self.seen: Dict[tuple, int] = {}
+        self.max_graphs, self.eager_steps = max_graphs, eager_steps
+        self.stats = {"eager": 0, "captures": 0, "replays": 0}
+        nc, nf = system.nerf_coarse, getattr(system, "nerf_fine", None)
+        if nf is not None and (nf.xyz_L, nf.dir_L, nf.c2f) != (nc.xyz_L, nc.dir_L, nc.c2f):
+            raise ValueError("coarse and fine fields must share the encoding configuration")
+
+    # ---- signature ---------------------------------------------------------------------------------------------------
+    def key(self, batch) -> tuple:
+        s = self.system
+        sm = s.get_schedule_mult(s._host_progress)
+        phase = 0 if sm == 0 else (2 if sm == 1 else 1)
+        n_s = round(sm * s.hparams["nerf.N_importance"]) if phase == 1 else 0  # rendering.py:283 (banker's rounding)
+        return (int(batch["img_idx"].shape[0]), phase, n_s)
+
+    def _providers(self):
+        s, m = self.system, self.system.nerf_coarse
+
+        def prog():
+            return float(torch.tensor(m.host_progress, dtype=torch.float32))  # what render_rays evaluates
+
+        return {"wk_xyz": lambda: band_weights(m.xyz_L, prog(), m.c2f),
+                "wk_dir": lambda: band_weights(m.dir_L, prog(), m.c2f),
+                "sched": lambda: [s.get_schedule_mult(s._host_progress)]}
+
+    # ---- capture -----------------------------------------------------------------------------------------------------
+    def _static_batch(self, batch):
+        R = int(batch["img_idx"].shape[0])
+        st = self.static.get(R)
+        if st is None:
+            st = {k: torch.empty_like(batch[k]) for k in _BATCH_KEYS if k in batch}
+            self.static[R] = st
+        return st
+
+    def _capture(self, key, static) -> _Entry:
+        s = self.system
+        s._last_rays = None  # an autograd graph kept alive from an earlier step would pin its AccumulateGrad nodes
+        if any(m.host_progress is None for m in s.models.values() if hasattr(m, "host_progress")):
+            raise RuntimeError("graph capture needs the host mirror of NeRF.progress (use NeRFSystem.set_progress)")
+        sync = s.grad_sync if (s.grad_sync is not None and s.grad_sync.world > 1) else None
+        e = _Entry()
+        e.scalars = StepScalars(self.device, self._providers())
+        e.g1, e.g2, e.replays = torch.cuda.CUDAGraph(), None, 0
+        with e.scalars:
+            with torch.cuda.graph(e.g1, pool=self.pool, stream=self.stream):
+                e.loss, e.loss_d = s._step_backward(static)
+                if sync is None:
+                    e.done = s._step_update()
+                    e.n_sync = 0
+                else:
+                    e.n_sync = sync.pack()
+            if sync is not None:
+                e.g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(e.g2, pool=self.pool, stream=self.stream):
+                    sync.unpack()
+                    e.done = s._step_update()
+        e.grads = [(p, p.grad) for p in s.parameters()]
+        self.stats["captures"] += 1
+        self.graphs[key] = e
+        while len(self.graphs) > self.max_graphs:
+            self.graphs.popitem(last=False)
+        return e
+
+    # ---- one training step -------------------------------------------------------------------------------------------
+    def __call__(self, batch, batch_nb: int = 0):
+        s = self.system
+        key = self.key(batch)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            e = self.graphs.get(key)
+            if e is None and self.seen.get(key, 0) < self.eager_steps:
+                self.seen[key] = self.seen.get(key, 0) + 1
+                self.stats["eager"] += 1
+                loss = s.training_step(batch, batch_nb)
+            else:
+                static = self._static_batch(batch)
+                for k, t in static.items():
+                    t.copy_(batch[k], non_blocking=True)
+                if e is None:
+                    e = self._capture(key, static)  # capture does not execute: the replay below performs this step
+                self.graphs.move_to_end(key)
+                e.scalars.upload()
+                e.g1.replay()
+                if e.g2 is not None:
+                    s.grad_sync.reduce(e.n_sync)
+                    e.g2.replay()
+                for p, g in e.grads:  # the tensors THIS graph writes (another graph's capture may have replaced them)
+                    p.grad = g
+                s._step_host(e.loss, e.loss_d, e.done)
+                e.replays += 1
+                self.stats["replays"] += 1
+                loss = e.loss
+        cur.wait_stream(self.stream)
+        return loss

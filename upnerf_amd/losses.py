@@ -8,6 +8,7 @@ import ctypes as C
 import torch
 from torch import nn
 
+from . import step_scalars
 from ._lib import LossArgs, LossGrads, check, lib, ptr, stream
 
 TERMS = ("l_depth_c", "l_feat_c", "l_rgb_c", "l_depth_f", "l_feat_f", "l_rgb_f", "l_beta", "l_alpha")
@@ -25,11 +26,13 @@ class _LossFn(torch.autograd.Function):
         ref = next(x for x in (dd, inv) if x is not None)
         R, dev = ref.shape[0], ref.device
         F = fg.shape[1] if fg is not None else 0
+        dyn = step_scalars.current()  # graph capture: the multiplier follows the schedule through device memory
         a = LossArgs(R=R, F=F, fine=int(fine), has_tw=int(twc is not None), sched=float(m), depth_mult=depth_mult,
                      alpha_reg=alpha_reg, near=near, far=far, depth_direct=ptr(dd), inv_depth=ptr(inv),
                      depth_scale_rows=ptr(rows), s_depth_c=ptr(sdc), s_depth_f=ptr(sdf), t_weight_c=ptr(twc),
                      t_weight_f=ptr(twf), feat_c=ptr(fc), feat_f=ptr(ff), feat_gt=ptr(fg), rgb_c=ptr(rc), rgb_f=ptr(rf),
-                     rgb_gt=ptr(rg), beta=ptr(beta), alpha=ptr(alpha))
+                     rgb_gt=ptr(rg), beta=ptr(beta), alpha=ptr(alpha),
+                     sched_dev=dyn.ptr_named("sched", 1) if dyn else None)
         depth = torch.empty(R, device=dev)
         terms = torch.empty(8, device=dev)
         scratch = torch.empty(64 * 8, device=dev)

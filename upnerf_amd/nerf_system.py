@@ -20,7 +20,7 @@ from torch import nn
 from .camera import refine_and_get_rays
 from .losses import UPNeRFLoss
 from .nerf import NeRF, fp32_round
-from .ops import embed_rows
+from .ops import embed_rows, reset_deferred
 from .optim import get_learning_rate, get_optimizer, get_scheduler
 from .parallel import GradSync
 from .rendering import render_rays
@@ -181,6 +181,7 @@ class NeRFSystem(_Base):
         return torch.where(d < near, torch.full_like(d, near), d)
 
     def compute_loss(self, batch, u_list=None, keep=None):
+        reset_deferred()  # nothing pending from a backward pass that raised
         rays = self.rays_from_batch(batch)
         self._last_rays = rays  # kept for tests (gradient w.r.t. the rays)
         sched_mult = self.get_schedule_mult(self._host_progress)
@@ -196,20 +197,40 @@ class NeRFSystem(_Base):
         if self.fine:
             self.nerf_fine.set_progress(progress)
 
-    def training_step(self, batch, batch_nb=0, u_list=None):
-        hp = self.hparams
-        loss, loss_d, results = self.compute_loss(batch, u_list=u_list)
-        opts = self.optimizers()
-        scheds = self.lr_schedulers()
+    def _opts_scheds(self):
+        opts, scheds = self.optimizers(), self.lr_schedulers()
         opts = opts if isinstance(opts, (list, tuple)) else [opts]
         scheds = scheds if isinstance(scheds, (list, tuple)) else [scheds]
-        for o in opts:
+        return list(opts), list(scheds)
+
+    # training_step = three pieces, so that graph_step.GraphedTrainingStep can capture the two that only enqueue device work
+    # (and put the gradient all-reduce between them) and replay them with the host bookkeeping done beside the replays
+    def _step_backward(self, batch, u_list=None):
+        """Forward, loss and backward; gradients are left in the parameters' .grad."""
+        loss, loss_d, _ = self.compute_loss(batch, u_list=u_list)
+        for o in self._opts_scheds()[0]:
             o.zero_grad()
         self.manual_backward(loss)
-        if self.grad_sync is not None:
-            self.grad_sync()
-        for o, s in zip(opts, scheds):
-            o.step()
+        return loss, loss_d
+
+    def _step_update(self):
+        """Both optimiser updates (device work only for FlatAdam; returns what _step_host needs to advance its counters)."""
+        done = []
+        for o in self._opts_scheds()[0]:
+            if hasattr(o, "step_device"):
+                done.append(o.step_device())
+            else:
+                o.step()
+                done.append(None)
+        return done
+
+    def _step_host(self, loss, loss_d, done):
+        """Host bookkeeping of one step: optimiser step counts, LR schedulers, global step, logs, progress."""
+        hp = self.hparams
+        opts, scheds = self._opts_scheds()
+        for o, s, runs in zip(opts, scheds, done):
+            if runs is not None:
+                o.step_host(runs)
             s.step()
         if not _HAVE_PL:
             self.global_step += len(opts)  # Lightning 1.9 counts one global step per optimizer.step (SURVEY.md Q5)
@@ -219,6 +240,12 @@ class NeRFSystem(_Base):
             self.log(f"train/{k}", v.detach(), prog_bar=True)
         if hp["pose.optimize"]:  # progress only advances with pose optimisation
             self.set_progress(self.global_step / (hp["max_steps"] * 2))
+
+    def training_step(self, batch, batch_nb=0, u_list=None):
+        loss, loss_d = self._step_backward(batch, u_list=u_list)
+        if self.grad_sync is not None:
+            self.grad_sync()
+        self._step_host(loss, loss_d, self._step_update())
         return loss
 
     # ---- validation (nerf_system.py:231-269 without the image logging; 318-324) -------------------------------------

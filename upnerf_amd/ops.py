@@ -92,13 +92,19 @@ class _DeferredWgrads:
     None every step).  `enabled = False` restores one launch per layer everywhere."""
 
     enabled = __import__("os").environ.get("UPNERF_DEFER_WGRADS", "1") != "0"  # diagnostic switch for A/B runs
+    check_adopted = __import__("os").environ.get("UPNERF_CHECK_DEFERRED", "0") == "1"  # debug: verify at every flush
     MAX_M = 16384  # larger problems go to upnerf_wgrad directly (they fill the GPU on their own)
     NSPLIT = 64
 
     def __init__(self):
-        self.groups, self.keep = [], []
+        self.groups, self.keep, self.owners = [], [], []
 
-    def add(self, M, gy, lda, N, x, ldb, K, gw, gb):
+    def clear(self):
+        """Drop whatever a failed backward pass left behind (its end-of-pass callback never ran)."""
+        self.groups, self.keep, self.owners = [], [], []
+
+    def add(self, M, gy, lda, N, x, ldb, K, gw, gb, owners=()):
+        self.owners += [(p, t.data_ptr()) for p, t in owners if t is not None]
         # one callback per entry: the first to run launches everything pending, the others find nothing (no state that
         # an exception inside a backward pass could leave behind; `keep` holds every tensor a pending group points at)
         torch.autograd.Variable._execution_engine.queue_callback(self.flush)
@@ -114,8 +120,14 @@ class _DeferredWgrads:
     def _launch(self):
         groups, self.groups = self.groups, []
         keep, self.keep = self.keep, []
+        owners, self.owners = self.owners, []
         if not groups:
             return
+        if self.check_adopted:
+            for p, addr in owners:
+                if p.grad is None or p.grad.data_ptr() != addr:
+                    raise RuntimeError("deferred weight gradient was not adopted by its parameter (autograd copied or "
+                                       "summed the still empty buffer)")
         arr = (_lib.WgradGroup * len(groups))(*groups)
         n = lib.upnerf_wgrad_grouped_scratch(arr, len(groups), self.NSPLIT)
         if n < 0:
@@ -129,6 +141,37 @@ class _DeferredWgrads:
 
 
 DEFERRED_WGRADS = _DeferredWgrads()
+
+
+def can_adopt(p) -> bool:
+    """True when autograd's AccumulateGrad will ADOPT a freshly allocated gradient tensor for the leaf `p` instead of
+    reading it (p.grad += g, a clone for a hook, ...): the precondition for handing it a buffer that is filled only at
+    the end of the backward pass.  Anything else takes the immediate path."""
+    return (p is not None and isinstance(p, torch.nn.Parameter) and p.is_leaf and p.grad is None
+            and not p._backward_hooks and not getattr(p, "_post_accumulate_grad_hooks", None))
+
+
+_DEFER_USES: Dict[int, list] = {}  # id(leaf) -> [forward uses with deferral requested since the last reset]
+
+
+def _defer_token(*leaves):
+    """Per-step use counters of the leaves a deferring call site consumes: a leaf that two deferring sites consume in
+    the same graph would have its two gradients SUMMED by autograd before AccumulateGrad sees them (i.e. read while still
+    empty), so the backward defers only while every counter is 1."""
+    toks = []
+    for p in leaves:
+        if p is not None:
+            t = _DEFER_USES.setdefault(id(p), [0])
+            t[0] += 1
+            toks.append(t)
+    return toks
+
+
+def reset_deferred():
+    """Start of a training step: forget groups a failed backward pass may have left pending and the use counters."""
+    DEFERRED_WGRADS.clear()
+    DEFERRED_EMBEDS.items = []
+    _DEFER_USES.clear()
 
 
 def scale_exponents(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
@@ -192,7 +235,8 @@ def linear_kn_view(x: torch.Tensor, w_base: torch.Tensor, w_off: int, ldw: int, 
     """y[M][N] = x[M][K] . Wv[K][N] where Wv is the strided view  w_base[w_off + k*ldw + n]  (a column block of a packed
     row-major matrix), read in place by the kernel."""
     M, K = x.shape
-    assert K % 8 == 0
+    if K % 8:
+        raise ValueError("linear_kn_view needs K to be a multiple of 8")
     x = x.contiguous()
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
     check(lib.upnerf_linear(M, N, K, ptr(x), K, w_base.data_ptr() + 4 * w_off, ldw, None, ptr(y), N, 2, stream()),
@@ -209,6 +253,8 @@ class HipLinear(torch.autograd.Function):
         y = linear_raw(x.detach(), w.detach(), None if b is None else b.detach(), act)
         ctx.save_for_backward(x, w, y if act == 1 else None)
         ctx.has_bias, ctx.act, ctx.defer = b is not None, act, defer_wgrad
+        ctx.owners = (w, b) if defer_wgrad else None  # the leaves themselves: the deferral rule is checked on them
+        ctx.tokens = _defer_token(w, b) if defer_wgrad else None
         return y
 
     @staticmethod
@@ -231,9 +277,13 @@ class HipLinear(torch.autograd.Function):
                     if K in (32, 64, 128, 256) else _vec_wgrad_wide(M, gy, N, xc, K, gw, gb)
             else:
                 Kp, Np = (K + 3) // 4 * 4, (N + 3) // 4 * 4
-                assert Kp == K and Np == N, "HipLinear needs in/out features that are multiples of 4 (or out <= 4)"
-                if ctx.defer and DEFERRED_WGRADS.enabled and M <= DEFERRED_WGRADS.MAX_M and not torch.is_grad_enabled():
-                    DEFERRED_WGRADS.add(M, gy, N, N, xc, K, K, gw, gb if ctx.has_bias else None)
+                if Kp != K or Np != N:
+                    raise ValueError("HipLinear needs in/out features that are multiples of 4 (or out <= 4)")
+                if (ctx.defer and DEFERRED_WGRADS.enabled and M <= DEFERRED_WGRADS.MAX_M and not torch.is_grad_enabled()
+                        and can_adopt(ctx.owners[0]) and (not ctx.has_bias or can_adopt(ctx.owners[1]))
+                        and all(t[0] == 1 for t in ctx.tokens)):
+                    DEFERRED_WGRADS.add(M, gy, N, N, xc, K, K, gw, gb if ctx.has_bias else None,
+                                        owners=((ctx.owners[0], gw), (ctx.owners[1], gb if ctx.has_bias else None)))
                     return gx, gw, gb if ctx.has_bias else None, None, None
                 for n0 in range(0, N, 256):
                     nn_ = min(256, N - n0)
@@ -269,12 +319,17 @@ class _DeferredEmbeds:
     def __init__(self):
         self.items = []
 
-    def add(self, idx, N, dim, g, out):
+    def add(self, idx, N, dim, g, out, owner=None):
         torch.autograd.Variable._execution_engine.queue_callback(self.flush)
-        self.items.append((idx, N, dim, g, out.data_ptr(), out.untyped_storage()))  # storage only: see _DeferredWgrads
+        # storage only: see _DeferredWgrads
+        self.items.append((idx, N, dim, g, out.data_ptr(), out.untyped_storage(), owner))
 
     def flush(self):
         items, self.items = self.items, []
+        if _DeferredWgrads.check_adopted:
+            for it in items:
+                if it[6] is not None and (it[6].grad is None or it[6].grad.data_ptr() != it[4]):
+                    raise RuntimeError("deferred table gradient was not adopted by its parameter")
         buckets = {}
         for it in items:
             buckets.setdefault((it[0].data_ptr(), it[0].numel(), it[1]), []).append(it)
@@ -297,6 +352,8 @@ class _EmbedRows(torch.autograd.Function):
     def forward(ctx, table, idx, defer: bool = False):
         ctx.save_for_backward(idx)
         ctx.shape, ctx.defer = tuple(table.shape), defer
+        ctx.owner = table if defer else None
+        ctx.tokens = _defer_token(table) if defer else None
         return table.detach().index_select(0, idx)
 
     @staticmethod
@@ -305,8 +362,9 @@ class _EmbedRows(torch.autograd.Function):
         N, dim = ctx.shape
         g = g.contiguous()
         out = torch.empty(N, dim, device=g.device, dtype=torch.float32)
-        if ctx.defer and DEFERRED_WGRADS.enabled and not torch.is_grad_enabled():
-            DEFERRED_EMBEDS.add(idx, N, dim, g, out)
+        if ctx.defer and DEFERRED_WGRADS.enabled and not torch.is_grad_enabled() and can_adopt(ctx.owner) \
+                and all(t[0] == 1 for t in ctx.tokens):
+            DEFERRED_EMBEDS.add(idx, N, dim, g, out, ctx.owner)
         else:
             check(lib.upnerf_embed_bwd(idx.numel(), N, dim, ptr(idx), ptr(g), ptr(out), stream()), "upnerf_embed_bwd")
         return out, None, None
@@ -327,5 +385,6 @@ def embed_rows(emb, idx: torch.Tensor, defer_grad: bool = False) -> torch.Tensor
 def adam_flat_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
     """In-place Adam update of a flat fp32 buffer (utils/optim.py:20-33 -> torch.optim.Adam semantics)."""
-    check(lib.upnerf_adam(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), lr, beta1, beta2, eps, 1 - beta1 ** step,
-                          1 - beta2 ** step, stream()), "upnerf_adam")
+    import math
+    check(lib.upnerf_adam(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), beta1, beta2, eps, lr / (1 - beta1 ** step),
+                          math.sqrt(1 - beta2 ** step), None, stream()), "upnerf_adam")

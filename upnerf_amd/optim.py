@@ -2,6 +2,8 @@
 ExponentialLR whose gamma takes the learning rate from lr to lr_end over max_step steps."""
 from __future__ import annotations
 
+import math
+
 import torch
 from torch.optim import SGD, Adam, AdamW
 from torch.optim.lr_scheduler import CosineAnnealingLR
@@ -40,31 +42,63 @@ class FlatAdam(torch.optim.Optimizer):
                 off += k
         self._steps = [0] * len(ps)
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        from .ops import adam_flat_
-        group = self.param_groups[0]
-        lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
+    def _plan(self):
+        """Maximal runs of consecutive parameters that have a gradient and share a step count."""
         live = [i for i, (p, _, _) in enumerate(self._spans) if p.grad is not None]
+        runs = []
+        if live:
+            run = [live[0]]
+            for i in live[1:]:
+                if i == run[-1] + 1 and self._steps[i] == self._steps[run[0]]:
+                    run.append(i)
+                else:
+                    runs.append(run)
+                    run = [i]
+            runs.append(run)
+        return live, runs
+
+    def _scalars(self, first: int):
+        """(step_size, sqrt(bias_corr2)) of the update that takes parameter `first` to its NEXT step count, formed in
+        double precision like torch.optim.Adam's Python scalars (the kernel receives them rounded to fp32)."""
+        group = self.param_groups[0]
+        b1, b2 = group["betas"]
+        t = self._steps[first] + 1
+        return (group["lr"] / (1 - b1 ** t), math.sqrt(1 - b2 ** t))
+
+    @torch.no_grad()
+    def step_device(self):
+        """The device half of step(): gather the gradients into the flat buffer and launch the update(s).  No host state
+        changes, so it can be captured in a HIP graph: under a capture (step_scalars.current()) the launches read the
+        step size and bias correction from device memory, refreshed before every replay."""
+        from . import step_scalars
+        from ._lib import check, lib, ptr, stream
+        group = self.param_groups[0]
+        (b1, b2), eps = group["betas"], group["eps"]
+        live, runs = self._plan()
         if not live:
-            return None
+            return []
         torch._foreach_copy_([self.flat_g[self._spans[i][1]:self._spans[i][1] + self._spans[i][2]].view_as(self._spans[i][0])
                               for i in live], [self._spans[i][0].grad for i in live])
-        run = [live[0]]
-        runs = []
-        for i in live[1:]:
-            if i == run[-1] + 1 and self._steps[i] == self._steps[run[0]]:
-                run.append(i)
-            else:
-                runs.append(run)
-                run = [i]
-        runs.append(run)
+        dyn = step_scalars.current()
         for run in runs:
             a, b = self._spans[run[0]][1], self._spans[run[-1]][1] + self._spans[run[-1]][2]
+            p, g, m, v = self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b]
+            step_size, bc2s = self._scalars(run[0])
+            dyn2 = dyn.ptr_fn(2, lambda first=run[0]: self._scalars(first)) if dyn is not None else None
+            check(lib.upnerf_adam(b - a, ptr(p), ptr(g), ptr(m), ptr(v), b1, b2, eps, step_size, bc2s, dyn2, stream()),
+                  "upnerf_adam")
+        return runs
+
+    def step_host(self, runs):
+        """The host half of step(): advance the per-parameter step counts of the runs step_device() updated."""
+        for run in runs:
             for i in run:
                 self._steps[i] += 1
-            adam_flat_(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], self._steps[run[0]],
-                       lr, b1, b2, eps)
+        self._opt_called = True  # what torch's LR schedulers look at to order optimizer.step() / scheduler.step()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.step_host(self.step_device())
         return None
 
     def state_dict(self):

@@ -11,7 +11,7 @@ checked (cheaply, by count and total size) in debug mode."""
 from __future__ import annotations
 
 import os
-from typing import Iterable, List
+from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -45,37 +45,59 @@ class GradSync:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group, self.check = group, check
         self._flat = None
+        self._live, self._views, self._n = [], [], 0
 
     @property
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
-    def __call__(self) -> int:
-        """All-reduce (mean) every gradient that exists; returns the number of floats exchanged."""
-        if self.world == 1:
+    # The exchange in three pieces (pack / reduce / unpack) so that a captured training step can keep the collective
+    # OUTSIDE its two HIP graphs: graph 1 ends with pack(), reduce() runs eagerly, graph 2 starts with unpack().
+    def pack(self) -> int:
+        """Copy every gradient that exists into the flat buffer; returns the number of floats (0: nothing to do)."""
+        self._live = [p for p in self.params if p.grad is not None]
+        n = sum(p.grad.numel() for p in self._live)
+        self._n = n
+        if n == 0 or self.world == 1:
             return 0
-        live = [p for p in self.params if p.grad is not None]
-        n = sum(p.grad.numel() for p in live)
-        if n == 0:
-            return 0
-        if self._flat is None or self._flat.numel() < n or self._flat.device != live[0].grad.device:
-            self._flat = torch.empty(n, device=live[0].grad.device, dtype=torch.float32)
+        dev = self._live[0].grad.device
+        if self._flat is None or self._flat.device != dev:
+            # allocated ONCE at the size of all parameters: captured graphs keep pointers into it
+            self._flat = torch.empty(sum(p.numel() for p in self.params), device=dev, dtype=torch.float32)
+        flat = self._flat[:n]
+        off, self._views = 0, []
+        for p in self._live:
+            k = p.grad.numel()
+            self._views.append(flat[off:off + k].view_as(p.grad))
+            off += k
+        torch._foreach_copy_(self._views, [p.grad for p in self._live])
+        return n
+
+    def reduce(self, n: Optional[int] = None) -> None:
+        """All-reduce (mean) of the first n floats of the packed buffer (default: what the last pack() wrote)."""
+        n = self._n if n is None else n
+        if n == 0 or self.world == 1:
+            return
         flat = self._flat[:n]
         if self.check:
-            sig = torch.tensor([len(live), n], device=flat.device, dtype=torch.int64)
+            sig = torch.tensor([len(self._live), n], device=flat.device, dtype=torch.int64)
             lo, hi = sig.clone(), sig.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
             if not (torch.equal(lo, sig) and torch.equal(hi, sig)):
                 raise RuntimeError("ranks disagree on which parameters received gradients")
-        off = 0
-        views = []
-        for p in live:
-            k = p.grad.numel()
-            views.append(flat[off:off + k].view_as(p.grad))
-            off += k
-        torch._foreach_copy_(views, [p.grad for p in live])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.mul_(1.0 / self.world)
-        torch._foreach_copy_([p.grad for p in live], views)
+
+    def unpack(self) -> None:
+        """Averaged gradients back into the parameters' .grad tensors."""
+        if self._n == 0 or self.world == 1:
+            return
+        torch._foreach_copy_([p.grad for p in self._live], self._views)
+
+    def __call__(self) -> int:
+        """All-reduce (mean) every gradient that exists; returns the number of floats exchanged."""
+        n = self.pack()
+        self.reduce()
+        self.unpack()
         return n

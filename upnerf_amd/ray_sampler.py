@@ -7,8 +7,9 @@ feature maps and the poses live in HBM (Brandenburg Gate at img_downscale 2: ~30
 shapes and values the reference's collated batch has -- including the bilinear feature interpolation and its quirk on
 the last row / column.  The shuffle is a device-side `torch.randperm` per epoch (the reference: DataLoader(shuffle=True)).
 
-With world_size > 1 every rank draws the same permutation (same seed) and takes its own contiguous slice of every
-global batch, which is what DistributedSampler gives the reference (train.py:70-72)."""
+With world_size > 1 every rank draws the same permutation (same seed), pads it by wrap-around to a multiple of the
+world size and takes every world_size-th index, exactly like the DistributedSampler the reference gets from Lightning
+(train.py:70-72): all ranks run the same number of batches per epoch."""
 from __future__ import annotations
 
 import ctypes as C
@@ -17,6 +18,21 @@ from typing import Dict, Iterator, Optional
 import torch
 
 from ._lib import GatherRaysArgs, check, lib, ptr, stream
+
+
+def epoch_indices(N: int, seed: int, epoch: int, rank: int = 0, world_size: int = 1, device="cuda") -> torch.Tensor:
+    """Ray indices rank `rank` trains on in epoch `epoch`, in order: a permutation of range(N) seeded by (seed + epoch)
+    -- the same on every rank -- padded by wrap-around to ceil(N / world) * world entries and strided by the world size
+    (torch.utils.data.DistributedSampler's rule), so every rank gets exactly ceil(N / world) indices."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + epoch)
+    perm = torch.randperm(N, device=device, generator=g)
+    if world_size > 1:
+        pad = -(-N // world_size) * world_size - N
+        if pad:
+            perm = torch.cat([perm, perm[:pad]])
+        perm = perm[rank::world_size].contiguous()
+    return perm
 
 
 class GpuRaySampler:
@@ -80,17 +96,27 @@ class GpuRaySampler:
         check(lib.upnerf_gather_rays(C.byref(a), stream()), "upnerf_gather_rays")
         return out
 
+    def n_batches(self, batch_size: int, world_size: int = 1, drop_last: bool = False) -> int:
+        """Batches per epoch, identical on every rank."""
+        if world_size == 1:
+            return self.N // batch_size if drop_last else -(-self.N // batch_size)
+        per_rank = -(-self.N // world_size)  # DistributedSampler: ceil(N / world) samples per rank after padding
+        return per_rank // batch_size if drop_last else -(-per_rank // batch_size)
+
     def batches(self, batch_size: int, seed: int = 0, epoch: int = 0, rank: int = 0, world_size: int = 1,
                 drop_last: bool = False, start: int = 0) -> Iterator[Dict[str, torch.Tensor]]:
         """One shuffled epoch of batches of `batch_size` rays PER RANK (Lightning semantics: batch_size is per rank).
         `start` = number of leading batches to leave out (a run resumed inside the epoch: same permutation, nothing
-        gathered for the batches already consumed)."""
-        g = torch.Generator(device=self.device)
-        g.manual_seed(seed + epoch)
-        perm = torch.randperm(self.N, device=self.device, generator=g)
-        step = batch_size * world_size
-        for lo in range(start * step, self.N, step):
-            sl = perm[lo + rank * batch_size: lo + (rank + 1) * batch_size]
-            if sl.numel() == 0 or (drop_last and sl.numel() < batch_size):
+        gathered for the batches already consumed).
+
+        world_size > 1 follows torch.utils.data.DistributedSampler (what Lightning wraps the reference's DataLoader in,
+        train.py:70-72): the permutation is padded by wrapping around to ceil(N / world) * world indices and rank k
+        takes indices k, k + world, k + 2 world, ... of it, so EVERY rank sees the same number of rays and therefore
+        the same number of batches per epoch (the last batch may be short, on all ranks alike)."""
+        perm = epoch_indices(self.N, seed, epoch, rank, world_size, self.device)
+        n = perm.numel()
+        for lo in range(start * batch_size, n, batch_size):
+            sl = perm[lo: lo + batch_size]
+            if drop_last and sl.numel() < batch_size:
                 return
             yield self.sample(sl)

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import _lib
+from . import _lib, step_scalars
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, X0, check, lib, ptr,
                    stream)
 from .ops import TIMER, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16x3_into, wgrad_into
@@ -103,11 +103,14 @@ class _FieldPass(torch.autograd.Function):
         a_rows_c = a_rows.detach().contiguous() if a_rows is not None else None
         joint, want_feat = cfg.mode <= 1, cfg.mode != 2
 
+        # per-step scalars: by value when run eagerly, from the device table of the capture in progress otherwise
+        dyn = step_scalars.current() if cfg.grad else None
         aux = None
         if cfg.use_rgb:
             aux = _empty(R, AUXK, device=dev)
             wk = (C.c_float * 4)(*cfg.wk_dir)
-            check(lib.upnerf_ray_aux(R, ptr(rays_d), ptr(a_rows_c), wk, ptr(aux), st), "upnerf_ray_aux")
+            check(lib.upnerf_ray_aux(R, ptr(rays_d), ptr(a_rows_c), wk, dyn.ptr_named("wk_dir", 4) if dyn else None,
+                                     ptr(aux), st), "upnerf_ray_aux")
 
         sigma_s = _empty(M, device=dev)
         sigma_c = _empty(M, device=dev) if cfg.use_cand else None
@@ -128,7 +131,7 @@ class _FieldPass(torch.autograd.Function):
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
                           rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1),
-                          P16=ptr(P16), wexp=ptr(wexp))
+                          P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None)
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
@@ -290,7 +293,8 @@ def sample_pdf(z_coarse: torch.Tensor, weights: torch.Tensor, n: int, det: bool,
     else:
         uu = u if u is not None else torch.rand(R, n, device=z_coarse.device)
         uu, rows = uu.contiguous(), R
-        assert tuple(uu.shape) == (R, n)
+        if tuple(uu.shape) != (R, n):
+            raise ValueError(f"sample_pdf: u has shape {tuple(uu.shape)}, expected {(R, n)}")
     stride = out.shape[1]
     check(lib.upnerf_sample_pdf(R, S, ptr(z_coarse), ptr(weights), ptr(uu), rows, n, out.data_ptr() + 4 * col0, stride,
                                 stream()), "upnerf_sample_pdf")
@@ -332,7 +336,8 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
     def draw(n):
         if draws is not None:
             t = draws.pop(0).to(dev, torch.float32).contiguous()
-            assert tuple(t.shape) == (R, n), (tuple(t.shape), (R, n))
+            if tuple(t.shape) != (R, n):
+                raise ValueError(f"u_list entry has shape {tuple(t.shape)}, expected {(R, n)}")
             return t
         return torch.rand(R, n, device=dev)
 

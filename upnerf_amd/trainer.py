@@ -71,7 +71,7 @@ class TopKCheckpoints:
 
 
 def _save(system, path: str, extra: dict) -> None:
-    d = checkpoint_dict(system, epoch=extra["loops"]["epoch"])
+    d = checkpoint_dict(system, epoch=extra["upnerf_loops"]["epoch"])
     d.update(extra)
     tmp = path + ".tmp"
     torch.save(d, tmp)
@@ -110,14 +110,17 @@ class Trainer:
     def _checkpoint(self, system, metrics: dict) -> None:
         if self.ckpts is None or not self.write_checkpoints:
             return
-        extra = {"loops": {"epoch": self.epoch, "batch_in_epoch": self.batch_in_epoch, "seed": self.seed},
-                 "callbacks": {"ModelCheckpoint": None},
-                 # the stratified-sampling draws of render_rays come from torch's generators
-                 "rng_states": {"torch": torch.get_rng_state(),
+        # private resume state under names Lightning does not reserve (its own `loops` / `callbacks` entries have another
+        # structure: a file with those keys in this shape would break trainer.fit(ckpt_path=...) of the reference)
+        extra = {"upnerf_loops": {"epoch": self.epoch, "batch_in_epoch": self.batch_in_epoch, "seed": self.seed},
+                 "upnerf_topk": None,
+                 # the stratified-sampling draws of render_rays come from torch's generators (rank 0's; every rank of a
+                 # data-parallel run seeds identically, trainer.setup_seed)
+                 "upnerf_rng": {"torch": torch.get_rng_state(),
                                 "cuda": torch.cuda.get_rng_state() if torch.cuda.is_available() else None}}
 
         def save(path):
-            extra["callbacks"]["ModelCheckpoint"] = self.ckpts.state_dict()
+            extra["upnerf_topk"] = self.ckpts.state_dict()
             _save(system, path, extra)
 
         self.ckpts.update(metrics.get(self.monitor, float("nan")), self.epoch, int(system.global_step), save)
@@ -125,12 +128,12 @@ class Trainer:
     def resume(self, system, ckpt_path: str) -> None:
         ck = read_checkpoint(ckpt_path)
         load_checkpoint(system, ck, resume=True)
-        loops = ck.get("loops", {})
+        loops = ck.get("upnerf_loops") or {}  # absent in a file written by the reference: start of the stored epoch
         self.epoch = int(loops.get("epoch", ck.get("epoch", 0)))
         self.batch_in_epoch = int(loops.get("batch_in_epoch", 0))
-        if self.ckpts is not None and isinstance(ck.get("callbacks"), dict):
-            self.ckpts.load_state_dict(ck["callbacks"].get("ModelCheckpoint") or {})
-        rng = ck.get("rng_states") or {}
+        if self.ckpts is not None and isinstance(ck.get("upnerf_topk"), dict):
+            self.ckpts.load_state_dict(ck["upnerf_topk"])
+        rng = ck.get("upnerf_rng") or {}
         if rng.get("torch") is not None:
             torch.set_rng_state(rng["torch"])
         if rng.get("cuda") is not None and torch.cuda.is_available():
@@ -206,7 +209,7 @@ def fit_from_config(hparams: dict, train_dataset, val_dataset=None, device="cuda
         system.enable_data_parallel()
     sampler = GpuRaySampler.from_dataset(train_dataset, device)
     bs = int(hparams["train.batch_size"])
-    n_batches = -(-len(sampler) // (bs * world_size))
+    n_batches = sampler.n_batches(bs, world_size)
     batches = lambda epoch, start=0: sampler.batches(bs, seed=int(hparams["seed"]), epoch=epoch, rank=rank,
                                                      world_size=world_size, start=start)
     val = []
