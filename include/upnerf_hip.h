@@ -134,6 +134,9 @@ typedef struct {
   const int32_t* wexp;           /* [16] per-matrix exponents from upnerf_frag16 */
   const float* wk_xyz_dev;       /* [10] DEVICE or NULL: overrides wk_xyz (read at execution time, so a captured HIP graph
                                     follows the schedule from one replay to the next) */
+  int32_t planes;                /* upnerf_field_fwd_f16x3 only: 0 or 2 = f16x3 (fp32-accurate hi/lo split, three MFMAs per
+                                    product); 1 = f16 (fp16 weights and activations, one MFMA per product, fp32 accumulate:
+                                    BASELINE.json configs[3]); the lo halves of P16 are then never read */
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -227,6 +230,7 @@ typedef struct {
   /* f16x3 variant only (upnerf_field_bwd_f16x3): */
   const void* PT16;              /* transposed set of upnerf_frag16 */
   const int32_t* wexp;           /* [16] */
+  int32_t planes;                /* as in upnerf_field_fwd_args: 0 / 2 = f16x3, 1 = f16 */
 } upnerf_field_bwd_args;
 
 int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream);
@@ -255,12 +259,13 @@ typedef struct {
 int upnerf_wgrad_grouped_scratch(const upnerf_wgrad_group* groups, int ngroups, int nsplit);
 int upnerf_wgrad_grouped(const upnerf_wgrad_group* groups, int ngroups, float* scratch, int nsplit, void* stream);
 
-/* Same contract, contraction on the f16 matrix cores with fp32-level accuracy: A and B are scaled by 2^*expo_a,
- * 2^*expo_b (DEVICE ints, chosen so that the scaled maxima are ~2^14), split into fp16 hi + lo parts, and
- * Ah Bh + Ah Bl + Al Bh is accumulated in fp32 (5.3x fewer matrix cycles than the fp32 MFMA; HBM-bound). */
+/* Same contract, contraction on the f16 matrix cores: A and B are scaled by 2^*expo_a, 2^*expo_b (DEVICE ints, chosen so
+ * that the scaled maxima are ~2^14).  planes 0 / 2 (f16x3): split into fp16 hi + lo parts, Ah Bh + Ah Bl + Al Bh
+ * accumulated in fp32 -- fp32-level accuracy at 5.3x fewer matrix cycles than the fp32 MFMA (HBM-bound).  planes 1 (f16):
+ * operands rounded to fp16, one MFMA per block, fp32 accumulate (the "f16" field mode). */
 int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
                        float* dW, int ldo, float* db, float* slabs, int nsplit, const int* expo_a,
-                       const int* expo_b, void* stream);
+                       const int* expo_b, int planes, void* stream);
 
 /* dw[c][k] = sum_m v[m*ldv + c] * X[m][k], c < nvec <= 3; dbv[c] = sum_m v[m*ldv + c]   (N=1/3 heads);
  * K in {32, 64, 128, 256}; scratch: nsplit * 4 * (K+1) floats */

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared():
     src = open(os.path.join(ROOT, "include", "upnerf_hip.h")).read()
+    # entry points of the diagnostic build (-DUPNERF_STAMPS, libupnerf_hip_stamps.so) are not part of the shipped library
+    src = re.sub(r"#ifdef UPNERF_STAMPS.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"^int\s+(upnerf_\w+)\s*\(", src, flags=re.M)))
 
 

@@ -362,12 +362,19 @@ def field_mode(hip, request):
     rd.FIELD_MODE = old
 
 
-@pytest.mark.parametrize("field_mode", ["f16x3", "f32"], indirect=True)
+# "f16" (BASELINE.json configs[3]: fp16 weights and activations, one MFMA per product, fp32 accumulate) is compared with the
+# same fp32 restatement at a STATED relaxed gate: 11-bit operands through ten chained layers give ~1e-3 on activations; the
+# gradients additionally see ReLU decisions flip on pre-activations within 1e-3 of zero (max-normalised gates below).
+TOL_ACT_F16, TOL_GRAD_F16 = 1e-2, 6e-2
+
+
+@pytest.mark.parametrize("field_mode", ["f16x3", "f32", "f16"], indirect=True)
 @pytest.mark.parametrize("name,typ", STAGE_CASES)
 def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     c = Case(name)
-    if field_mode == "f32" and c.cfgs()["nerf_coarse"].W != 256:
-        pytest.skip("64-wide fields run the fp32 kernels in either mode")
+    if field_mode != "f16x3" and c.cfgs()["nerf_coarse"].W != 256:
+        pytest.skip("64-wide fields run the fp32 kernels in either mode (and the f16 mode refuses them)")
+    TOL_ACT, TOL_GRAD = (TOL_ACT_F16, TOL_GRAD_F16) if field_mode == "f16" else (globals()["TOL_ACT"], globals()["TOL_GRAD"])
     s = _setup_pass(c, typ, hip)
     rd = hip["rendering"]
     model, pk = s["model"], s["model"].packer
@@ -403,7 +410,7 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
         return e < tol
 
     ok = True
-    ok &= cmp("x0", sv["x0"], f["x0"], 2e-6)
+    ok &= cmp("x0", sv["x0"], f["x0"], 1e-3 if field_mode == "f16" else 2e-6)  # f16: stored from the fp16 plane the layers read
     for l in range(pk.D):
         ok &= cmp(f"h{l}", sv["h"][l], f["h"][l], TOL_ACT)
     ok &= cmp("sigma_s", sv["sigma_s"], f["sigma_s"], TOL_ACT)

@@ -1,17 +1,29 @@
-// f16x3 building blocks: fp32-accurate contractions on the f16 matrix cores.
+// Building blocks of the field kernels on the f16 matrix cores (csrc/field16.hip), in two arithmetic modes:
+//   NP = 2 ("f16x3")  fp32-accurate: a 64-sample tile lives in LDS as TWO fp16 planes (hi, lo) with
+//                     value = (hi + lo) * 2^-e; every 32x32x16 block is three v_mfma_f32_32x32x16_f16
+//                     (hi*hi + hi*lo + lo*hi; fp16 products are exact in fp32, accumulation is fp32): 96 matrix cycles
+//                     instead of the 512 of eight v_mfma_f32_32x32x2_f32.  The split residue (lo*lo and the bits below
+//                     hi+lo) is 2^-22 relative -- the order of the fp32 rounding of the accumulation itself.
+//   NP = 1 ("f16")    fp16 weights and activations, ONE MFMA per block, fp32 accumulate (BASELINE.json configs[3]); the lo
+//                     planes / lo weight blocks are simply never written or read.
+// e is a per-tile, per-stage power-of-two exponent chosen so that the tile's largest magnitude lands in [2^13, 2^14)
+// (exact scaling, no overflow, full use of the fp16 range).  Weights are re-packed per step into hi/lo form in MFMA
+// fragment order with one exponent per matrix (upnerf_frag16).
 //
-// A tile of 64 samples lives in LDS as TWO fp16 planes (hi, lo) with  value = (hi + lo) * 2^-e,  e a per-tile,
-// per-tensor power-of-two exponent chosen so that the tile's largest magnitude lands in [2^13, 2^14).  Weights are
-// re-packed per step into the same hi/lo form in MFMA fragment order with one exponent per matrix.  Each 32x32x16
-// block is three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi; fp16 products are exact in fp32, accumulation is
-// fp32), i.e. 96 matrix cycles instead of the 512 of eight v_mfma_f32_32x32x2_f32.  The split residue (lo*lo and the
-// bits below hi+lo) is 2^-22 relative -- the same order as the fp32 rounding of the accumulation itself.
+// TRANSPOSED accumulators.  The contraction is issued as  D^T[n][m] = sum_k W[n][k] X[m][k]:  the weight fragment is the
+// MFMA's A operand, the activation fragment its B operand (both lane maps are the same: lane l holds row / column l&31,
+// k = 8*(l>>5) .. +8, so the operand loads are unchanged).  A lane then holds, for ITS sample row m = row0 + 32*mt +
+// (l&31), four CONSECUTIVE output features per register quad:  n = n0 + 32*nt + 8*(r>>2) + 4*(l>>5) + (r&3).
+// That turns the epilogue from 64 scalar 2-byte LDS writes + 64 scalar conversions per lane and layer into packed work:
+// v_cvt_pk_f16_f32 on register pairs, one v_fma_mix_f32 per residual, ds_write_b64 per quad and plane, 16-byte global
+// stores, per-row scalars (one LDS read per lane instead of one per register).
 #pragma once
 #include "common.cuh"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define WEXP_SLOTS 16  // exponent table: trunk layers 0..7, 8 = final, 9 = cand1, 10 = cand2, 11 = rgb1, 12 = head^T
 
@@ -29,17 +41,37 @@ __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
   lo = (_Float16)(x - (float)hi);
 }
 
+// x - (float)h for the fp16 value in half HALF of a packed pair, in ONE vector instruction (v_fma_mix_f32 reads the fp16
+// operand straight from its half register: h * -1.0 + x; exact, h is x rounded to 11 bits)
+template <int HALF>
+__device__ __forceinline__ float resid16(unsigned int hpair, float x) {
+  float r;
+  if constexpr (HALF == 0)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+  else
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+  return r;
+}
+
+// four fp32 values (already scaled) -> packed fp16 quads hi (and lo = the rounded residuals when NP == 2)
+template <int NP>
+__device__ __forceinline__ void split_quad(float x0, float x1, float x2, float x3, h4& hi, h4& lo) {
+  const h2 a = __builtin_convertvector(f32x2{x0, x1}, h2), b = __builtin_convertvector(f32x2{x2, x3}, h2);  // v_cvt_pk_f16_f32
+  hi = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+  if constexpr (NP == 2) {
+    const unsigned int ua = __builtin_bit_cast(unsigned int, a), ub = __builtin_bit_cast(unsigned int, b);
+    const h2 c = __builtin_convertvector(f32x2{resid16<0>(ua, x0), resid16<1>(ua, x1)}, h2);
+    const h2 d = __builtin_convertvector(f32x2{resid16<0>(ub, x2), resid16<1>(ub, x3)}, h2);
+    lo = __builtin_shufflevector(c, d, 0, 1, 2, 3);
+  }
+}
+
 // byte offset of element (row, k) in a [64][W] fp16 plane; 16-byte chunks XOR-swizzled by the row so that the 16 rows
 // one ds_read_b128 lane group touches fall into 16 different bank quads (512-byte rows: bank = 4 * (chunk % 16)).
 template <int W>
 __device__ __forceinline__ int poff(int row, int k) {
-  static_assert(W == 256, "f16x3 field kernels are built for W = 256");
+  static_assert(W == 256, "f16 field kernels are built for W = 256");
   return row * (W * 2) + ((((k >> 3) ^ (row & 15))) << 4) + ((k & 7) << 1);
-}
-
-// max over the 4 waves of a workgroup of per-wave maxima parked in LDS
-__device__ __forceinline__ float wg_max4(const float* smax) {
-  return fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
 }
 
 template <int MT, int NT>
@@ -50,31 +82,43 @@ __device__ __forceinline__ float acc_absmax(const f32x16 (&acc)[MT][NT]) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[mt][nt][r]));
+      for (int r = 0; r < 16; r += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(fabsf(acc[mt][nt][r]), fabsf(acc[mt][nt][r + 1])));
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
   return m;
 }
 
-template <int MT, int NT>
-__device__ __forceinline__ void mma16_step(f32x16 (&acc)[MT][NT], const h8 (&ah)[MT], const h8 (&al)[MT],
-                                           const h8 (&bh)[NT], const h8 (&bl)[NT]) {
+// acc[nt x mt] += W-fragment (A operand) . X-fragment (B operand): transposed product, see the header
+template <int NP, int MT, int NT>
+__device__ __forceinline__ void mma16_step(f32x16 (&acc)[MT][NT], const h8 (&xh)[MT], const h8 (&xl)[MT],
+                                           const h8 (&wh)[NT], const h8 (&wl)[NT]) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+      if constexpr (NP == 2) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[nt], xl[mt], acc[mt][nt], 0, 0, 0);
+      }
     }
 }
 
-// acc[64 rows][n0 .. n0+32*NT) += planes[:, kA0 .. kA0+K) . Wf[n][kB0 .. kB0+K)^T      (scaled integers-in-fp16)
+// acc (transposed) += planes[:, kA0 .. kA0+16*T) . Wf[n][kB0 .. kB0+16*T)^T      (scaled integers-in-fp16)
 //   Ph, Pl: LDS planes;  Wf: fragment-ordered hi/lo matrix with Kp16 = Kp/16 k-blocks per 32-column tile:
-//   byte ((ntile * Kp16 + t) * 2 + plane) * 1024 + lane * 16.   K % 32 == 0 (two k-blocks per pipeline trip).
-template <int W, int MT, int NT>
+//   byte ((ntile * Kp16 + t) * 2 + plane) * 1024 + lane * 16.   T = number of 16-deep k-blocks (compile time).
+// The loop is LATENCY-bound on the weight stream if only one k-block is in flight: a fragment comes from L2 (~650 cycles,
+// measured as the K-loop time per k-block in the f16 mode), while the MFMAs of one k-block take 384 (f16x3) or 128 (f16)
+// matrix cycles.  So the weight fragments travel through a RING of AHEAD+1 register sets: block t+AHEAD is requested
+// before the MFMAs of block t issue (AHEAD x MFMA time >= L2 latency); the activation fragments (LDS, ~100 cycles) stay
+// one block ahead.  One ring revolution is unrolled, so every ring index is a compile-time register name; sched_barrier
+// fences keep the requests ABOVE the matrix work (hipcc otherwise sinks them to their first use).
+template <int NP, int W, int T, int AHEAD, int MT, int NT>
 __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph, const char* Pl, int row0, int kA0,
-                                          const char* __restrict__ Wf, int Kp16, int n0, int kB0, int K, int lane) {
+                                          const char* __restrict__ Wf, int Kp16, int n0, int kB0, int lane) {
+  constexpr int SETS = (AHEAD + 1 > T) ? T : AHEAD + 1;  // ring size; the ring runs SETS - 1 blocks ahead
+  constexpr int AH = SETS - 1;
+  static_assert(SETS % 2 == 0 && T % SETS == 0, "ring size: even, dividing the number of k-blocks");
   const int i = lane & 31, hh = lane >> 5;
   const char* bp[NT];
   int arow[MT];
@@ -82,93 +126,213 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
   for (int nt = 0; nt < NT; ++nt) bp[nt] = Wf + ((size_t)((n0 >> 5) + nt) * Kp16 + (kB0 >> 4)) * 2048 + lane * 16;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) arow[mt] = row0 + 32 * mt + i;
-  const int T = K >> 4;
-  h8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
-  auto fetch = [&](h8 (&ah)[MT], h8 (&al)[MT], h8 (&bh)[NT], h8 (&bl)[NT], int t) {
+  h8 wh[SETS][NT], wl[SETS][NT], xh[2][MT], xl[2][MT];
+  auto loadw = [&](h8 (&h)[NT], h8 (&l)[NT], int t) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-#ifdef UPNERF_EXP_SAMEB  // timing experiment only (wrong results): every k-block re-reads block 0 -> L1 hits
-      bh[nt] = *(const h8*)(bp[nt] + (size_t)(t & 0) * 2048);
-      bl[nt] = *(const h8*)(bp[nt] + (size_t)(t & 0) * 2048 + 1024);
-#else
-      bh[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048);
-      bl[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048 + 1024);
-#endif
+      h[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048);
+      if constexpr (NP == 2) l[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048 + 1024);
     }
+  };
+  auto loadx = [&](h8 (&h)[MT], h8 (&l)[MT], int t) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int o = poff<W>(arow[mt], kA0 + 16 * t + 8 * hh);
-      ah[mt] = *(const h8*)(Ph + o);
-      al[mt] = *(const h8*)(Pl + o);
+      h[mt] = *(const h8*)(Ph + o);
+      if constexpr (NP == 2) l[mt] = *(const h8*)(Pl + o);
     }
   };
-  fetch(ah0, al0, bh0, bl0, 0);
+#pragma unroll
+  for (int t = 0; t < AH; ++t) loadw(wh[t], wl[t], t);
+  loadx(xh[0], xl[0], 0);
+  // all groups but the last: every request is in range (rolled: the unrolled form lets hipcc hoist all LDS addresses and spill)
 #pragma unroll 1
-  for (int t = 0; t < T; t += 2) {
-    fetch(ah1, al1, bh1, bl1, t + 1);
+  for (int t0 = 0; t0 < T - SETS; t0 += SETS) {
+#pragma unroll
+    for (int u = 0; u < SETS; ++u) {
+      loadw(wh[(u + AH) % SETS], wl[(u + AH) % SETS], t0 + u + AH);
+      loadx(xh[(u + 1) & 1], xl[(u + 1) & 1], t0 + u + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma16_step<NP>(acc, xh[u & 1], xl[u & 1], wh[u], wl[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // last group: requests past the end are dropped at compile time
+#pragma unroll
+  for (int u = 0; u < SETS; ++u) {
+    if (u + AH < SETS) loadw(wh[(u + AH) % SETS], wl[(u + AH) % SETS], T - SETS + u + AH);
+    if (u + 1 < SETS) loadx(xh[(u + 1) & 1], xl[(u + 1) & 1], T - SETS + u + 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma16_step(acc, ah0, al0, bh0, bl0);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(ah0, al0, bh0, bl0, (t + 2 < T) ? t + 2 : t);
-    __builtin_amdgcn_sched_barrier(0);
-    mma16_step(acc, ah1, al1, bh1, bl1);
+    mma16_step<NP>(acc, xh[u & 1], xl[u & 1], wh[u], wl[u]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// Same with the A operand converted on the fly from fp32 rows in global memory (short side inputs: encoding for the
-// skip connection, per-ray embedding rows): arow_ptr[mt] points at this lane's row at column 8*(lane>>5); `sc` = 2^e
-// is the scale of the LDS planes the same accumulators are fed from.  K % 16 == 0.
-template <int MT, int NT>
-__device__ __forceinline__ void mma16_glb(f32x16 (&acc)[MT][NT], const float* const (&arow_ptr)[MT], float sc,
+// Same with the activation operand converted on the fly from fp32 rows in global memory (short side inputs: encoding for
+// the skip connection, per-ray embedding rows): xrow_ptr[mt] points at this lane's row at column 8*(lane>>5); `e` is the
+// exponent of the LDS planes the same accumulators are fed from.  K % 16 == 0.
+template <int NP, int MT, int NT>
+__device__ __forceinline__ void mma16_glb(f32x16 (&acc)[MT][NT], const float* const (&xrow_ptr)[MT], int e,
                                           const char* __restrict__ Wf, int Kp16, int n0, int kB0, int K, int lane) {
   const int T = K >> 4;
 #pragma unroll 1
   for (int t = 0; t < T; ++t) {
-    h8 ah[MT], al[MT], bh[NT], bl[NT];
+    h8 xh[MT], xl[MT], wh[NT], wl[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const char* p = Wf + ((size_t)((n0 >> 5) + nt) * Kp16 + (kB0 >> 4) + t) * 2048 + lane * 16;
-      bh[nt] = *(const h8*)p;
-      bl[nt] = *(const h8*)(p + 1024);
+      wh[nt] = *(const h8*)p;
+      if constexpr (NP == 2) wl[nt] = *(const h8*)(p + 1024);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const f32x4 x0 = *(const f32x4*)(arow_ptr[mt] + 16 * t), x1 = *(const f32x4*)(arow_ptr[mt] + 16 * t + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        _Float16 h, l;
-        split16(x0[j] * sc, h, l); ah[mt][j] = h; al[mt][j] = l;
-        split16(x1[j] * sc, h, l); ah[mt][4 + j] = h; al[mt][4 + j] = l;
-      }
+      const f32x4 x0 = *(const f32x4*)(xrow_ptr[mt] + 16 * t), x1 = *(const f32x4*)(xrow_ptr[mt] + 16 * t + 4);
+      h4 a, b, c, d;
+      split_quad<NP>(ldexpf(x0[0], e), ldexpf(x0[1], e), ldexpf(x0[2], e), ldexpf(x0[3], e), a, c);
+      split_quad<NP>(ldexpf(x1[0], e), ldexpf(x1[1], e), ldexpf(x1[2], e), ldexpf(x1[3], e), b, d);
+      xh[mt] = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+      if constexpr (NP == 2) xl[mt] = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
     }
-    mma16_step(acc, ah, al, bh, bl);
+    mma16_step<NP>(acc, xh, xl, wh, wl);
   }
 }
 
-// Write accumulator values (already in natural units) into the hi/lo planes at column offset c0 with scale 2^e.
-template <int W, int MT, int NT>
+// ---- transposed-accumulator epilogue pieces ---------------------------------------------------------------------------
+// this lane's sample row of m-tile mt:  row0 + 32*mt + (lane&31);  its columns of quad (nt, q): see acc_col
+__device__ __forceinline__ int acc_col(int n0, int nt, int q, int hh) { return n0 + 32 * nt + 8 * q + 4 * hh; }
+
+// per-column vector (bias, head weight, per-ray gradient row) in this lane's quads: v[nt][q] = src[acc_col .. +4)
+template <int NT>
+__device__ __forceinline__ void load_cols(f32x4 (&v)[NT][4], const float* __restrict__ src, int n0, int hh) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[nt][q] = *(const f32x4*)&src[acc_col(n0, nt, q, hh)];
+}
+
+// Write accumulator values (natural units) into the planes at column offset c0 with scale 2^e: one ds_write_b64 per quad
+// and plane.
+template <int NP, int W, int MT, int NT>
 __device__ __forceinline__ void acc_to_planes(const f32x16 (&acc)[MT][NT], char* Ph, char* Pl, int row0, int n0, int c0,
-                                              float sc, int lane) {
+                                              int e, int lane) {
   const int i = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = row0 + 32 * mt + i;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h4 hi, lo;
+        split_quad<NP>(ldexpf(acc[mt][nt][4 * q], e), ldexpf(acc[mt][nt][4 * q + 1], e), ldexpf(acc[mt][nt][4 * q + 2], e),
+                       ldexpf(acc[mt][nt][4 * q + 3], e), hi, lo);
+        const int o = poff<W>(row, c0 + acc_col(n0, nt, q, hh));
+        *(h4*)(Ph + o) = hi;
+        if constexpr (NP == 2) *(h4*)(Pl + o) = lo;
+      }
+  }
+}
+
+// Accumulators (natural units) -> row-major fp32 global tile, straight from the registers: 16 bytes per lane and quad (the
+// two lane halves of a row make 32 contiguous bytes; the four quads of an n-tile complete the row's 128-byte line).
+template <int MT, int NT>
+__device__ __forceinline__ void acc_store_global(const f32x16 (&acc)[MT][NT], float* __restrict__ dst, int ldg, int m0,
+                                                 int M, int row0, int n0, int lane) {
+  const int i = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + row0 + 32 * mt + i;
+    if (m < M) {
+      float* __restrict__ p = dst + (size_t)m * ldg;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)&p[acc_col(n0, nt, q, hh)] =
+              f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+    }
+  }
+}
+
+// v = fma(acc, un, bias[col]) (optionally ReLU) ; bias in this lane's quads
+template <bool RELU, int MT, int NT>
+__device__ __forceinline__ void acc_fma_bias(f32x16 (&acc)[MT][NT], float un, const f32x4 (&bias)[NT][4]) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int o = poff<W>(row, c0 + n0 + 32 * nt + i);
-        _Float16 h, l;
-        split16(acc[mt][nt][r] * sc, h, l);
-        *(_Float16*)(Ph + o) = h;
-        *(_Float16*)(Pl + o) = l;
+        const float v = fmaf(acc[mt][nt][r], un, bias[nt][r >> 2][r & 3]);
+        acc[mt][nt][r] = RELU ? fmaxf(v, 0.0f) : v;
       }
+}
+
+// v = relu(fma(acc, un, bias)) with the sign bits packed per lane: bit e = (mt*NT + nt)*16 + r of the 64-bit word says
+// whether this lane's accumulator element e is positive (2 KiB per 64-row tile and layer instead of re-reading the 64 KiB
+// activation tile in the backward pass, which uses the same wave tiling for the gradient of that activation).
+template <int MT, int NT>
+__device__ __forceinline__ unsigned long long acc_fma_relu_pack(f32x16 (&acc)[MT][NT], float un,
+                                                                const f32x4 (&bias)[NT][4]) {
+  static_assert(MT * NT * 16 <= 64, "mask word is 64 bits");
+  unsigned int lo = 0u, hi = 0u;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int e = (mt * NT + nt) * 16 + r;
+        const float v = fmaxf(fmaf(acc[mt][nt][r], un, bias[nt][r >> 2][r & 3]), 0.0f);
+        acc[mt][nt][r] = v;
+        if (e < 32) lo |= (v > 0.0f) ? (1u << e) : 0u;
+        else hi |= (v > 0.0f) ? (1u << (e - 32)) : 0u;
+      }
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void acc_scale(f32x16 (&acc)[MT][NT], float un) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= un;
+}
+
+// fp32 accumulators -> swizzled fp32 LDS scratch [rows][ldw] (16-byte granules, common.cuh:swz4)
+template <int MT, int NT>
+__device__ __forceinline__ void acc_to_lds_t(const f32x16 (&acc)[MT][NT], float* Hs, int ldw, int row0, int n0, int lane) {
+  const int i = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)&Hs[swz4(row0 + 32 * mt + i, acc_col(n0, nt, q, hh), ldw)] =
+            f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+}
+
+// hi (+ lo) of 8 consecutive plane elements as fp32
+template <int NP, int W>
+__device__ __forceinline__ void plane_row8(const char* Ph, const char* Pl, int row, int col, float (&out)[8]) {
+  const int o = poff<W>(row, col);
+  const h8 vh = *(const h8*)(Ph + o);
+  if constexpr (NP == 2) {
+    const h8 vl = *(const h8*)(Pl + o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = (float)vh[j] + (float)vl[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = (float)vh[j];
+  }
 }
 
 // dot of plane row segment [c0, c0+K) with w[0..K), split over the TPR adjacent threads that share a row; K is a
 // compile-time constant and the weight loads are issued before anything consumes them.
-template <int W, int TPR, int K>
+template <int NP, int W, int TPR, int K>
 __device__ __forceinline__ float rowdot16(const char* Ph, const char* Pl, int row, int part, int c0,
                                           const float* __restrict__ w, float unscale) {
   constexpr int N8 = K / TPR / 8;
@@ -182,12 +346,12 @@ __device__ __forceinline__ float rowdot16(const char* Ph, const char* Pl, int ro
   float s = 0.0f;
 #pragma unroll
   for (int q = 0; q < N8; ++q) {
-    const int o = poff<W>(row, c0 + kb + 8 * q);
-    const h8 vh = *(const h8*)(Ph + o), vl = *(const h8*)(Pl + o);
+    float v[8];
+    plane_row8<NP, W>(Ph, Pl, row, c0 + kb + 8 * q, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      s += ((float)vh[j] + (float)vl[j]) * w0[q][j];
-      s += ((float)vh[4 + j] + (float)vl[4 + j]) * w1[q][j];
+      s += v[j] * w0[q][j];
+      s += v[4 + j] * w1[q][j];
     }
   }
 #pragma unroll

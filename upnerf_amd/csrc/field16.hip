@@ -1,29 +1,40 @@
-// Fused NeRF field on the f16 matrix cores with the 3-term hi/lo split (csrc/common16.cuh): same stages, same
-// outputs and the same wave tiling as csrc/field.hip, fp32-level accuracy, ~5x less matrix-pipe time per contraction.
+// Fused NeRF field on the f16 matrix cores (csrc/common16.cuh): PE -> 8x256 trunk (skip) -> density / final / candidate /
+// colour heads in one kernel per pass, forward and backward data-gradient chain, in two arithmetic modes selected by
+// `planes` in the argument structs:
+//   f16x3 (NP = 2, default)  fp32-accurate 3-term hi/lo split, fp32 in / fp32 out: the headline configuration;
+//   f16   (NP = 1)           fp16 weights and activations, one MFMA per product, fp32 accumulate, fp32 encoding / heads /
+//                            stores (BASELINE.json configs[3]).
 //
 // Reference behaviour: models/nerf.py:80-124 (NeRF.forward), 126-147 (positional_encoding), evaluated by
-// models/rendering.py:102-122.  What differs from field.hip:
-//   * the 64-sample tile lives in LDS as two fp16 planes (hi, lo) carrying  value * 2^e  with one exponent per tile
-//     and stage, picked from the tile's running maximum (wave max -> 4 floats in LDS -> the barrier every epilogue
-//     already has);
-//   * weights arrive pre-split (upnerf_frag16) with one exponent per matrix (table wexp); the epilogue folds both
-//     exponents into the fma that adds the bias:  v = fma(acc, 2^-(e_tile + e_w), bias);
-//   * every tensor kept for the backward pass is written from the planes (hi + lo is the fp32 value to ~2^-24), i.e.
-//     the weight-gradient kernels see exactly the operand the forward contraction used.
+// models/rendering.py:102-122.  Layout of the work:
+//   * a workgroup owns 64 samples; their activations live in LDS as fp16 planes carrying  value * 2^e  with one exponent
+//     per tile and stage, picked from the tile's running maximum (wave max -> 4 floats in LDS -> the barrier every
+//     epilogue already has);
+//   * weights arrive pre-split (upnerf_frag16) with one exponent per matrix (table wexp) and stream L2 -> registers in MFMA
+//     fragment order; the epilogue folds both exponents into the fma that adds the bias: v = fma(acc, 2^-(e_tile+e_w), b);
+//   * the contraction is issued TRANSPOSED (weights as the A operand): a lane owns one sample row and four consecutive
+//     features per register quad, so the epilogue works on packed pairs / quads (common16.cuh header);
+//   * trunk / final activations and all pre-activation gradients are stored straight from the accumulators (16 bytes per
+//     lane and quad), the 128-wide head activations from the planes.
 #include "common16.cuh"
 
 #define F16_TILE 64
-// Waves per workgroup: 4 (one 64 x 64 output block per wave; what ships) or 8 (64 x 32 blocks: half the accumulators and
-// half the epilogue per wave, four waves per SIMD instead of two -- measured 14-20 % SLOWER: twice the LDS operand
-// traffic, twice the weight bytes per MFMA and ~30 spilled registers under the 128-VGPR cap; needs 512 mask words
-// per tile and layer from the caller).
-#ifndef F16_WAVES
 #define F16_WAVES 4
-#endif
 #define F16_THREADS (64 * F16_WAVES)
-// two workgroups per CU = 2 or 4 waves per SIMD (the latter caps a wave at 128 VGPRs); hipcc takes the second
-// __launch_bounds__ argument as the minimum number of waves per SIMD
-#define F16_WAVES_PER_EU (F16_WAVES / 2)
+// two workgroups per CU = 2 waves per SIMD; hipcc takes the second __launch_bounds__ argument as the minimum number of
+// waves per SIMD
+#define F16_WAVES_PER_EU 2
+// Weight fragments are requested this many 16-deep k-blocks ahead of the MFMAs that consume them.  Measured with the stamps
+// build (per wave and trunk layer): f16 mode 10.4k cycles per K loop one block ahead = 650 cycles per k-block = the L2
+// latency, 8.1k three ahead and 8.3k seven ahead -- from there on the loop is bound by the bytes the CU can pull from L2
+// (~32 B/clk: 128 KB of fp16 weights per 64-row tile and layer).  The f16x3 mode moves twice the bytes (16.5k cycles per K
+// loop at every depth: bandwidth-bound already one block ahead), deeper rings only add register pressure there.
+#ifndef F16_AHEAD_X3
+#define F16_AHEAD_X3 1
+#endif
+#ifndef F16_AHEAD_F16
+#define F16_AHEAD_F16 3
+#endif
 
 // Diagnostic build only (make -C upnerf_amd/csrc stamps, -DUPNERF_STAMPS): per-phase shader-clock stamps of the forward
 // trunk loop, accumulated in registers and flushed once per workgroup (tools/stamps_field16.py).  Never compiled into
@@ -54,12 +65,12 @@ __device__ unsigned long long upnerf_stamp_acc[16];  // [0..7] forward trunk pha
 
 namespace {
 
-// How the F16_WAVES waves of a workgroup share a [TILE x N] output tile (32 x 32 MFMA tiles); same rules as WaveTile in
+// How the 4 waves of a workgroup share a [TILE x N] output tile (32 x 32 MFMA tiles); same rules as WaveTile in
 // common.cuh: surplus waves of a narrow layer recompute a piece another wave owns.
 template <int N, int TILE>
 struct WaveTile16 {
   static constexpr int NW = F16_WAVES;
-  static constexpr int NT = (N >= 256 && NW == 4) ? 2 : 1;
+  static constexpr int NT = (N >= 256) ? 2 : 1;
   static constexpr int NG = N / 32 / NT;
   static constexpr int MG = TILE / 32;
   static constexpr int WN = NG >= NW ? NW : NG;
@@ -78,25 +89,11 @@ __device__ __forceinline__ float wg_max(const float* smax) {
 
 __device__ __forceinline__ float pow2f(int n) { return ldexpf(1.0f, n); }
 
-// hi + lo of one fp16 pair of planes as fp32, in ONE vector instruction: v_fma_mix_f32 reads both fp16 operands straight
-// from the halves of their registers (hi * 1.0 + lo; the sum of a hi/lo pair is exact in fp32).  HALF selects the half.
-template <int HALF>
-__device__ __forceinline__ float mix_sum(unsigned int wh, unsigned int wl) {
-  float r;
-  if constexpr (HALF == 0)
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(wh), "v"(wl));
-  else
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(wh), "v"(wl));
-  return r;
-}
-
 // LDS planes -> row-major fp32 global tensor, coalesced (8 columns = 32 bytes per thread, whole rows per wave).  The
-// LDS reads of BATCH row groups are issued before the first conversion, so their latency is paid once per batch
-// (BATCH = 0: the whole tile at once, 64 registers for a 256-wide tile -- used where the accumulators are dead).
-template <int W, int TILE, int NCOLS, int BATCH = 1>
+// LDS reads of BATCH row groups are issued before the first conversion, so their latency is paid once per batch.
+template <int NP, int W, int TILE, int NCOLS, int BATCH = 1>
 __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, float unscale,
                                              float* __restrict__ dst, int ldg, int m0, int M, int tid) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   constexpr int GPR = NCOLS >> 3, ITER = TILE * GPR / F16_THREADS;
   static_assert(TILE * GPR % F16_THREADS == 0, "whole passes of the workgroup");
   constexpr int B = (BATCH == 0 || BATCH > ITER) ? ITER : BATCH;
@@ -104,102 +101,35 @@ __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int
   const bool whole = m0 + TILE <= M;
 #pragma unroll 1
   for (int it0 = 0; it0 < ITER; it0 += B) {
-    u32x4 wh[B], wl[B];
+    h8 wh[B], wl[B];
 #pragma unroll
     for (int j = 0; j < B; ++j) {
       const int idx = tid + (it0 + j) * F16_THREADS, row = idx / GPR, g = idx % GPR;
       const int o = poff<W>(row, c0 + 8 * g);
-      wh[j] = *(const u32x4*)(Ph + o);
-      wl[j] = *(const u32x4*)(Pl + o);
+      wh[j] = *(const h8*)(Ph + o);
+      if constexpr (NP == 2) wl[j] = *(const h8*)(Pl + o);
     }
 #pragma unroll
     for (int j = 0; j < B; ++j) {
       const int idx = tid + (it0 + j) * F16_THREADS, row = idx / GPR, g = idx % GPR;
       f32x4 o0, o1;
-      o0[0] = mix_sum<0>(wh[j][0], wl[j][0]) * unscale;
-      o0[1] = mix_sum<1>(wh[j][0], wl[j][0]) * unscale;
-      o0[2] = mix_sum<0>(wh[j][1], wl[j][1]) * unscale;
-      o0[3] = mix_sum<1>(wh[j][1], wl[j][1]) * unscale;
-      o1[0] = mix_sum<0>(wh[j][2], wl[j][2]) * unscale;
-      o1[1] = mix_sum<1>(wh[j][2], wl[j][2]) * unscale;
-      o1[2] = mix_sum<0>(wh[j][3], wl[j][3]) * unscale;
-      o1[3] = mix_sum<1>(wh[j][3], wl[j][3]) * unscale;
-#ifdef UPNERF_EXP_NOSTORE  // timing experiment only: everything but the global stores (kept alive by an impossible branch)
-      if (o0[0] + o0[1] + o0[2] + o0[3] + o1[0] + o1[1] + o1[2] + o1[3] == 123.456f) {
-#else
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if constexpr (NP == 2) {
+          o0[c] = ((float)wh[j][c] + (float)wl[j][c]) * unscale;
+          o1[c] = ((float)wh[j][4 + c] + (float)wl[j][4 + c]) * unscale;
+        } else {
+          o0[c] = (float)wh[j][c] * unscale;
+          o1[c] = (float)wh[j][4 + c] * unscale;
+        }
+      }
       if (whole || m0 + row < M) {
-#endif
         float* p = &dst[(size_t)(m0 + row) * ldg + 8 * g];
         *(f32x4*)p = o0;
         *(f32x4*)(p + 4) = o1;
       }
     }
   }
-}
-
-// Accumulators (natural units) -> row-major fp32 global tile, straight from the registers: for one register index the 64
-// lanes cover 32 consecutive columns of two rows, i.e. two full 128-byte lines per store instruction; no LDS round
-// trip.  (The planes keep (hi + lo) 2^-e of the same values: they differ from what is stored here by the 2^-22 split
-// residue only.)
-template <int MT, int NT>
-__device__ __forceinline__ void acc_store_global(const f32x16 (&acc)[MT][NT], float* __restrict__ dst, int ldg, int m0,
-                                                 int M, int row0, int n0, int lane) {
-  const int i = lane & 31, hh = lane >> 5;
-  float* __restrict__ base = dst + (size_t)m0 * ldg + (size_t)(row0 + 4 * hh) * ldg + n0 + i;
-  if (m0 + F16_TILE <= M) {  // whole tile (all but the last workgroup): no per-row predicate
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          base[(size_t)(32 * mt + (r & 3) + 8 * (r >> 2)) * ldg + 32 * nt] = acc[mt][nt][r];
-    return;
-  }
-  const int rows_left = M - m0 - row0 - 4 * hh;  // rows of this lane's group that exist
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dr = 32 * mt + (r & 3) + 8 * (r >> 2);
-        if (dr < rows_left) base[(size_t)dr * ldg + 32 * nt] = acc[mt][nt][r];
-      }
-}
-
-// v = relu(fma(acc, un, bias)) with the sign bits packed in the accumulator layout (common.cuh); bias[nt] = this lane's
-// column of tile nt, loaded by the caller BEFORE the contraction (an L2 round trip otherwise sits in front of the epilogue)
-template <int MT, int NT>
-__device__ __forceinline__ unsigned long long acc_fma_relu_pack(f32x16 (&acc)[MT][NT], float un,
-                                                                const float (&bias)[NT]) {
-  static_assert(MT * NT * 16 <= 64, "mask word is 64 bits");
-  unsigned int lo = 0u, hi = 0u;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float b = bias[nt];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int e = (mt * NT + nt) * 16 + r;
-        const float v = fmaxf(fmaf(acc[mt][nt][r], un, b), 0.0f);
-        acc[mt][nt][r] = v;
-        if (e < 32) lo |= (v > 0.0f) ? (1u << e) : 0u;
-        else hi |= (v > 0.0f) ? (1u << (e - 32)) : 0u;
-      }
-    }
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void acc_scale(f32x16 (&acc)[MT][NT], float un) {
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= un;
 }
 
 __device__ __forceinline__ float wave_max(float m) {
@@ -212,16 +142,27 @@ __device__ __forceinline__ void track(float* __restrict__ slot, float mx, int ti
   if (slot && tid == 0) atomicMax((unsigned int*)slot, __float_as_uint(mx));
 }
 
+// four fp32 values * 2^e -> one 8-byte write per plane at (row, col % 4 == 0)
+template <int NP, int W>
+__device__ __forceinline__ void put_quad(char* Ph, char* Pl, int row, int col, const f32x4& v, int e) {
+  h4 hi, lo;
+  split_quad<NP>(ldexpf(v[0], e), ldexpf(v[1], e), ldexpf(v[2], e), ldexpf(v[3], e), hi, lo);
+  const int o = poff<W>(row, col);
+  *(h4*)(Ph + o) = hi;
+  if constexpr (NP == 2) *(h4*)(Pl + o) = lo;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
-template <int TILE>
+template <int NP, int TILE>
 __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
   constexpr int W = 256, W2 = 128;
+  constexpr int AH = NP == 2 ? F16_AHEAD_X3 : F16_AHEAD_F16;  // weight k-blocks in flight (common16.cuh:mma16_lds)
   constexpr int TPR = F16_THREADS / TILE;
-  __shared__ __attribute__((aligned(16))) char planes[2 * TILE * W * 2];
+  __shared__ __attribute__((aligned(16))) char planes[NP * TILE * W * 2];
   __shared__ float smax[F16_WAVES], smaxb[F16_WAVES];
   __shared__ float xyz_s[TILE * 3];
   char* Ph = planes;
-  char* Pl = planes + TILE * W * 2;
+  char* Pl = planes + (NP - 1) * TILE * W * 2;  // NP == 1: never dereferenced
   using TW = WaveTile16<W, TILE>;
   using TH = WaveTile16<W2, TILE>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -279,7 +220,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
       split16(v * sc, h, l);
       const int o = poff<W>(row, col);
       *(_Float16*)(Ph + o) = h;
-      *(_Float16*)(Pl + o) = l;
+      if constexpr (NP == 2) *(_Float16*)(Pl + o) = l;
     };
     const float* __restrict__ wkd = a.wk_xyz_dev;  // per-step band weights from device memory under graph replay
     for (int it = tid; it < TILE * 3; it += F16_THREADS) {
@@ -299,7 +240,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     }
   }
   __syncthreads();
-  tile_store16<W, TILE, UPNERF_X0>(Ph, Pl, 0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
+  tile_store16<NP, W, TILE, UPNERF_X0>(Ph, Pl, 0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
 
   // ---- trunk (nerf.py:84-87)
   STAMP(7);  // sample positions + encoding + x0 store
@@ -307,12 +248,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     STAMP(0);
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
-    float bl[TW::NT];
-#pragma unroll
-    for (int nt = 0; nt < TW::NT; ++nt) bl[nt] = P[L.b[l] + n0 + 32 * nt + li];
-    const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);  // wave-uniform; asked for before the contraction
+    const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);
     if (l == 0) {
-      mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[0], UPNERF_X0 / 16, n0, 0, UPNERF_X0, lane);
+      mma16_lds<NP, W, UPNERF_X0 / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[0], UPNERF_X0 / 16, n0, 0, lane);
     } else if (l == L.skip) {
       const float* ap[TW::MT];
 #pragma unroll
@@ -321,12 +259,14 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
         m = m < M ? m : M - 1;
         ap[mt] = a.x0 + (size_t)m * UPNERF_X0 + 8 * hh;
       }
-      mma16_glb(acc, ap, pow2f(ecur), P16 + 4 * (size_t)L.w[l], (UPNERF_X0 + W) / 16, n0, 0, UPNERF_X0, lane);
-      mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[l], (UPNERF_X0 + W) / 16, n0, UPNERF_X0, W, lane);
+      mma16_glb<NP>(acc, ap, ecur, P16 + 4 * (size_t)L.w[l], (UPNERF_X0 + W) / 16, n0, 0, UPNERF_X0, lane);
+      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[l], (UPNERF_X0 + W) / 16, n0, UPNERF_X0, lane);
     } else {
-      mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[l], W / 16, n0, 0, W, lane);
+      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[l], W / 16, n0, 0, lane);
     }
     STAMP(1);
+    f32x4 bl[TW::NT][4];
+    load_cols(bl, P + L.b[l], n0, hh);
     const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wel)), bl);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
@@ -339,7 +279,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     track(a.amax ? a.amax + l : nullptr, mx, tid);
     if (l + 1 == L.skip) mx = fmaxf(mx, x0max);  // the skip layer feeds x0 rows through the same accumulators
     ecur = scale_exp(mx);
-    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     STAMP(4);
     __syncthreads();
     STAMP(5);
@@ -354,7 +294,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
   const int prow = tid / TPR, phalf = tid % TPR, pm = m0 + prow;
   // ---- shared density head (nerf.py:89): softplus(w . h + b)
   {
-    const float pre = rowdot16<W, TPR, W>(Ph, Pl, prow, phalf, 0, P + L.wsig, pow2f(-ecur)) + P[L.bsig];
+    const float pre = rowdot16<NP, W, TPR, W>(Ph, Pl, prow, phalf, 0, P + L.wsig, pow2f(-ecur)) + P[L.bsig];
     if (phalf == 0 && pm < M) a.sigma_s[pm] = softplus_f(pre);
   }
   // density-only pass (nerf.py:90-91 `sigma_only`): nobody consumes e, so the pass ends here
@@ -366,10 +306,10 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
   {
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
-    mma16_lds<W>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, W, lane);
-    const float* __restrict__ bias = P + L.be;
-    const float un = pow2f(-(ecur + wexp[8]));
-    acc_map(acc, row0, n0, lane, [&](float v, int, int col) { return fmaf(v, un, bias[col]); });
+    f32x4 be[TW::NT][4];
+    load_cols(be, P + L.be, n0, hh);
+    mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, lane);
+    acc_fma_bias<false>(acc, pow2f(-(ecur + wexp[8])), be);
     if (a.e) acc_store_global(acc, a.e, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
@@ -377,7 +317,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     const float mx = wg_max(smax);
     track(a.amax ? a.amax + D : nullptr, mx, tid);
     ecur = scale_exp(fmaxf(mx, sidemax));  // the heads feed per-ray rows through the same accumulators
-    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
   }
   STAMP(5);  // density head + xyz_encoding_final
@@ -398,26 +338,25 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
   float mr = 0.0f, mc = 0.0f;
   if (a.use_rgb) {
     acc_zero(accr);
-    mma16_lds<W>(accr, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, 0, W, lane);
+    f32x4 br[TH::NT][4];
+    load_cols(br, P + L.br1, hn0, hh);
+    mma16_lds<NP, W, W / 16, AH>(accr, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, 0, lane);
     const float* ap[TH::MT];
 #pragma unroll
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.aux + (size_t)rayrow[mt] * UPNERF_AUXK + 8 * hh;
-    mma16_glb(accr, ap, pow2f(ecur), P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, W, UPNERF_AUXK, lane);
-    const float* __restrict__ bias = P + L.br1;
-    const float un = pow2f(-(ecur + wexp[11]));
-    acc_map(accr, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(fmaf(v, un, bias[col]), 0.0f); });
+    mma16_glb<NP>(accr, ap, ecur, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, W, UPNERF_AUXK, lane);
+    acc_fma_bias<true>(accr, pow2f(-(ecur + wexp[11])), br);
     mr = acc_absmax(accr);
   }
   if (a.use_cand) {
     acc_zero(accc);
-    mma16_lds<W>(accc, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, 0, W, lane);
+    f32x4 bc[TH::NT][4];
+    load_cols(bc, P + L.bc1, hn0, hh);
+    mma16_lds<NP, W, W / 16, AH>(accc, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, 0, lane);
     const float* ap[TH::MT];
 #pragma unroll
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.c_rows + (size_t)rayrow[mt] * UPNERF_CK + 8 * hh;
-    mma16_glb(accc, ap, pow2f(ecur), P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, UPNERF_CK, lane);
-    float bc[TH::NT];
-#pragma unroll
-    for (int nt = 0; nt < TH::NT; ++nt) bc[nt] = P[L.bc1 + hn0 + 32 * nt + li];
+    mma16_glb<NP>(accc, ap, ecur, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, UPNERF_CK, lane);
     const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), bc);
     if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * F16_THREADS + tid] = bits;
     mc = acc_absmax(accc);
@@ -433,34 +372,34 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     track(a.amax && a.use_cand ? a.amax + D + 1 : nullptr, mxc, tid);
     ecur = scale_exp(fmaxf(mxr, mxc));
   }
-  if (a.use_rgb) acc_to_planes<W>(accr, Ph, Pl, hrow0, hn0, 0, pow2f(ecur), lane);
-  if (a.use_cand) acc_to_planes<W>(accc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
+  if (a.use_rgb) acc_to_planes<NP, W>(accr, Ph, Pl, hrow0, hn0, 0, ecur, lane);
+  if (a.use_cand) acc_to_planes<NP, W>(accc, Ph, Pl, hrow0, hn0, W2, ecur, lane);
   __syncthreads();
   if (a.use_rgb) {
-    if (a.r1) tile_store16<W, TILE, W2>(Ph, Pl, 0, pow2f(-ecur), a.r1, W2, m0, M, tid);
+    if (a.r1) tile_store16<NP, W, TILE, W2>(Ph, Pl, 0, pow2f(-ecur), a.r1, W2, m0, M, tid);
     // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float pre = rowdot16<W, TPR, W2>(Ph, Pl, prow, phalf, 0, P + L.wr2 + c * W2, pow2f(-ecur)) + P[L.br2 + c];
+      const float pre = rowdot16<NP, W, TPR, W2>(Ph, Pl, prow, phalf, 0, P + L.wr2 + c * W2, pow2f(-ecur)) + P[L.br2 + c];
       if (phalf == 0 && pm < M) a.rgb[(size_t)pm * 3 + c] = sigmoid_f(pre);
     }
   }
   if (a.use_cand) {
-    if (a.g1) tile_store16<W, TILE, W2>(Ph, Pl, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
+    if (a.g1) tile_store16<NP, W, TILE, W2>(Ph, Pl, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
     f32x16 acc[TH::MT][TH::NT];
     acc_zero(acc);
-    mma16_lds<W>(acc, Ph, Pl, hrow0, W2, P16 + 4 * (size_t)L.wc2, W2 / 16, hn0, 0, W2, lane);
-    const float* __restrict__ bias = P + L.bc2;
-    const float un = pow2f(-(ecur + wexp[10]));
-    acc_map(acc, hrow0, hn0, lane, [&](float v, int, int col) { return fmaxf(fmaf(v, un, bias[col]), 0.0f); });
+    f32x4 b2[TH::NT][4];
+    load_cols(b2, P + L.bc2, hn0, hh);
+    mma16_lds<NP, W, W2 / 16, AH>(acc, Ph, Pl, hrow0, W2, P16 + 4 * (size_t)L.wc2, W2 / 16, hn0, 0, lane);
+    acc_fma_bias<true>(acc, pow2f(-(ecur + wexp[10])), b2);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
     ecur = scale_exp(wg_max(smax));
-    acc_to_planes<W>(acc, Ph, Pl, hrow0, hn0, W2, pow2f(ecur), lane);
+    acc_to_planes<NP, W>(acc, Ph, Pl, hrow0, hn0, W2, ecur, lane);
     __syncthreads();
-    if (a.g2) tile_store16<W, TILE, W2>(Ph, Pl, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
-    const float pre = rowdot16<W, TPR, W2>(Ph, Pl, prow, phalf, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
+    if (a.g2) tile_store16<NP, W, TILE, W2>(Ph, Pl, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
+    const float pre = rowdot16<NP, W, TPR, W2>(Ph, Pl, prow, phalf, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
     if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
   }
   STAMP(6);  // colour / candidate heads
@@ -469,13 +408,16 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
 
 // ------------------------------------------------------------------------------------------------------------------
 // Backward data-gradient chain (autograd of nerf.py:80-124), stage for stage as field.hip:field_bwd_kernel.
-template <int TILE>
+template <int NP, int TILE>
 __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
   constexpr int W = 256, W2 = 128;
+  constexpr int AH = NP == 2 ? F16_AHEAD_X3 : F16_AHEAD_F16;
   constexpr int MAXRAYS = 3;            // rays a 64-sample tile can touch when S >= 32
   constexpr int GPR = W2 / 4;           // 16-byte groups per half-width row
   constexpr int EPT = TILE * GPR / F16_THREADS;  // groups per thread in the elementwise stages
-  __shared__ __attribute__((aligned(16))) char planes[2 * TILE * W * 2];
+  constexpr int PLANE_BYTES = NP * TILE * W * 2;
+  constexpr int LDS_BYTES = PLANE_BYTES < TILE * UPNERF_X0 * 4 ? TILE * UPNERF_X0 * 4 : PLANE_BYTES;
+  __shared__ __attribute__((aligned(16))) char planes[LDS_BYTES];
   __shared__ float smax[F16_WAVES], smaxb[F16_WAVES];
   __shared__ float pre_s[TILE];
   __shared__ __attribute__((aligned(16))) float wfj[MAXRAYS][TILE];  // w_feat[row] on the row's ray slot, else 0
@@ -484,7 +426,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
   __shared__ float dpc_s[TILE], cwj_s[TILE];
   __shared__ __attribute__((aligned(16))) float dprgb_s[TILE][4];
   char* Ph = planes;
-  char* Pl = planes + TILE * W * 2;
+  char* Pl = planes + (NP - 1) * TILE * W * 2;
   using TW = WaveTile16<W, TILE>;
   using TH = WaveTile16<W2, TILE>;
   using TX = WaveTile16<UPNERF_X0, TILE>;
@@ -578,24 +520,10 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
       const float mx = wg_max(smax);
       track(a.gmax ? a.gmax + D + 2 : nullptr, mx, tid);
       const int eg2 = scale_exp(mx);
-      const float sc = pow2f(eg2);
 #pragma unroll
-      for (int q = 0; q < EPT; ++q) {
-        const int row = er0 + ERS * q, g = eg;
-        h4 vh, vl;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          _Float16 h, l;
-          split16(vals[q][c] * sc, h, l);
-          vh[c] = h;
-          vl[c] = l;
-        }
-        const int o = poff<W>(row, W2 + 4 * g);
-        *(h4*)(Ph + o) = vh;
-        *(h4*)(Pl + o) = vl;
-      }
+      for (int q = 0; q < EPT; ++q) put_quad<NP, W>(Ph, Pl, er0 + ERS * q, W2 + 4 * eg, vals[q], eg2);
       __syncthreads();
-      mma16_lds<W>(accg, Ph, Pl, hrow0, W2, PT16 + 4 * (size_t)L.t_wc2, W2 / 16, hn0, 0, W2, lane);
+      mma16_lds<NP, W, W2 / 16, AH>(accg, Ph, Pl, hrow0, W2, PT16 + 4 * (size_t)L.t_wc2, W2 / 16, hn0, 0, lane);
       acc_scale(accg, pow2f(-(eg2 + wexp[10])));
       acc_apply_mask(accg, hm[(size_t)D * hm_stride]);
       mg1 = acc_absmax(accg);
@@ -642,27 +570,13 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
       track(a.gmax && a.use_rgb ? a.gmax + D + 3 : nullptr, mxr, tid);
       erg = scale_exp(fmaxf(mxg, mxr));
     }
-    const float sc = pow2f(erg);
-    if (a.use_cand) acc_to_planes<W>(accg, Ph, Pl, hrow0, hn0, W2, sc, lane);
+    if (a.use_cand) acc_to_planes<NP, W>(accg, Ph, Pl, hrow0, hn0, W2, erg, lane);
     if (a.use_rgb) {
 #pragma unroll
-      for (int q = 0; q < EPT; ++q) {
-        const int row = er0 + ERS * q, g = eg;
-        h4 vh, vl;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          _Float16 h, l;
-          split16(valr[q][c] * sc, h, l);
-          vh[c] = h;
-          vl[c] = l;
-        }
-        const int o = poff<W>(row, 4 * g);
-        *(h4*)(Ph + o) = vh;
-        *(h4*)(Pl + o) = vl;
-      }
+      for (int q = 0; q < EPT; ++q) put_quad<NP, W>(Ph, Pl, er0 + ERS * q, 4 * eg, valr[q], erg);
     }
     __syncthreads();
-    if (a.use_cand) tile_store16<W, TILE, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
+    if (a.use_cand) tile_store16<NP, W, TILE, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
   }
 
   STAMP(0);  // head stages (elementwise d g2 / d r1, 128-wide contraction, plane writes)
@@ -673,7 +587,10 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     acc_zero(acc);
     const int ks = a.use_rgb ? 0 : W2;
     const int kl = (a.use_rgb ? W2 : 0) + (a.use_cand ? W2 : 0);
-    if (kl > 0) mma16_lds<W>(acc, Ph, Pl, row0, ks, PT16 + 4 * (size_t)L.t_head, W / 16, n0, ks, kl, lane);
+    if (kl == W)
+      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_head, W / 16, n0, 0, lane);
+    else if (kl == W2)
+      mma16_lds<NP, W, W2 / 16, AH>(acc, Ph, Pl, row0, ks, PT16 + 4 * (size_t)L.t_head, W / 16, n0, ks, lane);;
     acc_scale(acc, pow2f(-(erg + wexp[12])));
     if (a.g_E_s) {
       const int mlast = (m0 + TILE < M ? m0 + TILE : M) - 1;
@@ -681,19 +598,16 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
 #pragma unroll
       for (int j = 0; j < MAXRAYS; ++j) {
         if (j < nr) {
-          float gv[TW::NT];
+          f32x4 gv[TW::NT][4];
+          load_cols(gv, a.g_E_s + (size_t)(ray0 + j) * W, n0, hh);
 #pragma unroll
-          for (int nt = 0; nt < TW::NT; ++nt) gv[nt] = a.g_E_s[(size_t)(ray0 + j) * W + n0 + 32 * nt + li];
+          for (int mt = 0; mt < TW::MT; ++mt) {
+            const float wv = wfj[j][row0 + 32 * mt + li];  // zero unless this lane's row belongs to ray slot j
 #pragma unroll
-          for (int mt = 0; mt < TW::MT; ++mt)
+            for (int nt = 0; nt < TW::NT; ++nt)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-              const f32x4 wv = *(const f32x4*)&wfj[j][row0 + 32 * mt + 8 * rq + 4 * hh];
-#pragma unroll
-              for (int nt = 0; nt < TW::NT; ++nt)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[mt][nt][4 * rq + u] = fmaf(wv[u], gv[nt], acc[mt][nt][4 * rq + u]);
-            }
+              for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(wv, gv[nt][r >> 2][r & 3], acc[mt][nt][r]);
+          }
         }
       }
     }
@@ -704,7 +618,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     const float mx = wg_max(smax);
     track(a.gmax ? a.gmax + D : nullptr, mx, tid);
     ecur = scale_exp(mx);
-    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
   }
   STAMP(1);  // d e
@@ -713,10 +627,18 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     const unsigned long long bits = hm[(size_t)(D - 1) * hm_stride];
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
-    mma16_lds<W>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_we, W / 16, n0, 0, W, lane);
-    const float* __restrict__ ws = P + L.wsig;
+    f32x4 ws[TW::NT][4];
+    load_cols(ws, P + L.wsig, n0, hh);
+    mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_we, W / 16, n0, 0, lane);
     const float un = pow2f(-(ecur + wexp[8]));
-    acc_map(acc, row0, n0, lane, [&](float v, int row, int col) { return fmaf(v, un, ws[col] * pre_s[row]); });
+#pragma unroll
+    for (int mt = 0; mt < TW::MT; ++mt) {
+      const float ps = pre_s[row0 + 32 * mt + li];
+#pragma unroll
+      for (int nt = 0; nt < TW::NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], un, ws[nt][r >> 2][r & 3] * ps);
+    }
     acc_apply_mask(acc, bits);
     acc_store_global(acc, a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
@@ -725,7 +647,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     const float mx = wg_max(smax);
     track(a.gmax ? a.gmax + (D - 1) : nullptr, mx, tid);
     ecur = scale_exp(mx);
-    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
   }
   STAMP(2);  // d h_{D-1}
@@ -735,13 +657,13 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
   for (int l = D - 1; l >= 1; --l) {
     const unsigned long long bits = hm[(size_t)(l - 1) * hm_stride];  // arrives under the contraction below
     if (a.need_dxyz && l == L.skip) {
-      mma16_lds<W>(accx, Ph, Pl, xrow0, 0, PT16 + 4 * (size_t)L.t_skipx, W / 16, xn0, 0, W, lane);
+      mma16_lds<NP, W, W / 16, AH>(accx, Ph, Pl, xrow0, 0, PT16 + 4 * (size_t)L.t_skipx, W / 16, xn0, 0, lane);
       acc_scale(accx, pow2f(-(ecur + wexp[l])));  // natural units: the layer-0 term arrives at another exponent
     }
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
     const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);  // wave-uniform; asked for before the contraction
-    mma16_lds<W>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_w[l], W / 16, n0, 0, W, lane);
+    mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_w[l], W / 16, n0, 0, lane);
     acc_scale(acc, pow2f(-(ecur + wel)));
     acc_apply_mask(acc, bits);
     acc_store_global(acc, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, row0, n0, lane);
@@ -751,7 +673,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     const float mx = wg_max(smax);
     track(a.gmax ? a.gmax + (l - 1) : nullptr, mx, tid);
     ecur = scale_exp(mx);
-    acc_to_planes<W>(acc, Ph, Pl, row0, n0, 0, pow2f(ecur), lane);
+    acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
   }
   STAMP(3);  // D-1 trunk layers
@@ -763,15 +685,15 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
   {
     f32x16 acc0[TX::MT][TX::NT];
     acc_zero(acc0);
-    mma16_lds<W>(acc0, Ph, Pl, xrow0, 0, PT16 + 4 * (size_t)L.t_w[0], W / 16, xn0, 0, W, lane);
+    mma16_lds<NP, W, W / 16, AH>(acc0, Ph, Pl, xrow0, 0, PT16 + 4 * (size_t)L.t_w[0], W / 16, xn0, 0, lane);
     const float un = pow2f(-(ecur + wexp[0]));
 #pragma unroll
     for (int r = 0; r < 16; ++r) accx[0][0][r] = fmaf(acc0[0][0][r], un, accx[0][0][r]);
   }
   static_assert(TX::MT == 1 && TX::NT == 1, "d x0 tiling");
   __syncthreads();
-  float* Gs = (float*)planes;  // fp32 [TILE][64] scratch over the (now dead) hi plane
-  acc_to_lds(accx, Gs, UPNERF_X0, xrow0, xn0, 0, lane);
+  float* Gs = (float*)planes;  // fp32 [TILE][64] scratch over the (now dead) planes
+  acc_to_lds_t(accx, Gs, UPNERF_X0, xrow0, xn0, lane);
   __syncthreads();
   for (int it = tid; it < TILE * 3; it += F16_THREADS) {
     const int row = it / 3, n = it - row * 3, m = m0 + row;
@@ -825,10 +747,14 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
     return UPNERF_EINVAL;
   if (a->use_cand && (!a->c_rows || !a->sigma_c)) return UPNERF_EINVAL;
   if (a->use_rgb && (!a->aux || !a->rgb)) return UPNERF_EINVAL;
+  if (a->planes != 0 && a->planes != 1 && a->planes != 2) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
-  hipLaunchKernelGGL((field16_fwd_kernel<F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
+  if (a->planes == 1)
+    hipLaunchKernelGGL((field16_fwd_kernel<1, F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
+  else
+    hipLaunchKernelGGL((field16_fwd_kernel<2, F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
   return (int)hipGetLastError();
 }
 
@@ -845,9 +771,13 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->use_rgb && (!a->d_rgb || !a->rgb || !a->r1 || !a->gz_r1 || !a->dpre_rgb)) return UPNERF_EINVAL;
   if (a->g_E_s && !a->w_feat_s) return UPNERF_EINVAL;
   if (a->need_dxyz && (!a->dxyz || !a->x0)) return UPNERF_EINVAL;
+  if (a->planes != 0 && a->planes != 1 && a->planes != 2) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
-  hipLaunchKernelGGL((field16_bwd_kernel<F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
+  if (a->planes == 1)
+    hipLaunchKernelGGL((field16_bwd_kernel<1, F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
+  else
+    hipLaunchKernelGGL((field16_bwd_kernel<2, F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
   return (int)hipGetLastError();
 }

@@ -641,15 +641,17 @@ extern "C" int upnerf_wgrad(int M, const float* A, int lda, int N, const float* 
 
 extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
                                           const int* expo_a, const int* expo_b, float* slabs, float* bslabs,
-                                          int nsplit, int rows, int TN, int TK, void* stream);
+                                          int nsplit, int rows, int TN, int TK, int planes, void* stream);
 
-// Same contract as upnerf_wgrad, contraction on the f16 matrix cores with a 3-term hi/lo split (wgrad_f16x3.hip).
-// expo_a, expo_b: DEVICE ints: A is scaled by 2^*expo_a and B by 2^*expo_b before the fp16 split.
+// Same contract as upnerf_wgrad, contraction on the f16 matrix cores (wgrad_f16x3.hip): planes 0 / 2 = 3-term hi/lo
+// split (fp32-level accuracy), planes 1 = operands rounded to fp16, one MFMA per block.
+// expo_a, expo_b: DEVICE ints: A is scaled by 2^*expo_a and B by 2^*expo_b before the conversion to fp16.
 extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW,
                                   int ldo, float* db, float* slabs, int nsplit, const int* expo_a, const int* expo_b,
-                                  void* stream) {
+                                  int planes, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b)
     return UPNERF_EINVAL;
+  if (planes != 0 && planes != 1 && planes != 2) return UPNERF_EINVAL;
   if ((N & 3) || (K & 3) || (lda & 3) || (ldb & 3) || (ldo & 3)) return UPNERF_EINVAL;
   int TN, TK;
   wgrad_shape(N, K, &TN, &TK);
@@ -658,7 +660,7 @@ extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const f
   const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
   float* bslabs = slabs + (size_t)nsplit * gy * gz * TN * TK;
   int rc = upnerf_wgrad_f16x3_partial(M, A, lda, N, B, ldb, K, expo_a, expo_b, slabs, bslabs, nsplit, rows, TN, TK,
-                                      stream);
+                                      planes, stream);
   if (rc) return rc;
   const int quads = N * (K / 4);
   int rblocks = (quads + 63) / 64;

@@ -42,8 +42,10 @@ __device__ __forceinline__ h4 tr_read(const char* base, int byteoff) {
 // 512 threads = 8 waves per workgroup, one workgroup per CU, two waves per SIMD: the fp32 -> (hi, lo) conversion of one
 // wave overlaps the MFMAs of the other, each thread stages half as many rows (two register sets fit: the loads of chunk
 // c+2 are in flight while chunk c is contracted), and each wave keeps at most 128 accumulator registers.
+// NP = 2: f16x3 (hi/lo split of both operands, three MFMAs per block, fp32-level accuracy); NP = 1: f16 (operands rounded
+// to fp16, one MFMA per block, fp32 accumulate: the "f16" field mode of BASELINE.json configs[3]).
 #define FX_THREADS 512
-template <int MTW, int NTW>
+template <int NP, int MTW, int NTW>
 __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                                   const float* __restrict__ B, int ldb,
                                                                   const int* __restrict__ expo_a, const int* __restrict__ expo_b,
@@ -97,11 +99,13 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
     const f2 x0 = f2{v[0], v[1]} * s, x1 = f2{v[2], v[3]} * s;
     const hh2 h0 = __builtin_convertvector(x0, hh2), h1 = __builtin_convertvector(x1, hh2);
-    const hh2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f2), hh2);
-    const hh2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f2), hh2);
     const int off = himg<FX_CHUNK>(row, col);
     *(h4*)(hi + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
-    *(h4*)(lo + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+    if constexpr (NP == 2) {
+      const hh2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f2), hh2);
+      const hh2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f2), hh2);
+      *(h4*)(lo + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+    }
   };
   auto lstore = [&](const f32x4 (&ra)[A4], const f32x4 (&rb)[B4], int buf) {
     char* base = lds + buf * (2 * SZA + 2 * SZB);
@@ -131,22 +135,29 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       for (int mt = 0; mt < MT; ++mt) {
         const int o0 = himg<FX_CHUNK>(16 * kk + trow, n0 + 32 * mt + tcol), o1 = himg<FX_CHUNK>(16 * kk + trow + 4, n0 + 32 * mt + tcol);
         const h4 x0 = tr_read(base, o0), x1 = tr_read(base, o1);
-        const h4 y0 = tr_read(base + SZA, o0), y1 = tr_read(base + SZA, o1);
         ah[mt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-        al[mt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (NP == 2) {
+          const h4 y0 = tr_read(base + SZA, o0), y1 = tr_read(base + SZA, o1);
+          al[mt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int o0 = himg<FX_CHUNK>(16 * kk + trow, k0 + 32 * nt + tcol), o1 = himg<FX_CHUNK>(16 * kk + trow + 4, k0 + 32 * nt + tcol);
         const h4 x0 = tr_read(base + 2 * SZA, o0), x1 = tr_read(base + 2 * SZA, o1);
-        const h4 y0 = tr_read(base + 2 * SZA + SZB, o0), y1 = tr_read(base + 2 * SZA + SZB, o1);
         const h8 bh = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-        const h8 bl = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+        h8 bl;
+        if constexpr (NP == 2) {
+          const h4 y0 = tr_read(base + 2 * SZA + SZB, o0), y1 = tr_read(base + 2 * SZA + SZB, o1);
+          bl = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+          if constexpr (NP == 2) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+          }
         }
       }
     }
@@ -213,12 +224,16 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
 }
 
 template <int MTW, int NTW>
-int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const int* expo_a, const int* expo_b, float* slabs,
-           float* bslabs, int nsplit, int rows, hipStream_t st) {
+int launch(int planes, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const int* expo_a, const int* expo_b,
+           float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   dim3 grid(nsplit, (N + TN - 1) / TN, (K + TK - 1) / TK);
-  hipLaunchKernelGGL((wgrad_f16x3_kernel<MTW, NTW>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs,
-                     bslabs, rows);
+  if (planes == 1)
+    hipLaunchKernelGGL((wgrad_f16x3_kernel<1, MTW, NTW>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b,
+                       slabs, bslabs, rows);
+  else
+    hipLaunchKernelGGL((wgrad_f16x3_kernel<2, MTW, NTW>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b,
+                       slabs, bslabs, rows);
   return (int)hipGetLastError();
 }
 
@@ -228,15 +243,15 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
 // kernel sums.  expo_a, expo_b: DEVICE pointers to the two exponents.  Returns the block shape through TN/TK.
 extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
                                           const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows, int TN,
-                                          int TK, void* stream) {
+                                          int TK, int planes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (TN == 256 && TK == 256) return launch<4, 4>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 256 && TK == 128) return launch<4, 2>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 256 && TK == 64) return launch<4, 1>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 128 && TK == 256) return launch<2, 4>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 128 && TK == 128) return launch<2, 2>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 128 && TK == 64) return launch<2, 1>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 64 && TK == 256) return launch<1, 4>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 64 && TK == 128) return launch<1, 2>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  return launch<1, 1>(M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 256 && TK == 256) return launch<4, 4>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 256 && TK == 128) return launch<4, 2>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 256 && TK == 64) return launch<4, 1>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 128 && TK == 256) return launch<2, 4>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 128 && TK == 128) return launch<2, 2>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 128 && TK == 64) return launch<2, 1>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 64 && TK == 256) return launch<1, 4>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 64 && TK == 128) return launch<1, 2>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  return launch<1, 1>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
 }

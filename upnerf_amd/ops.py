@@ -182,7 +182,7 @@ def scale_exponents(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
 
 def wgrad_f16x3_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor, ldb: int, K: int, dW_ptr: int, ldo: int,
                      db_ptr: Optional[int], device, expo: Optional[torch.Tensor] = None, expo_a: Optional[int] = None,
-                     expo_b: Optional[int] = None, a_off: int = 0, b_off: int = 0):
+                     expo_b: Optional[int] = None, a_off: int = 0, b_off: int = 0, planes: int = 2):
     """upnerf_wgrad with the contraction on the f16 matrix cores (3-term hi/lo split, fp32-level accuracy).
     Scale exponents: `expo` (device int32 [2]) or raw device pointers expo_a / expo_b; computed from A, B if absent."""
     ns = nsplit_for(M)
@@ -193,7 +193,8 @@ def wgrad_f16x3_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor,
         expo_a, expo_b = expo.data_ptr(), expo.data_ptr() + 4
     rc = TIMER.run(f"wgrad16_{N}x{K}", lambda: lib.upnerf_wgrad_f16x3(M, A.data_ptr() + 4 * a_off, lda, N,
                                                                       B.data_ptr() + 4 * b_off, ldb, K, dW_ptr, ldo,
-                                                                      db_ptr, ptr(ws), ns, expo_a, expo_b, stream()),
+                                                                      db_ptr, ptr(ws), ns, expo_a, expo_b, planes,
+                                                                      stream()),
                    units=M)
     check(rc, "upnerf_wgrad_f16x3")
 

@@ -24,14 +24,28 @@ from .ops import TIMER, embed_rows, hip_linear, linear_kn_view, linear_raw, nspl
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
-# Arithmetic of the field contractions: "f16x3" = 3-term fp16 split on the f16 matrix cores (fp32-level accuracy,
-# csrc/field16.hip; needs W = 256 and >= 32 samples per ray, other shapes use the fp32 kernels), "f32" = fp32 MFMA
-# (csrc/field.hip) everywhere.  Both are HIP kernels of libupnerf_hip.so; there is no non-HIP path.
-FIELD_MODE = "f16x3"
+# Arithmetic of the field contractions (all HIP kernels of libupnerf_hip.so; there is no non-HIP path):
+#   "f16x3"  3-term fp16 hi/lo split on the f16 matrix cores, fp32-level accuracy (csrc/field16.hip; needs W = 256 and
+#            >= 32 samples per ray, other shapes use the fp32 kernels) -- the default, BASELINE.json configs[1]
+#   "f32"    fp32 MFMA (csrc/field.hip) everywhere
+#   "f16"    fp16 weights and activations, ONE MFMA per product, fp32 accumulate; encoding, density / colour outputs,
+#            compositing, loss and optimiser stay fp32 (BASELINE.json configs[3]; same shape limits as f16x3, and no
+#            silent fallback: an unsupported shape raises)
+FIELD_MODE = __import__("os").environ.get("UPNERF_FIELD_MODE", "f16x3")  # env: diagnostic tools only
+_MODES = ("f16x3", "f32", "f16")
 
 
 def _field16_ok(pk, S: int) -> bool:
-    return FIELD_MODE == "f16x3" and pk.W == 256 and S >= 32
+    if FIELD_MODE not in _MODES:
+        raise ValueError(f"unknown FIELD_MODE {FIELD_MODE!r} (one of {_MODES})")
+    ok = pk.W == 256 and S >= 32
+    if FIELD_MODE == "f16" and not ok:
+        raise ValueError("FIELD_MODE 'f16' needs W = 256 and at least 32 samples per ray")
+    return FIELD_MODE != "f32" and ok
+
+
+def _planes() -> int:
+    return 1 if FIELD_MODE == "f16" else 2
 
 
 _LINSPACE: Dict[tuple, torch.Tensor] = {}
@@ -131,7 +145,8 @@ class _FieldPass(torch.autograd.Function):
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
                           rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1),
-                          P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None)
+                          P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None,
+                          planes=_planes())
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
@@ -154,7 +169,7 @@ class _FieldPass(torch.autograd.Function):
         check(TIMER.run("composite_fwd", lambda: lib.upnerf_composite_fwd(C.byref(ca), st), units=M),
               "upnerf_composite_fwd")
 
-        ctx.cfg, ctx.dims = cfg, (R, S)
+        ctx.cfg, ctx.dims, ctx.planes = cfg, (R, S), _planes()
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
                          sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, hmask=hmask, amax=amax, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp,
@@ -215,7 +230,7 @@ class _FieldPass(torch.autograd.Function):
                           g_G_c=ptr(gG), x0=ptr(sv["x0"]), h=ptr(sv["h"]), g1=ptr(sv["g1"]), g2=ptr(sv["g2"]),
                           r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
-                          dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]))
+                          dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes)
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
         check(TIMER.run("field_bwd", lambda: bwd_fn(C.byref(L), C.byref(fb), st), units=M), "upnerf_field_bwd")
 
@@ -239,7 +254,7 @@ class _FieldPass(torch.autograd.Function):
 
             def wg(gz, lda, N, Bt, ldb, K, off, ldo, boff, ia, ib, b_off=0):
                 wgrad_f16x3_into(M, gz, lda, N, Bt, ldb, K, at(off), ldo, None if boff is None else at(boff), dev,
-                                 expo_a=EA(ia), expo_b=EB(ib), b_off=b_off)
+                                 expo_a=EA(ia), expo_b=EB(ib), b_off=b_off, planes=ctx.planes)
 
             for l in range(D):
                 gz = gz_h[l]
