@@ -137,6 +137,11 @@ typedef struct {
   int32_t planes;                /* upnerf_field_fwd_f16x3 only: 0 or 2 = f16x3 (fp32-accurate hi/lo split, three MFMAs per
                                     product); 1 = f16 (fp16 weights and activations, one MFMA per product, fp32 accumulate:
                                     BASELINE.json configs[3]); the lo halves of P16 are then never read */
+  const float* wnorm;            /* upnerf_field_fwd_f16x3 only.  NULL: the LDS-tile kernel (64 samples per workgroup in LDS
+                                    planes, weights streamed per wave; P16 in natural k order).  Non-NULL ([64] from
+                                    upnerf_frag16, P16 written with perm_fwd = 1): the register-resident kernel (128 samples per
+                                    workgroup, activations chained through registers, weights staged ONCE per workgroup in
+                                    LDS by DMA).  Same outputs, same hmask layout: either forward kernel pairs with upnerf_field_bwd_f16x3 */
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -385,13 +390,18 @@ int upnerf_pack(float* P, const upnerf_pack_desc* descs, int ndesc, int unpack, 
  * (2^14 / max|.| over all their elements), written to wexp[exp_id].  Destination element (r, k) of a [rows][dst_kp]
  * matrix at float offset dst_off:  byte dst_off*4 + (((r/32)*(dst_kp/16) + k/16)*2 + plane)*1024
  *                                       + (((k/8)%2)*32 + r%32)*16 + (k%8)*2,   plane 0 = hi, 1 = lo.
- * `amax_scratch` [16] floats is zeroed and used inside. */
+ * `amax_scratch` [16] floats is zeroed and used inside.
+ * perm_fwd / perm_bwd = 1 write the k index inside every 16-deep block in the order in which a converted 32x32 MFMA result
+ * presents its rows as the next product's operand -- element j of lane half h holds k = 8(j/4) + 4h + j%4 instead of
+ * 8h + j: (k%8) above becomes ((k%16)/8)*4 + k%4 and ((k/8)%2) becomes ((k%16)/4)%2 -- what the register-resident field
+ * kernels (upnerf_field_fwd_f16x3 with activations chained through registers) read.
+ * wnorm (DEVICE [64] or NULL): receives max_r sum_c |X[r][c]| per descriptor, forward set at [0..), transposed set at [32..). */
 typedef struct {
   int32_t src_off, src_ld, transpose, rows, cols, dst_off, dst_kp, dst_k0, exp_id;
 } upnerf_frag16_desc;
 int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, const upnerf_frag16_desc* fwd, int nfwd,
                   const upnerf_frag16_desc* bwd, int nbwd, float* amax_scratch /*[16]*/, int32_t* wexp /*[16]*/,
-                  void* stream);
+                  int perm_fwd, int perm_bwd, float* wnorm, void* stream);
 
 /* ---- a18: fused Adam on a flat fp32 buffer (torch.optim.Adam semantics, utils/optim.py:20-33) ----
  * step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t), both formed by the host in double precision and rounded
@@ -411,6 +421,8 @@ int upnerf_set_scalars(float* dst, int n, const float* vals, void* stream);
 /* Diagnostic build only (make -C upnerf_amd/csrc stamps -> libupnerf_hip_stamps.so, never the shipped library): per-phase
  * shader-clock sums accumulated by the f16x3 field kernels; out16[0..7] forward trunk phases, [8..15] backward stages. */
 int upnerf_stamps_read(unsigned long long* out16, int reset);
+/* same for the register-resident forward kernel (field16r.hip): 8 phase sums of its slab loop */
+int upnerf_stamps_read_r(unsigned long long* out8, int reset);
 #endif
 
 #ifdef __cplusplus

@@ -35,7 +35,7 @@ class FieldFwdArgs(C.Structure):
                 ("wk_xyz", C.c_float * 10), ("P", _fp),
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
                 ("x0", _fp), ("h", _fp), ("hmask", _fp), ("amax", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp),
-                ("P16", _fp), ("wexp", _fp), ("wk_xyz_dev", _fp), ("planes", C.c_int32)]
+                ("P16", _fp), ("wexp", _fp), ("wk_xyz_dev", _fp), ("planes", C.c_int32), ("wnorm", _fp)]
 
 
 class CompositeFwdArgs(C.Structure):
@@ -137,7 +137,7 @@ _SIGNATURES = {
     "upnerf_field_bwd": [C.POINTER(Layout), C.POINTER(FieldBwdArgs), _p],
     "upnerf_field_fwd_f16x3": [C.POINTER(Layout), C.POINTER(FieldFwdArgs), _p],
     "upnerf_field_bwd_f16x3": [C.POINTER(Layout), C.POINTER(FieldBwdArgs), _p],
-    "upnerf_frag16": [_p, _p, _p, C.POINTER(Frag16Desc), _i, C.POINTER(Frag16Desc), _i, _p, _p, _p],
+    "upnerf_frag16": [_p, _p, _p, C.POINTER(Frag16Desc), _i, C.POINTER(Frag16Desc), _i, _p, _p, _i, _i, _p, _p],
     "upnerf_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_grouped_scratch": [C.POINTER(WgradGroup), _i, _i],

@@ -739,6 +739,8 @@ extern "C" int upnerf_stamps_read(unsigned long long* out16, int reset) {
 }
 #endif
 
+int upnerf_field16r_fwd_launch(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);  // field16r.hip
+
 extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream) {
   int rc = check_layout16(L);
   if (rc) return rc;
@@ -750,6 +752,7 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->planes != 0 && a->planes != 1 && a->planes != 2) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
+  if (a->wnorm) return upnerf_field16r_fwd_launch(L, a, stream);  // register-resident kernel (field16r.hip)
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
   if (a->planes == 1)
     hipLaunchKernelGGL((field16_fwd_kernel<1, F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);

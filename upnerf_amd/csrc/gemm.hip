@@ -542,8 +542,26 @@ __global__ void frag16_amax_kernel(const float* __restrict__ src, Frag16Descs D,
     atomicMax((unsigned int*)&amax[q.exp_id], __float_as_uint(fabsf(frag16_src(src, q, r, c))));
   }
 }
+// wnorm[j] = max over the rows r of descriptor j of sum_c |X[r][c]|  (the operator norm that bounds |X h|_inf by
+// wnorm * |h|_inf: the register-resident field kernels pick their activation exponents from it before a layer's
+// outputs exist).  One wave per row; non-negative floats order like their bit patterns.
+__global__ void frag16_rownorm_kernel(const float* __restrict__ src, Frag16Descs D, float* __restrict__ wnorm) {
+  int row = blockIdx.x, j = 0;
+  while (j < D.n && row >= D.d[j].rows) row -= D.d[j++].rows;
+  if (j >= D.n) return;
+  const upnerf_frag16_desc q = D.d[j];
+  float s = 0.0f;
+  for (int c = threadIdx.x; c < q.cols; c += 64) s += fabsf(frag16_src(src, q, row, c));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if (threadIdx.x == 0) atomicMax((unsigned int*)&wnorm[j], __float_as_uint(s));
+}
+
+// perm: k order inside a 16-deep block.  0: element j of lane half h holds k = 8h + j (operands read from memory);
+// 1: k = 8(j>>2) + 4h + (j&3) -- the order in which a 32x32 MFMA result, converted in place, presents its rows as the next
+// product's operand (cdna_hip_programming.md "An accumulator tile as the next MFMA's operand").
 __global__ void frag16_write_kernel(const float* __restrict__ src, char* __restrict__ dst, Frag16Descs D,
-                                    const float* __restrict__ amax, int* __restrict__ wexp) {
+                                    const float* __restrict__ amax, int* __restrict__ wexp, int perm) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (wexp && blockIdx.x == 0 && threadIdx.x < 16) wexp[threadIdx.x] = frag16_exp(amax[threadIdx.x]);
   if (idx >= D.start[D.n]) return;
@@ -555,8 +573,10 @@ __global__ void frag16_write_kernel(const float* __restrict__ src, char* __restr
   const float x = ldexpf(frag16_src(src, q, r, c), frag16_exp(amax[q.exp_id]));
   const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
   const int k = q.dst_k0 + c;
+  const int kk = k & 15;
+  const int h = perm ? (kk >> 2) & 1 : kk >> 3, jj = perm ? ((kk >> 3) << 2) | (kk & 3) : kk & 7;
   const size_t base = (size_t)q.dst_off * 4 + ((size_t)(r >> 5) * (q.dst_kp >> 4) + (k >> 4)) * 2048 +
-                      ((((k >> 3) & 1) << 5) + (r & 31)) * 16 + (k & 7) * 2;
+                      ((h << 5) + (r & 31)) * 16 + jj * 2;
   *(_Float16*)(dst + base) = hi;
   *(_Float16*)(dst + base + 1024) = lo;
 }
@@ -788,7 +808,8 @@ static int frag16_build(const upnerf_frag16_desc* descs, int n, Frag16Descs* D) 
 }
 
 extern "C" int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, const upnerf_frag16_desc* fwd, int nfwd,
-                             const upnerf_frag16_desc* bwd, int nbwd, float* amax_scratch, int32_t* wexp, void* stream) {
+                             const upnerf_frag16_desc* bwd, int nbwd, float* amax_scratch, int32_t* wexp, int perm_fwd,
+                             int perm_bwd, float* wnorm, void* stream) {
   if (!src || !dst_fwd || !dst_bwd || !amax_scratch || !wexp) return UPNERF_EINVAL;
   Frag16Descs F, Bd;
   int rc = frag16_build(fwd, nfwd, &F);
@@ -801,9 +822,17 @@ extern "C" int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, con
   hipLaunchKernelGGL(frag16_amax_kernel, dim3((F.start[nfwd] + 255) / 256), dim3(256), 0, st, src, F, amax_scratch);
   hipLaunchKernelGGL(frag16_amax_kernel, dim3((Bd.start[nbwd] + 255) / 256), dim3(256), 0, st, src, Bd, amax_scratch);
   hipLaunchKernelGGL(frag16_write_kernel, dim3((F.start[nfwd] + 255) / 256), dim3(256), 0, st, src, (char*)dst_fwd, F,
-                     amax_scratch, wexp);
+                     amax_scratch, wexp, perm_fwd);
   hipLaunchKernelGGL(frag16_write_kernel, dim3((Bd.start[nbwd] + 255) / 256), dim3(256), 0, st, src, (char*)dst_bwd, Bd,
-                     amax_scratch, (int*)nullptr);
+                     amax_scratch, (int*)nullptr, perm_bwd);
+  if (wnorm) {  // [64]: forward descriptors at 0.., transposed ones at 32..
+    HIP_TRY(hipMemsetAsync(wnorm, 0, 64 * sizeof(float), st));
+    int rf = 0, rb = 0;
+    for (int j = 0; j < nfwd; ++j) rf += fwd[j].rows;
+    for (int j = 0; j < nbwd; ++j) rb += bwd[j].rows;
+    hipLaunchKernelGGL(frag16_rownorm_kernel, dim3(rf), dim3(64), 0, st, src, F, wnorm);
+    hipLaunchKernelGGL(frag16_rownorm_kernel, dim3(rb), dim3(64), 0, st, src, Bd, wnorm + 32);
+  }
   return (int)hipGetLastError();
 }
 

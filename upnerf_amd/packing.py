@@ -321,18 +321,20 @@ class NerfPacker:
         return self._desc16_cache
 
     @torch.no_grad()
-    def frag16_hip(self, P: torch.Tensor):
-        """(P16, PT16, wexp): every matrix of P (and its transposed copy) as scaled fp16 (hi, lo) MFMA fragments with
-        one power-of-two exponent per matrix id -- what upnerf_field_fwd_f16x3 / upnerf_field_bwd_f16x3 read."""
+    def frag16_hip(self, P: torch.Tensor, perm_fwd: bool = False):
+        """(P16, PT16, wexp, wnorm): every matrix of P (and its transposed copy) as scaled fp16 (hi, lo) MFMA fragments with
+        one power-of-two exponent per matrix id -- what upnerf_field_fwd_f16x3 / upnerf_field_bwd_f16x3 read.  perm_fwd: the
+        forward set in the k order of the register-resident forward kernel, plus the row norms it bounds its exponents with."""
         from ._lib import check, lib, ptr, stream
         fd, nf, bd, nb = self._descs16()
         P16 = torch.zeros(self.L.total, device=P.device, dtype=torch.float32)
         PT16 = torch.zeros(self.L.t_total, device=P.device, dtype=torch.float32)
         scratch = torch.empty(16, device=P.device, dtype=torch.float32)
         wexp = torch.empty(16, device=P.device, dtype=torch.int32)
-        check(lib.upnerf_frag16(ptr(P), ptr(P16), ptr(PT16), fd, nf, bd, nb, ptr(scratch), ptr(wexp), stream()),
-              "upnerf_frag16")
-        return P16, PT16, wexp
+        wnorm = torch.empty(64, device=P.device, dtype=torch.float32) if perm_fwd else None
+        check(lib.upnerf_frag16(ptr(P), ptr(P16), ptr(PT16), fd, nf, bd, nb, ptr(scratch), ptr(wexp), int(perm_fwd), 0,
+                                ptr(wnorm), stream()), "upnerf_frag16")
+        return P16, PT16, wexp, wnorm
 
     # ------------------------------------------------------------------ MFMA fragment order (no grad)
     @staticmethod

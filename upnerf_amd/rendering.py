@@ -44,6 +44,11 @@ def _field16_ok(pk, S: int) -> bool:
     return FIELD_MODE != "f32" and ok
 
 
+# Forward kernel of the f16x3 / f16 modes: "regs" = register-resident activations, weights staged once per 128-sample
+# workgroup in LDS (csrc/field16r.hip); "lds" = 64-sample tile in LDS planes, weights streamed per wave (csrc/field16.hip).
+FIELD_FWD_KERNEL = __import__("os").environ.get("UPNERF_FIELD_FWD", "lds")
+
+
 def _planes() -> int:
     return 1 if FIELD_MODE == "f16" else 2
 
@@ -107,9 +112,9 @@ class _FieldPass(torch.autograd.Function):
         rays_o, rays_d, z = rays_o.detach().contiguous(), rays_d.detach().contiguous(), z.detach().contiguous()
         P = P.detach().contiguous()
         use16 = _field16_ok(pk, S)
-        P16 = PT16 = wexp = None
+        P16 = PT16 = wexp = wnorm = None
         if use16:  # matrices as scaled fp16 (hi, lo) fragments, forward and transposed sets in one pass
-            P16, PT16, wexp = pk.frag16_hip(P)
+            P16, PT16, wexp, wnorm = pk.frag16_hip(P, perm_fwd=FIELD_FWD_KERNEL == "regs")
             PF = P  # the kernel reads only the vectors from it
         else:
             PF = pk.frag_hip(P)  # what the kernels read: matrices in MFMA fragment order
@@ -146,7 +151,7 @@ class _FieldPass(torch.autograd.Function):
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
                           rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1),
                           P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None,
-                          planes=_planes())
+                          planes=_planes(), wnorm=ptr(wnorm))
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
