@@ -363,9 +363,11 @@ def field_mode(hip, request):
 
 
 # "f16" (BASELINE.json configs[3]: fp16 weights and activations, one MFMA per product, fp32 accumulate) is compared with the
-# same fp32 restatement at a STATED relaxed gate: 11-bit operands through ten chained layers give ~1e-3 on activations; the
-# gradients additionally see ReLU decisions flip on pre-activations within 1e-3 of zero (max-normalised gates below).
-TOL_ACT_F16, TOL_GRAD_F16 = 1e-2, 1e-1
+# same fp32 restatement at STATED relaxed gates: 11-bit operands through ten chained layers give ~1e-3 on activations
+# (max-normalised gate 1e-2).  Gradients: a ReLU whose pre-activation lies within 1e-3 of zero may decide the other way in
+# fp16, which changes single entries by their full size, so the gate is on the whole tensor -- relative L2 error 6e-2 --
+# plus a loose cap on any single entry (max-normalised 0.5).
+TOL_ACT_F16, TOL_GRAD_F16, TOL_GRAD_F16_MAX = 1e-2, 6e-2, 0.5
 
 
 @pytest.mark.parametrize("field_mode", ["f16x3", "f32", "f16"], indirect=True)
@@ -404,10 +406,17 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     errs = {}
 
     def cmp(tag, got, ref, tol):
-        e = rel_err(cpu(got).reshape(-1), ref.detach().reshape(-1))
-        if not e < tol:
+        g, r = cpu(got).reshape(-1).double(), ref.detach().reshape(-1).double()
+        e = rel_err(g, r)
+        if field_mode == "f16" and tol == TOL_GRAD:  # gradients in the fp16 mode: relative L2 + a cap on single entries
+            l2 = float((g - r).norm() / r.norm().clamp_min(1e-30))
+            ok_ = l2 < tol and e < TOL_GRAD_F16_MAX
+            e = l2
+        else:
+            ok_ = e < tol
+        if not ok_:
             errs[tag] = float(f"{e:.3g}")
-        return e < tol
+        return ok_
 
     ok = True
     ok &= cmp("x0", sv["x0"], f["x0"], 1e-3 if field_mode == "f16" else 2e-6)  # f16: stored from the fp16 plane the layers read

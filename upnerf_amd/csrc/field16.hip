@@ -161,6 +161,10 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
   __shared__ __attribute__((aligned(16))) char planes[NP * TILE * W * 2];
   __shared__ float smax[F16_WAVES], smaxb[F16_WAVES];
   __shared__ float xyz_s[TILE * 3];
+  // per-layer offsets of the layout: read from LDS inside the layer loop.  Indexing the by-value struct with the runtime
+  // layer makes hipcc copy it to scratch and fetch the entry with a VMEM load + s_waitcnt vmcnt(0) -- a full drain of the
+  // previous layer's activation stores at the top of every layer.
+  __shared__ int loff_s[2 * UPNERF_MAX_D];
   char* Ph = planes;
   char* Pl = planes + (NP - 1) * TILE * W * 2;  // NP == 1: never dereferenced
   using TW = WaveTile16<W, TILE>;
@@ -175,6 +179,13 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
   const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
   const int D = L.D;
   STAMP_DECL;
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < UPNERF_MAX_D; ++l) {
+      loff_s[l] = L.w[l];
+      loff_s[UPNERF_MAX_D + l] = L.b[l];
+    }
+  }
 
   // ---- sample positions (rendering.py:251 / 308) and the maxima that bound the side inputs of this tile
   {
@@ -249,8 +260,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
     const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);
+    const int wl = __builtin_amdgcn_readfirstlane(loff_s[l]), bl_off = __builtin_amdgcn_readfirstlane(loff_s[UPNERF_MAX_D + l]);
     if (l == 0) {
-      mma16_lds<NP, W, UPNERF_X0 / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[0], UPNERF_X0 / 16, n0, 0, lane);
+      mma16_lds<NP, W, UPNERF_X0 / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, UPNERF_X0 / 16, n0, 0, lane);
     } else if (l == L.skip) {
       const float* ap[TW::MT];
 #pragma unroll
@@ -259,14 +271,14 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
         m = m < M ? m : M - 1;
         ap[mt] = a.x0 + (size_t)m * UPNERF_X0 + 8 * hh;
       }
-      mma16_glb<NP>(acc, ap, ecur, P16 + 4 * (size_t)L.w[l], (UPNERF_X0 + W) / 16, n0, 0, UPNERF_X0, lane);
-      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[l], (UPNERF_X0 + W) / 16, n0, UPNERF_X0, lane);
+      mma16_glb<NP>(acc, ap, ecur, P16 + 4 * (size_t)wl, (UPNERF_X0 + W) / 16, n0, 0, UPNERF_X0, lane);
+      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, (UPNERF_X0 + W) / 16, n0, UPNERF_X0, lane);
     } else {
-      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.w[l], W / 16, n0, 0, lane);
+      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, W / 16, n0, 0, lane);
     }
     STAMP(1);
     f32x4 bl[TW::NT][4];
-    load_cols(bl, P + L.b[l], n0, hh);
+    load_cols(bl, P + bl_off, n0, hh);
     const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wel)), bl);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
@@ -425,6 +437,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
   // the candidate density, its compositing weight, the three d pre-activations of the colour output
   __shared__ float dpc_s[TILE], cwj_s[TILE];
   __shared__ __attribute__((aligned(16))) float dprgb_s[TILE][4];
+  __shared__ int loff_s[UPNERF_MAX_D];  // t_w[l] (see the forward kernel: no runtime index into the by-value struct)
   char* Ph = planes;
   char* Pl = planes + (NP - 1) * TILE * W * 2;
   using TW = WaveTile16<W, TILE>;
@@ -443,6 +456,10 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
   const unsigned long long* __restrict__ hm = (const unsigned long long*)a.hmask + (size_t)blockIdx.x * F16_THREADS + tid;
   const size_t hm_stride = (size_t)gridDim.x * F16_THREADS;
 
+  if (tid == 64) {
+#pragma unroll
+    for (int l = 0; l < UPNERF_MAX_D; ++l) loff_s[l] = L.t_w[l];
+  }
   // softplus'(x) = 1 - exp(-softplus(x)); per-row feature weight on its ray slot; per-row scalars of the head stages
   if (tid < TILE) {
     const int m = m0 + tid;
@@ -663,7 +680,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
     const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);  // wave-uniform; asked for before the contraction
-    mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_w[l], W / 16, n0, 0, lane);
+    mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)__builtin_amdgcn_readfirstlane(loff_s[l]), W / 16, n0, 0, lane);
     acc_scale(acc, pow2f(-(ecur + wel)));
     acc_apply_mask(acc, bits);
     acc_store_global(acc, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, row0, n0, lane);
