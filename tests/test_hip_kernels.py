@@ -706,3 +706,72 @@ def test_flat_adam_follows_torch_adam_including_skipped_parameters():
     sd = o_me.state_dict()
     assert int(sd["state"][2]["step"]) == 4 and int(sd["state"][0]["step"]) == 5
     assert rel_err(sd["state"][4]["exp_avg"].cpu(), o_ref.state_dict()["state"][4]["exp_avg"]) < 2e-6
+
+
+def _philox4x32_10(c, k):
+    """numpy restatement of Philox4x32-10 (Salmon et al., SC'11): c [N,4] uint32 counters, k (k0, k1)."""
+    import numpy as np
+    c = c.astype(np.uint64).copy()
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & MASK
+        n2 = ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & MASK
+        c = np.stack([n0, p1 & MASK, n2, p0 & MASK], 1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & MASK
+        k1 = (k1 + np.uint64(0xBB67AE85)) & MASK
+    return c.astype(np.uint32)
+
+
+def test_keyed_uniform_draws_follow_the_philox_spec_and_the_global_row(hip):
+    """upnerf_uniform_keyed: values = Philox4x32-10(counter (row0 + r, c / 4, step, draw), key seed) >> 8 scaled by 2^-24;
+    a batch drawn in two halves with their global row offsets equals the batch drawn at once (rank-count invariance,
+    SURVEY.md 8e); the step can come from device memory (graph replay)."""
+    import numpy as np
+    lib, ptr, stream, check = hip["lib"].lib, hip["lib"].ptr, hip["lib"].stream, hip["lib"].check
+    R, n, seed, step, draw = 37, 90, 0x1234567890ABCDEF, 4711, 2
+    out = torch.empty(R, n, device="cuda")
+    check(lib.upnerf_uniform_keyed(R, n, seed, step, None, 100, draw, ptr(out), stream()), "uniform")
+    q4 = (n + 3) // 4
+    rr, qq = np.meshgrid(np.arange(R), np.arange(q4), indexing="ij")
+    ctr = np.stack([100 + rr.ravel(), qq.ravel(), np.full(R * q4, step), np.full(R * q4, draw)], 1).astype(np.uint32)
+    ref = _philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32)).reshape(R, q4 * 4)[:, :n]
+    ref = (ref >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+    assert np.array_equal(cpu(out).numpy(), ref)
+    assert 0.0 <= float(out.min()) and float(out.max()) < 1.0 and abs(float(out.mean()) - 0.5) < 0.03
+    a, b = torch.empty(20, n, device="cuda"), torch.empty(17, n, device="cuda")
+    step_dev = torch.tensor([float(step)], device="cuda")
+    check(lib.upnerf_uniform_keyed(20, n, seed, 0, ptr(step_dev), 100, draw, ptr(a), stream()), "uniform")
+    check(lib.upnerf_uniform_keyed(17, n, seed, 0, ptr(step_dev), 120, draw, ptr(b), stream()), "uniform")
+    assert torch.equal(torch.cat([a, b]), out)
+
+
+def test_two_virtual_ranks_draw_what_one_rank_draws(hip):
+    """NeRFSystem passes render_rays the key (seed, step, global row): the sampled depths of a 256-ray batch rendered at once
+    equal, bit for bit, those of its two 128-ray halves rendered as ranks 0 and 1 would (rows 0.. and 128..)."""
+    from upnerf_amd import synth
+    from upnerf_amd.nerf_system import NeRFSystem, SyntheticDataset, default_hparams
+    hp = default_hparams(**{"nerf.N_samples": 32, "nerf.N_importance": 32, "train.batch_size": 256, "max_steps": 100, "seed": 11})
+    torch.manual_seed(0)
+    s = NeRFSystem(hp, SyntheticDataset(5))
+    s.setup()
+    s.cuda()
+    s.global_step = 60
+    s.set_progress(0.3)
+    batch = {k: v.cuda() for k, v in synth.batch(256, 5, seed=3).items()}
+
+    def depths(b, row0):
+        s._rng_row0 = row0
+        keep = {}
+        with torch.no_grad():
+            rays = s.rays_from_batch(b)
+            s(rays, b["feats"], b["img_idx"], s.get_schedule_mult(s._host_progress), keep=keep)
+        return keep["z_coarse"].clone(), keep["z_fine"].clone()
+
+    zc, zf = depths(batch, 0)
+    halves = [depths({k: v[lo:lo + 128] for k, v in batch.items()}, lo) for lo in (0, 128)]
+    assert torch.equal(zc, torch.cat([h[0] for h in halves])) and torch.equal(zf, torch.cat([h[1] for h in halves]))
+    s.global_step = 62  # another step: other numbers
+    zc2, _ = depths(batch, 0)
+    assert not torch.equal(zc, zc2)

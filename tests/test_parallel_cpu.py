@@ -109,3 +109,88 @@ def test_single_process_is_a_noop():
     before = m.mlp[0].weight.grad.clone()
     assert parallel.GradSync(m.parameters())() == 0
     assert torch.equal(m.mlp[0].weight.grad, before)
+
+
+class _TwoFields(torch.nn.Module):
+    """NeRFSystem-shaped parameter list: a `fine` field whose gradients autograd completes first (the early bucket), a
+    `coarse` field, a head that receives a gradient only in some phases, a per-image table."""
+
+    def __init__(self):
+        super().__init__()
+        self.coarse = torch.nn.Linear(6, 6)
+        self.fine = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
+        self.fine_head = torch.nn.Linear(6, 2)      # part of the fine field, used in phase 1 only
+        self.table = torch.nn.Embedding(9, 6)
+
+
+def _loss2(m, idx, phase):
+    h = torch.tanh(m.coarse(m.table(idx)))
+    out = m.fine(h)
+    if phase == 1:
+        out = out + m.fine_head(h)
+    return (out ** 2).mean()
+
+
+def _worker_overlap(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from upnerf_amd import parallel
+    parallel.init_from_env("gloo")
+    torch.manual_seed(0)
+    m = _TwoFields()
+    early = list(m.fine.parameters()) + list(m.fine_head.parameters())
+    sync = parallel.GradSync(m.parameters(), check=True, early=early)
+    g = torch.Generator().manual_seed(7)
+    idx_all = torch.randint(0, 9, (6, 8), generator=g)
+    out = []
+    for step, phase in enumerate([0, 0, 1, 1, 0, 1]):  # first step of a phase learns its count, later ones launch early
+        for p in m.parameters():
+            p.grad = None
+        sync.begin(phase)
+        idx = idx_all[step][rank * 4:(rank + 1) * 4]
+        _loss2(m, idx, phase).backward()
+        n = sync()
+        out.append((n, {k: (None if p.grad is None else p.grad.numpy().copy()) for k, p in m.named_parameters()}))
+    q.put((rank, out, dict(sync.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_bucket_allreduce_world2_gloo():
+    """The fine field's gradients are reduced from a post-accumulate-grad hook while backward still runs (overlap with the
+    tail of backward; the reference gets this from DDP, train.py:70-72): same averages as the flat reduce,
+    phase-dependent parameter sets handled (the head without a gradient in phase 0 stays None on both ranks)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    (_, out0, st0), (_, out1, st1) = res
+    assert st0 == st1 == {"early_launches": 4, "late_only": 2}, (st0, st1)
+    # single-process reference on the full batches
+    torch.manual_seed(0)
+    m = _TwoFields()
+    g = torch.Generator().manual_seed(7)
+    idx_all = torch.randint(0, 9, (6, 8), generator=g)
+    for step, phase in enumerate([0, 0, 1, 1, 0, 1]):
+        for p in m.parameters():
+            p.grad = None
+        _loss2(m, idx_all[step], phase).backward()
+        n0, g0 = out0[step]
+        n1, g1 = out1[step]
+        assert n0 == n1 == sum(p.grad.numel() for p in m.parameters() if p.grad is not None)
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                assert g0[k] is None and g1[k] is None, (step, k)
+            else:
+                a, b = torch.from_numpy(g0[k]), torch.from_numpy(g1[k])
+                assert torch.equal(a, b) and torch.allclose(a, p.grad, atol=1e-6), (step, k)

@@ -228,6 +228,38 @@ __global__ void sample_coarse_kernel(int R, int S, const float* __restrict__ nea
   }
 }
 
+// ---- uniform draws keyed by (seed, step, global ray, draw, column): Philox4x32-10 (Salmon et al., SC'11; the generator
+// family torch.rand uses on the GPU), counter = (global ray, column / 4, step, draw), key = seed.  The value depends on the
+// ray's GLOBAL row in the data-parallel batch, not on the rank that renders it: 1 rank x 8192 rays and 2 ranks x 4096 draw
+// the same numbers.  u = (x >> 8) * 2^-24, 24 random bits in [0, 1) like torch.rand.
+__device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (unsigned int)p1;
+  c[3] = (unsigned int)p0;
+  c[0] = n0;
+  c[2] = n2;
+}
+__global__ void uniform_keyed_kernel(int R, int n, unsigned int seed_lo, unsigned int seed_hi, int step,
+                                     const float* __restrict__ step_dev, int row0, int draw, float* __restrict__ out) {
+  const int q4 = (n + 3) >> 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * q4) return;
+  const int r = idx / q4, q = idx - r * q4;
+  if (step_dev) step = (int)step_dev[0];  // graph replay: the step counter lives in device memory (exact in fp32 below 2^24)
+  unsigned int c[4] = {(unsigned int)(row0 + r), (unsigned int)q, (unsigned int)step, (unsigned int)draw};
+  unsigned int k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (4 * q + j < n) out[(size_t)r * n + 4 * q + j] = (float)(c[j] >> 8) * (1.0f / 16777216.0f);
+}
+
 // ---- a11: sample_pdf (rendering.py:7-50); one wave per ray, cdf kept in LDS.
 #define PDF_MAXS 1024
 __global__ __launch_bounds__(NTHREADS) void sample_pdf_kernel(int R, int S, const float* __restrict__ z,
@@ -518,6 +550,15 @@ extern "C" int upnerf_sample_coarse(int R, int S, const float* near_far, const f
   const long long n = (long long)R * S;
   hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R, S,
                      near_far, steps, u, perturb, use_disp, z_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_uniform_keyed(int R, int n, uint64_t seed, int step, const float* step_dev, int row0, int draw, float* out,
+                                    void* stream) {
+  if (R <= 0 || n <= 0 || !out || step < 0 || row0 < 0 || draw < 0) return UPNERF_EINVAL;
+  const long long total = (long long)R * ((n + 3) / 4);
+  hipLaunchKernelGGL(uniform_keyed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R, n,
+                     (unsigned int)seed, (unsigned int)(seed >> 32), step, step_dev, row0, draw, out);
   return (int)hipGetLastError();
 }
 

@@ -72,7 +72,8 @@ class GraphedTrainingStep:
 
         return {"wk_xyz": lambda: band_weights(m.xyz_L, prog(), m.c2f),
                 "wk_dir": lambda: band_weights(m.dir_L, prog(), m.c2f),
-                "sched": lambda: [s.get_schedule_mult(s._host_progress)]}
+                "sched": lambda: [s.get_schedule_mult(s._host_progress)],
+                "step": lambda: [float(s.global_step)]}  # Philox counter of the stratified-sampling draws
 
     # ---- capture -----------------------------------------------------------------------------------------------------
     def _static_batch(self, batch):

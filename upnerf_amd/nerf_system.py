@@ -17,6 +17,7 @@ from collections import defaultdict
 import torch
 from torch import nn
 
+from . import step_scalars
 from .camera import refine_and_get_rays
 from .losses import UPNeRFLoss
 from .nerf import NeRF, fp32_round
@@ -137,6 +138,11 @@ class NeRFSystem(_Base):
     # ---- forward (nerf_system.py:93-148) -------------------------------------------------------------
     def forward(self, rays, feats, img_idx, sched_mult, train=True, u_list=None, keep=None):
         hp = self.hparams
+        rng = None
+        if train and u_list is None and hp.get("rng.keyed", True) and hp["nerf.perturb"] > 0:
+            # stratified-sampling draws keyed by (seed, optimisation step, GLOBAL row of the ray): the reference draws from the
+            # process-wide generator (rendering.py:248, 29), whose numbers depend on the rank count
+            rng = {"seed": int(hp.get("seed", 0)), "step": int(self.global_step), "row0": self.rng_row0(rays.shape[0])}
         sched_phase = 0 if sched_mult == 0 else (2 if sched_mult == 1 else 1)
         B = rays.shape[0]
         results = defaultdict(list)
@@ -147,7 +153,8 @@ class NeRFSystem(_Base):
                               N_samples=hp["nerf.N_samples"], use_disp=hp["nerf.use_disp"],
                               perturb=hp["nerf.perturb"] if train else 0, N_importance=hp["nerf.N_importance"],
                               white_back=getattr(self.train_dataset, "white_back", False),
-                              encode_feat=hp["nerf.feat_dim"] > 0, validation=not train, u_list=u_list, keep=keep)
+                              encode_feat=hp["nerf.feat_dim"] > 0, validation=not train, u_list=u_list, keep=keep,
+                              rng=None if rng is None else dict(rng, row0=rng["row0"] + i))
             for k, v in out.items():
                 results[k] += [v]
         results = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in results.items()}
@@ -163,6 +170,13 @@ class NeRFSystem(_Base):
             else:
                 results["rgb_coarse"] = results["s_rgb_coarse"]
         return results
+
+    def rng_row0(self, rows: int) -> int:
+        """Global row of this rank's first ray in the data-parallel batch (`rows` rays per rank); tests may pin it."""
+        if getattr(self, "_rng_row0", None) is not None:
+            return int(self._rng_row0)
+        import torch.distributed as dist
+        return dist.get_rank() * rows if dist.is_available() and dist.is_initialized() else 0
 
     # ---- pieces of training_step, exposed for tests and the benchmark ------------------------------------
     def rays_from_batch(self, batch):
@@ -210,6 +224,11 @@ class NeRFSystem(_Base):
         loss, loss_d, _ = self.compute_loss(batch, u_list=u_list)
         for o in self._opts_scheds()[0]:
             o.zero_grad()
+        if self.grad_sync is not None and step_scalars.current() is None:
+            # eager step: the fine field's gradients are all-reduced while the rest of backward runs.  (Under graph capture
+            # the collective stays between the two graphs of a step, graph_step.py.)
+            sm = self.get_schedule_mult(self._host_progress)
+            self.grad_sync.begin(0 if sm == 0 else (2 if sm == 1 else 1))
         self.manual_backward(loss)
         return loss, loss_d
 
@@ -281,9 +300,12 @@ class NeRFSystem(_Base):
             self.log(k, v)
         return out
 
-    def enable_data_parallel(self, check=False):
-        """Average gradients over torch.distributed ranks after every backward (one flat all-reduce)."""
-        self.grad_sync = GradSync([p for p in self.parameters()], check=check)
+    def enable_data_parallel(self, check=False, overlap=True):
+        """Average gradients over torch.distributed ranks after every backward.  overlap: the fine field's gradients (the
+        first the backward pass completes) are all-reduced on a side stream while the rest of the backward pass runs
+        (parallel.GradSync); the remaining gradients follow in one flat all-reduce at the end."""
+        early = list(self.nerf_fine.parameters()) if (overlap and self.fine) else []
+        self.grad_sync = GradSync([p for p in self.parameters()], check=check, early=early)
 
     def get_schedule_mult(self, progress):
         s, e = self.candidate_schedule

@@ -39,13 +39,79 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
 
 
 class GradSync:
-    """Average the gradients of `params` across ranks with one flat all-reduce."""
+    """Average the gradients of `params` across ranks with one flat all-reduce -- or, with `early` given, two: the
+    parameters in `early` (the fine field: autograd produces its gradients first) are reduced on a side stream
+    as soon as the last of them has its gradient, while the backward pass of the coarse field, the tables and the pose
+    still runs; everything else follows at the end.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, check: bool = False):
+    Which parameters receive a gradient depends only on the schedule phase, so the number of `early`
+    gradients to wait for is LEARNED per phase key (`begin(key)`): the first step of a phase reduces everything at the end,
+    later steps launch the early bucket from a post-accumulate-grad hook.  Gradients filled at the end of the backward pass
+    (ops._DeferredWgrads / _DeferredEmbeds) must not be in `early`."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, check: bool = False,
+                 early: Iterable[torch.nn.Parameter] = ()):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group, self.check = group, check
         self._flat = None
         self._live, self._views, self._n = [], [], 0
+        early_ids = {id(p) for p in early}
+        self.early: List[torch.nn.Parameter] = [p for p in self.params if id(p) in early_ids]
+        self._expected = {}        # phase key -> number of early parameters that receive a gradient
+        self._key, self._seen, self._work = None, 0, None
+        self._early_flat, self._early_live, self._stream = None, [], None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.early]
+        self.stats = {"early_launches": 0, "late_only": 0}
+
+    # ---- early bucket ------------------------------------------------------------------------------------------------------
+    def begin(self, key) -> None:
+        """Start of a backward pass in schedule phase `key`."""
+        self._key, self._seen, self._work, self._early_live = key, 0, None, []
+
+    def _on_grad(self, p) -> None:
+        if self._key is None or self.world == 1:
+            return
+        self._seen += 1
+        if self._expected.get(self._key) == self._seen:
+            self._launch_early()
+
+    def _launch_early(self) -> None:
+        live = [p for p in self.early if p.grad is not None]
+        n = sum(p.grad.numel() for p in live)
+        dev = live[0].grad.device
+        if self._early_flat is None or self._early_flat.device != dev:
+            self._early_flat = torch.empty(sum(p.numel() for p in self.early), device=dev, dtype=torch.float32)
+        flat = self._early_flat[:n]
+        views, off = [], 0
+        for p in live:
+            k = p.grad.numel()
+            views.append(flat[off:off + k].view_as(p.grad))
+            off += k
+        if dev.type == "cuda":
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(dev)
+            self._stream.wait_stream(torch.cuda.current_stream(dev))  # the gradients are complete on the compute stream
+            with torch.cuda.stream(self._stream):
+                torch._foreach_copy_(views, [p.grad for p in live])
+                self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            torch._foreach_copy_(views, [p.grad for p in live])
+            self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._early_live, self._early_views = live, views
+        self.stats["early_launches"] += 1
+
+    def _finish_early(self) -> set:
+        """Wait for the early all-reduce and write the averages back; returns the ids of the parameters it covered."""
+        if self._work is None:
+            return set()
+        self._work.wait()
+        flat = self._early_flat[:sum(v.numel() for v in self._early_views)]
+        if flat.is_cuda:
+            torch.cuda.current_stream(flat.device).wait_stream(self._stream)
+        flat.mul_(1.0 / self.world)
+        torch._foreach_copy_([p.grad for p in self._early_live], self._early_views)
+        self._work = None
+        return {id(p) for p in self._early_live}
 
     @property
     def world(self) -> int:
@@ -53,9 +119,9 @@ class GradSync:
 
     # The exchange in three pieces (pack / reduce / unpack) so that a captured training step can keep the collective
     # OUTSIDE its two HIP graphs: graph 1 ends with pack(), reduce() runs eagerly, graph 2 starts with unpack().
-    def pack(self) -> int:
-        """Copy every gradient that exists into the flat buffer; returns the number of floats (0: nothing to do)."""
-        self._live = [p for p in self.params if p.grad is not None]
+    def pack(self, skip: set = frozenset()) -> int:
+        """Copy every gradient that exists (and is not in `skip`) into the flat buffer; returns the number of floats."""
+        self._live = [p for p in self.params if p.grad is not None and id(p) not in skip]
         n = sum(p.grad.numel() for p in self._live)
         self._n = n
         if n == 0 or self.world == 1:
@@ -96,8 +162,14 @@ class GradSync:
         torch._foreach_copy_([p.grad for p in self._live], self._views)
 
     def __call__(self) -> int:
-        """All-reduce (mean) every gradient that exists; returns the number of floats exchanged."""
-        n = self.pack()
+        """All-reduce (mean) every gradient that exists; returns the number of floats exchanged (at the end of backward)."""
+        if self._key is not None and self.world > 1:  # remember how many early gradients this phase produces
+            self._expected[self._key] = sum(1 for p in self.early if p.grad is not None)
+        done = self._finish_early()
+        if not done:
+            self.stats["late_only"] += 1
+        n = self.pack(skip=done)
         self.reduce()
         self.unpack()
-        return n
+        self._key = None
+        return n + sum(p.grad.numel() for p in self._early_live if id(p) in done)

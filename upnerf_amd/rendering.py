@@ -336,6 +336,10 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
     unknown kwargs (sched_phase, white_back, validation) accepted and ignored, same result keys
     per schedule phase.  `test_time` is dead in the reference (Q1) and is ignored here too.
 
+    Extension for training (NeRFSystem passes it): kwargs["rng"] = dict(seed, step, row0) draws the stratified-sampling
+    uniforms from a Philox counter keyed by (seed, step, row0 + ray, draw, column) instead of torch.rand -- the same numbers
+    whatever the number of ranks the global batch is split over.
+
     Extensions used by the parity tests: kwargs["u_list"] = explicit uniform draws consumed in the reference's RNG
     call order (coarse jitter [R,Nc], then the sample_pdf draws); kwargs["keep"] = dict that receives the sampled
     depths (z_coarse, z_fine).
@@ -353,13 +357,28 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
     R = rays.shape[0]
     st = stream()
 
+    rng = kwargs.get("rng")  # dict(seed, step, row0): keyed draws (upnerf_uniform_keyed); absent: torch.rand like the reference
+    n_drawn = [0]
+
     def draw(n):
         if draws is not None:
             t = draws.pop(0).to(dev, torch.float32).contiguous()
             if tuple(t.shape) != (R, n):
                 raise ValueError(f"u_list entry has shape {tuple(t.shape)}, expected {(R, n)}")
             return t
-        return torch.rand(R, n, device=dev)
+        if rng is None:
+            return torch.rand(R, n, device=dev)
+        # Philox keyed by (seed, step, global ray, draw, column): independent of how the batch is split over ranks; under
+        # graph replay the step counter is read from the per-step scalar table
+        t = _empty(R, n, device=dev)
+        n_drawn[0] += 1
+        if n == 0:
+            return t
+        dyn = step_scalars.current()
+        check(lib.upnerf_uniform_keyed(R, n, int(rng["seed"]) & 0xFFFFFFFFFFFFFFFF, int(rng["step"]),
+                                       dyn.ptr_named("step", 1) if dyn else None, int(rng["row0"]), n_drawn[0] - 1, ptr(t), st),
+              "upnerf_uniform_keyed")
+        return t
 
     rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
     near_far = rays[:, 6:8].detach().contiguous()
