@@ -29,6 +29,7 @@ class Case:
         self.use_disp = bool(c("use_disp", 0))
         self.identity_c2w = bool(c("identity_c2w", 1))
         self.sigma_bias = float(c("sigma_bias", 0.0))
+        self.sigma_gain, self.trunk_gain = float(c("sigma_gain", 1.0)), float(c("trunk_gain", 1.0))
         c2f = self.g["cfg_c2f"]
         self.c2f = None if c2f[0] < 0 else (float(c2f[0]), float(c2f[1]))
         self.encode_candidate = None if "cfg_encode_candidate" not in self.g else bool(c("encode_candidate"))
@@ -45,7 +46,8 @@ class Case:
         """{"nerf_coarse": params, ..., "embedding_*": weight, "se3_refine": weight, "depth_scale": weight}."""
         st = {}
         for typ in ("coarse", "fine") if self.fine else ("coarse",):
-            sd = synth.nerf_state(typ, seed=self.seed, progress=self.progress, sigma_bias=self.sigma_bias, **self.nerf_kw())
+            sd = synth.nerf_state(typ, seed=self.seed, progress=self.progress, sigma_bias=self.sigma_bias,
+                                  sigma_gain=self.sigma_gain, trunk_gain=self.trunk_gain, **self.nerf_kw())
             sd.pop("progress")
             st[f"nerf_{typ}"] = {k: v.to(dtype).requires_grad_(requires_grad) for k, v in sd.items()}
         st["transient_net"] = {k: v.to(dtype).requires_grad_(requires_grad)

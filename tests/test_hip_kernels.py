@@ -349,7 +349,8 @@ def _setup_pass(c, typ, hip):
 
 
 STAGE_CASES = [("cfg1_small", "coarse"), ("cfg2_phase0", "coarse"), ("cfg2_phase1", "fine"), ("cfg2_phase2", "fine"),
-               ("small_nocand", "fine"), ("small_round_half", "fine"), ("small_allmasked", "coarse")]
+               ("small_nocand", "fine"), ("small_round_half", "fine"), ("small_allmasked", "coarse"),
+               ("cfg2_trained_p08", "fine"), ("cfg2_trained_p045", "fine")]  # "trained-like" magnitudes, all bands on
 
 
 @pytest.fixture

@@ -81,7 +81,8 @@ def build(case):
     models, sds = {}, {}
     for typ in ("coarse", "fine") if case["Nf"] > 0 else ("coarse",):
         m = ref_nerf.NeRF(typ, c2f=case["c2f"], **kw)
-        sd = synth.nerf_state(typ, seed=case["seed"], progress=case["progress"], sigma_bias=case.get("sigma_bias", 0.0), **kw)
+        sd = synth.nerf_state(typ, seed=case["seed"], progress=case["progress"], sigma_bias=case.get("sigma_bias", 0.0),
+                              sigma_gain=case.get("sigma_gain", 1.0), trunk_gain=case.get("trunk_gain", 1.0), **kw)
         m.load_state_dict(sd)
         if case.get("encode_candidate") is False:
             m.encode_candidate = False
@@ -187,6 +188,13 @@ CASES = {
     "cfg2_phase0": dict(BASE, R=6, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.05, perturb=1.0, pose_opt=True),
     "cfg2_phase1": dict(BASE, R=6, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.3, perturb=1.0, pose_opt=True),
     "cfg2_phase2": dict(BASE, R=6, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.8, perturb=1.0, pose_opt=True),
+    # "trained-like" statistics at the config #2 shape: trunk weights x1.6 and density heads x24 (densities
+    # from 0 to ~50, saturated alphas, activations over several decades -- what the per-tile / per-tensor exponents of the
+    # f16x3 split have to follow), all ten encoding bands on (progress 0.8, sched 1) resp. eight and a half (0.45, sched 0.96)
+    "cfg2_trained_p08": dict(BASE, R=6, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.8, perturb=1.0, pose_opt=True,
+                             sigma_gain=24.0, trunk_gain=1.6),
+    "cfg2_trained_p045": dict(BASE, R=6, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.45, perturb=1.0, pose_opt=True,
+                              sigma_gain=24.0, trunk_gain=1.6),
     # deterministic resampling (validation path: perturb=0 -> det=True), non-identity c2w
     "cfg2_det_phase1": dict(BASE, R=5, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.25, perturb=0.0,
                             pose_opt=True, identity_c2w=False),
