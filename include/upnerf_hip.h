@@ -150,6 +150,13 @@ typedef struct {
                                     upnerf_frag16, P16 written with perm_fwd = 1): the register-resident kernel (128 samples per
                                     workgroup, activations chained through registers, weights staged ONCE per workgroup in
                                     LDS by DMA).  Same outputs, same hmask layout: either forward kernel pairs with upnerf_field_bwd_f16x3 */
+  /* f16 mode (planes == 1) with fp16 STORAGE of the trunk activations: halves what the pass writes and what the weight-
+   * gradient kernels read back (upnerf_wgrad_f16p).  h16[l][m][k] = fp16(h_l[m][k] * 2^hexp[l][m / 64]): the content of the
+   * LDS plane of the 64-sample tile, copied out as it stands, with the tile's power-of-two exponent beside it. */
+  uint16_t* h16;                 /* [D][M][W] fp16 bits, or NULL (fp32 `h` as above) */
+  int32_t* hexp;                 /* [D][ceil(M/64)] */
+  int32_t h_last_only;           /* with h16: `h` (if non-NULL) receives layer D-1 only, as [M][W] fp32 (density-head and
+                                    final-layer weight gradients read it) */
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -244,6 +251,8 @@ typedef struct {
   const void* PT16;              /* transposed set of upnerf_frag16 */
   const int32_t* wexp;           /* [16] */
   int32_t planes;                /* as in upnerf_field_fwd_args: 0 / 2 = f16x3, 1 = f16 */
+  uint16_t* gz16;                /* f16 mode: [D][M][W] fp16 bits of gz_h, tile-scaled like h16 (then gz_h may be NULL) */
+  int32_t* gzexp;                /* [D][ceil(M/64)] */
 } upnerf_field_bwd_args;
 
 int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream);
@@ -279,6 +288,14 @@ int upnerf_wgrad_grouped(const upnerf_wgrad_group* groups, int ngroups, float* s
 int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
                        float* dW, int ldo, float* db, float* slabs, int nsplit, const int* expo_a,
                        const int* expo_b, int planes, void* stream);
+
+/* Same contraction for the f16 field mode with fp16-STORED operands: A16 [M][lda] fp16 bits scaled per 64-row tile by
+ * 2^aexp[m / 64] (upnerf_field_bwd_f16x3's gz16 / gzexp); B either fp16 the same way (b_is_f16 = 1: B16 / bexp, from h16 /
+ * hexp) or fp32 row-major (b_is_f16 = 0: x0).  Operands are brought to the tensor-wide exponents *expo_a / *expo_b on load
+ * (exact power-of-two scaling in fp16), one MFMA per block, fp32 accumulate.  Reads 1 KB per sample and layer instead of 2. */
+int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
+                      const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, float* slabs, int nsplit,
+                      const int* expo_a, const int* expo_b, void* stream);
 
 /* dw[c][k] = sum_m v[m*ldv + c] * X[m][k], c < nvec <= 3; dbv[c] = sum_m v[m*ldv + c]   (N=1/3 heads);
  * K in {32, 64, 128, 256}; scratch: nsplit * 4 * (K+1) floats */

@@ -421,8 +421,11 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
 
     ok = True
     ok &= cmp("x0", sv["x0"], f["x0"], 1e-3 if field_mode == "f16" else 2e-6)  # f16: stored from the fp16 plane the layers read
+    hs = sv["h"] if sv.get("h16") is None else rd.dequant16(sv["h16"], sv["hexp"])  # f16 mode stores fp16 tiles + exponents
     for l in range(pk.D):
-        ok &= cmp(f"h{l}", sv["h"][l], f["h"][l], TOL_ACT)
+        ok &= cmp(f"h{l}", hs[l], f["h"][l], TOL_ACT)
+    if sv.get("h16") is not None:
+        ok &= cmp("h_last_fp32", sv["h"][0], f["h"][pk.D - 1], TOL_ACT)
     ok &= cmp("sigma_s", sv["sigma_s"], f["sigma_s"], TOL_ACT)
     ok &= cmp("e", sv["e"], f["e"], TOL_ACT)
     if s["use_cand"]:

@@ -35,7 +35,8 @@ class FieldFwdArgs(C.Structure):
                 ("wk_xyz", C.c_float * 10), ("P", _fp),
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
                 ("x0", _fp), ("h", _fp), ("hmask", _fp), ("amax", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp),
-                ("P16", _fp), ("wexp", _fp), ("wk_xyz_dev", _fp), ("planes", C.c_int32), ("wnorm", _fp)]
+                ("P16", _fp), ("wexp", _fp), ("wk_xyz_dev", _fp), ("planes", C.c_int32), ("wnorm", _fp),
+                ("h16", _fp), ("hexp", _fp), ("h_last_only", C.c_int32)]
 
 
 class CompositeFwdArgs(C.Structure):
@@ -66,7 +67,7 @@ class FieldBwdArgs(C.Structure):
                 ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp), ("hmask", _fp), ("gmax", _fp),
                 ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp),
-                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32)]
+                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("gz16", _fp), ("gzexp", _fp)]
 
 
 class LossArgs(C.Structure):
@@ -141,6 +142,7 @@ _SIGNATURES = {
     "upnerf_frag16": [_p, _p, _p, C.POINTER(Frag16Desc), _i, C.POINTER(Frag16Desc), _i, _p, _p, _i, _i, _p, _p],
     "upnerf_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p],
+    "upnerf_wgrad_f16p": [_i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p],
     "upnerf_wgrad_grouped_scratch": [C.POINTER(WgradGroup), _i, _i],
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],

@@ -132,6 +132,21 @@ __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int
   }
 }
 
+// The hi plane of the tile (columns [0, W)) -> row-major fp16 global tensor, as it stands (16 bytes per thread and step);
+// the tile's exponent goes to its slot of the exponent table.  f16 mode only.
+template <int W, int TILE>
+__device__ __forceinline__ void tile_copy16(const char* Ph, int e, uint16_t* __restrict__ dst, int32_t* __restrict__ dexp, int m0,
+                                            int M, int tid) {
+  constexpr int GPR = W >> 3, ITER = TILE * GPR / F16_THREADS;
+  if (tid == 0) dexp[m0 / TILE] = e;
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * F16_THREADS, row = idx / GPR, g = idx % GPR;
+    const f32x4 v = *(const f32x4*)(Ph + poff<W>(row, 8 * g));
+    if (m0 + row < M) *(f32x4*)((char*)dst + ((size_t)(m0 + row) * W + 8 * g) * 2) = v;
+  }
+}
+
 __device__ __forceinline__ float wave_max(float m) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
@@ -283,7 +298,8 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * F16_THREADS + tid] = bits;
-    if (a.h) acc_store_global(acc, a.h + (size_t)l * M * W, W, m0, M, row0, n0, lane);
+    if (a.h && !(a.h16 && a.h_last_only && l != D - 1))
+      acc_store_global(acc, a.h + (a.h_last_only ? 0 : (size_t)l * M * W), W, m0, M, row0, n0, lane);
     STAMP(2);
     __syncthreads();
     STAMP(3);
@@ -295,6 +311,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     STAMP(4);
     __syncthreads();
     STAMP(5);
+    if constexpr (NP == 1) {  // fp16 storage: the plane IS the stored tile (the next write to it is a barrier away)
+      if (a.h16) tile_copy16<W, TILE>(Ph, ecur, a.h16 + (size_t)l * M * W, a.hexp + (size_t)l * gridDim.x, m0, M, tid);
+    }
     STAMP(6);
   }
 
@@ -657,7 +676,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], un, ws[nt][r >> 2][r & 3] * ps);
     }
     acc_apply_mask(acc, bits);
-    acc_store_global(acc, a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, row0, n0, lane);
+    if (a.gz_h) acc_store_global(acc, a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
@@ -666,6 +685,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     ecur = scale_exp(mx);
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
+    if constexpr (NP == 1) {
+      if (a.gz16) tile_copy16<W, TILE>(Ph, ecur, a.gz16 + (size_t)(D - 1) * M * W, a.gzexp + (size_t)(D - 1) * gridDim.x, m0, M, tid);
+    }
   }
   STAMP(2);  // d h_{D-1}
   // ---- trunk, last layer to first
@@ -683,7 +705,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)__builtin_amdgcn_readfirstlane(loff_s[l]), W / 16, n0, 0, lane);
     acc_scale(acc, pow2f(-(ecur + wel)));
     acc_apply_mask(acc, bits);
-    acc_store_global(acc, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, row0, n0, lane);
+    if (a.gz_h) acc_store_global(acc, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
@@ -692,6 +714,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     ecur = scale_exp(mx);
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
+    if constexpr (NP == 1) {
+      if (a.gz16) tile_copy16<W, TILE>(Ph, ecur, a.gz16 + (size_t)(l - 1) * M * W, a.gzexp + (size_t)(l - 1) * gridDim.x, m0, M, tid);
+    }
   }
   STAMP(3);  // D-1 trunk layers
   if (!a.need_dxyz) {
@@ -769,6 +794,7 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->planes != 0 && a->planes != 1 && a->planes != 2) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
+  if (a->h16 && (a->planes != 1 || !a->hexp || a->wnorm)) return UPNERF_EINVAL;  // fp16 storage: f16 mode, LDS-tile kernel
   if (a->wnorm) return upnerf_field16r_fwd_launch(L, a, stream);  // register-resident kernel (field16r.hip)
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
   if (a->planes == 1)
@@ -781,7 +807,7 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
 extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream) {
   int rc = check_layout16(L);
   if (rc) return rc;
-  if (!a || a->R <= 0 || a->S <= 0 || !a->P || !a->PT16 || !a->wexp || !a->d_sigma_s || !a->sigma_s || !a->gz_h ||
+  if (!a || a->R <= 0 || a->S <= 0 || !a->P || !a->PT16 || !a->wexp || !a->d_sigma_s || !a->sigma_s || (!a->gz_h && !a->gz16) ||
       !a->gz_e || !a->dpre_sig_s || !a->hmask)
     return UPNERF_EINVAL;
   if (a->S < 32) return UPNERF_EUNSUP;  // at most 3 rays per 64-sample tile
@@ -792,6 +818,7 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->g_E_s && !a->w_feat_s) return UPNERF_EINVAL;
   if (a->need_dxyz && (!a->dxyz || !a->x0)) return UPNERF_EINVAL;
   if (a->planes != 0 && a->planes != 1 && a->planes != 2) return UPNERF_EINVAL;
+  if (a->gz16 && (a->planes != 1 || !a->gzexp)) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);

@@ -690,6 +690,35 @@ extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const f
   return (int)hipGetLastError();
 }
 
+extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, const int* aexp, int N, const void* B, int ldb,
+                                         const int* bexp, int b_is_f16, int K, const int* expo_a, const int* expo_b, float* slabs,
+                                         float* bslabs, int nsplit, int rows, int TN, int TK, void* stream);
+
+// upnerf_wgrad with fp16-stored, tile-scaled operands (the f16 field mode): same slabs + fixed-order reduction.
+extern "C" int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
+                                 const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, float* slabs, int nsplit,
+                                 const int* expo_a, const int* expo_b, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A16 || !aexp || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b)
+    return UPNERF_EINVAL;
+  if (b_is_f16 && !bexp) return UPNERF_EINVAL;
+  if ((N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || (ldo & 3)) return UPNERF_EINVAL;
+  int TN, TK;
+  wgrad_shape(N, K, &TN, &TK);
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = (((M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
+  float* bslabs = slabs + (size_t)nsplit * gy * gz * TN * TK;
+  int rc = upnerf_wgrad_f16p_partial(M, A16, lda, aexp, N, B, ldb, bexp, b_is_f16, K, expo_a, expo_b, slabs, bslabs, nsplit, rows,
+                                     TN, TK, stream);
+  if (rc) return rc;
+  const int quads = N * (K / 4);
+  int rblocks = (quads + 63) / 64;
+  if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(NTHREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
+                     ldo, db);
+  return (int)hipGetLastError();
+}
+
 extern "C" int upnerf_wgrad_grouped_scratch(const upnerf_wgrad_group* groups, int ngroups, int nsplit) {
   if (!groups || ngroups <= 0 || ngroups > UPNERF_MAX_WGRAD_GROUPS || nsplit <= 0) return UPNERF_EINVAL;
   long long tiles = 0;

@@ -223,6 +223,193 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
   }
 }
 
+// ---- fp16-STORED operands (the f16 field mode, upnerf_wgrad_f16p): A16 (and B16 when PKB) hold fp16 values scaled per
+// 64-row tile by 2^exp[m / 64] (the LDS planes of the field kernels, copied out as they stood).  A thread moves 8 columns
+// (16 bytes) at a time, brings them to the tensor-wide exponent with an exact fp16 power-of-two multiply and drops them into
+// the same LDS image the fp32 path builds; one MFMA per block.  Half the HBM bytes of the fp32-stored operands.
+template <int MTW, int NTW, int PKB>
+__global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N, int K, const uint16_t* __restrict__ A, int lda,
+                                                                 const int* __restrict__ aexp, const void* __restrict__ Bv, int ldb,
+                                                                 const int* __restrict__ bexp, const int* __restrict__ expo_a,
+                                                                 const int* __restrict__ expo_b, float* __restrict__ slabs,
+                                                                 float* __restrict__ bslabs, int rows_per_split) {
+  constexpr int TN = 64 * MTW, TK = 64 * NTW;
+  constexpr int FX_CHUNK = (MTW * NTW == 16) ? FX_CHUNK_BIG : 32;
+  constexpr int PN = (TN + 127) / 128, PK = (TK + 127) / 128;
+  constexpr int SZA = PN * FX_CHUNK * 256, SZB = PK * FX_CHUNK * 256;
+  constexpr int A8 = FX_CHUNK * TN / 8 / FX_THREADS;                       // 16-byte pieces of A per thread
+  constexpr int B8 = PKB ? FX_CHUNK * TK / 8 / FX_THREADS : 0;             // ... of a packed B
+  constexpr int B4 = PKB ? 0 : FX_CHUNK * TK / 4 / FX_THREADS;             // 16-byte pieces of an fp32 B
+  static_assert(A8 >= 1 && (B8 >= 1 || B4 >= 1), "tile too small for 512 threads");
+  constexpr int WK = (TK >= 128) ? 4 : 2, WN = 8 / WK;
+  constexpr int MT = (TN / WN >= 32) ? TN / WN / 32 : 1, NT = TK / WK / 32;
+  static_assert(TN / WN >= 32, "packed variant is built for 256-row blocks");
+  __shared__ __attribute__((aligned(16))) char lds[2 * (SZA + SZB)];  // [buffer][A | B], one plane each
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int wn = wave / WK, wk = wave % WK;
+  const int n0 = wn * 32 * MT, k0 = wk * 32 * NT;
+  const int split = blockIdx.x;
+  const int nblk = blockIdx.y * TN, kblk = blockIdx.z * TK;
+  const int mbeg = split * rows_per_split;
+  const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  const int ea = expo_a[0], eb = expo_b[0];
+  const float* __restrict__ Bf = (const float*)Bv;
+  const uint16_t* __restrict__ Bh = (const uint16_t*)Bv;
+
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this thread's 8 columns of A, summed over its rows (natural units)
+
+  h8 ra0[A8], ra1[A8], rbp0[B8 ? B8 : 1], rbp1[B8 ? B8 : 1];
+  f32x4 rbf0[B4 ? B4 : 1], rbf1[B4 ? B4 : 1];
+  int xa0[A8], xa1[A8], xb0[B8 ? B8 : 1], xb1[B8 ? B8 : 1];  // tile exponents of the rows just loaded
+  const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto gload = [&](h8 (&ra)[A8], int (&xa)[A8], h8 (&rbp)[B8 ? B8 : 1], int (&xb)[B8 ? B8 : 1], f32x4 (&rbf)[B4 ? B4 : 1], int mc) {
+#pragma unroll
+    for (int q = 0; q < A8; ++q) {
+      const int idx = tid + q * FX_THREADS, row = idx / (TN / 8), c8 = idx - row * (TN / 8);
+      const int m = mc + row;
+      const bool ok = m < mend && nblk + 8 * c8 < N;
+      ra[q] = ok ? *(const h8*)&A[(size_t)m * lda + nblk + 8 * c8] : zero8;
+      xa[q] = ok ? aexp[m >> 6] : 0;
+    }
+    if constexpr (PKB) {
+#pragma unroll
+      for (int q = 0; q < B8; ++q) {
+        const int idx = tid + q * FX_THREADS, row = idx / (TK / 8), c8 = idx - row * (TK / 8);
+        const int m = mc + row;
+        const bool ok = m < mend && kblk + 8 * c8 < K;
+        rbp[q] = ok ? *(const h8*)&Bh[(size_t)m * ldb + kblk + 8 * c8] : zero8;
+        xb[q] = ok ? bexp[m >> 6] : 0;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < B4; ++q) {
+        const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
+        const int m = mc + row;
+        rbf[q] = (m < mend && kblk + 4 * c4 < K) ? *(const f32x4*)&Bf[(size_t)m * ldb + kblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto pw2h = [](int e) {  // 2^e as fp16 (e clamped to what fp16 holds; far-below-maximum tiles flush towards zero)
+    e = e > 15 ? 15 : (e < -24 ? -24 : e);
+    return (_Float16)ldexpf(1.0f, e);
+  };
+  auto lstore = [&](const h8 (&ra)[A8], const int (&xa)[A8], const h8 (&rbp)[B8 ? B8 : 1], const int (&xb)[B8 ? B8 : 1],
+                    const f32x4 (&rbf)[B4 ? B4 : 1], int buf) {
+    char* base = lds + buf * (SZA + SZB);
+#pragma unroll
+    for (int q = 0; q < A8; ++q) {
+      const int idx = tid + q * FX_THREADS, row = idx / (TN / 8), c8 = idx - row * (TN / 8);
+      const float inv = ldexpf(1.0f, -xa[q]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum[j] += (float)ra[q][j] * inv;
+      const _Float16 f = pw2h(ea - xa[q]);
+      h8 v = ra[q];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * f;
+      *(h8*)(base + himg<FX_CHUNK>(row, 8 * c8)) = v;
+    }
+    if constexpr (PKB) {
+#pragma unroll
+      for (int q = 0; q < B8; ++q) {
+        const int idx = tid + q * FX_THREADS, row = idx / (TK / 8), c8 = idx - row * (TK / 8);
+        const _Float16 f = pw2h(eb - xb[q]);
+        h8 v = rbp[q];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * f;
+        *(h8*)(base + SZA + himg<FX_CHUNK>(row, 8 * c8)) = v;
+      }
+    } else {
+      const float sb = ldexpf(1.0f, eb);
+#pragma unroll
+      for (int q = 0; q < B4; ++q) {
+        const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+        const hh2 h0 = __builtin_convertvector(f2{rbf[q][0], rbf[q][1]} * sb, hh2), h1 = __builtin_convertvector(f2{rbf[q][2], rbf[q][3]} * sb, hh2);
+        *(h4*)(base + SZA + himg<FX_CHUNK>(row, 4 * c4)) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+      }
+    }
+  };
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int trow = 8 * (g >> 1) + tq, tcol = 16 * (g & 1) + 4 * tp;
+  auto contract = [&](int buf) {
+    const char* base = lds + buf * (SZA + SZB);
+#pragma unroll
+    for (int kk = 0; kk < FX_CHUNK / 16; ++kk) {
+      h8 ah[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int o0 = himg<FX_CHUNK>(16 * kk + trow, n0 + 32 * mt + tcol), o1 = himg<FX_CHUNK>(16 * kk + trow + 4, n0 + 32 * mt + tcol);
+        const h4 x0 = tr_read(base, o0), x1 = tr_read(base, o1);
+        ah[mt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int o0 = himg<FX_CHUNK>(16 * kk + trow, k0 + 32 * nt + tcol), o1 = himg<FX_CHUNK>(16 * kk + trow + 4, k0 + 32 * nt + tcol);
+        const h4 x0 = tr_read(base + SZA, o0), x1 = tr_read(base + SZA, o1);
+        const h8 bh = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+      }
+    }
+  };
+  // two register sets: the loads of chunk c+2 are in flight while chunk c is contracted (rows beyond mend load as zeros)
+  gload(ra0, xa0, rbp0, xb0, rbf0, mbeg);
+  gload(ra1, xa1, rbp1, xb1, rbf1, mbeg + FX_CHUNK);
+#pragma unroll 1
+  for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
+    lstore(ra0, xa0, rbp0, xb0, rbf0, 0);
+    __syncthreads();
+    gload(ra0, xa0, rbp0, xb0, rbf0, mc + 2 * FX_CHUNK);
+    contract(0);
+    lstore(ra1, xa1, rbp1, xb1, rbf1, 1);
+    __syncthreads();
+    gload(ra1, xa1, rbp1, xb1, rbf1, mc + 3 * FX_CHUNK);
+    contract(1);
+  }
+  const float unscale = ldexpf(1.0f, -(ea + eb));
+  const size_t blk = ((size_t)split * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+  float* slab = slabs + blk * TN * TK;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        slab[n * TK + k0 + 32 * nt + li] = acc[mt][nt][r] * unscale;
+      }
+  if (bslabs && blockIdx.z == 0) {
+    // column sums: thread t owns columns 8*(t % (TN/8)) ..+7; the threads sharing them meet in LDS
+    __syncthreads();
+    float* red = (float*)lds;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    constexpr int Q = TN / 8, G = FX_THREADS / Q;
+    if (tid < TN) {
+      const int grp = tid >> 3, j = tid & 7;
+      float sacc = 0.0f;
+#pragma unroll
+      for (int t = 0; t < G; ++t) sacc += red[(grp + t * Q) * 8 + j];
+      bslabs[((size_t)split * gridDim.y + blockIdx.y) * TN + tid] = sacc;
+    }
+  }
+}
+
+template <int MTW, int NTW, int PKB>
+int launch_p(int M, int N, int K, const uint16_t* A, int lda, const int* aexp, const void* B, int ldb, const int* bexp,
+             const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st) {
+  constexpr int TN = 64 * MTW, TK = 64 * NTW;
+  dim3 grid(nsplit, (N + TN - 1) / TN, (K + TK - 1) / TK);
+  hipLaunchKernelGGL((wgrad_f16p_kernel<MTW, NTW, PKB>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, aexp, B, ldb, bexp, expo_a,
+                     expo_b, slabs, bslabs, rows);
+  return (int)hipGetLastError();
+}
+
 template <int MTW, int NTW>
 int launch(int planes, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const int* expo_a, const int* expo_b,
            float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st) {
@@ -254,4 +441,17 @@ extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N,
   if (TN == 64 && TK == 256) return launch<1, 4>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
   if (TN == 64 && TK == 128) return launch<1, 2>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
   return launch<1, 1>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+}
+
+// Packed-operand variant behind upnerf_wgrad_f16p (gemm.hip): blocks of 256 x 256 (both operands fp16-stored) and
+// 256 x 64 (fp32 B: the encoding).  Returns UPNERF_EUNSUP for any other block shape.
+extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, const int* aexp, int N, const void* B, int ldb,
+                                         const int* bexp, int b_is_f16, int K, const int* expo_a, const int* expo_b, float* slabs,
+                                         float* bslabs, int nsplit, int rows, int TN, int TK, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (TN == 256 && TK == 256 && b_is_f16)
+    return launch_p<4, 4, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  if (TN == 256 && TK == 64 && !b_is_f16)
+    return launch_p<4, 1, 0>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+  return UPNERF_EUNSUP;
 }

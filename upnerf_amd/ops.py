@@ -199,6 +199,19 @@ def wgrad_f16x3_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor,
     check(rc, "upnerf_wgrad_f16x3")
 
 
+def wgrad_f16p_into(M: int, A16: torch.Tensor, lda: int, aexp: torch.Tensor, N: int, B: torch.Tensor, ldb: int,
+                    bexp: Optional[torch.Tensor], K: int, dW_ptr: int, ldo: int, db_ptr: Optional[int], device, expo_a: int,
+                    expo_b: int):
+    """upnerf_wgrad for the f16 field mode's fp16-STORED operands: A16 [M][lda] fp16 scaled per 64-row tile by 2^aexp[tile]
+    (gz16 / gzexp), B the same (fp16, bexp) or fp32 rows (bexp None: the encoding x0)."""
+    ns = nsplit_for(M)
+    ws = workspace("wgrad", ns * (256 * 256 + 256), device)
+    rc = TIMER.run(f"wgrad16p_{N}x{K}", lambda: lib.upnerf_wgrad_f16p(M, ptr(A16), lda, ptr(aexp), N, ptr(B), ldb, ptr(bexp),
+                                                                     int(bexp is not None), K, dW_ptr, ldo, db_ptr, ptr(ws), ns,
+                                                                     expo_a, expo_b, stream()), units=M)
+    check(rc, "upnerf_wgrad_f16p")
+
+
 def vec_wgrad_into(M: int, v: torch.Tensor, ldv: int, nvec: int, X: torch.Tensor, ldx: int, K: int, dw_ptr: int,
                    dbv_ptr: Optional[int], device):
     ns = nsplit_for(M)

@@ -20,7 +20,8 @@ import torch
 from . import _lib, step_scalars
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, X0, check, lib, ptr,
                    stream)
-from .ops import TIMER, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16x3_into, wgrad_into
+from .ops import (TIMER, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16p_into,
+                  wgrad_f16x3_into, wgrad_into)
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
@@ -138,7 +139,14 @@ class _FieldPass(torch.autograd.Function):
         # the backward pass reads -- 8 of the 11 KB per sample -- and keep what compositing needs (e, g2) plus x0.
         train = cfg.grad and any(ctx.needs_input_grad)
         x0 = _empty(M, X0, device=dev)
-        h = _empty(D, M, W, device=dev) if train else None
+        # f16 mode: trunk activations are STORED as fp16 (the kernel's LDS plane per 64-sample tile + the tile's exponent):
+        # half the bytes written here and read back by the weight-gradient kernels; fp32 only for the last layer (its
+        # consumers are the density-head and final-layer weight gradients)
+        store16 = train and use16 and FIELD_MODE == "f16" and wnorm is None
+        ntile = (M + _lib.TILE_ROWS - 1) // _lib.TILE_ROWS
+        h16 = torch.empty(D, M, W, device=dev, dtype=torch.float16) if store16 else None
+        hexp = torch.empty(D, ntile, device=dev, dtype=torch.int32) if store16 else None
+        h = (_empty(1, M, W, device=dev) if store16 else _empty(D, M, W, device=dev)) if train else None
         e = _empty(M, W, device=dev) if (train or want_feat) else None
         hmask = torch.empty((D + 1) * ((M + _lib.TILE_ROWS - 1) // _lib.TILE_ROWS) * 256, device=dev,
                             dtype=torch.int64) if train else None
@@ -151,7 +159,7 @@ class _FieldPass(torch.autograd.Function):
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
                           rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1),
                           P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None,
-                          planes=_planes(), wnorm=ptr(wnorm))
+                          planes=_planes(), wnorm=ptr(wnorm), h16=ptr(h16), hexp=ptr(hexp), h_last_only=int(store16))
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
@@ -177,7 +185,7 @@ class _FieldPass(torch.autograd.Function):
         ctx.cfg, ctx.dims, ctx.planes = cfg, (R, S), _planes()
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, hmask=hmask, amax=amax, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp,
                          w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s)
         z0 = torch.zeros(0, device=dev)
@@ -218,7 +226,11 @@ class _FieldPass(torch.autograd.Function):
         P = sv["P"]
         use16 = sv["PT16"] is not None
         PT = None if use16 else pk.frag_t_hip(P)
-        gz_h, gz_e = _empty(D, M, W, device=dev), _empty(M, W, device=dev)
+        store16 = sv.get("h16") is not None
+        gz_e = _empty(M, W, device=dev)
+        gz_h = None if store16 else _empty(D, M, W, device=dev)
+        gz16 = torch.empty(D, M, W, device=dev, dtype=torch.float16) if store16 else None
+        gzexp = torch.empty(D, sv["hexp"].shape[1], device=dev, dtype=torch.int32) if store16 else None
         gz_g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
         gz_g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
         gz_r1 = _empty(M, W2, device=dev) if cfg.use_rgb else None
@@ -235,12 +247,14 @@ class _FieldPass(torch.autograd.Function):
                           g_G_c=ptr(gG), x0=ptr(sv["x0"]), h=ptr(sv["h"]), g1=ptr(sv["g1"]), g2=ptr(sv["g2"]),
                           r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
-                          dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes)
+                          dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, gz16=ptr(gz16),
+                          gzexp=ptr(gzexp))
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
         check(TIMER.run("field_bwd", lambda: bwd_fn(C.byref(L), C.byref(fb), st), units=M), "upnerf_field_bwd")
 
         if _DEBUG_SINK is not None:
-            _DEBUG_SINK.update(d_sigma_s=d_sigma_s, d_sigma_c=d_sigma_c, d_rgb=d_rgb, gz_h=gz_h, gz_e=gz_e, gz_g1=gz_g1,
+            _DEBUG_SINK.update(d_sigma_s=d_sigma_s, d_sigma_c=d_sigma_c, d_rgb=d_rgb,
+                               gz_h=gz_h if gz_h is not None else dequant16(gz16, gzexp), gz_e=gz_e, gz_g1=gz_g1,
                                gz_g2=gz_g2, gz_r1=gz_r1, dpre_s=dpre_s, dpre_c=dpre_c, dpre_rgb=dpre_rgb, dxyz=dxyz)
         # ---- weight gradients, written straight into a buffer with P's layout
         dP = torch.zeros(L.total, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
@@ -261,7 +275,22 @@ class _FieldPass(torch.autograd.Function):
                 wgrad_f16x3_into(M, gz, lda, N, Bt, ldb, K, at(off), ldo, None if boff is None else at(boff), dev,
                                  expo_a=EA(ia), expo_b=EB(ib), b_off=b_off, planes=ctx.planes)
 
-            for l in range(D):
+            if store16:  # fp16-stored operands (1 KB per sample and layer instead of 2)
+                h16, hexp = sv["h16"], sv["hexp"]
+
+                def wgp(l, B, ldb, bexp, K, off, ldo, boff, ib):
+                    wgrad_f16p_into(M, gz16[l], W, gzexp[l], W, B, ldb, bexp, K, at(off), ldo, None if boff is None else at(boff),
+                                    dev, EA(l), EB(ib))
+
+                for l in range(D):
+                    if l == 0:
+                        wgp(0, x0, X0, None, X0, L.w[0], X0, L.b[0], D + 4)
+                    elif l == pk.skip:
+                        wgp(l, x0, X0, None, X0, L.w[l], X0 + W, L.b[l], D + 4)
+                        wgp(l, h16[l - 1], W, hexp[l - 1], W, L.w[l] + X0, X0 + W, None, l - 1)
+                    else:
+                        wgp(l, h16[l - 1], W, hexp[l - 1], W, L.w[l], W, L.b[l], l - 1)
+            for l in (range(D) if not store16 else ()):
                 gz = gz_h[l]
                 if l == 0:
                     wg(gz, W, W, x0, X0, X0, L.w[0], X0, L.b[0], 0, D + 4)
@@ -270,8 +299,9 @@ class _FieldPass(torch.autograd.Function):
                     wg(gz, W, W, h[l - 1], W, W, L.w[l] + X0, X0 + W, None, l, l - 1)
                 else:
                     wg(gz, W, W, h[l - 1], W, W, L.w[l], W, L.b[l], l, l - 1)
-            wg(gz_e, W, W, h[D - 1], W, W, L.we, W, L.be, D, D - 1)
-            vec_wgrad_into(M, dpre_s, 1, 1, h[D - 1], W, W, at(L.wsig), at(L.bsig), dev)
+            h_last = h[0] if store16 else h[D - 1]
+            wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
+            vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
         if cfg.use_cand:
             rs = _empty(R, W2, device=dev)
             check(lib.upnerf_ray_sum(R, S, ptr(gz_g1), W2, ptr(rs), st), "upnerf_ray_sum")
@@ -297,6 +327,13 @@ class _FieldPass(torch.autograd.Function):
             check(lib.upnerf_ray_geom_bwd(R, S, ptr(dxyz), ptr(sv["z"]), ptr(d_o), ptr(d_d), st), "upnerf_ray_geom_bwd")
         ctx.saved = None
         return d_o, d_d, None, d_c_rows, d_a_rows, dP, None
+
+
+def dequant16(t16: torch.Tensor, texp: torch.Tensor) -> torch.Tensor:
+    """fp32 view of an fp16-stored, tile-scaled tensor [D][M][W] with exponents [D][ceil(M/64)] (tests, debugging)."""
+    D, M, W = t16.shape
+    scale = torch.ldexp(torch.ones((), device=t16.device), -texp.float()).repeat_interleave(_lib.TILE_ROWS, dim=1)[:, :M]
+    return t16.float() * scale[:, :, None]
 
 
 def sample_pdf(z_coarse: torch.Tensor, weights: torch.Tensor, n: int, det: bool, out: torch.Tensor, col0: int,
