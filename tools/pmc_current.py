@@ -1,0 +1,32 @@
+"""Write profiles/pmc_current.json: the HBM bytes per launch bench.py puts into `roofline.traffic`, tagged with the hash
+of the HIP sources they were measured on (bench.py ignores the file when the hash, field mode, config or progress differ).
+
+    python tools/pmc_current.py profiles/r02_pmc.json --field f16x3 --config brandenburg --progress 0.3
+"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("pmc_json")
+ap.add_argument("--field", default="f16x3")
+ap.add_argument("--config", default="brandenburg")
+ap.add_argument("--progress", type=float, default=0.3)
+a = ap.parse_args()
+pmc = json.load(open(a.pmc_json))
+np_ = "1" if a.field == "f16" else "2"
+pick = {"field_fwd": (f"field16_fwd_kernel<{np_}, 64>" if a.field != "f32" else "field_fwd_kernel<256, 64>"),
+        "field_bwd": (f"field16_bwd_kernel<{np_}, 64>" if a.field != "f32" else "field_bwd_kernel<256, 64>"),
+        "wgrad16_256x256": f"wgrad_f16x3_kernel<{np_}, 4, 4>", "wgrad16p_256x256": "wgrad_f16p_kernel<4, 4, 1>",
+        "wgrad_256x256": "wgrad_kernel<4, 4>"}
+kern = {}
+for name, key in pick.items():
+    t = pmc.get(key)
+    if t and "fetch_bytes_per_launch" in t and "write_bytes_per_launch" in t:
+        kern[name] = {"kernel": key, "fetch_bytes_per_launch": t["fetch_bytes_per_launch"],
+                      "write_bytes_per_launch": t["write_bytes_per_launch"], "mfma_busy": t.get("mfma_busy")}
+out = {"src_sha16": bench.source_sha16(), "field": a.field, "config": a.config, "progress": a.progress,
+       "file": os.path.basename(a.pmc_json), "kernels": kern}
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_current.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

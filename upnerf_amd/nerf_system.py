@@ -147,6 +147,22 @@ class NeRFSystem(_Base):
         B = rays.shape[0]
         results = defaultdict(list)
         chunk = B if train else hp["val.chunk_size"]
+        # TransientNet (models/nerf_system.py:128-146) depends on the batch only, not on the rendering: with
+        # hparams["hip.side_stream"] its ~20 small launches (and, through autograd's stream bookkeeping, their backward)
+        # run on a side stream BESIDE the field kernels; the blend below waits for it.  Off by default: measured 19.89 vs
+        # 20.0 ms per step (inside the noise), and a captured graph with a fork / join costs the host 9 ms per replay
+        # instead of 0.3 (hipGraphLaunch walks the branches synchronously).
+        t_side = None
+        if (train and sched_mult > 0 and self.transient_net is not None and rays.is_cuda
+                and hp.get("hip.side_stream", False)):
+            cur = torch.cuda.current_stream(rays.device)
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(rays.device)
+            self._side_stream.wait_stream(cur)
+            with torch.cuda.stream(self._side_stream):
+                t_side = self.transient_net(feats, img_idx)
+            for v in t_side.values():
+                v.record_stream(cur)  # consumed by the blend / loss on the main stream
         for i in range(0, B, chunk):
             out = render_rays(models=self.models, embeddings=self.embeddings, rays=rays[i:i + chunk],
                               img_idx=img_idx[i:i + chunk], sched_mult=sched_mult, sched_phase=sched_phase,
@@ -160,7 +176,11 @@ class NeRFSystem(_Base):
         results = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in results.items()}
         if sched_mult > 0:
             if self.transient_net is not None:
-                t = self.transient_net(feats, img_idx)
+                if t_side is not None:
+                    torch.cuda.current_stream(rays.device).wait_stream(self._side_stream)
+                    t = t_side
+                else:
+                    t = self.transient_net(feats, img_idx)
                 t_rgbs, t_alphas, t_betas = t["rgb"], t["alpha"], t["beta"]
                 results["rgb_coarse"] = results["s_rgb_coarse"] * (1 - t_alphas.detach()) \
                     + t_rgbs.detach() * t_alphas.detach()
