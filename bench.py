@@ -24,6 +24,7 @@ Extra objects on the line:
                 between graph nodes), so the events bracket the same kernels in eager steps run right after it.
   phases        the three schedule phases BASELINE configs[1] asks for (progress 0.05 / 0.3 / 0.8), same K and W each
   strict_f32    the same step with every contraction on the fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of the f16x3 split
+  wgrad_f16     the same step with fp16-stored operands for the trunk weight gradients (an option; see its note)
   cpu_baseline  the CPU oracle (oracle/upnerf_oracle.py, a port of the reference's arithmetic) timed on this box's host
                 cores on a bounded sample of the same workload incl. the Adam update (rank 0, N == 1 only).
 """
@@ -167,7 +168,7 @@ class Bench:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def leg(self, progress, field, graph, timer_only=None, steps=None, warmup=None):
+    def leg(self, progress, field, graph, timer_only=None, steps=None, warmup=None, wgrad_store=None):
         """Build a fresh system, warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks)."""
         import torch
         import torch.distributed as dist
@@ -177,6 +178,7 @@ class Bench:
         steps = self.args.steps if steps is None else steps
         warmup = self.args.warmup if warmup is None else warmup
         rendering.FIELD_MODE = field
+        rendering.WGRAD_STORE = wgrad_store or "f32"
         sysm = build_system(self.dev, progress, self.rays, self.n_images)
         if self.world > 1:
             sysm.enable_data_parallel()
@@ -286,6 +288,15 @@ def main():
         for p in (0.05, 0.3, 0.8):
             phases[str(p)] = main_leg if abs(p - args.progress) < 1e-9 else B.leg(p, field, graph)[0]
         extras["phases"] = {k: {x: v[x] for x in ("value", "ms_per_step", "sched_mult")} for k, v in phases.items()}
+        if field == "f16x3":
+            w16, _ = B.leg(args.progress, field, graph, wgrad_store="f16")
+            extras["wgrad_f16"] = {"value": w16["value"], "ms_per_step": w16["ms_per_step"],
+                                   "note": "same step with the operands of the trunk WEIGHT gradients (activations and their "
+                                           "gradients) stored as fp16 tiles + per-tile exponents: half the HBM bytes of the "
+                                           "field / weight-gradient kernels, one MFMA per product in dW = gz^T h.  Forward pass "
+                                           "and data-gradient chain are unchanged (bitwise the outputs of `value`); a weight "
+                                           "gradient carries ~3e-4 of unbiased rounding noise (golden gradient gates 1e-3 stay "
+                                           "green, tests/test_hip_parity.py).  An option (rendering.WGRAD_STORE), not `value`."}
         if field != "f32":
             f32, _ = B.leg(args.progress, "f32", graph)
             extras["strict_f32"] = {"value": f32["value"], "ms_per_step": f32["ms_per_step"], "dtype": "f32",

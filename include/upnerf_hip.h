@@ -150,8 +150,9 @@ typedef struct {
                                     upnerf_frag16, P16 written with perm_fwd = 1): the register-resident kernel (128 samples per
                                     workgroup, activations chained through registers, weights staged ONCE per workgroup in
                                     LDS by DMA).  Same outputs, same hmask layout: either forward kernel pairs with upnerf_field_bwd_f16x3 */
-  /* f16 mode (planes == 1) with fp16 STORAGE of the trunk activations: halves what the pass writes and what the weight-
-   * gradient kernels read back (upnerf_wgrad_f16p).  h16[l][m][k] = fp16(h_l[m][k] * 2^hexp[l][m / 64]): the content of the
+  /* fp16 STORAGE of the trunk activations (always in the f16 mode; an option in the f16x3 mode, where it rounds only the
+   * operands of the weight gradients): halves what the pass writes and what the weight-gradient kernels read back
+   * (upnerf_wgrad_f16p).  h16[l][m][k] = fp16(h_l[m][k] * 2^hexp[l][m / 64]): the content of the
    * LDS plane of the 64-sample tile, copied out as it stands, with the tile's power-of-two exponent beside it. */
   uint16_t* h16;                 /* [D][M][W] fp16 bits, or NULL (fp32 `h` as above) */
   int32_t* hexp;                 /* [D][ceil(M/64)] */
@@ -251,7 +252,7 @@ typedef struct {
   const void* PT16;              /* transposed set of upnerf_frag16 */
   const int32_t* wexp;           /* [16] */
   int32_t planes;                /* as in upnerf_field_fwd_args: 0 / 2 = f16x3, 1 = f16 */
-  uint16_t* gz16;                /* f16 mode: [D][M][W] fp16 bits of gz_h, tile-scaled like h16 (then gz_h may be NULL) */
+  uint16_t* gz16;                /* [D][M][W] fp16 bits of gz_h, tile-scaled like h16 (then gz_h may be NULL) */
   int32_t* gzexp;                /* [D][ceil(M/64)] */
 } upnerf_field_bwd_args;
 

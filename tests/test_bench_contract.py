@@ -31,6 +31,7 @@ def test_default_shape_bench_line():
     assert set(d["phases"]) == {"0.05", "0.3", "0.8"} and all(v["value"] > 50_000 for v in d["phases"].values())
     assert d["phases"]["0.3"]["value"] == d["value"]
     assert d["strict_f32"]["dtype"] == "f32" and 50_000 < d["strict_f32"]["value"] < d["value"]
+    assert d["wgrad_f16"]["value"] > 0.95 * d["value"] and "option" in d["wgrad_f16"]["note"]
     rays = d["config"]["rays_per_gpu"]
     assert rays == 4096 and d["config"]["N_samples"] == 64 and d["config"]["N_importance"] == 128
     assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

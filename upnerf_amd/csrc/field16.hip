@@ -311,9 +311,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     STAMP(4);
     __syncthreads();
     STAMP(5);
-    if constexpr (NP == 1) {  // fp16 storage: the plane IS the stored tile (the next write to it is a barrier away)
-      if (a.h16) tile_copy16<W, TILE>(Ph, ecur, a.h16 + (size_t)l * M * W, a.hexp + (size_t)l * gridDim.x, m0, M, tid);
-    }
+    // fp16 storage: the (hi) plane IS the stored tile -- the next write to it is a barrier away.  (f16x3 mode: an option;
+    // the weight-gradient operand then is the activation rounded to fp16, the forward chain keeps hi + lo.)
+    if (a.h16) tile_copy16<W, TILE>(Ph, ecur, a.h16 + (size_t)l * M * W, a.hexp + (size_t)l * gridDim.x, m0, M, tid);
     STAMP(6);
   }
 
@@ -685,9 +685,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     ecur = scale_exp(mx);
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
-    if constexpr (NP == 1) {
-      if (a.gz16) tile_copy16<W, TILE>(Ph, ecur, a.gz16 + (size_t)(D - 1) * M * W, a.gzexp + (size_t)(D - 1) * gridDim.x, m0, M, tid);
-    }
+    if (a.gz16) tile_copy16<W, TILE>(Ph, ecur, a.gz16 + (size_t)(D - 1) * M * W, a.gzexp + (size_t)(D - 1) * gridDim.x, m0, M, tid);
   }
   STAMP(2);  // d h_{D-1}
   // ---- trunk, last layer to first
@@ -714,9 +712,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     ecur = scale_exp(mx);
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
-    if constexpr (NP == 1) {
-      if (a.gz16) tile_copy16<W, TILE>(Ph, ecur, a.gz16 + (size_t)(l - 1) * M * W, a.gzexp + (size_t)(l - 1) * gridDim.x, m0, M, tid);
-    }
+    if (a.gz16) tile_copy16<W, TILE>(Ph, ecur, a.gz16 + (size_t)(l - 1) * M * W, a.gzexp + (size_t)(l - 1) * gridDim.x, m0, M, tid);
   }
   STAMP(3);  // D-1 trunk layers
   if (!a.need_dxyz) {
@@ -794,7 +790,7 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->planes != 0 && a->planes != 1 && a->planes != 2) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
-  if (a->h16 && (a->planes != 1 || !a->hexp || a->wnorm)) return UPNERF_EINVAL;  // fp16 storage: f16 mode, LDS-tile kernel
+  if (a->h16 && (!a->hexp || a->wnorm)) return UPNERF_EINVAL;  // fp16 storage: LDS-tile kernel only
   if (a->wnorm) return upnerf_field16r_fwd_launch(L, a, stream);  // register-resident kernel (field16r.hip)
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
   if (a->planes == 1)
@@ -818,7 +814,7 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->g_E_s && !a->w_feat_s) return UPNERF_EINVAL;
   if (a->need_dxyz && (!a->dxyz || !a->x0)) return UPNERF_EINVAL;
   if (a->planes != 0 && a->planes != 1 && a->planes != 2) return UPNERF_EINVAL;
-  if (a->gz16 && (a->planes != 1 || !a->gzexp)) return UPNERF_EINVAL;
+  if (a->gz16 && !a->gzexp) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
