@@ -480,6 +480,19 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     assert ok, "BWD over tolerance: " + repr(errs)
 
 
+@pytest.mark.parametrize("name,typ", [("cfg2_phase0", "coarse"), ("cfg2_phase1", "fine"), ("cfg2_phase2", "fine"),
+                                      ("cfg2_trained_p045", "fine")])
+def test_register_resident_forward_kernel_stage_by_stage(hip, name, typ, monkeypatch):
+    """csrc/field16r.hip (activations chained through registers, weights staged once per 128-sample workgroup in LDS; not the
+    default) against the same fp32 restatement and gates as the default kernel, paired with the default
+    backward kernel (it writes the ReLU masks in that kernel's layout)."""
+    rd = hip["rendering"]
+    monkeypatch.setattr(rd, "FIELD_FWD_KERNEL", "regs")
+    monkeypatch.setattr(rd, "FIELD_MODE", "f16x3")
+    test_field_pass_stage_by_stage.__wrapped__(hip, name, typ, "f16x3") if hasattr(test_field_pass_stage_by_stage, "__wrapped__") \
+        else test_field_pass_stage_by_stage(hip, name, typ, "f16x3")
+
+
 @pytest.mark.parametrize("R,S,mode,use_cand,use_rgb", [(7, 40, 1, True, True), (5, 33, 0, True, False),
                                                          (3, 200, 2, False, True), (9, 32, 3, False, False)])
 def test_field_f16x3_matches_fp32_kernels_on_ragged_tiles(hip, R, S, mode, use_cand, use_rgb):
