@@ -76,10 +76,13 @@ def test_replayed_steps_are_bitwise_the_eager_steps(perturb):
         step = GraphedTrainingStep(s) if mode == "graph" else s.training_step
         torch.manual_seed(123)
         torch.cuda.manual_seed(123)
-        losses = []
+        losses, other = [], torch.zeros(64, device="cuda")
         for i in range(26):
             loss = step(batches[i % 3], i)
             losses.append(float(loss.detach()))
+            # device work of somebody else on the null stream between the steps (a validation render, a logger): a memset node
+            # inside the replayed graph once lost its place in the order after exactly this (csrc/gemm.hip zero_floats_kernel)
+            other.add_(1.0)
         torch.cuda.synchronize()
         runs[mode] = (_state(s), losses, dict(s.logged), step.stats if mode == "graph" else None)
     st = runs["graph"][3]

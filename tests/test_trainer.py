@@ -106,6 +106,16 @@ def test_fit_validates_checkpoints_and_resumes_bitwise(tmp_path):
     for k in sa:
         assert torch.equal(sa[k], sc[k]), k
     assert [h["val/psnr"] for h in tc.history] == [h["val/psnr"] for h in ta.history if h["step"] > 12]
+    assert ta.step_fn.stats["replays"] > 0  # the loop replays captured graphs ...
+
+    # ... and lands on the bits of the eager loop
+    torch.manual_seed(11)
+    d = _system(I)
+    td = Trainer(MAX, val_check_interval=0.25, dirpath=str(tmp_path / "d"), seed=3, graph=False).fit(d, batches, n_batches, val)
+    sd = d.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sd[k]), k
+    assert [h["val/psnr"] for h in td.history] == [h["val/psnr"] for h in ta.history]
 
 
 @pytest.mark.gpu
@@ -201,3 +211,47 @@ def test_tto_stages_recover_the_appearance_and_pose_of_a_held_out_image():
     tr2 = run_stage(app, batches, 4, max_epochs=3, val_batches=[b])
     assert len(tr2.history) == 3 and app.global_step == 3 * 4 and all(torch.isfinite(p).all() for p in app.parameters())
     assert all(p.grad is None for p in app.nerf_fine.parameters())  # frozen fields: no weight gradients computed
+
+
+@pytest.mark.gpu
+def test_evaluation_route_from_a_checkpoint(tmp_path):
+    """eval.py:13-42 + nerf_system_optmize.py:254-317 on a checkpoint file: pose error of the training cameras after Sim(3)
+    alignment, then a TTO system with the checkpoint's fields whose held-out camera starts from the aligned ground truth,
+    and a full-image render from it."""
+    from upnerf_amd import synth
+    from upnerf_amd.checkpoint import save_checkpoint
+    from upnerf_amd.nerf_system_optimize import eval_train_poses, tto_from_checkpoint
+    from upnerf_amd.pose_align import refined_poses
+    I = 6
+    trained = _system(I)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        trained.se3_refine.weight.copy_((torch.rand(I, 6, generator=g) - 0.5).cuda() * torch.tensor([.4, .4, .4, 2., 2., 2.]).cuda())
+    path = save_checkpoint(trained, str(tmp_path / "last.ckpt"))
+    ident = torch.eye(3, 4).repeat(I, 1, 1)
+    frame = refined_poses(trained.se3_refine.weight, ident.cuda()).cpu()  # cameras in the trained frame
+    # ground truth = the same cameras seen from a world that differs by one similarity (c2w convention: R' = QR, t' = sQt+b)
+    Q = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    Q = Q * torch.sign(torch.linalg.det(Q))
+    to_gt = lambda P: torch.cat([Q @ P[..., :3], 1.8 * (Q @ P[..., 3:]) + torch.tensor([[0.5], [-0.2], [1.0]])], -1)
+    out = eval_train_poses(path, ident, to_gt(frame))
+    assert out["train/pose_R"] < 0.05 and out["train/pose_t"] < 1e-4  # degrees (acos floor near 0) / scene units
+    worse = eval_train_poses(path, ident, to_gt(frame.roll(1, 0)))
+    assert worse["train/pose_R"] > 1.0
+
+    held_out = torch.cat([frame[:2, :, :3], frame[:2, :, 3:] + 0.3], -1)  # two cameras that were not trained on
+    tto, init = tto_from_checkpoint(path, pose_optimize=True, n_test_images=2, gt_train_poses=to_gt(frame),
+                                    gt_test_poses=to_gt(held_out), **{"val.chunk_size": 96})
+    assert float((init - held_out).abs().max()) < 2e-5
+    sd = trained.state_dict()
+    for k, v in tto.nerf_fine.state_dict().items():
+        if k != "progress":  # test-time optimisation runs with every encoding band on (nerf_system_optmize.py:265)
+            assert torch.equal(v, sd["nerf_fine." + k]), k
+    assert tto.embedding_fine_a.weight.shape[0] == 2 and float(tto.se3_refine.weight.abs().max()) == 0.0
+    b = {k: v.cuda() for k, v in synth.batch(400, 2, seed=3).items()}  # one 20x20 "image" of test camera 1
+    b["img_idx"] = torch.ones_like(b["img_idx"])
+    b["c2w"] = init[1].cuda().expand(400, 3, 4).contiguous()
+    res = tto.validation_step(b)
+    assert res["s_rgb_fine"].shape == (400, 3) and torch.isfinite(res["s_rgb_fine"]).all() and torch.isfinite(res["val_psnr"])
+    whole = tto.validation_step({k: v[:96] for k, v in b.items()})["s_rgb_fine"]  # chunked render == one chunk
+    assert torch.equal(res["s_rgb_fine"][:96], whole)

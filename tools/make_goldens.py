@@ -29,7 +29,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 
-_ed = types.ModuleType("easydict"); _ed.EasyDict = dict; sys.modules["easydict"] = _ed
+class _AttrDict(dict):  # procrustes_analysis (camera.py:381) returns edict(...) and its callers read fields as attributes
+    __getattr__ = dict.__getitem__
+
+
+_ed = types.ModuleType("easydict"); _ed.EasyDict = _AttrDict; sys.modules["easydict"] = _ed
 _ko = types.ModuleType("kornia"); _ko.create_meshgrid = None; sys.modules["kornia"] = _ko
 sys.path.insert(0, REF)
 
@@ -253,6 +257,61 @@ def leaf_fixtures():
     print("leaf fixtures written")
 
 
+def pose_align_fixture():
+    """Pose evaluation / TTO pose initialisation: eval.py:28-40 and nerf_system_optmize.py:279-317.  utils/metric.py cannot
+    be imported (lpips, kornia.losses are absent), so its three pose helpers (metric.py:34-62: a dozen lines of glue over
+    utils/camera.py) are re-stated here with the reference's own camera functions, as run_case does for nerf_system.py."""
+    P, lie = ref_camera.pose, ref_camera.lie
+
+    def parse_raw(p):  # metric.py:34-39
+        flip = P(R=torch.diag(torch.tensor([1, -1, -1])))
+        return P.compose([flip, P.invert(P.compose([flip, p[:3]]))])
+
+    def prealign(pose, gt):  # metric.py:42-52
+        z = torch.zeros(1, 1, 3)
+        c, cg = ref_camera.cam2world(z, pose)[:, 0], ref_camera.cam2world(z, gt)[:, 0]
+        s = ref_camera.procrustes_analysis(cg, c)
+        ca = (c - s.t1) / s.s1 @ s.R.t() * s.s0 + s.t0
+        Ra = pose[..., :3] @ s.R.t()
+        return P(R=Ra, t=(-Ra @ ca[..., None])[..., 0]), s
+
+    N, T = 12, 3
+    gt_se3 = synth.uniform("pa_gt", (N + T, 6), 5) * torch.tensor([0.6, 0.6, 0.6, 2.0, 2.0, 2.0])
+    gt_all = lie.se3_to_SE3(gt_se3)
+    gt_train, gt_test = gt_all[:N], gt_all[N:]
+    # the trained frame: GT moved by one similarity (rotation, scale 1.7, shift) + a small per-camera error; built on the
+    # camera centres / world-to-camera rotations the way the alignment itself reads them
+    G = lie.se3_to_SE3(torch.tensor([0.3, -0.2, 0.5, 0.4, -0.1, 0.2]))
+    R_g = G[:, :3]
+    noise = lie.se3_to_SE3(synth.uniform("pa_noise", (N, 6), 5) * 0.02)
+    raw = []
+    for i in range(N):
+        R, t = gt_train[i, :, :3], gt_train[i, :, 3]
+        raw.append(P.compose([noise[i], P(R=R_g @ R, t=1.7 * (R_g @ t) + G[:, 3])]))
+    noised = torch.stack(raw)
+    se3 = synth.uniform("pa_se3", (N, 6), 5) * 0.05
+    refined = P.compose([lie.se3_to_SE3(se3), noised])  # eval.py:33-34
+    pr = torch.stack([parse_raw(p) for p in refined.float()])
+    gt = torch.stack([parse_raw(p) for p in gt_train.float()])
+    al, s = prealign(pr, gt)
+    R_err = ref_camera.rotation_distance(al[..., :3], gt[..., :3])  # metric.py:55-62
+    t_err = (al[..., 3] - gt[..., 3]).norm(dim=-1)
+    # TTO initial poses (nerf_system_optmize.py:279-317), with the trained se(3) composed with identity poses (line 286)
+    ref_id = P.compose([lie.se3_to_SE3(se3), torch.stack([torch.eye(3, 4)] * N)])
+    pr_id = torch.stack([parse_raw(p) for p in ref_id.float()])
+    _, s2 = prealign(pr_id, gt)
+    te = torch.stack([parse_raw(p) for p in gt_test.float()])
+    cg = ref_camera.cam2world(torch.zeros(1, 1, 3), te)[:, 0]
+    ca = (cg - s2.t0) / s2.s0 @ s2.R * s2.s1 + s2.t1
+    Ra = te[..., :3] @ s2.R
+    init = torch.stack([parse_raw(p) for p in P(R=Ra, t=(-Ra @ ca[..., None])[..., 0]).float()])
+    out = {"se3": se3, "noised": noised, "gt_train": gt_train, "gt_test": gt_test, "refined": refined, "eval_pred": pr,
+           "eval_gt": gt, "aligned": al, "sim_R": s.R, "sim_t0": s.t0, "sim_t1": s.t1, "sim_s0": s.s0, "sim_s1": s.s1,
+           "R_err": R_err, "t_err": t_err, "refined_identity": ref_id, "init_test": init}
+    np.savez_compressed(os.path.join(OUT, "pose_align.npz"), **{k: np.asarray(v) for k, v in out.items()})
+    print("pose alignment fixture written; mean R error (deg)", float(R_err.mean()) * 180 / math.pi, "t", float(t_err.mean()))
+
+
 def sampler_fixture():
     """Train-split ray sampler (datasets/phototourism.py:420-454): the REAL PhototourismDataset.__getitem__ run on small
     synthetic buffers (three images of different sizes, one 6x6x384 feature map each), default-collated.  The dataset
@@ -399,6 +458,8 @@ if __name__ == "__main__":
         leaf_fixtures()
     if not only or "sampler" in only:
         sampler_fixture()
+    if not only or "pose_align" in only:
+        pose_align_fixture()
     if not only or "state_keys" in only:
         state_key_fixture()
     if not only or "config" in only:

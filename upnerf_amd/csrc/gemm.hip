@@ -500,6 +500,13 @@ __device__ __forceinline__ int frag16_exp(float mx) {
 __device__ __forceinline__ float frag16_src(const float* __restrict__ src, const upnerf_frag16_desc& q, int r, int c) {
   return q.transpose ? src[q.src_off + (size_t)c * q.src_ld + r] : src[q.src_off + (size_t)r * q.src_ld + c];
 }
+// Zeroing by kernel, not hipMemsetAsync: inside a captured HIP graph a memset node was observed to lose its order against
+// the kernel nodes around it when the null stream had run a kernel since the previous replay (the maxima then still held
+// what the previous owner of the memory left there; tools/graph_vs_eager_trainer.py found it).  A kernel node is ordered.
+__global__ void zero_floats_kernel(float* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+
 __global__ void frag16_amax_kernel(const float* __restrict__ src, Frag16Descs D, float* __restrict__ amax) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   float v = 0.0f;
@@ -846,7 +853,7 @@ extern "C" int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, con
   rc = frag16_build(bwd, nbwd, &Bd);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(amax_scratch, 0, 16 * sizeof(float), st));
+  hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, amax_scratch, 16);
   // maxima over the forward matrices and over the transposed ones (ids that exist only there, e.g. the fused head)
   hipLaunchKernelGGL(frag16_amax_kernel, dim3((F.start[nfwd] + 255) / 256), dim3(256), 0, st, src, F, amax_scratch);
   hipLaunchKernelGGL(frag16_amax_kernel, dim3((Bd.start[nbwd] + 255) / 256), dim3(256), 0, st, src, Bd, amax_scratch);
@@ -855,7 +862,7 @@ extern "C" int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, con
   hipLaunchKernelGGL(frag16_write_kernel, dim3((Bd.start[nbwd] + 255) / 256), dim3(256), 0, st, src, (char*)dst_bwd, Bd,
                      amax_scratch, (int*)nullptr, perm_bwd);
   if (wnorm) {  // [64]: forward descriptors at 0.., transposed ones at 32..
-    HIP_TRY(hipMemsetAsync(wnorm, 0, 64 * sizeof(float), st));
+    hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, wnorm, 64);
     int rf = 0, rb = 0;
     for (int j = 0; j < nfwd; ++j) rf += fwd[j].rows;
     for (int j = 0; j < nbwd; ++j) rb += bwd[j].rows;

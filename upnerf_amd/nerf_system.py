@@ -66,6 +66,8 @@ except Exception:
 
 
 class NeRFSystem(_Base):
+    supports_graph_step = True  # training_step splits into _step_backward / _step_update / _step_host (graph_step.py)
+
     def __init__(self, hparams, train_dataset=None, val_dataset=None):
         super().__init__()
         self.save_hyperparameters(hparams)

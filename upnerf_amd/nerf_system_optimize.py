@@ -2,10 +2,15 @@
 (forward 84-111, training_step 113-150, validation_step 152-188) for ONE held-out image -- frozen NeRF weights, a
 fresh appearance embedding and (pose stage) the image's se(3) refinement are optimised against the colour loss.
 
+`eval_train_poses` and `tto_from_checkpoint` are the two things eval.py / tto.py do with a trained checkpoint before
+rendering: the pose error of the training cameras after Sim(3) alignment (eval.py:13-42) and a TTO system whose fields
+come from the checkpoint and whose held-out cameras start from the aligned ground truth
+(nerf_system_optmize.py:254-317); the pose algebra is in pose_align.py.
+
 Differences by design: the reference leaves the NeRF weights trainable-but-unused (it computes and discards all
 weight gradients); here they are frozen, so the backward pass skips every weight-gradient
-kernel.  Pose initialisation by Sim(3) alignment to GT (nerf_system_optmize.py:267-332), SSIM/LPIPS and the pickle
-bookkeeping are outside the accelerated path: the caller passes the initial pose."""
+kernel.  SSIM/LPIPS and the pickle
+bookkeeping are outside the accelerated path."""
 from __future__ import annotations
 
 import torch
@@ -19,6 +24,8 @@ from .rendering import render_rays
 
 
 class NeRFSystemOptimize(NeRFSystem):
+    supports_graph_step = False  # its own training_step (torch AdamW in the appearance stage): eager launches
+
     def __init__(self, hparams, train_dataset=None, val_dataset=None, pose_optimize=True):
         super().__init__(hparams, train_dataset, val_dataset)
         self.pose_optimize = pose_optimize
@@ -114,3 +121,43 @@ def run_stage(system: NeRFSystemOptimize, train_batches, n_batches_per_epoch: in
     budget = int(system.global_step) + max_epochs * n_batches_per_epoch * n_opt
     return Trainer(budget, val_check_interval=1.0, dirpath=None).fit(system, train_batches, n_batches_per_epoch,
                                                                       val_batches)
+
+
+def eval_train_poses(checkpoint, noised_poses, gt_poses, device="cuda") -> dict:
+    """eval.py:13-42: trained se(3) refinements composed with the (noised) training poses, Sim(3)-aligned to the ground
+    truth; mean rotation error in degrees and mean translation error, as eval.py prints them, plus the per-image values."""
+    import math
+    from .checkpoint import read_checkpoint
+    from .pose_align import pose_metric, refined_poses
+    se3 = read_checkpoint(checkpoint)["state_dict"]["se3_refine.weight"]
+    refined = refined_poses(se3.to(device), noised_poses.to(device)).cpu()
+    err, aligned, gt = pose_metric(refined, gt_poses)
+    if err is None:
+        return {"train/pose_R": None, "train/pose_t": None, "refined": refined, "aligned": aligned}
+    return {"train/pose_R": float(err["R"].mean()) * 180.0 / math.pi, "train/pose_t": float(err["t"].mean()),
+            "R": err["R"], "t": err["t"], "refined": refined, "aligned": aligned}
+
+
+def tto_from_checkpoint(checkpoint, pose_optimize: bool, n_test_images: int = 1, gt_train_poses=None, gt_test_poses=None,
+                        device="cuda", **overrides):
+    """NeRFSystemOptimize for the held-out images of a trained run (nerf_system_optmize.py:254-317): hyper-parameters and
+    fields from the checkpoint, a fresh appearance row per test image and, when ground-truth poses are given, their
+    initial cameras in the frame the model was trained in.  Returns (system, initial test poses or None)."""
+    from .checkpoint import read_checkpoint
+    from .pose_align import init_test_poses, refined_poses
+    ck = read_checkpoint(checkpoint)
+    hp = dict(ck["hyper_parameters"])
+    hp.update(overrides)
+    sd = ck["state_dict"]
+    n_train = sd["se3_refine.weight"].shape[0] if "se3_refine.weight" in sd else sd["embedding_fine_a.weight"].shape[0]
+    from .nerf_system import SyntheticDataset
+    system = NeRFSystemOptimize(hp, SyntheticDataset(n_train), pose_optimize=pose_optimize)
+    keep = {k: v for k, v in sd.items() if not k.startswith(("embedding_fine_a.", "se3_refine."))}
+    system.model_setup(trained_state=keep, n_test_images=n_test_images)
+    system.to(device)
+    init = None
+    if gt_train_poses is not None and gt_test_poses is not None:
+        ident = torch.eye(3, 4).repeat(n_train, 1, 1)  # line 286: the trained refinements over identity poses
+        init = init_test_poses(refined_poses(sd["se3_refine.weight"].to(device), ident.to(device)).cpu(),
+                               gt_train_poses, gt_test_poses)
+    return system, init

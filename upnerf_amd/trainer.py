@@ -81,7 +81,8 @@ def _save(system, path: str, extra: dict) -> None:
 class Trainer:
     def __init__(self, max_steps: int, val_check_interval=0.25, dirpath: Optional[str] = None, save_top_k: int = 2,
                  monitor: str = "val/psnr", mode: str = "max", seed: int = 0, log: Optional[Callable[[dict], None]] = None,
-                 write_checkpoints: bool = True):
+                 write_checkpoints: bool = True, graph: bool = True):
+        self.graph = graph  # replay the step from HIP graphs (graph_step.py; bitwise the eager step); False = eager launches
         self.max_steps, self.val_check_interval = int(max_steps), val_check_interval
         self.dirpath, self.monitor, self.seed = dirpath, monitor, seed
         self.write_checkpoints = write_checkpoints  # False on ranks > 0: they read last.ckpt but never write
@@ -147,6 +148,11 @@ class Trainer:
         if ckpt_path is not None:
             self.resume(system, ckpt_path)
         every = self._val_every(n_batches_per_epoch)
+        step = system.training_step
+        if self.graph and getattr(system, "supports_graph_step", False) and next(system.parameters()).is_cuda:
+            from .graph_step import GraphedTrainingStep
+            step = GraphedTrainingStep(system)  # after resume(): the captured graphs hold the addresses of the Adam state
+        self.step_fn = step
         while system.global_step < self.max_steps:
             skip = self.batch_in_epoch
             if skip and len(inspect.signature(train_batches).parameters) >= 2:
@@ -156,7 +162,7 @@ class Trainer:
             for i, batch in it:
                 if i < skip:
                     continue  # consumed before the checkpoint this run resumed from
-                system.training_step(batch, i)
+                step(batch, i)
                 self.batch_in_epoch = i + 1
                 done = system.global_step >= self.max_steps
                 if (self.batch_in_epoch % every == 0 or done) and len(val_batches):
@@ -218,7 +224,8 @@ def fit_from_config(hparams: dict, train_dataset, val_dataset=None, device="cuda
         val.append({k: (v.to(device)[None] if torch.is_tensor(v) else v) for k, v in item.items()})
     max_steps = int(hparams["max_steps"]) * (2 if hparams["pose.optimize"] else 1)  # train.py:64-67
     trainer = Trainer(max_steps, hparams.get("val.log_interval", 0.25), dirpath=os.path.join(save_dir, "ckpts"),
-                      seed=int(hparams["seed"]), log=log, write_checkpoints=rank == 0)
+                      seed=int(hparams["seed"]), log=log, write_checkpoints=rank == 0,
+                      graph=bool(hparams.get("hip.graph", True)))
     if rank == 0:
         save_yaml(hparams, os.path.join(save_dir, "config.yaml"))
     trainer.fit(system, batches, n_batches, val, ckpt_path=hparams.get("resume_ckpt"))
