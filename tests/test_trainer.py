@@ -196,6 +196,7 @@ def test_tto_stages_recover_the_appearance_and_pose_of_a_held_out_image():
         for lo in range(0, R, 256):
             yield {k: v[perm[lo:lo + 256]] for k, v in b.items()}
 
+    torch.manual_seed(5)  # the fresh appearance row is drawn from torch's generator
     pose = tto_system(True)
     start = float(pose.validation_step(b)["val_psnr"])
     tr = run_stage(pose, batches, 4, max_epochs=12, val_batches=[b])
@@ -205,11 +206,19 @@ def test_tto_stages_recover_the_appearance_and_pose_of_a_held_out_image():
     err0 = float(truth.se3_refine.weight.detach().norm())
     assert float((pose.se3_refine.weight - truth.se3_refine.weight).detach().norm()) < err0  # moved towards the true offset
 
+    assert tr.step_fn.stats["replays"] >= 40  # one graph replay per step ...
+    torch.manual_seed(5)
+    eager = tto_system(True)  # ... on the bits of the eager loop
+    run_stage(eager, batches, 4, max_epochs=12, val_batches=[b], graph=False)
+    assert torch.equal(eager.se3_refine.weight, pose.se3_refine.weight)
+    assert torch.equal(eager.embedding_fine_a.weight, pose.embedding_fine_a.weight)
+
     app = tto_system(False)  # appearance stage starts from the optimised pose (eval.py feeds it as the camera)
     with torch.no_grad():
         app.embedding_fine_a.weight.copy_(pose.embedding_fine_a.weight)
     tr2 = run_stage(app, batches, 4, max_epochs=3, val_batches=[b])
     assert len(tr2.history) == 3 and app.global_step == 3 * 4 and all(torch.isfinite(p).all() for p in app.parameters())
+    assert tr2.step_fn.stats["replays"] >= 8  # torch's AdamW (capturable) sits inside the replayed graph
     assert all(p.grad is None for p in app.nerf_fine.parameters())  # frozen fields: no weight gradients computed
 
 

@@ -33,13 +33,13 @@ def main():
     dev = torch.device("cuda", 0)
     sysm = bench.build_system(dev, a.progress)
     sysm.hparams["val.chunk_size"] = a.chunk
-    b = synth.batch(a.pixels, bench.N_IMAGES, seed=7)
+    b = synth.batch(a.pixels, 763, seed=7)
     b["img_idx"] = torch.full_like(b["img_idx"], 3)  # one image
     batch = {k: v.to(dev)[None] for k, v in b.items()}
     if a.tto >= 0:
         from upnerf_amd.nerf_system import SyntheticDataset
         from upnerf_amd.nerf_system_optimize import NeRFSystemOptimize
-        tto = NeRFSystemOptimize(dict(sysm.hparams), SyntheticDataset(bench.N_IMAGES), pose_optimize=True)
+        tto = NeRFSystemOptimize(dict(sysm.hparams), SyntheticDataset(763), pose_optimize=True)
         tto.model_setup(trained_state=sysm.state_dict(), n_test_images=1)
         tto.coarse_sigma_only = bool(a.tto)
         sysm = tto.to(dev)

@@ -24,7 +24,7 @@ from .rendering import render_rays
 
 
 class NeRFSystemOptimize(NeRFSystem):
-    supports_graph_step = False  # its own training_step (torch AdamW in the appearance stage): eager launches
+    supports_graph_step = True  # the step splits like NeRFSystem's (graph_step.py): one graph replay per TTO step
 
     def __init__(self, hparams, train_dataset=None, val_dataset=None, pose_optimize=True):
         super().__init__(hparams, train_dataset, val_dataset)
@@ -55,8 +55,10 @@ class NeRFSystemOptimize(NeRFSystem):
     def configure_optimizers(self):
         if self.pose_optimize:  # nerf_system_optmize.py:48-58
             opts = [get_optimizer("adam", 5e-3, [self.embedding_fine_a]), get_optimizer("adam", 1e-4, [self.se3_refine])]
-        else:  # appearance stage: AdamW(1e-1) (lines 59-64)
-            opts = [torch.optim.AdamW(self.embedding_fine_a.parameters(), lr=1e-1)]
+        else:  # appearance stage: AdamW(1e-1) (lines 59-64); capturable: its step counter lives on the device, so the update
+            # can sit inside the replayed graph (same update rule; on a CPU system the flag is not available)
+            on_gpu = self.embedding_fine_a.weight.is_cuda
+            opts = [torch.optim.AdamW(self.embedding_fine_a.parameters(), lr=1e-1, **({"capturable": True} if on_gpu else {}))]
         scheds = [{"scheduler": torch.optim.lr_scheduler.ConstantLR(o, factor=1.0, total_iters=0), "interval": "step"}
                   for o in opts]
         return opts, scheds
@@ -83,16 +85,24 @@ class NeRFSystemOptimize(NeRFSystem):
         loss = ((res["s_rgb_fine"] - batch["rgbs"]) ** 2).mean()  # nerf_system_optmize.py:129
         return loss, {"rgb": loss}, res
 
-    def training_step(self, batch, batch_nb=0, u_list=None):
-        loss, _, _ = self.compute_loss(batch, u_list=u_list)
-        opts = self.optimizers()
-        opts = opts if isinstance(opts, (list, tuple)) else [opts]
-        for o in opts:
+    # the three pieces of a step (NeRFSystem.training_step composes them; graph_step.GraphedTrainingStep captures the first two)
+    def _step_backward(self, batch, u_list=None):
+        loss, loss_d, _ = self.compute_loss(batch, u_list=u_list)
+        for o in self._opts_scheds()[0]:
             o.zero_grad()
         self.manual_backward(loss)
-        for o in opts:
-            o.step()
+        return loss, loss_d
+
+    def _step_host(self, loss, loss_d, done):
+        opts, _ = self._opts_scheds()
+        for o, runs in zip(opts, done):
+            if runs is not None:
+                o.step_host(runs)
         self.global_step += len(opts)
+
+    def training_step(self, batch, batch_nb=0, u_list=None):
+        loss, loss_d = self._step_backward(batch, u_list=u_list)
+        self._step_host(loss, loss_d, self._step_update())
         return loss
 
     @torch.no_grad()
@@ -111,7 +121,8 @@ class NeRFSystemOptimize(NeRFSystem):
         return out
 
 
-def run_stage(system: NeRFSystemOptimize, train_batches, n_batches_per_epoch: int, max_epochs: int, val_batches=()):
+def run_stage(system: NeRFSystemOptimize, train_batches, n_batches_per_epoch: int, max_epochs: int, val_batches=(),
+              graph: bool = True):
     """One test-time-optimisation stage the way tto.py:56-91 runs it: `max_epochs` passes over the held-out image's rays
     (50 for the pose stage, 20 for the appearance stage), a validation render after every epoch, no checkpoints.
     Returns the Trainer (its `history` holds val/psnr per epoch)."""
@@ -119,8 +130,8 @@ def run_stage(system: NeRFSystemOptimize, train_batches, n_batches_per_epoch: in
     opts = system.optimizers()
     n_opt = len(opts) if isinstance(opts, (list, tuple)) else 1
     budget = int(system.global_step) + max_epochs * n_batches_per_epoch * n_opt
-    return Trainer(budget, val_check_interval=1.0, dirpath=None).fit(system, train_batches, n_batches_per_epoch,
-                                                                      val_batches)
+    return Trainer(budget, val_check_interval=1.0, dirpath=None, graph=graph).fit(system, train_batches, n_batches_per_epoch,
+                                                                                   val_batches)
 
 
 def eval_train_poses(checkpoint, noised_poses, gt_poses, device="cuda") -> dict:
