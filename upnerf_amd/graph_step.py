@@ -90,11 +90,14 @@ class GraphedTrainingStep:
         if any(m.host_progress is None for m in s.models.values() if hasattr(m, "host_progress")):
             raise RuntimeError("graph capture needs the host mirror of NeRF.progress (use NeRFSystem.set_progress)")
         sync = s.grad_sync if (s.grad_sync is not None and s.grad_sync.world > 1) else None
+        # with a process group alive its watchdog thread polls events while this thread captures: only THIS thread's calls
+        # are held to the capture rules then (the work of the autograd thread lands in the capture through the stream)
+        mode = "thread_local" if sync is not None else "global"
         e = _Entry()
         e.scalars = StepScalars(self.device, self._providers())
         e.g1, e.g2, e.replays = torch.cuda.CUDAGraph(), None, 0
         with e.scalars:
-            with torch.cuda.graph(e.g1, pool=self.pool, stream=self.stream):
+            with torch.cuda.graph(e.g1, pool=self.pool, stream=self.stream, capture_error_mode=mode):
                 e.loss, e.loss_d = s._step_backward(static)
                 if sync is None:
                     e.done = s._step_update()
@@ -103,7 +106,7 @@ class GraphedTrainingStep:
                     e.n_sync = sync.pack()
             if sync is not None:
                 e.g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(e.g2, pool=self.pool, stream=self.stream):
+                with torch.cuda.graph(e.g2, pool=self.pool, stream=self.stream, capture_error_mode=mode):
                     sync.unpack()
                     e.done = s._step_update()
         e.grads = [(p, p.grad) for p in s.parameters()]
