@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UPNERF_ABI_VERSION 2
+#define UPNERF_ABI_VERSION 3
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
@@ -442,6 +442,11 @@ int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float b
  * rates, Adam bias corrections, BARF band weights and the schedule multiplier of that step. */
 #define UPNERF_MAX_SCALARS 96
 int upnerf_set_scalars(float* dst, int n, const float* vals, void* stream);
+
+/* out[i] = 14 - ceil(log2(max(maxima[i], 1e-30))), i < n <= 64: the power-of-two exponents that upnerf_wgrad_f16x3 /
+ * upnerf_wgrad_f16p take (expo_a / expo_b) from the maxima the field kernels track in `amax` / `gmax`; device to device, no
+ * host synchronisation (replaces rendering.py's five ATen launches per table). */
+int upnerf_scale_exponents(const float* maxima, int n, int32_t* out, void* stream);
 
 #ifdef UPNERF_STAMPS
 /* Diagnostic build only (make -C upnerf_amd/csrc stamps -> libupnerf_hip_stamps.so, never the shipped library): per-phase

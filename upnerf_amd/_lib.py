@@ -158,6 +158,7 @@ _SIGNATURES = {
     "upnerf_frag_copy": [_p, _p, C.POINTER(FragDesc), _i, _p],
     "upnerf_adam": [C.c_int64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p],
     "upnerf_set_scalars": [_p, _i, C.POINTER(C.c_float), _p],
+    "upnerf_scale_exponents": [_p, _i, _p, _p],
 }
 MAX_SCALARS = 96
 EXPORTS = tuple(_SIGNATURES)
@@ -179,7 +180,7 @@ def _load():
 
 
 lib = _load()
-ABI_VERSION = 2
+ABI_VERSION = 3
 if lib.upnerf_abi_version() != ABI_VERSION:
     raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
 

@@ -612,6 +612,13 @@ __global__ void adam_kernel(long long n, float* __restrict__ p, const float* __r
 struct ScalarPack {
   float v[UPNERF_MAX_SCALARS];
 };
+// out[i] = 14 - ceil(log2(max(v[i], 1e-30))): the power-of-two exponent that brings a tracked maximum to ~2^14 (the scales
+// of the f16x3 weight gradients), the arithmetic of the five ATen launches it replaces, in their order
+__global__ void scale_exponents_kernel(const float* __restrict__ v, int n, int* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i < n) out[i] = (int)(14.0f - ceilf(log2f(fmaxf(v[i], 1e-30f))));
+}
+
 __global__ void set_scalars_kernel(float* __restrict__ dst, int n, ScalarPack s) {
   const int i = threadIdx.x;
   if (i < n) dst[i] = s.v[i];
@@ -877,6 +884,12 @@ extern "C" int upnerf_adam(int64_t n, float* p, const float* g, float* m, float*
   if (n <= 0 || !p || !g || !m || !v) return UPNERF_EINVAL;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n, p,
                      g, m, v, beta1, beta2, eps, step_size, bc2_sqrt, dyn2);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_scale_exponents(const float* maxima, int n, int32_t* out, void* stream) {
+  if (!maxima || !out || n <= 0 || n > 64) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(scale_exponents_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, maxima, n, out);
   return (int)hipGetLastError();
 }
 

@@ -46,7 +46,20 @@ class _LossFn(torch.autograd.Function):
         a, t = ctx.args, ctx.keep
         (dd, inv, rows, sdc, sdf, twc, twf, fc, ff, fg, rc, rf, rg, beta, alpha) = t
         need = ctx.needs_input_grad[1:]
-        new = lambda x, ok: torch.zeros_like(x) if (x is not None and ok) else None
+        # one zero fill for all gradient buffers (slices of one arena, each starting on a 256-byte boundary)
+        want = [(x, ok) for x, ok in ((dd, need[0]), (rows, need[2]), (sdc, need[3]), (sdf, need[4]), (fc, need[7]), (ff, need[8]),
+                                      (rc, need[10]), (rf, need[11]), (beta, need[13]), (alpha, need[14]))]
+        pad = lambda n: (n + 63) // 64 * 64
+        arena = torch.zeros(sum(pad(x.numel()) for x, ok in want if x is not None and ok) or 1, device=g_terms.device)
+        cursor = [0]
+
+        def new(x, ok):
+            if x is None or not ok:
+                return None
+            o = cursor[0]
+            cursor[0] += pad(x.numel())
+            return arena[o:o + x.numel()].view(x.shape)
+
         d_dd, d_rows = new(dd, need[0]), new(rows, need[2])
         d_sdc, d_sdf, d_fc, d_ff = new(sdc, need[3]), new(sdf, need[4]), new(fc, need[7]), new(ff, need[8])
         d_rc, d_rf, d_beta, d_alpha = new(rc, need[10]), new(rf, need[11]), new(beta, need[13]), new(alpha, need[14])
@@ -62,6 +75,32 @@ class _LossFn(torch.autograd.Function):
 
 def tensors_like(ctx, i):
     return ctx.keep[i]
+
+
+class _SumSelected(torch.autograd.Function):
+    """Sum of the terms a phase uses, as ONE node of the autograd graph (the reference sums the dict's values with Python's
+    `sum`: eight adds forward and, backward, eight one-hot gradients of the `terms[i]` views added up again)."""
+
+    @staticmethod
+    def forward(ctx, terms, mask):
+        ctx.save_for_backward(mask)
+        return torch.where(mask, terms, 0.0).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None
+
+
+_MASKS = {}
+
+
+def _term_mask(m, fine, device):
+    key = (m < 1, m > 0, bool(fine), device)
+    if key not in _MASKS:
+        on = [m < 1, m < 1, m > 0, fine and m < 1, fine and m < 1, fine and m > 0, fine and m > 0, fine and m > 0]
+        _MASKS[key] = torch.tensor(on, dtype=torch.bool, device=device)
+    return _MASKS[key]
 
 
 def _terms_to_dict(terms, m, fine):
@@ -102,7 +141,14 @@ class UPNeRFLoss(nn.Module):
             g("s_rgb_coarse") if m > 0 else None, g("s_rgb_fine") if (m > 0 and fine) else None, rgb if m > 0 else None,
             beta.reshape(-1) if (beta is not None and m > 0 and fine) else None,
             alpha.reshape(-1) if (alpha is not None and m > 0 and fine) else None)
+        self.last_terms = (terms, m, fine)
         return _terms_to_dict(terms, m, fine), depth
+
+    def total(self):
+        """Sum of the terms of the last call as one autograd node (what `sum(loss_d.values())` computes; the summation order,
+        hence the last bit of the value, may differ -- the gradients do not)."""
+        terms, m, fine = self.last_terms
+        return _SumSelected.apply(terms, _term_mask(m, fine, terms.device))
 
     def forward(self, inputs, rgb_targets, feat_targets, depth_targets, schedule_mult):
         """Reference calling convention (losses.py:21): depth targets already computed by the caller."""

@@ -224,7 +224,7 @@ class NeRFSystem(_Base):
         results = self(rays, batch["feats"], batch["img_idx"], sched_mult, u_list=u_list, keep=keep)
         loss_d, _depth = self.loss.forward_with_prior(results, batch["rgbs"], batch["feats"], batch["inv_depths"],
                                                       embed_rows(self.depth_scale, batch["img_idx"], defer_grad=True), sched_mult)
-        return sum(l for l in loss_d.values()), loss_d, results
+        return self.loss.total(), loss_d, results
 
     def set_progress(self, progress: float):
         """Host-side copy of NeRF.progress (avoids the reference's per-step .item() sync)."""

@@ -275,8 +275,9 @@ class _FieldPass(torch.autograd.Function):
             h, x0 = sv["h"], sv["x0"]
             # power-of-two scales of the f16x3 contraction: 2^14 / max|.| per tensor, from the maxima the field kernels
             # tracked (device side, no host sync).  ea[i] pairs with gmax slot i, eb[i] with amax slot i.
-            ea = (14 - torch.ceil(torch.log2(gmax.clamp_min(1e-30)))).to(torch.int32)
-            eb = (14 - torch.ceil(torch.log2(sv["amax"].clamp_min(1e-30)))).to(torch.int32)
+            ea, eb = torch.empty(16, device=dev, dtype=torch.int32), torch.empty(16, device=dev, dtype=torch.int32)
+            check(lib.upnerf_scale_exponents(ptr(gmax), 16, ptr(ea), st), "upnerf_scale_exponents")
+            check(lib.upnerf_scale_exponents(ptr(sv["amax"]), 16, ptr(eb), st), "upnerf_scale_exponents")
             EA = lambda i: ea.data_ptr() + 4 * i
             EB = lambda i: eb.data_ptr() + 4 * i
             ctx_keep = (ea, eb)
