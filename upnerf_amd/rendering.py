@@ -368,14 +368,34 @@ def sample_pdf(z_coarse: torch.Tensor, weights: torch.Tensor, n: int, det: bool,
                                 stream()), "upnerf_sample_pdf")
 
 
+_ZEROS = {}
+
+
+def _zeros(rows, cols, device):
+    """Cached [rows, cols] zero block (K padding of _project_feat; never written)."""
+    key = (rows, cols, device)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(rows, cols, device=device)
+    return _ZEROS[key]
+
+
 def _project_feat(model, E_s, sum_sfeat, G_c=None, t_weight=None):
     """feat map = W_f (sum w e) + b_f sum w  [+ W_cf (sum w_c g) + b_cf sum w_c]  (nerf.py:95,100 composited by
-    rendering.py:166-177)."""
-    feat = hip_linear(E_s, model.feat_share_layer.weight) + sum_sfeat[:, None] * model.feat_share_layer.bias
+    rendering.py:166-177) as ONE product [E_s | sum w | G_c | sum w_c | 0] . [W_f | b_f | W_cf | b_cf | 0]^T: the bias terms
+    ride along as one more input column each (three launches forward and a handful backward instead of ~35 elementwise
+    and reduction launches; K padded to the next multiple of 32 for the weight-gradient kernel)."""
+    fs = model.feat_share_layer
+    xs, ws = [E_s, sum_sfeat[:, None]], [fs.weight, fs.bias[:, None]]
     if G_c is not None:
-        feat = feat + hip_linear(G_c, model.feat_candidate_layer.weight, defer_wgrad=True) \
-            + t_weight[:, None] * model.feat_candidate_layer.bias
-    return feat
+        fc = model.feat_candidate_layer
+        xs += [G_c, t_weight[:, None]]
+        ws += [fc.weight, fc.bias[:, None]]
+    K = sum(x.shape[1] for x in xs)
+    pad = (-K) % 32
+    if pad:
+        xs.append(_zeros(E_s.shape[0], pad, E_s.device))
+        ws.append(_zeros(fs.weight.shape[0], pad, E_s.device))
+    return hip_linear(torch.cat(xs, 1), torch.cat(ws, 1))
 
 
 def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use_disp=False, perturb=0,
