@@ -202,11 +202,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_grouped_reduce_kernel(WgradGro
 // One thread per 4 consecutive k (16-byte loads); the splits are dealt round-robin to RG = 4 thread groups whose
 // partial sums meet in LDS; each group keeps 4 loads in flight.  The reduction is a pure HBM stream (nsplit x N x K x 4
 // bytes), so what matters is bytes in flight, not arithmetic.
-#define RED_RG 4
-__global__ __launch_bounds__(NTHREADS) void wgrad_reduce_kernel(int N, int K, int TN, int TK, int nsplit,
-                                                               const float* __restrict__ slabs,
-                                                               const float* __restrict__ bslabs, float* __restrict__ dW,
-                                                               int ldo, float* __restrict__ db) {
+#define RED_RG 8
+#define RED_THREADS (64 * RED_RG)
+__global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_kernel(int N, int K, int TN, int TK, int nsplit,
+                                                                 const float* __restrict__ slabs,
+                                                                 const float* __restrict__ bslabs, float* __restrict__ dW,
+                                                                 int ldo, float* __restrict__ db) {
   __shared__ f32x4 part[RED_RG][64];
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int q = blockIdx.x * 64 + lane;  // index of a group of 4 consecutive k
@@ -217,26 +218,31 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_reduce_kernel(int N, int K, in
   const int by = n / TN, bz = k / TK;
   const size_t off = ((size_t)by * gz + bz) * TN * TK + (size_t)(n - by * TN) * TK + (k - bz * TK);
   const size_t stride = (size_t)gy * gz * TN * TK;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  // 8 waves x 8 loads of 16 bytes per lane = 64 KiB in flight per workgroup (one workgroup per CU at 256 x 256): at 16 KiB
+  // the 67 MB of slabs of a 256 x 256 layer came in at 2.7 TB/s
+  f32x4 s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (ok) {
     int sp = rg;
-    for (; sp + 3 * RED_RG < nsplit; sp += 4 * RED_RG) {
-      const f32x4 a = *(const f32x4*)&slabs[off + (size_t)sp * stride];
-      const f32x4 b = *(const f32x4*)&slabs[off + (size_t)(sp + RED_RG) * stride];
-      const f32x4 c = *(const f32x4*)&slabs[off + (size_t)(sp + 2 * RED_RG) * stride];
-      const f32x4 d = *(const f32x4*)&slabs[off + (size_t)(sp + 3 * RED_RG) * stride];
-      s0 += a; s1 += b; s2 += c; s3 += d;
+    for (; sp + 7 * RED_RG < nsplit; sp += 8 * RED_RG) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)&slabs[off + (size_t)(sp + u * RED_RG) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += v[u];
     }
-    for (; sp < nsplit; sp += RED_RG) s0 += *(const f32x4*)&slabs[off + (size_t)sp * stride];
+    for (; sp < nsplit; sp += RED_RG) s[0] += *(const f32x4*)&slabs[off + (size_t)sp * stride];
   }
-  part[rg][lane] = (s0 + s1) + (s2 + s3);
+  part[rg][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   if (rg == 0 && ok) {
-    const f32x4 t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const f32x4 t = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+                    ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
     *(f32x4*)&dW[(size_t)n * ldo + k] = t;
   }
   if (db) {
-    const int idx = blockIdx.x * NTHREADS + threadIdx.x;
+    const int idx = blockIdx.x * RED_THREADS + threadIdx.x;
     if (idx < N) {
       const int bby = idx / TN;
       float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -668,7 +674,7 @@ extern "C" int upnerf_wgrad(int M, const float* A, int lda, int N, const float* 
   const int quads = N * (K / 4);
   int rblocks = (quads + 63) / 64;
   if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;  // the bias sum needs one thread per row
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(NTHREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(RED_THREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
                      ldo, db);
   return (int)hipGetLastError();
 }
@@ -699,7 +705,7 @@ extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const f
   const int quads = N * (K / 4);
   int rblocks = (quads + 63) / 64;
   if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(NTHREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(RED_THREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
                      ldo, db);
   return (int)hipGetLastError();
 }
@@ -728,7 +734,7 @@ extern "C" int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int3
   const int quads = N * (K / 4);
   int rblocks = (quads + 63) / 64;
   if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(NTHREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(RED_THREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
                      ldo, db);
   return (int)hipGetLastError();
 }
