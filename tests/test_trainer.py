@@ -264,3 +264,49 @@ def test_evaluation_route_from_a_checkpoint(tmp_path):
     assert res["s_rgb_fine"].shape == (400, 3) and torch.isfinite(res["s_rgb_fine"]).all() and torch.isfinite(res["val_psnr"])
     whole = tto.validation_step({k: v[:96] for k, v in b.items()})["s_rgb_fine"]  # chunked render == one chunk
     assert torch.equal(res["s_rgb_fine"][:96], whole)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,store", [("f16x3", "f32"), ("f16x3", "f16"), ("f16", "f32"), ("f32", "f32")])
+def test_student_learns_the_colours_a_teacher_renders(mode, store, monkeypatch):
+    """System-level check of the gradient signs and scales in every arithmetic mode: a teacher (random fields, schedule
+    finished) renders the colours of a fixed set of rays, a student with other weights is trained on them through the
+    graph-replayed step, and its colour loss has to fall by more than half within 120 iterations."""
+    from upnerf_amd import rendering, synth
+    from upnerf_amd.graph_step import GraphedTrainingStep
+    from upnerf_amd.nerf_system import NeRFSystem, SyntheticDataset, default_hparams
+    monkeypatch.setattr(rendering, "FIELD_MODE", mode)
+    monkeypatch.setattr(rendering, "WGRAD_STORE", store)
+    I, R, B = 4, 2048, 256
+    hp = default_hparams(**{"nerf.N_samples": 32, "nerf.N_importance": 32, "train.batch_size": B, "max_steps": 1000,
+                            "nerf.perturb": 1.0, "optimizer.lr": 1e-3})
+
+    def system(seed):
+        torch.manual_seed(seed)
+        s = NeRFSystem(hp, SyntheticDataset(I))
+        s.setup()
+        s = s.cuda()
+        s.global_step = 1600  # progress 0.8: schedule finished, colour terms only
+        s.set_progress(0.8)
+        return s
+
+    data = {k: v.cuda() for k, v in synth.batch(R, I, seed=31).items()}
+    teacher = system(100)
+    with torch.no_grad():
+        for m in (teacher.nerf_coarse, teacher.nerf_fine):  # denser, more colourful than a fresh initialisation
+            m.share_sigma[0].bias.add_(1.5)
+            m.rgb_share_layer[0].weight.mul_(4.0)
+        out = teacher.validation_step({k: v[None] for k, v in data.items()})["results"]
+        data["rgbs"] = out["rgb_fine"].clamp(0, 1).contiguous()
+    assert float(data["rgbs"].std()) > 0.02  # there is something to learn
+    student = system(7)
+    step = GraphedTrainingStep(student)
+    losses = []
+    for i in range(120):
+        lo = (i * B) % R
+        step({k: v[lo:lo + B].contiguous() for k, v in data.items()}, i)
+        losses.append(float(student.logged["train/l_rgb_f"]))
+    first, last = sum(losses[:10]) / 10, sum(losses[-10:]) / 10
+    assert all(torch.isfinite(p).all() for p in student.parameters())
+    assert last < 0.5 * first, (first, last)
+    assert step.stats["replays"] >= 100
