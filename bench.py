@@ -346,7 +346,7 @@ def main():
         ach = kern[dom]["tflops_algorithmic"]
         # HBM bytes per launch come from rocprofv3 PMC passes (tools/pmc_collect.sh; they cannot be collected live): used
         # only when the committed profile was taken from THIS build on THIS workload, otherwise null
-        traffic, source = None, None
+        traffic, source, step_bytes = None, None, None
         meta_p = os.path.join(ROOT, "profiles", "pmc_current.json")
         if os.path.exists(meta_p):
             meta = json.load(open(meta_p))
@@ -356,9 +356,11 @@ def main():
                 if t:
                     traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
                     source = f"profiles/{meta.get('file')} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same sources)"
+                    step_bytes = meta.get("hbm_bytes_per_step")
         peak = PEAK[field] if dom.startswith("field") else (PEAK["f16"] if field == "f16" else PEAK["f16x3"])
         line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                             "frac": ach / peak, "traffic": traffic, "traffic_source": source,
+                            "hbm_bytes_per_step": step_bytes,  # all kernels of a step, same PMC passes (null with traffic)
                             "avg_launch_ms": kern[dom]["avg_ms"],
                             "note": "achieved = algorithmic (fp32-equivalent) FLOPs / HIP-event launch time, averaged over "
                                     "the coarse and fine launches of eager steps run right after the timed region; peak = "

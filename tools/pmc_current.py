@@ -26,7 +26,14 @@ for name, key in pick.items():
     if t and "fetch_bytes_per_launch" in t and "write_bytes_per_launch" in t:
         kern[name] = {"kernel": key, "fetch_bytes_per_launch": t["fetch_bytes_per_launch"],
                       "write_bytes_per_launch": t["write_bytes_per_launch"], "mfma_busy": t.get("mfma_busy")}
-out = {"src_sha16": bench.source_sha16(), "field": a.field, "config": a.config, "progress": a.progress,
+# all kernels of one step: (FETCH x2 + WRITE) x dispatches, over the steps the PMC run made (two field forward launches each)
+fwd = pmc.get(pick["field_fwd"], {})
+steps = fwd.get("dispatches", 0) / 2
+step_bytes = None
+if steps:
+    step_bytes = sum((t.get("fetch_bytes_per_launch", 0) + t.get("write_bytes_per_launch", 0)) * t.get("dispatches", 0)
+                     for t in pmc.values() if isinstance(t, dict)) / steps
+out = {"src_sha16": bench.source_sha16(), "hbm_bytes_per_step": step_bytes, "field": a.field, "config": a.config, "progress": a.progress,
        "file": os.path.basename(a.pmc_json), "kernels": kern}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_current.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
