@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UPNERF_ABI_VERSION 3
+#define UPNERF_ABI_VERSION 4
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
@@ -130,7 +130,9 @@ typedef struct {
    * always required (the skip layer re-reads it). */
   float* x0;                     /* [M][64] */
   float* h;                      /* [D][M][W] post-ReLU trunk activations */
-  uint64_t* hmask;               /* [D][ceil(M/64)][256] ReLU sign bits of h in the kernels' accumulator layout */
+  uint64_t* hmask;               /* ReLU sign bits of h in the kernels' accumulator layout, private to a forward / backward kernel
+                                    pair: [D + 1][tiles][threads per workgroup] words.  (D + 1) * ceil(M/128) * 512 words cover
+                                    either tiling */
   float* amax;                   /* [16] or NULL: running max|.| (atomicMax; zero it first) of h_0..h_{D-1} (slots 0..D-1),
                                     e (D), g1 (D+1), r1 (D+3), x0 (D+4) -- scale exponents of upnerf_wgrad_f16x3 */
   float* e;                      /* [M][W]   xyz_encoding_final output */
@@ -145,11 +147,12 @@ typedef struct {
   int32_t planes;                /* upnerf_field_fwd_f16x3 only: 0 or 2 = f16x3 (fp32-accurate hi/lo split, three MFMAs per
                                     product); 1 = f16 (fp16 weights and activations, one MFMA per product, fp32 accumulate:
                                     BASELINE.json configs[3]); the lo halves of P16 are then never read */
-  const float* wnorm;            /* upnerf_field_fwd_f16x3 only.  NULL: the LDS-tile kernel (64 samples per workgroup in LDS
-                                    planes, weights streamed per wave; P16 in natural k order).  Non-NULL ([64] from
-                                    upnerf_frag16, P16 written with perm_fwd = 1): the register-resident kernel (128 samples per
-                                    workgroup, activations chained through registers, weights staged ONCE per workgroup in
-                                    LDS by DMA).  Same outputs, same hmask layout: either forward kernel pairs with upnerf_field_bwd_f16x3 */
+  int32_t tile_rows;             /* upnerf_field_fwd_f16x3 only: samples per workgroup.  0 or 64: four waves, two workgroups per CU.
+                                    128 (needs S >= 64): eight waves, software-pipelined trunk, each weight fragment enters the
+                                    CU once per 128 samples; needs x0f when the field has a skip layer.  The backward pass of the
+                                    same evaluation must be given the same value (the hmask layout follows the tile) */
+  const float* wnorm;            /* reserved, must be NULL (selected a register-resident forward kernel that left the library:
+                                    tools/repro/field16r.hip) */
   /* fp16 STORAGE of the trunk activations (always in the f16 mode; an option in the f16x3 mode, where it rounds only the
    * operands of the weight gradients): halves what the pass writes and what the weight-gradient kernels read back
    * (upnerf_wgrad_f16p).  h16[l][m][k] = fp16(h_l[m][k] * 2^hexp[l][m / 64]): the content of the
@@ -158,6 +161,9 @@ typedef struct {
   int32_t* hexp;                 /* [D][ceil(M/64)] */
   int32_t h_last_only;           /* with h16: `h` (if non-NULL) receives layer D-1 only, as [M][W] fp32 (density-head and
                                     final-layer weight gradients read it) */
+  void* x0f;                     /* upnerf_field_fwd_f16x3 with 128-sample tiles and a skip layer: scratch of ceil(M/128) * 32768
+                                    bytes.  The workgroup parks the encoding of its tile there as fp16 operand fragments and
+                                    reads them back at the skip layer (the planes hold h_{skip-1} by then) */
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -252,8 +258,11 @@ typedef struct {
   const void* PT16;              /* transposed set of upnerf_frag16 */
   const int32_t* wexp;           /* [16] */
   int32_t planes;                /* as in upnerf_field_fwd_args: 0 / 2 = f16x3, 1 = f16 */
+  int32_t tile_rows;             /* as in upnerf_field_fwd_args; must equal the forward pass's */
   uint16_t* gz16;                /* [D][M][W] fp16 bits of gz_h, tile-scaled like h16 (then gz_h may be NULL) */
   int32_t* gzexp;                /* [D][ceil(M/64)] */
+  void* xs;                      /* 128-sample tiles with a skip layer and need_dxyz: scratch of ceil(M/128) * 32768 bytes (the
+                                    forward pass's x0f may be reused: its content is dead by now) */
 } upnerf_field_bwd_args;
 
 int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream);

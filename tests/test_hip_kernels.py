@@ -480,22 +480,36 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     assert ok, "BWD over tolerance: " + repr(errs)
 
 
-@pytest.mark.parametrize("name,typ", [("cfg2_phase0", "coarse"), ("cfg2_phase1", "fine"), ("cfg2_phase2", "fine"),
-                                      ("cfg2_trained_p045", "fine")])
-def test_register_resident_forward_kernel_stage_by_stage(hip, name, typ, monkeypatch):
-    """csrc/field16r.hip (activations chained through registers, weights staged once per 128-sample workgroup in LDS; not the
-    default) against the same fp32 restatement and gates as the default kernel, paired with the default
-    backward kernel (it writes the ReLU masks in that kernel's layout)."""
-    rd = hip["rendering"]
-    monkeypatch.setattr(rd, "FIELD_FWD_KERNEL", "regs")
-    monkeypatch.setattr(rd, "FIELD_MODE", "f16x3")
-    test_field_pass_stage_by_stage.__wrapped__(hip, name, typ, "f16x3") if hasattr(test_field_pass_stage_by_stage, "__wrapped__") \
-        else test_field_pass_stage_by_stage(hip, name, typ, "f16x3")
+@pytest.mark.parametrize("field_mode", ["f16x3", "f16"], indirect=True)
+@pytest.mark.parametrize("name,typ", STAGE_CASES)
+def test_pipelined_128_sample_kernels_stage_by_stage(hip, name, typ, field_mode, monkeypatch):
+    """The eight-wave, software-pipelined kernels of the 128-sample tile (csrc/pipe16.cuh; rendering.FIELD_TILE = 128, opt-in)
+    against the same fp32 restatement at the same gates as the default 64-sample kernels: every activation, every
+    pre-activation gradient, every parameter gradient."""
+    c = Case(name)
+    if c.cfgs()["nerf_coarse"].W != 256:
+        pytest.skip("64-wide fields run the fp32 kernels")
+    monkeypatch.setattr(hip["rendering"], "FIELD_TILE", 128)
+    fn = getattr(test_field_pass_stage_by_stage, "__wrapped__", test_field_pass_stage_by_stage)
+    fn(hip, name, typ, field_mode)
 
 
 @pytest.mark.parametrize("R,S,mode,use_cand,use_rgb", [(7, 40, 1, True, True), (5, 33, 0, True, False),
                                                          (3, 200, 2, False, True), (9, 32, 3, False, False)])
 def test_field_f16x3_matches_fp32_kernels_on_ragged_tiles(hip, R, S, mode, use_cand, use_rgb):
+    _ragged_tiles(hip, R, S, mode, use_cand, use_rgb)
+
+
+@pytest.mark.parametrize("R,S,mode,use_cand,use_rgb", [(5, 70, 1, True, True), (3, 200, 2, False, True),
+                                                         (2, 129, 0, True, False), (1, 64, 3, False, False)])
+def test_pipelined_128_sample_kernels_on_ragged_tiles(hip, R, S, mode, use_cand, use_rgb, monkeypatch):
+    """The same comparison for the 128-sample kernels: last tile ragged (M % 128 != 0, also M < 128 and a tile whose second
+    row half is empty), tiles straddling up to three rays, per-half exponents that differ."""
+    monkeypatch.setattr(hip["rendering"], "FIELD_TILE", 128)
+    _ragged_tiles(hip, R, S, mode, use_cand, use_rgb)
+
+
+def _ragged_tiles(hip, R, S, mode, use_cand, use_rgb):
     """f16x3 kernels against the fp32 kernels on shapes whose tiles are ragged (M % 64 != 0) and straddle up to three
     rays; large and tiny magnitudes mixed so that the per-tile exponents differ between tiles and stages."""
     from upnerf_amd import synth

@@ -35,8 +35,8 @@ class FieldFwdArgs(C.Structure):
                 ("wk_xyz", C.c_float * 10), ("P", _fp),
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
                 ("x0", _fp), ("h", _fp), ("hmask", _fp), ("amax", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp),
-                ("P16", _fp), ("wexp", _fp), ("wk_xyz_dev", _fp), ("planes", C.c_int32), ("wnorm", _fp),
-                ("h16", _fp), ("hexp", _fp), ("h_last_only", C.c_int32)]
+                ("P16", _fp), ("wexp", _fp), ("wk_xyz_dev", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("wnorm", _fp),
+                ("h16", _fp), ("hexp", _fp), ("h_last_only", C.c_int32), ("x0f", _fp)]
 
 
 class CompositeFwdArgs(C.Structure):
@@ -67,7 +67,7 @@ class FieldBwdArgs(C.Structure):
                 ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp), ("hmask", _fp), ("gmax", _fp),
                 ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp),
-                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("gz16", _fp), ("gzexp", _fp)]
+                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("gz16", _fp), ("gzexp", _fp), ("xs", _fp)]
 
 
 class LossArgs(C.Structure):
@@ -180,7 +180,7 @@ def _load():
 
 
 lib = _load()
-ABI_VERSION = 3
+ABI_VERSION = 4
 if lib.upnerf_abi_version() != ABI_VERSION:
     raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
 

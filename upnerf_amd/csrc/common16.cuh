@@ -268,6 +268,21 @@ __device__ __forceinline__ void acc_fma_bias(f32x16 (&acc)[MT][NT], float un, co
       }
 }
 
+// the same with one scale per half of the wave's m-tiles (row halves of the tile that carry different exponents; a wave
+// whose rows all lie in one half passes the same value twice)
+template <bool RELU, int MT, int NT>
+__device__ __forceinline__ void acc_fma_bias_h(f32x16 (&acc)[MT][NT], float un_lo, float un_hi, const f32x4 (&bias)[NT][4]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = fmaf(acc[mt][nt][r], (2 * mt < MT) ? un_lo : un_hi, bias[nt][r >> 2][r & 3]);
+        acc[mt][nt][r] = RELU ? fmaxf(v, 0.0f) : v;
+      }
+}
+
 // v = relu(fma(acc, un, bias)) with the sign bits packed per lane: bit e = (mt*NT + nt)*16 + r of the 64-bit word says
 // whether this lane's accumulator element e is positive (2 KiB per 64-row tile and layer instead of re-reading the 64 KiB
 // activation tile in the backward pass, which uses the same wave tiling for the gradient of that activation).

@@ -17,10 +17,20 @@
 //   * trunk / final activations and all pre-activation gradients are stored straight from the accumulators (16 bytes per
 //     lane and quad), the 128-wide head activations from the planes.
 #include "common16.cuh"
+#include "pipe16.cuh"
+#include <type_traits>
 
+// Two tilings of the same kernels (template parameters TILE, NW):
+//   64 samples x 4 waves, two workgroups per CU: a wave owns 64 columns x all 64 rows (MT = 2, NT = 2); every workgroup
+//                         pulls a layer's whole weight matrix from L2 (4 KB per sample and layer in the f16x3 mode);
+//   128 samples x 8 waves, one workgroup per CU (the default when a ray has >= 64 samples): a wave owns ONE 32-column
+//                         n-tile for all 128 rows (MT = 4, NT = 1), so each weight fragment enters the CU once per 128
+//                         rows -- half the L2 -> CU weight stream per sample -- and no two waves of the CU ever ask for
+//                         the same fragment.
 #define F16_TILE 64
 #define F16_WAVES 4
-#define F16_THREADS (64 * F16_WAVES)
+#define F16_TILE_BIG 128
+#define F16_WAVES_BIG 8
 // two workgroups per CU = 2 waves per SIMD; hipcc takes the second __launch_bounds__ argument as the minimum number of
 // waves per SIMD
 #define F16_WAVES_PER_EU 2
@@ -67,84 +77,91 @@ namespace {
 
 // How the 4 waves of a workgroup share a [TILE x N] output tile (32 x 32 MFMA tiles); same rules as WaveTile in
 // common.cuh: surplus waves of a narrow layer recompute a piece another wave owns.
-template <int N, int TILE>
+template <int N, int TILE, int NWAVES>
 struct WaveTile16 {
-  static constexpr int NW = F16_WAVES;
-  static constexpr int NT = (N >= 256) ? 2 : 1;
-  static constexpr int NG = N / 32 / NT;
-  static constexpr int MG = TILE / 32;
-  static constexpr int WN = NG >= NW ? NW : NG;
-  static constexpr int WM = (NW / WN) < MG ? (NW / WN) : MG;
-  static constexpr int MT = MG / WM;
+  static constexpr int NW = NWAVES;
+  static constexpr int MG = TILE / 32;                       // 32-row m-tiles of the workgroup's tile
+  static constexpr int WN = (N / 32) >= NW ? NW : (N / 32);  // waves side by side along N
+  static constexpr int NT = (N / 32) / WN;                   // n-tiles per wave
+  static constexpr int WM = (NW / WN) < MG ? (NW / WN) : MG; // row groups
+  static constexpr int MT = MG / WM;                         // m-tiles per wave
   __device__ static __forceinline__ int n0(int wave) { return (wave % WN) * 32 * NT; }
   __device__ static __forceinline__ int row0(int wave) { return ((wave / WN) % WM) * 32 * MT; }
 };
 
+template <int NW>
 __device__ __forceinline__ float wg_max(const float* smax) {
   float m = smax[0];
 #pragma unroll
-  for (int w = 1; w < F16_WAVES; ++w) m = fmaxf(m, smax[w]);
+  for (int w = 1; w < NW; ++w) m = fmaxf(m, smax[w]);
   return m;
 }
 
 __device__ __forceinline__ float pow2f(int n) { return ldexpf(1.0f, n); }
 
-// LDS planes -> row-major fp32 global tensor, coalesced (8 columns = 32 bytes per thread, whole rows per wave).  The
-// LDS reads of BATCH row groups are issued before the first conversion, so their latency is paid once per batch.
-template <int NP, int W, int TILE, int NCOLS, int BATCH = 1>
-__device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, float unscale,
+// LDS planes -> row-major fp32 global tensor in WHOLE LINES: a thread converts four columns (8 bytes of each plane) and
+// stores 16 bytes; consecutive threads take consecutive chunks of a row, so one wave-wide store is 1 KiB contiguous (a
+// whole 256-column row, two 128-column rows, four 64-column rows).  Stores shaped by the MFMA layouts instead (a lane = a
+// row, 16 or 32 bytes of it) touch 32 lines per instruction: the vector memory path then moves ~14 B/clk/CU and HBM takes
+// partial lines at ~3.5 TB/s; whole lines were measured at about twice that (round 3).  The LDS reads of BATCH
+// iterations are issued before the first conversion.
+template <int NP, int W, int TILE, int THREADS, int NCOLS, int BATCH = 4>
+__device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, float unscale, float unscale2,
                                              float* __restrict__ dst, int ldg, int m0, int M, int tid) {
-  constexpr int GPR = NCOLS >> 3, ITER = TILE * GPR / F16_THREADS;
-  static_assert(TILE * GPR % F16_THREADS == 0, "whole passes of the workgroup");
+  constexpr int GPR = NCOLS >> 2, ITER = TILE * GPR / THREADS;
+  static_assert(TILE * GPR % THREADS == 0, "whole passes of the workgroup");
   constexpr int B = (BATCH == 0 || BATCH > ITER) ? ITER : BATCH;
   static_assert(ITER % B == 0, "whole batches");
   const bool whole = m0 + TILE <= M;
 #pragma unroll 1
   for (int it0 = 0; it0 < ITER; it0 += B) {
-    h8 wh[B], wl[B];
+    u32x2_t wh[B], wl[B];
 #pragma unroll
     for (int j = 0; j < B; ++j) {
-      const int idx = tid + (it0 + j) * F16_THREADS, row = idx / GPR, g = idx % GPR;
-      const int o = poff<W>(row, c0 + 8 * g);
-      wh[j] = *(const h8*)(Ph + o);
-      if constexpr (NP == 2) wl[j] = *(const h8*)(Pl + o);
+      const int idx = tid + (it0 + j) * THREADS, row = idx / GPR, g = idx % GPR;
+      const int o = poff<W>(row, c0 + 4 * g);
+      wh[j] = *(const u32x2_t*)(Ph + o);
+      if constexpr (NP == 2) wl[j] = *(const u32x2_t*)(Pl + o);
     }
 #pragma unroll
     for (int j = 0; j < B; ++j) {
-      const int idx = tid + (it0 + j) * F16_THREADS, row = idx / GPR, g = idx % GPR;
-      f32x4 o0, o1;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if constexpr (NP == 2) {
-          o0[c] = ((float)wh[j][c] + (float)wl[j][c]) * unscale;
-          o1[c] = ((float)wh[j][4 + c] + (float)wl[j][4 + c]) * unscale;
-        } else {
-          o0[c] = (float)wh[j][c] * unscale;
-          o1[c] = (float)wh[j][4 + c] * unscale;
-        }
-      }
-      if (whole || m0 + row < M) {
-        float* p = &dst[(size_t)(m0 + row) * ldg + 8 * g];
-        *(f32x4*)p = o0;
-        *(f32x4*)(p + 4) = o1;
-      }
+      const int idx = tid + (it0 + j) * THREADS, row = idx / GPR, g = idx % GPR;
+      const float un = row < TILE / 2 ? unscale : unscale2;  // the two row halves may carry different exponents
+      f32x4 v;
+      if constexpr (NP == 2)
+        v = f32x4{mix16<0>(wh[j][0], un, mix16<0>(wl[j][0], un, 0.f)), mix16<1>(wh[j][0], un, mix16<1>(wl[j][0], un, 0.f)),
+                  mix16<0>(wh[j][1], un, mix16<0>(wl[j][1], un, 0.f)), mix16<1>(wh[j][1], un, mix16<1>(wl[j][1], un, 0.f))};
+      else
+        v = f32x4{mix16<0>(wh[j][0], un, 0.f), mix16<1>(wh[j][0], un, 0.f), mix16<0>(wh[j][1], un, 0.f), mix16<1>(wh[j][1], un, 0.f)};
+      if (whole || m0 + row < M) *(f32x4*)&dst[(size_t)(m0 + row) * ldg + 4 * g] = v;
     }
   }
 }
+template <int NP, int W, int TILE, int THREADS, int NCOLS, int BATCH = 4>
+__device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, float unscale, float* __restrict__ dst,
+                                             int ldg, int m0, int M, int tid) {
+  tile_store16<NP, W, TILE, THREADS, NCOLS, BATCH>(Ph, Pl, c0, unscale, unscale, dst, ldg, m0, M, tid);
+}
 
 // The hi plane of the tile (columns [0, W)) -> row-major fp16 global tensor, as it stands (16 bytes per thread and step);
-// the tile's exponent goes to its slot of the exponent table.  f16 mode only.
-template <int W, int TILE>
-__device__ __forceinline__ void tile_copy16(const char* Ph, int e, uint16_t* __restrict__ dst, int32_t* __restrict__ dexp, int m0,
-                                            int M, int tid) {
-  constexpr int GPR = W >> 3, ITER = TILE * GPR / F16_THREADS;
-  if (tid == 0) dexp[m0 / TILE] = e;
+// the tile's exponent goes to its slot(s) of the exponent table, which has one entry per 64 rows whatever the kernel's
+// tile (the weight-gradient kernel reads it per 64-row block).  f16 storage only.
+template <int W, int TILE, int THREADS>
+__device__ __forceinline__ void tile_copy16(const char* Ph, int e, int e2, uint16_t* __restrict__ dst, int32_t* __restrict__ dexp,
+                                            int m0, int M, int tid) {
+  constexpr int GPR = W >> 3, ITER = TILE * GPR / THREADS;
+  if (tid < TILE / 64 && m0 + 64 * tid < M) dexp[m0 / 64 + tid] = tid == 0 ? e : e2;
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
-    const int idx = tid + it * F16_THREADS, row = idx / GPR, g = idx % GPR;
+    const int idx = tid + it * THREADS, row = idx / GPR, g = idx % GPR;
     const f32x4 v = *(const f32x4*)(Ph + poff<W>(row, 8 * g));
     if (m0 + row < M) *(f32x4*)((char*)dst + ((size_t)(m0 + row) * W + 8 * g) * 2) = v;
   }
+}
+template <int W, int TILE, int THREADS>
+__device__ __forceinline__ void tile_copy16(const char* Ph, int e, uint16_t* __restrict__ dst, int32_t* __restrict__ dexp, int m0,
+                                            int M, int tid) {
+  tile_copy16<W, TILE, THREADS>(Ph, e, e, dst, dexp, m0, M, tid);
 }
 
 __device__ __forceinline__ float wave_max(float m) {
@@ -153,8 +170,22 @@ __device__ __forceinline__ float wave_max(float m) {
   return m;
 }
 
-__device__ __forceinline__ void track(float* __restrict__ slot, float mx, int tid) {
-  if (slot && tid == 0) atomicMax((unsigned int*)slot, __float_as_uint(mx));
+// Running maxima (scales of the weight-gradient contraction) are collected per workgroup in an LDS table and folded into the
+// global table ONCE, by the last instructions of the kernel: a global atomic counts in the issuing wave's vmcnt until it has
+// been performed at its L2 channel -- behind every other workgroup's atomic on the same address -- and the wave's next wait
+// for a weight fragment waits for it too (vmcnt retires in order).  In the pipelined trunk that cost 20k cycles per phase.
+__device__ __forceinline__ void track(unsigned int* mx_s, int slot, float mx, int tid) {
+  if (tid == 0) mx_s[slot] = max(mx_s[slot], __float_as_uint(mx));  // non-negative floats order like their bit patterns
+}
+__device__ __forceinline__ void track_wave(unsigned int* mx_s, int slot, float mx, int lane) {
+  if (lane == 0) atomicMax(&mx_s[slot], __float_as_uint(mx));  // LDS atomic (several waves at once)
+}
+__device__ __forceinline__ void track_flush(const unsigned int* mx_s, float* __restrict__ dst, int tid) {
+  __syncthreads();
+  if (dst && tid < 16) {
+    const unsigned int v = mx_s[tid];
+    if (v) atomicMax((unsigned int*)dst + tid, v);
+  }
 }
 
 // four fp32 values * 2^e -> one 8-byte write per plane at (row, col % 4 == 0)
@@ -167,23 +198,252 @@ __device__ __forceinline__ void put_quad(char* Ph, char* Pl, int row, int col, c
   if constexpr (NP == 2) *(h4*)(Pl + o) = lo;
 }
 
+
+// ---- pipelined trunk of the forward pass, 128-sample tile (csrc/pipe16.cuh) -----------------------------------------------
+// Runs trunk layers 0 .. D-1 for the tile in the planes (layer 0 in lockstep: its K is 64), leaves h_{D-1} in the planes
+// with one exponent per row half (ehalf), and has stored what the backward pass needs: h_0 .. h_{D-1} (fp32 rows or fp16
+// rows + exponents), the ReLU sign bits, the running maxima.  Returns D (no trunk layer left for the caller).
+template <int NP, int W, int NW>
+__device__ __forceinline__ int fwd_trunk_pipelined(const upnerf_layout& L, const upnerf_field_fwd_args& a, char* Ph, char* Pl,
+                                                   float* smax, float* smaxb, unsigned int* mx_s, const int* loff_s,
+                                                   const float* bias_s, int (&ehalf)[2], int m0, int M, int tid) {
+  constexpr int TILE = F16_TILE_BIG, THREADS = 64 * NW;
+  static_assert(NW == 8 && W == 256, "one 32-column n-tile per wave");
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, hh = lane >> 5;
+  const int D = L.D, n0 = 32 * wave;
+  const char* __restrict__ P16 = (const char*)a.P16;
+  const int* __restrict__ wexp = a.wexp;
+  const int rbyteA = li * (W * 2), rsw = li & 15;
+  const bool train = a.h != nullptr || a.h16 != nullptr;
+  const int n64 = (M + 63) >> 6;
+  const size_t hm_stride32 = (size_t)gridDim.x * THREADS * 2;
+
+  // ---- the encoding planes as operand fragments in global memory (skip connection, read back at layer L.skip):
+  // x0f[tile][t = 0..3][mt = 0..3][plane][lane] x 16 bytes
+  char* x0f = a.x0f ? (char*)a.x0f + (size_t)blockIdx.x * (UPNERF_X0 / 16 * 4 * 2 * 1024) : nullptr;
+  if (x0f && L.skip > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = wave * 4 + j, p = f & 1, mt = (f >> 1) & 3, t = f >> 3;
+      if (NP == 2 || p == 0) {
+        const int o = (32 * mt + li) * (W * 2) + (((2 * t + hh) ^ rsw) << 4);
+        *(h8*)(x0f + (size_t)f * 1024 + lane * 16) = *(const h8*)((p ? Pl : Ph) + o);
+      }
+    }
+  }
+
+  f32x16 acc[4];
+  int eA = ehalf[0], eB = ehalf[1];
+  const int e_x0 = eA;
+  STAMP_DECL;
+  // weight fragment base of layer l for this wave's n-tile, first k-block kb0
+  // (every helper takes the lane id as an argument: inside the layer loop it is rebuilt per stage, see there)
+  auto wbase = [&](int l, int kp16, int kb0, int lane) -> const char* {
+    const int wl = __builtin_amdgcn_readfirstlane(loff_s[l]);
+    return P16 + 4 * (size_t)wl + ((size_t)wave * kp16 + kb0) * 2048 + lane * 16;
+  };
+  // max |bias| over this wave's 32 columns of layer l
+  auto bias_absmax = [&](int l, int lane) { return wave_max_nn(fabsf(bias_s[l * W + n0 + (lane & 31)])); };
+  // bound of a half's outputs from the maximum of its accumulators, shared through LDS at the next barrier
+  auto publish = [&](float* slot, float accmax, int e_in, int wel, float bmax, int lane) {
+    if (lane == 0) slot[wave] = fmaf(accmax, pow2f(-(e_in + wel)), bmax);
+  };
+  auto finish_half = [&](int l, int half, unsigned int bits, float vmax, int e_out, int lane) {
+    if (a.hmask)
+      ((unsigned int*)a.hmask)[(size_t)l * hm_stride32 + ((size_t)blockIdx.x * THREADS + wave * 64 + lane) * 2 + half] = bits;
+    track_wave(mx_s, l, ldexpf(wave_max_nn(vmax), -e_out), lane);
+  };
+
+  // ---- layer 0 (K = 64) in lockstep; its epilogue of half B already rides in layer 1's phase 1
+  int wel_prev, eB_in_prev;
+  {
+    const char* wp = wbase(0, UPNERF_X0 / 16, 0, lane);
+    h8 wh[4], wl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pl_ldw<NP>(wh[t], wl[t], wp, t);
+    pl_zero<0>(acc);
+    pl_zero<1>(acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      XFrag<NP> xa, xb;
+      pl_ldx<NP, W>(xa, Ph, Pl, rbyteA, rsw, t, hh);
+      pl_ldx<NP, W>(xb, Ph, Pl, rbyteA + 64 * W * 2, rsw, t, hh);
+      pl_mma<NP, 0>(acc, xa, wh[t], wl[t]);
+      pl_mma<NP, 1>(acc, xb, wh[t], wl[t]);
+    }
+    const int wel = __builtin_amdgcn_readfirstlane(wexp[0]);
+    const float bmax = bias_absmax(0, lane);
+    publish(smax, pl_absmax<0>(acc), eA, wel, bmax, lane);
+    publish(smaxb, pl_absmax<1>(acc), eB, wel, bmax, lane);
+    __syncthreads();  // every wave has read the encoding planes; the bounds are in LDS; the x0f stores have completed
+    const int eAo = bound_exp(wg_max<NW>(smax)), eBo = bound_exp(wg_max<NW>(smaxb));
+    unsigned int bits = 0u;
+    float vmax = 0.0f;
+    const float s = pow2f(-(eA + wel)), pe = pow2f(eAo);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) pl_epi_quad<NP, W, 0, true>(acc, c, bias_s, s, pe, Ph, Pl, rbyteA, rsw, n0, hh, bits, vmax);
+    finish_half(0, 0, bits, vmax, eAo, lane);
+    wel_prev = wel;
+    eB_in_prev = eB;
+    eA = eAo;
+    eB = eBo;  // exponent the planes of B will carry once layer 0's epilogue of B has run (phase 1 of layer 1)
+    pl_barrier();  // planes A hold h_0
+  }
+
+  STAMP(6);  // layer 0
+  // ---- layers 1 .. D-1, software-pipelined
+  WPre<NP> wpre;
+  if (D > 1) {
+    const bool sk = 1 == L.skip;
+    const char* wp1 = wbase(1, sk ? (UPNERF_X0 + W) / 16 : W / 16, sk ? UPNERF_X0 / 16 : 0, lane);
+    pl_ldw<NP>(wpre.h[0], wpre.l[0], wp1, 0);
+    pl_ldw<NP>(wpre.h[1], wpre.l[1], wp1, 1);
+  }
+  unsigned int bitsB = 0u;
+  float vmaxB = 0.0f;
+#pragma unroll 1
+  for (int l = 1; l < D; ++l) {
+    // Every per-lane constant of the stage is rebuilt here from v_mbcnt (two instructions, no input register): values that
+    // merely pass through the loop would be spilled in front of it and reloaded inside -- and a scratch reload is a vector
+    // memory load whose wait also waits for every older activation store of the wave.
+    int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 31, hh = lane >> 5, rbyteA = li * (W * 2), rsw = li & 15;
+    const bool sk = l == L.skip, skn = l + 1 == L.skip;
+    const char* wp = wbase(l, sk ? (UPNERF_X0 + W) / 16 : W / 16, sk ? UPNERF_X0 / 16 : 0, lane);
+    const char* wpn = l + 1 < D ? wbase(l + 1, skn ? (UPNERF_X0 + W) / 16 : W / 16, skn ? UPNERF_X0 / 16 : 0, lane) : nullptr;
+    const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);
+    const int eA_in = eA, eB_in = eB;  // exponents of h_{l-1} in the planes (B: after phase 1)
+    // the encoding part of the skip layer: 4 k-blocks from the fragment copy in global memory, then the accumulators move
+    // to the exponent of the planes this half is about to read
+    auto skip_part = [&](auto half_c, int e_in) {
+      constexpr int H = decltype(half_c)::value;
+      const char* wx = wbase(l, (UPNERF_X0 + W) / 16, 0, lane);
+#pragma unroll
+      for (int t = 0; t < UPNERF_X0 / 16; ++t) {
+        h8 wh, wl;
+        pl_ldw<NP>(wh, wl, wx, t);
+        XFrag<NP> x;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const char* f = x0f + (size_t)(((t * 4 + 2 * H + mt) * 2) * 1024) + lane * 16;
+          x.h[mt] = *(const h8*)f;
+          if constexpr (NP == 2) x.l[mt] = *(const h8*)(f + 1024);
+        }
+        pl_mma<NP, H>(acc, x, wh, wl);
+      }
+      pl_scale<H>(acc, pow2f(e_in - e_x0));
+    };
+    // destinations of h_{l-1}: written from the planes in 16-row pieces of whole lines, four pieces per row half and stage
+    auto piece = [&](int half, int j, float un) {
+      const int r0 = m0 + 64 * half;
+#ifdef PL_EXP_STOREL2  // timing experiment: every store lands in one L2-resident megabyte per XCD (no HBM write stream)
+      float* b32 = a.h ? a.h + (size_t)(r0 % (64 * TILE)) * W : nullptr;
+      uint16_t* b16 = nullptr;
+#else
+      float* b32 = (a.h && !a.h16) ? a.h + ((size_t)(l - 1) * M + r0) * W : nullptr;
+      uint16_t* b16 = a.h16 ? a.h16 + ((size_t)(l - 1) * M + r0) * W : nullptr;
+#endif
+      pl_store_piece<NP, W>(Ph, Pl, 64 * half, j, lane, wave, b32, b16, M - r0, un);
+    };
+    if (a.h16 && wave == 0 && lane == 0) {
+      a.hexp[(size_t)(l - 1) * n64 + (m0 >> 6)] = eA_in;
+      if (m0 + 64 < M) a.hexp[(size_t)(l - 1) * n64 + (m0 >> 6) + 1] = eB_in;
+    }
+    const float unA = pow2f(-eA_in), unB = pow2f(-eB_in);
+    // epilogue state
+    const float sB = pow2f(-(eB_in_prev + wel_prev)), peB = pow2f(eB_in);  // half B of layer l-1 -> planes B at exponent eB_in
+    const float* bias_prev = bias_s + (l - 1) * W;
+    const float* bias_cur = bias_s + l * W;
+    unsigned int bitsA = 0u;
+    float vmaxA = 0.0f, sA = 0.0f, peA = 0.0f;
+    int eAo = 0, eBo = 0;
+    pl_zero<0>(acc);
+    if (sk) skip_part(std::integral_constant<int, 0>{}, eA_in);
+    pl_stage<NP, W>(
+        acc, Ph, Pl, rbyteA, rsw, hh, wp, wpre, wpn,
+        /* epiB */ [&](int c) { pl_epi_quad<NP, W, 1, true>(acc, c, bias_prev, sB, peB, Ph, Pl, rbyteA + 64 * W * 2, rsw, n0, hh, bitsB, vmaxB); },
+        /* epiA */ [&](int c) { pl_epi_quad<NP, W, 0, true>(acc, c, bias_cur, sA, peA, Ph, Pl, rbyteA, rsw, n0, hh, bitsA, vmaxA); },
+        /* pieceA */ [&](int j) { if (train) piece(0, j, unA); },
+        /* pieceB */ [&](int j) { if (train) piece(1, j, unB); },
+        /* preB */ [&]() {
+          pl_zero<1>(acc);
+          if (sk) skip_part(std::integral_constant<int, 1>{}, eB_in);
+        },
+        /* endP1 */ [&]() {
+          STAMP(0);
+          finish_half(l - 1, 1, bitsB, vmaxB, eB_in, lane);
+          bitsB = 0u;
+          vmaxB = 0.0f;
+          pl_barrier();  // planes B hold h_{l-1}
+          STAMP(1);
+        },
+        /* endP2 */ [&]() {
+          STAMP(2);
+          publish(smax, pl_absmax<0>(acc), eA_in, wel, bias_absmax(l, lane), lane);
+          pl_barrier();  // every wave is done reading planes A; the bound of A is in LDS
+          STAMP(3);
+          eAo = bound_exp(wg_max<NW>(smax));
+          sA = pow2f(-(eA_in + wel));
+          peA = pow2f(eAo);
+        },
+        /* endP3 */ [&]() {
+          STAMP(4);
+          finish_half(l, 0, bitsA, vmaxA, eAo, lane);
+          publish(smaxb, pl_absmax<1>(acc), eB_in, wel, bias_absmax(l, lane), lane);
+          pl_barrier();  // planes A hold h_l; every wave is done reading planes B; the bound of B is in LDS
+          STAMP(5);
+          eBo = bound_exp(wg_max<NW>(smaxb));
+        });
+    wel_prev = wel;
+    eB_in_prev = eB_in;
+    eA = eAo;
+    eB = eBo;
+  }
+  // ---- drain: epilogue of half B of the last layer
+  {
+    const float sB = pow2f(-(eB_in_prev + wel_prev)), peB = pow2f(eB);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      pl_epi_quad<NP, W, 1, true>(acc, c, bias_s + (D - 1) * W, sB, peB, Ph, Pl, rbyteA + 64 * W * 2, rsw, n0, hh, bitsB, vmaxB);
+    finish_half(D - 1, 1, bitsB, vmaxB, eB, lane);
+    pl_barrier();
+  }
+  ehalf[0] = eA;
+  ehalf[1] = eB;
+  STAMP(7);  // drain
+  {
+    const int lane = tid & 63;
+    (void)lane;
+    STAMP_FLUSH;
+  }
+  // h_{D-1} has no later K loop of this function to ride in: planes -> global, whole rows
+  if (train) {
+    if (a.h16) tile_copy16<W, TILE, THREADS>(Ph, eA, eB, a.h16 + (size_t)(D - 1) * M * W, a.hexp + (size_t)(D - 1) * n64, m0, M, tid);
+  }
+  return D;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
-template <int NP, int TILE>
-__global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
-  constexpr int W = 256, W2 = 128;
+template <int NP, int TILE, int NW>
+__global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
+  constexpr int W = 256, W2 = 128, THREADS = 64 * NW;
   constexpr int AH = NP == 2 ? F16_AHEAD_X3 : F16_AHEAD_F16;  // weight k-blocks in flight (common16.cuh:mma16_lds)
-  constexpr int TPR = F16_THREADS / TILE;
+  constexpr int TPR = THREADS / TILE;
   __shared__ __attribute__((aligned(16))) char planes[NP * TILE * W * 2];
-  __shared__ float smax[F16_WAVES], smaxb[F16_WAVES];
+  __shared__ float smax[NW], smaxb[NW];
+  __shared__ unsigned int mx_s[16];  // running maxima of this workgroup (track / track_flush)
   __shared__ float xyz_s[TILE * 3];
   // per-layer offsets of the layout: read from LDS inside the layer loop.  Indexing the by-value struct with the runtime
   // layer makes hipcc copy it to scratch and fetch the entry with a VMEM load + s_waitcnt vmcnt(0) -- a full drain of the
   // previous layer's activation stores at the top of every layer.
   __shared__ int loff_s[2 * UPNERF_MAX_D];
+  // trunk biases [D][W] for the pipelined trunk of the 128-sample tile (its epilogues read them from LDS)
+  __shared__ __attribute__((aligned(16))) float bias_s[TILE == F16_TILE_BIG ? UPNERF_MAX_D * W : 4];
   char* Ph = planes;
   char* Pl = planes + (NP - 1) * TILE * W * 2;  // NP == 1: never dereferenced
-  using TW = WaveTile16<W, TILE>;
-  using TH = WaveTile16<W2, TILE>;
+  using TW = WaveTile16<W, TILE, NW>;
+  using TH = WaveTile16<W2, TILE, NW>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE;
@@ -200,6 +460,12 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
       loff_s[l] = L.w[l];
       loff_s[UPNERF_MAX_D + l] = L.b[l];
     }
+  }
+  if (tid < 16) mx_s[tid] = 0u;
+  if constexpr (TILE == F16_TILE_BIG) {
+#pragma unroll
+    for (int l = 0; l < UPNERF_MAX_D; ++l)
+      if (l < D && tid < W) bias_s[l * W + tid] = P[L.b[l] + tid];
   }
 
   // ---- sample positions (rendering.py:251 / 308) and the maxima that bound the side inputs of this tile
@@ -224,9 +490,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     const int mlast = (m0 + TILE < M ? m0 + TILE : M) - 1;
     const int ray0 = m0 / S, nr = mlast / S - ray0 + 1;
     if (a.use_rgb)
-      for (int idx = tid; idx < nr * UPNERF_AUXK; idx += F16_THREADS) sm = fmaxf(sm, fabsf(a.aux[(size_t)ray0 * UPNERF_AUXK + idx]));
+      for (int idx = tid; idx < nr * UPNERF_AUXK; idx += THREADS) sm = fmaxf(sm, fabsf(a.aux[(size_t)ray0 * UPNERF_AUXK + idx]));
     if (a.use_cand)
-      for (int idx = tid; idx < nr * UPNERF_CK; idx += F16_THREADS) sm = fmaxf(sm, fabsf(a.c_rows[(size_t)ray0 * UPNERF_CK + idx]));
+      for (int idx = tid; idx < nr * UPNERF_CK; idx += THREADS) sm = fmaxf(sm, fabsf(a.c_rows[(size_t)ray0 * UPNERF_CK + idx]));
     xm = wave_max(xm);
     sm = wave_max(sm);
     if (lane == 0) {
@@ -235,8 +501,8 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     }
   }
   __syncthreads();
-  const float x0max = wg_max(smax), sidemax = wg_max(smaxb);
-  track(a.amax ? a.amax + D + 4 : nullptr, x0max, tid);
+  const float x0max = wg_max<NW>(smax), sidemax = wg_max<NW>(smaxb);
+  track(mx_s, D + 4, x0max, tid);
   int ecur = scale_exp(x0max);
   // ---- BARF-masked encoding (nerf.py:126-147) straight into the planes
   {
@@ -249,7 +515,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
       if constexpr (NP == 2) *(_Float16*)(Pl + o) = l;
     };
     const float* __restrict__ wkd = a.wk_xyz_dev;  // per-step band weights from device memory under graph replay
-    for (int it = tid; it < TILE * 3; it += F16_THREADS) {
+    for (int it = tid; it < TILE * 3; it += THREADS) {
       const int row = it / 3, n = it - row * 3;
       const float xv = xyz_s[row * 3 + n];
       put(row, n, xv);
@@ -266,11 +532,25 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     }
   }
   __syncthreads();
-  tile_store16<NP, W, TILE, UPNERF_X0>(Ph, Pl, 0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
+  tile_store16<NP, W, TILE, THREADS, UPNERF_X0>(Ph, Pl, 0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
 
+  // fp32 copy of trunk activation h_lidx for the weight gradients, from the planes (with fp16 storage only the last layer)
+  auto store_h32 = [&](int lidx, float un0, float un1) {
+#ifndef UPNERF_EXP_NOSTORE
+    if (a.h && (!a.h_last_only || lidx == D - 1))
+      tile_store16<NP, W, TILE, THREADS, W>(Ph, Pl, 0, un0, un1, a.h + (a.h_last_only ? 0 : (size_t)lidx * M * W), W, m0, M, tid);
+#endif
+  };
   // ---- trunk (nerf.py:84-87)
   STAMP(7);  // sample positions + encoding + x0 store
-  for (int l = 0; l < D; ++l) {
+  // exponents of the two row halves of the planes (rows [0, TILE/2) and [TILE/2, TILE)): the lockstep stages keep them equal
+  int ehalf[2] = {ecur, ecur};
+  int lfirst = 0;  // first trunk layer the lockstep loop below still has to run
+  if constexpr (TILE == F16_TILE_BIG) {
+    lfirst = fwd_trunk_pipelined<NP, W, NW>(L, a, Ph, Pl, smax, smaxb, mx_s, loff_s, bias_s, ehalf, m0, M, tid);
+    ecur = ehalf[0];
+  }
+  for (int l = lfirst; l < D; ++l) {
     STAMP(0);
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
@@ -292,28 +572,30 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
       mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, W / 16, n0, 0, lane);
     }
     STAMP(1);
+    // h_{l-1} leaves from the planes this K loop has just read, in whole lines, behind the loop's last wait for a weight
+    // fragment: the epilogue, two barriers and the plane write pass before the wave waits for a load again
+    if (l >= 1) store_h32(l - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
     f32x4 bl[TW::NT][4];
     load_cols(bl, P + bl_off, n0, hh);
     const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wel)), bl);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
-    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * F16_THREADS + tid] = bits;
-    if (a.h && !(a.h16 && a.h_last_only && l != D - 1))
-      acc_store_global(acc, a.h + (a.h_last_only ? 0 : (size_t)l * M * W), W, m0, M, row0, n0, lane);
+    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * THREADS + tid] = bits;
     STAMP(2);
     __syncthreads();
     STAMP(3);
-    float mx = wg_max(smax);
-    track(a.amax ? a.amax + l : nullptr, mx, tid);
+    float mx = wg_max<NW>(smax);
+    track(mx_s, l, mx, tid);
     if (l + 1 == L.skip) mx = fmaxf(mx, x0max);  // the skip layer feeds x0 rows through the same accumulators
     ecur = scale_exp(mx);
+    ehalf[0] = ehalf[1] = ecur;
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     STAMP(4);
     __syncthreads();
     STAMP(5);
     // fp16 storage: the (hi) plane IS the stored tile -- the next write to it is a barrier away.  (f16x3 mode: an option;
     // the weight-gradient operand then is the activation rounded to fp16, the forward chain keeps hi + lo.)
-    if (a.h16) tile_copy16<W, TILE>(Ph, ecur, a.h16 + (size_t)l * M * W, a.hexp + (size_t)l * gridDim.x, m0, M, tid);
+    if (a.h16) tile_copy16<W, TILE, THREADS>(Ph, ecur, a.h16 + (size_t)l * M * W, a.hexp + (size_t)l * ((M + 63) >> 6), m0, M, tid);
     STAMP(6);
   }
 
@@ -325,12 +607,14 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
   const int prow = tid / TPR, phalf = tid % TPR, pm = m0 + prow;
   // ---- shared density head (nerf.py:89): softplus(w . h + b)
   {
-    const float pre = rowdot16<NP, W, TPR, W>(Ph, Pl, prow, phalf, 0, P + L.wsig, pow2f(-ecur)) + P[L.bsig];
+    const float pre = rowdot16<NP, W, TPR, W>(Ph, Pl, prow, phalf, 0, P + L.wsig, pow2f(-(prow >= TILE / 2 ? ehalf[1] : ehalf[0]))) + P[L.bsig];
     if (phalf == 0 && pm < M) a.sigma_s[pm] = softplus_f(pre);
   }
   // density-only pass (nerf.py:90-91 `sigma_only`): nobody consumes e, so the pass ends here
   if (!a.e && !a.use_rgb && !a.use_cand) {
+    store_h32(D - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
     STAMP_FLUSH_AT(8);
+    track_flush(mx_s, a.amax, tid);
     return;
   }
   // ---- xyz_encoding_final (nerf.py:93), no activation
@@ -340,20 +624,28 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     f32x4 be[TW::NT][4];
     load_cols(be, P + L.be, n0, hh);
     mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, lane);
-    acc_fma_bias<false>(acc, pow2f(-(ecur + wexp[8])), be);
-    if (a.e) acc_store_global(acc, a.e, W, m0, M, row0, n0, lane);
+    store_h32(D - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
+    acc_fma_bias_h<false>(acc, pow2f(-(ehalf[0] + wexp[8])), pow2f(-(ehalf[1] + wexp[8])), be);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    const float mx = wg_max(smax);
-    track(a.amax ? a.amax + D : nullptr, mx, tid);
+    const float mx = wg_max<NW>(smax);
+    track(mx_s, D, mx, tid);
     ecur = scale_exp(fmaxf(mx, sidemax));  // the heads feed per-ray rows through the same accumulators
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
   }
   STAMP(5);  // density head + xyz_encoding_final
+  // e (no activation) leaves from the planes too: behind the K loop of the first head that reads it, or here
+  bool e_pending = a.e != nullptr;
+  auto store_e = [&]() {
+    if (e_pending) tile_store16<NP, W, TILE, THREADS, W>(Ph, Pl, 0, pow2f(-ecur), a.e, W, m0, M, tid);
+    e_pending = false;
+  };
   if (!a.use_rgb && !a.use_cand) {
+    store_e();
     STAMP_FLUSH_AT(8);
+    track_flush(mx_s, a.amax, tid);
     return;
   }
 
@@ -372,6 +664,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     f32x4 br[TH::NT][4];
     load_cols(br, P + L.br1, hn0, hh);
     mma16_lds<NP, W, W / 16, AH>(accr, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, 0, lane);
+    store_e();
     const float* ap[TH::MT];
 #pragma unroll
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.aux + (size_t)rayrow[mt] * UPNERF_AUXK + 8 * hh;
@@ -384,12 +677,13 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     f32x4 bc[TH::NT][4];
     load_cols(bc, P + L.bc1, hn0, hh);
     mma16_lds<NP, W, W / 16, AH>(accc, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, 0, lane);
+    store_e();
     const float* ap[TH::MT];
 #pragma unroll
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.c_rows + (size_t)rayrow[mt] * UPNERF_CK + 8 * hh;
     mma16_glb<NP>(accc, ap, ecur, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, UPNERF_CK, lane);
     const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), bc);
-    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * F16_THREADS + tid] = bits;
+    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * THREADS + tid] = bits;
     mc = acc_absmax(accc);
   }
   if (lane == 0) {
@@ -398,16 +692,16 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
   }
   __syncthreads();
   {
-    const float mxr = wg_max(smax), mxc = wg_max(smaxb);
-    track(a.amax && a.use_rgb ? a.amax + D + 3 : nullptr, mxr, tid);
-    track(a.amax && a.use_cand ? a.amax + D + 1 : nullptr, mxc, tid);
+    const float mxr = wg_max<NW>(smax), mxc = wg_max<NW>(smaxb);
+    if (a.use_rgb) track(mx_s, D + 3, mxr, tid);
+    if (a.use_cand) track(mx_s, D + 1, mxc, tid);
     ecur = scale_exp(fmaxf(mxr, mxc));
   }
   if (a.use_rgb) acc_to_planes<NP, W>(accr, Ph, Pl, hrow0, hn0, 0, ecur, lane);
   if (a.use_cand) acc_to_planes<NP, W>(accc, Ph, Pl, hrow0, hn0, W2, ecur, lane);
   __syncthreads();
   if (a.use_rgb) {
-    if (a.r1) tile_store16<NP, W, TILE, W2>(Ph, Pl, 0, pow2f(-ecur), a.r1, W2, m0, M, tid);
+    if (a.r1) tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, 0, pow2f(-ecur), a.r1, W2, m0, M, tid);
     // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -416,7 +710,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     }
   }
   if (a.use_cand) {
-    if (a.g1) tile_store16<NP, W, TILE, W2>(Ph, Pl, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
+    if (a.g1) tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
     f32x16 acc[TH::MT][TH::NT];
     acc_zero(acc);
     f32x4 b2[TH::NT][4];
@@ -426,30 +720,163 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_fwd_ker
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    ecur = scale_exp(wg_max(smax));
+    ecur = scale_exp(wg_max<NW>(smax));
     acc_to_planes<NP, W>(acc, Ph, Pl, hrow0, hn0, W2, ecur, lane);
     __syncthreads();
-    if (a.g2) tile_store16<NP, W, TILE, W2>(Ph, Pl, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
+    if (a.g2) tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
     const float pre = rowdot16<NP, W, TPR, W2>(Ph, Pl, prow, phalf, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
     if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
   }
   STAMP(6);  // colour / candidate heads
   STAMP_FLUSH_AT(8);
+  track_flush(mx_s, a.amax, tid);
+}
+
+
+// ---- pipelined trunk of the backward pass, 128-sample tile (csrc/pipe16.cuh) ----------------------------------------------
+// In: the planes hold gz_{D-1} with the exponents ehalf.  Runs the data-gradient stages
+// l = D-1 .. 1 (gz_{l-1} = mask_{l-1} (gz_l . W_l)), stores gz_{D-1} .. gz_0 (fp32 rows or fp16 rows + exponents) and the
+// running maxima, parks the skip layer's encoding term (d x0 += gz_skip . W_skip,x) in `xs` (this tile's 32 KiB of the
+// forward pass's x0f scratch, in accumulator order), and leaves gz_0 in the planes with the exponents ehalf.
+template <int NP, int W, int NW>
+__device__ __forceinline__ void bwd_trunk_pipelined(const upnerf_layout& L, const upnerf_field_bwd_args& a, char* Ph, char* Pl,
+                                                    float* smax, float* smaxb, unsigned int* mx_s, const int* loff_s,
+                                                    int (&ehalf)[2], int m0, int M, int tid) {
+  constexpr int TILE = F16_TILE_BIG, THREADS = 64 * NW;
+  static_assert(NW == 8 && W == 256, "one 32-column n-tile per wave");
+  using TX = WaveTile16<UPNERF_X0, TILE, NW>;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = L.D, n0 = 32 * wave;
+  const char* __restrict__ PT16 = (const char*)a.PT16;
+  const int* __restrict__ wexp = a.wexp;
+  const int n64 = (M + 63) >> 6;
+  const size_t hm_stride32 = (size_t)gridDim.x * THREADS * 2;
+  const bool store32 = a.gz_h != nullptr, store16 = a.gz16 != nullptr;
+  f32x16 acc[4];
+  int eA = ehalf[0], eB = ehalf[1];
+  auto wbase = [&](int l, int lane) -> const char* {
+    const int wl = __builtin_amdgcn_readfirstlane(loff_s[l]);
+    return PT16 + 4 * (size_t)wl + (size_t)wave * (W / 16) * 2048 + lane * 16;
+  };
+  auto mask32 = [&](int l, int half, int lane) -> unsigned int {
+    return ((const unsigned int*)a.hmask)[(size_t)l * hm_stride32 + ((size_t)blockIdx.x * THREADS + wave * 64 + lane) * 2 + half];
+  };
+  auto publish = [&](float* slot, float accmax, int e_in, int wel, int lane) {
+    if (lane == 0) slot[wave] = accmax * pow2f(-(e_in + wel));
+  };
+  auto finish_half = [&](int l, float vmax, int e_out, int lane) {  // l: index of the gradient just written (gz_l)
+    track_wave(mx_s, l, ldexpf(wave_max_nn(vmax), -e_out), lane);
+  };
+  WPre<NP> wpre;
+  if (D > 1) {
+    const int lane = tid & 63;
+    const char* wp1 = wbase(D - 1, lane);
+    pl_ldw<NP>(wpre.h[0], wpre.l[0], wp1, 0);
+    pl_ldw<NP>(wpre.h[1], wpre.l[1], wp1, 1);
+  }
+  float vmaxB = 0.0f, spB = 0.0f;
+  unsigned int bitsB = 0u;
+  bool pendB = false;  // half B of the previous stage still has its epilogue to run
+#pragma unroll 1
+  for (int l = D - 1; l >= 1; --l) {
+    int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));  // per-stage rebuild, see the forward pass
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 31, hh = lane >> 5, rbyteA = li * (W * 2), rsw = li & 15;
+    const char* wp = wbase(l, lane);
+    const char* wpn = l > 1 ? wbase(l - 1, lane) : nullptr;
+    const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);
+    const int eA_in = eA, eB_in = eB;  // exponents of gz_l in the planes (B: once phase 1 has written it)
+    const unsigned int bitsA = mask32(l - 1, 0, lane);
+    const unsigned int bitsBn = mask32(l - 1, 1, lane);
+    // gz_l rides out in this stage's K loop
+    const bool st = store32 || (store16 && l < D - 1);  // fp16 rows of gz_{D-1}: copied out by the caller
+    auto piece = [&](int half, int j, float un) {
+      const int r0 = m0 + 64 * half;
+      float* b32 = store16 ? nullptr : a.gz_h + ((size_t)l * M + r0) * W;
+      uint16_t* b16 = store16 ? a.gz16 + ((size_t)l * M + r0) * W : nullptr;
+      pl_store_piece<NP, W>(Ph, Pl, 64 * half, j, lane, wave, b32, b16, M - r0, un);
+    };
+    if (st && store16 && wave == 0 && lane == 0) {
+      a.gzexp[(size_t)l * n64 + (m0 >> 6)] = eA_in;
+      if (m0 + 64 < M) a.gzexp[(size_t)l * n64 + (m0 >> 6) + 1] = eB_in;
+    }
+    const float unA = pow2f(-eA_in), unB = pow2f(-eB_in);
+    float vmaxA = 0.0f, spA = 0.0f;
+    int eAo = 0, eBo = 0;
+    pl_zero<0>(acc);
+    pl_stage<NP, W>(
+        acc, Ph, Pl, rbyteA, rsw, hh, wp, wpre, wpn,
+        /* epiB */ [&](int c) { if (pendB) pl_epi_bwd_quad<NP, W, 1>(acc, c, spB, bitsB, Ph, Pl, rbyteA + 64 * W * 2, rsw, n0, hh, vmaxB); },
+        /* epiA */ [&](int c) { pl_epi_bwd_quad<NP, W, 0>(acc, c, spA, bitsA, Ph, Pl, rbyteA, rsw, n0, hh, vmaxA); },
+        /* pieceA */ [&](int j) { if (st) piece(0, j, unA); },
+        /* pieceB */ [&](int j) { if (st) piece(1, j, unB); },
+        /* preB */ [&]() { pl_zero<1>(acc); },
+        /* endP1 */ [&]() {
+          if (pendB) finish_half(l, vmaxB, eB_in, lane);
+          vmaxB = 0.0f;
+          pl_barrier();  // planes B hold gz_l
+          // the encoding term of the skip layer: both row halves of gz_skip are in the planes during this phase only
+          if (a.need_dxyz && l == L.skip) {
+            f32x16 accx[TX::MT][TX::NT];
+            acc_zero(accx);
+            const int xn0 = TX::n0(wave), xrow0 = TX::row0(wave);
+            mma16_lds<NP, W, W / 16, 1>(accx, Ph, Pl, xrow0, 0, PT16 + 4 * (size_t)L.t_skipx, W / 16, xn0, 0, lane);
+            const float un = pow2f(-((xrow0 >= TILE / 2 ? eB_in : eA_in) + wel));
+            float* xs = (float*)((char*)a.xs + (size_t)blockIdx.x * (UPNERF_X0 / 16 * 4 * 2 * 1024)) + (size_t)wave * 1024 + lane * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *(f32x4*)(xs + q * 256) = f32x4{accx[0][0][4 * q] * un, accx[0][0][4 * q + 1] * un, accx[0][0][4 * q + 2] * un, accx[0][0][4 * q + 3] * un};
+          }
+        },
+        /* endP2 */ [&]() {
+          publish(smax, pl_absmax<0>(acc), eA_in, wel, lane);
+          pl_barrier();  // every wave is done reading planes A; the bound of A is in LDS
+          eAo = bound_exp(wg_max<NW>(smax));
+          spA = pow2f(eAo - eA_in - wel);
+        },
+        /* endP3 */ [&]() {
+          finish_half(l - 1, vmaxA, eAo, lane);
+          publish(smaxb, pl_absmax<1>(acc), eB_in, wel, lane);
+          pl_barrier();  // planes A hold gz_{l-1}; every wave is done reading planes B; the bound of B is in LDS
+          eBo = bound_exp(wg_max<NW>(smaxb));
+        });
+    spB = pow2f(eBo - eB_in - wel);
+    bitsB = bitsBn;
+    pendB = true;
+    eA = eAo;
+    eB = eBo;
+  }
+  // ---- drain: epilogue of half B of the last stage
+  if (pendB) {
+    const int lane = tid & 63, li = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      pl_epi_bwd_quad<NP, W, 1>(acc, c, spB, bitsB, Ph, Pl, li * (W * 2) + 64 * W * 2, li & 15, n0, hh, vmaxB);
+    finish_half(0, vmaxB, eB, lane);
+    pl_barrier();
+  }
+  ehalf[0] = eA;
+  ehalf[1] = eB;
+  if (D > 1) {  // gz_0 has no later K loop of this function to ride in
+    if (store16) tile_copy16<W, TILE, THREADS>(Ph, eA, eB, a.gz16, a.gzexp, m0, M, tid);
+    else if (store32) tile_store16<NP, W, TILE, THREADS, W>(Ph, Pl, 0, pow2f(-eA), pow2f(-eB), a.gz_h, W, m0, M, tid);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Backward data-gradient chain (autograd of nerf.py:80-124), stage for stage as field.hip:field_bwd_kernel.
-template <int NP, int TILE>
-__global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
-  constexpr int W = 256, W2 = 128;
+template <int NP, int TILE, int NW>
+__global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
+  constexpr int W = 256, W2 = 128, THREADS = 64 * NW;
   constexpr int AH = NP == 2 ? F16_AHEAD_X3 : F16_AHEAD_F16;
   constexpr int MAXRAYS = 3;            // rays a 64-sample tile can touch when S >= 32
   constexpr int GPR = W2 / 4;           // 16-byte groups per half-width row
-  constexpr int EPT = TILE * GPR / F16_THREADS;  // groups per thread in the elementwise stages
+  constexpr int EPT = TILE * GPR / THREADS;  // groups per thread in the elementwise stages
   constexpr int PLANE_BYTES = NP * TILE * W * 2;
   constexpr int LDS_BYTES = PLANE_BYTES < TILE * UPNERF_X0 * 4 ? TILE * UPNERF_X0 * 4 : PLANE_BYTES;
   __shared__ __attribute__((aligned(16))) char planes[LDS_BYTES];
-  __shared__ float smax[F16_WAVES], smaxb[F16_WAVES];
+  __shared__ float smax[NW], smaxb[NW];
+  __shared__ unsigned int mx_s[16];  // running maxima of this workgroup (track / track_flush)
   __shared__ float pre_s[TILE];
   __shared__ __attribute__((aligned(16))) float wfj[MAXRAYS][TILE];  // w_feat[row] on the row's ray slot, else 0
   // per-row scalars of the head stages, computed once per row (not once per 16-byte column group): d pre-activation of
@@ -459,9 +886,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
   __shared__ int loff_s[UPNERF_MAX_D];  // t_w[l] (see the forward kernel: no runtime index into the by-value struct)
   char* Ph = planes;
   char* Pl = planes + (NP - 1) * TILE * W * 2;
-  using TW = WaveTile16<W, TILE>;
-  using TH = WaveTile16<W2, TILE>;
-  using TX = WaveTile16<UPNERF_X0, TILE>;
+  using TW = WaveTile16<W, TILE, NW>;
+  using TH = WaveTile16<W2, TILE, NW>;
+  using TX = WaveTile16<UPNERF_X0, TILE, NW>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE, D = L.D;
@@ -472,13 +899,14 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
   const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
   const int xn0 = TX::n0(wave), xrow0 = TX::row0(wave);
   const int ray0 = m0 / S;
-  const unsigned long long* __restrict__ hm = (const unsigned long long*)a.hmask + (size_t)blockIdx.x * F16_THREADS + tid;
-  const size_t hm_stride = (size_t)gridDim.x * F16_THREADS;
+  const unsigned long long* __restrict__ hm = (const unsigned long long*)a.hmask + (size_t)blockIdx.x * THREADS + tid;
+  const size_t hm_stride = (size_t)gridDim.x * THREADS;
 
   if (tid == 64) {
 #pragma unroll
     for (int l = 0; l < UPNERF_MAX_D; ++l) loff_s[l] = L.t_w[l];
   }
+  if (tid >= 64 && tid < 80) mx_s[tid - 64] = 0u;
   // softplus'(x) = 1 - exp(-softplus(x)); per-row feature weight on its ray slot; per-row scalars of the head stages
   if (tid < TILE) {
     const int m = m0 + tid;
@@ -512,9 +940,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     for (int q = 0; q < MAXRAYS; ++q) wfj[q][tid] = (q == j) ? wf : 0.0f;
   }
   __syncthreads();
-  // column group and first row of this thread in the elementwise head stages (row advances by F16_THREADS / GPR per step)
+  // column group and first row of this thread in the elementwise head stages (row advances by THREADS / GPR per step)
   const int eg = tid % GPR, er0 = tid / GPR;
-  constexpr int ERS = F16_THREADS / GPR;
+  constexpr int ERS = THREADS / GPR;
 
   STAMP_DECL;
   int erg = 0;  // exponent of the [gz_r1 | gz_g1] planes
@@ -553,8 +981,8 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
       lmax = wave_max(lmax);
       if (lane == 0) smax[wave] = lmax;
       __syncthreads();
-      const float mx = wg_max(smax);
-      track(a.gmax ? a.gmax + D + 2 : nullptr, mx, tid);
+      const float mx = wg_max<NW>(smax);
+      track(mx_s, D + 2, mx, tid);
       const int eg2 = scale_exp(mx);
 #pragma unroll
       for (int q = 0; q < EPT; ++q) put_quad<NP, W>(Ph, Pl, er0 + ERS * q, W2 + 4 * eg, vals[q], eg2);
@@ -601,9 +1029,9 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     }
     __syncthreads();  // also: every wave is done reading the gz_g2 planes
     {
-      const float mxg = wg_max(smax), mxr = wg_max(smaxb);
-      track(a.gmax && a.use_cand ? a.gmax + D + 1 : nullptr, mxg, tid);
-      track(a.gmax && a.use_rgb ? a.gmax + D + 3 : nullptr, mxr, tid);
+      const float mxg = wg_max<NW>(smax), mxr = wg_max<NW>(smaxb);
+      if (a.use_cand) track(mx_s, D + 1, mxg, tid);
+      if (a.use_rgb) track(mx_s, D + 3, mxr, tid);
       erg = scale_exp(fmaxf(mxg, mxr));
     }
     if (a.use_cand) acc_to_planes<NP, W>(accg, Ph, Pl, hrow0, hn0, W2, erg, lane);
@@ -612,7 +1040,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
       for (int q = 0; q < EPT; ++q) put_quad<NP, W>(Ph, Pl, er0 + ERS * q, 4 * eg, valr[q], erg);
     }
     __syncthreads();
-    if (a.use_cand) tile_store16<NP, W, TILE, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
+    if (a.use_cand) tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
   }
 
   STAMP(0);  // head stages (elementwise d g2 / d r1, 128-wide contraction, plane writes)
@@ -647,12 +1075,11 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
         }
       }
     }
-    acc_store_global(acc, a.gz_e, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    const float mx = wg_max(smax);
-    track(a.gmax ? a.gmax + D : nullptr, mx, tid);
+    const float mx = wg_max<NW>(smax);
+    track(mx_s, D, mx, tid);
     ecur = scale_exp(mx);
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
@@ -666,6 +1093,8 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     f32x4 ws[TW::NT][4];
     load_cols(ws, P + L.wsig, n0, hh);
     mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_we, W / 16, n0, 0, lane);
+    // gz_e leaves from the planes this K loop has just read, in whole lines (see the forward kernel)
+    tile_store16<NP, W, TILE, THREADS, W>(Ph, Pl, 0, pow2f(-ecur), a.gz_e, W, m0, M, tid);
     const float un = pow2f(-(ecur + wexp[8]));
 #pragma unroll
     for (int mt = 0; mt < TW::MT; ++mt) {
@@ -676,21 +1105,39 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], un, ws[nt][r >> 2][r & 3] * ps);
     }
     acc_apply_mask(acc, bits);
-    if (a.gz_h) acc_store_global(acc, a.gz_h + (size_t)(D - 1) * M * W, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    const float mx = wg_max(smax);
-    track(a.gmax ? a.gmax + (D - 1) : nullptr, mx, tid);
+    const float mx = wg_max<NW>(smax);
+    track(mx_s, D - 1, mx, tid);
     ecur = scale_exp(mx);
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
-    if (a.gz16) tile_copy16<W, TILE>(Ph, ecur, a.gz16 + (size_t)(D - 1) * M * W, a.gzexp + (size_t)(D - 1) * gridDim.x, m0, M, tid);
+    if (a.gz16) tile_copy16<W, TILE, THREADS>(Ph, ecur, a.gz16 + (size_t)(D - 1) * M * W, a.gzexp + (size_t)(D - 1) * ((M + 63) >> 6), m0, M, tid);
   }
   STAMP(2);  // d h_{D-1}
   // ---- trunk, last layer to first
   f32x16 accx[TX::MT][TX::NT];
   acc_zero(accx);
+  int ehalf[2] = {ecur, ecur};
+  auto store_gz32 = [&](int lidx, float un0, float un1) {
+#ifndef UPNERF_EXP_NOSTORE
+    if (a.gz_h) tile_store16<NP, W, TILE, THREADS, W>(Ph, Pl, 0, un0, un1, a.gz_h + (size_t)lidx * M * W, W, m0, M, tid);
+#endif
+  };
+  if (D == 1) store_gz32(0, pow2f(-ecur), pow2f(-ecur));
+  if constexpr (TILE == F16_TILE_BIG) {
+    bwd_trunk_pipelined<NP, W, NW>(L, a, Ph, Pl, smax, smaxb, mx_s, loff_s, ehalf, m0, M, tid);
+    if (a.need_dxyz && L.skip > 0) {  // the skip layer's encoding term, parked by the pipelined trunk in accumulator order
+      const float* xs = (const float*)((const char*)a.xs + (size_t)blockIdx.x * (UPNERF_X0 / 16 * 4 * 2 * 1024)) + (size_t)wave * 1024 + lane * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *(const f32x4*)(xs + q * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accx[0][0][4 * q + j] = v[j];
+      }
+    }
+  } else {
   for (int l = D - 1; l >= 1; --l) {
     const unsigned long long bits = hm[(size_t)(l - 1) * hm_stride];  // arrives under the contraction below
     if (a.need_dxyz && l == L.skip) {
@@ -701,22 +1148,28 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     acc_zero(acc);
     const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);  // wave-uniform; asked for before the contraction
     mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)__builtin_amdgcn_readfirstlane(loff_s[l]), W / 16, n0, 0, lane);
+    store_gz32(l, pow2f(-ecur), pow2f(-ecur));  // gz_l: the planes this K loop has just read
     acc_scale(acc, pow2f(-(ecur + wel)));
     acc_apply_mask(acc, bits);
-    if (a.gz_h) acc_store_global(acc, a.gz_h + (size_t)(l - 1) * M * W, W, m0, M, row0, n0, lane);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
     __syncthreads();
-    const float mx = wg_max(smax);
-    track(a.gmax ? a.gmax + (l - 1) : nullptr, mx, tid);
+    const float mx = wg_max<NW>(smax);
+    track(mx_s, l - 1, mx, tid);
     ecur = scale_exp(mx);
+    ehalf[0] = ehalf[1] = ecur;
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
-    if (a.gz16) tile_copy16<W, TILE>(Ph, ecur, a.gz16 + (size_t)(l - 1) * M * W, a.gzexp + (size_t)(l - 1) * gridDim.x, m0, M, tid);
+    if (a.gz16) tile_copy16<W, TILE, THREADS>(Ph, ecur, a.gz16 + (size_t)(l - 1) * M * W, a.gzexp + (size_t)(l - 1) * ((M + 63) >> 6), m0, M, tid);
+  }
   }
   STAMP(3);  // D-1 trunk layers
+  if constexpr (TILE != F16_TILE_BIG) {
+    if (D > 1) store_gz32(0, pow2f(-ecur), pow2f(-ecur));  // gz_0: still in the planes
+  }
   if (!a.need_dxyz) {
     STAMP_FLUSH_AT(8);
+    track_flush(mx_s, a.gmax, tid);
     return;
   }
   // ---- d x0 (first layer + skip) -> d xyz through the encoding
@@ -724,7 +1177,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
     f32x16 acc0[TX::MT][TX::NT];
     acc_zero(acc0);
     mma16_lds<NP, W, W / 16, AH>(acc0, Ph, Pl, xrow0, 0, PT16 + 4 * (size_t)L.t_w[0], W / 16, xn0, 0, lane);
-    const float un = pow2f(-(ecur + wexp[0]));
+    const float un = pow2f(-((xrow0 >= TILE / 2 ? ehalf[1] : ehalf[0]) + wexp[0]));
 #pragma unroll
     for (int r = 0; r < 16; ++r) accx[0][0][r] = fmaf(acc0[0][0][r], un, accx[0][0][r]);
   }
@@ -733,7 +1186,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
   float* Gs = (float*)planes;  // fp32 [TILE][64] scratch over the (now dead) planes
   acc_to_lds_t(accx, Gs, UPNERF_X0, xrow0, xn0, lane);
   __syncthreads();
-  for (int it = tid; it < TILE * 3; it += F16_THREADS) {
+  for (int it = tid; it < TILE * 3; it += THREADS) {
     const int row = it / 3, n = it - row * 3, m = m0 + row;
     if (m >= M) continue;
     const float* __restrict__ x0 = a.x0 + (size_t)m * UPNERF_X0 + 3 + 20 * n;
@@ -753,6 +1206,17 @@ __global__ __launch_bounds__(F16_THREADS, F16_WAVES_PER_EU) void field16_bwd_ker
   }
   STAMP(4);  // d x0 -> d xyz
   STAMP_FLUSH_AT(8);
+  track_flush(mx_s, a.gmax, tid);
+}
+
+// Rows per workgroup: 64 (`want` = 0 or 64), or 128 (needs S >= 64: a 128-row tile then touches at most three rays, and the
+// backward kernel keeps three ray slots).  The forward and the backward pass of one field evaluation must use the same
+// value: the ReLU sign bits (hmask) are laid out per workgroup tile.  The 128-sample pipelined kernels are correct but, as
+// measured in round 3, not yet faster than two 64-sample workgroups per CU: opt-in.
+int tile_rows16(int want, int S) {
+  if (want == 0 || want == F16_TILE) return F16_TILE;
+  if (want == F16_TILE_BIG && S >= 64) return F16_TILE_BIG;
+  return -1;
 }
 
 int check_layout16(const upnerf_layout* L) {
@@ -777,8 +1241,6 @@ extern "C" int upnerf_stamps_read(unsigned long long* out16, int reset) {
 }
 #endif
 
-int upnerf_field16r_fwd_launch(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);  // field16r.hip
-
 extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream) {
   int rc = check_layout16(L);
   if (rc) return rc;
@@ -790,13 +1252,24 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->planes != 0 && a->planes != 1 && a->planes != 2) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
-  if (a->h16 && (!a->hexp || a->wnorm)) return UPNERF_EINVAL;  // fp16 storage: LDS-tile kernel only
-  if (a->wnorm) return upnerf_field16r_fwd_launch(L, a, stream);  // register-resident kernel (field16r.hip)
-  const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
-  if (a->planes == 1)
-    hipLaunchKernelGGL((field16_fwd_kernel<1, F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
-  else
-    hipLaunchKernelGGL((field16_fwd_kernel<2, F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
+  if (a->h16 && !a->hexp) return UPNERF_EINVAL;
+  if (a->wnorm) return UPNERF_EUNSUP;  // the register-resident forward kernel left the library (tools/repro/field16r.hip)
+  const int tile = tile_rows16(a->tile_rows, a->S);
+  if (tile < 0) return UPNERF_EINVAL;
+  if (tile == F16_TILE_BIG && L->skip > 0 && !a->x0f) return UPNERF_EINVAL;
+  const int grid = (int)((M + tile - 1) / tile);
+  const hipStream_t st = (hipStream_t)stream;
+  if (tile == F16_TILE_BIG) {
+    if (a->planes == 1)
+      hipLaunchKernelGGL((field16_fwd_kernel<1, F16_TILE_BIG, F16_WAVES_BIG>), dim3(grid), dim3(64 * F16_WAVES_BIG), 0, st, *L, *a);
+    else
+      hipLaunchKernelGGL((field16_fwd_kernel<2, F16_TILE_BIG, F16_WAVES_BIG>), dim3(grid), dim3(64 * F16_WAVES_BIG), 0, st, *L, *a);
+  } else {
+    if (a->planes == 1)
+      hipLaunchKernelGGL((field16_fwd_kernel<1, F16_TILE, F16_WAVES>), dim3(grid), dim3(64 * F16_WAVES), 0, st, *L, *a);
+    else
+      hipLaunchKernelGGL((field16_fwd_kernel<2, F16_TILE, F16_WAVES>), dim3(grid), dim3(64 * F16_WAVES), 0, st, *L, *a);
+  }
   return (int)hipGetLastError();
 }
 
@@ -817,10 +1290,21 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->gz16 && !a->gzexp) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
-  const int grid = (int)((M + F16_TILE - 1) / F16_TILE);
-  if (a->planes == 1)
-    hipLaunchKernelGGL((field16_bwd_kernel<1, F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
-  else
-    hipLaunchKernelGGL((field16_bwd_kernel<2, F16_TILE>), dim3(grid), dim3(F16_THREADS), 0, (hipStream_t)stream, *L, *a);
+  const int tile = tile_rows16(a->tile_rows, a->S);
+  if (tile < 0) return UPNERF_EINVAL;
+  if (tile == F16_TILE_BIG && a->need_dxyz && L->skip > 0 && !a->xs) return UPNERF_EINVAL;
+  const int grid = (int)((M + tile - 1) / tile);
+  const hipStream_t st = (hipStream_t)stream;
+  if (tile == F16_TILE_BIG) {
+    if (a->planes == 1)
+      hipLaunchKernelGGL((field16_bwd_kernel<1, F16_TILE_BIG, F16_WAVES_BIG>), dim3(grid), dim3(64 * F16_WAVES_BIG), 0, st, *L, *a);
+    else
+      hipLaunchKernelGGL((field16_bwd_kernel<2, F16_TILE_BIG, F16_WAVES_BIG>), dim3(grid), dim3(64 * F16_WAVES_BIG), 0, st, *L, *a);
+  } else {
+    if (a->planes == 1)
+      hipLaunchKernelGGL((field16_bwd_kernel<1, F16_TILE, F16_WAVES>), dim3(grid), dim3(64 * F16_WAVES), 0, st, *L, *a);
+    else
+      hipLaunchKernelGGL((field16_bwd_kernel<2, F16_TILE, F16_WAVES>), dim3(grid), dim3(64 * F16_WAVES), 0, st, *L, *a);
+  }
   return (int)hipGetLastError();
 }

@@ -45,9 +45,6 @@ def _field16_ok(pk, S: int) -> bool:
     return FIELD_MODE != "f32" and ok
 
 
-# Forward kernel of the f16x3 / f16 modes: "regs" = register-resident activations, weights staged once per 128-sample
-# workgroup in LDS (csrc/field16r.hip); "lds" = 64-sample tile in LDS planes, weights streamed per wave (csrc/field16.hip).
-FIELD_FWD_KERNEL = __import__("os").environ.get("UPNERF_FIELD_FWD", "lds")
 # Storage of the trunk activations / their gradients between the field kernels and the weight-gradient kernels in the f16x3
 # mode (the f16 mode always uses "f16"):
 #   "f32"  (default) fp32 tensors; weight gradients contracted with the 3-term split: fp32-accurate end to end
@@ -58,6 +55,10 @@ FIELD_FWD_KERNEL = __import__("os").environ.get("UPNERF_FIELD_FWD", "lds")
 #   (Also measured and dropped: lossless hi + lo fp16 PAIRS -- the same bytes as fp32 -- gave the field kernels and the
 #   weight-gradient kernel nothing: 2.69 / 2.65 / 0.25 ms against 2.69 / 2.66 / 0.22.  It is the bytes, not the store pattern.)
 WGRAD_STORE = __import__("os").environ.get("UPNERF_WGRAD_STORE", "f32")
+# Samples per workgroup of the f16x3 / f16 field kernels (include/upnerf_hip.h: tile_rows): 0 / 64 = four-wave workgroups of 64
+# samples (default), 128 = the eight-wave software-pipelined kernels (rays of >= 64 samples; falls back to 64 below that).
+# Forward and backward pass always get the same value.
+FIELD_TILE = int(__import__("os").environ.get("UPNERF_FIELD_TILE", "0"))
 
 
 def _planes() -> int:
@@ -125,7 +126,7 @@ class _FieldPass(torch.autograd.Function):
         use16 = _field16_ok(pk, S)
         P16 = PT16 = wexp = wnorm = None
         if use16:  # matrices as scaled fp16 (hi, lo) fragments, forward and transposed sets in one pass
-            P16, PT16, wexp, wnorm = pk.frag16_hip(P, perm_fwd=FIELD_FWD_KERNEL == "regs")
+            P16, PT16, wexp, wnorm = pk.frag16_hip(P)
             PF = P  # the kernel reads only the vectors from it
         else:
             PF = pk.frag_hip(P)  # what the kernels read: matrices in MFMA fragment order
@@ -153,23 +154,28 @@ class _FieldPass(torch.autograd.Function):
         # half the bytes written here and read back by the weight-gradient kernels; fp32 only for the last layer (its
         # consumers are the density-head and final-layer weight gradients)
         store16 = train and use16 and (FIELD_MODE == "f16" or WGRAD_STORE == "f16") and wnorm is None
-        ntile = (M + _lib.TILE_ROWS - 1) // _lib.TILE_ROWS
+        ntile = (M + 63) // 64  # exponent tables: one entry per 64 rows whatever the kernel's tile
         h16 = torch.empty(D, M, W, device=dev, dtype=torch.float16) if store16 else None
         hexp = torch.empty(D, ntile, device=dev, dtype=torch.int32) if store16 else None
         h = (_empty(1, M, W, device=dev) if store16 else _empty(D, M, W, device=dev)) if train else None
         e = _empty(M, W, device=dev) if (train or want_feat) else None
-        hmask = torch.empty((D + 1) * ((M + _lib.TILE_ROWS - 1) // _lib.TILE_ROWS) * 256, device=dev,
+        hmask = torch.empty((D + 1) * ((M + 127) // 128) * 512, device=dev,  # 64 bits per lane and tile, either tiling
                             dtype=torch.int64) if train else None
         amax = torch.zeros(16, device=dev) if train else None  # running max|.| (scales of the f16x3 weight gradients)
         g1 = _empty(M, W2, device=dev) if (cfg.use_cand and train) else None
         g2 = _empty(M, W2, device=dev) if (cfg.use_cand and (train or joint)) else None
         r1 = _empty(M, W2, device=dev) if (cfg.use_rgb and train) else None
+        # 128-sample tiles (S >= 64): scratch for the encoding as operand fragments, read back at the skip layer
+        tile = 128 if (FIELD_TILE == 128 and S >= 64) else 64
+        x0f = (torch.empty(((M + 127) // 128) * 32768, device=dev, dtype=torch.uint8)
+               if (use16 and pk.skip > 0 and tile == 128) else None)
         fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
                           rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1),
                           P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None,
-                          planes=_planes(), wnorm=ptr(wnorm), h16=ptr(h16), hexp=ptr(hexp), h_last_only=int(store16))
+                          planes=_planes(), tile_rows=tile, wnorm=ptr(wnorm), h16=ptr(h16), hexp=ptr(hexp),
+                          h_last_only=int(store16), x0f=ptr(x0f))
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
@@ -192,10 +198,10 @@ class _FieldPass(torch.autograd.Function):
         check(TIMER.run("composite_fwd", lambda: lib.upnerf_composite_fwd(C.byref(ca), st), units=M),
               "upnerf_composite_fwd")
 
-        ctx.cfg, ctx.dims, ctx.planes = cfg, (R, S), _planes()
+        ctx.cfg, ctx.dims, ctx.planes, ctx.tile_rows = cfg, (R, S), _planes(), tile
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
                          w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s)
         z0 = torch.zeros(0, device=dev)
@@ -257,7 +263,7 @@ class _FieldPass(torch.autograd.Function):
                           g_G_c=ptr(gG), x0=ptr(sv["x0"]), h=ptr(sv["h"]), g1=ptr(sv["g1"]), g2=ptr(sv["g2"]),
                           r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
-                          dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, gz16=ptr(gz16),
+                          dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, tile_rows=ctx.tile_rows, xs=ptr(sv.get("x0f")), gz16=ptr(gz16),
                           gzexp=ptr(gzexp))
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
         check(TIMER.run("field_bwd", lambda: bwd_fn(C.byref(L), C.byref(fb), st), units=M), "upnerf_field_bwd")
@@ -343,7 +349,7 @@ class _FieldPass(torch.autograd.Function):
 def dequant16(t16: torch.Tensor, texp: torch.Tensor) -> torch.Tensor:
     """fp32 view of an fp16-stored, tile-scaled tensor [D][M][W] with exponents [D][ceil(M/64)] (tests, debugging)."""
     D, M, W = t16.shape
-    scale = torch.ldexp(torch.ones((), device=t16.device), -texp.float()).repeat_interleave(_lib.TILE_ROWS, dim=1)[:, :M]
+    scale = torch.ldexp(torch.ones((), device=t16.device), -texp.float()).repeat_interleave(64, dim=1)[:, :M]
     return t16.float() * scale[:, :, None]
 
 
