@@ -25,6 +25,9 @@ Extra objects on the line:
   phases        the three schedule phases BASELINE configs[1] asks for (progress 0.05 / 0.3 / 0.8), same K and W each
   strict_f32    the same step with every contraction on the fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of the f16x3 split
   wgrad_f16     the same step with fp16-stored operands for the trunk weight gradients (an option; see its note)
+  trevi         BASELINE.json configs[3] (8192 rays, 1689 images, fp16 field mode): value, ms_per_step, dtype, its own roofline
+  tto           BASELINE.json configs[4]: pose stage and appearance stage at 1024 rays per step (graph replay), and the no-grad
+                render rate of a full held-out image (4096-ray chunks, density-only coarse pass)
   cpu_baseline  the CPU oracle (oracle/upnerf_oracle.py, a port of the reference's arithmetic) timed on this box's host
                 cores on a bounded sample of the same workload incl. the Adam update (rank 0, N == 1 only).
 """
@@ -156,9 +159,9 @@ def cpu_baseline(progress, n_images, rays=768, iters=3):
 
 
 class Bench:
-    def __init__(self, args, rank, world, dev):
+    def __init__(self, args, rank, world, dev, config=None):
         self.args, self.rank, self.world, self.dev = args, rank, world, dev
-        self.cfg = CONFIGS[args.config]
+        self.cfg = CONFIGS[config or args.config]
         self.rays, self.n_images = self.cfg["rays"], self.cfg["n_images"]
 
     def barrier(self):
@@ -215,6 +218,85 @@ class Bench:
         return out, summ
 
 
+def roofline_of(kern, field, mac, note_extra=""):
+    """`roofline` object of the dominant field kernel from a kernel-timing summary (HIP events on the launch stream)."""
+    per_sample = {"field_fwd": 2 * mac, "field_bwd": 2 * mac}
+    dom = max((n for n in kern if n in per_sample), key=lambda n: kern[n]["ms_per_step"])
+    ach = per_sample[dom] * kern[dom]["units_per_launch"] / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+    return {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK[field], "unit": "TFLOP/s", "frac": ach / PEAK[field],
+            "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"], "note": note_extra}
+
+
+def trevi_object(args, rank, world, dev):
+    """BASELINE.json configs[3] beside the headline: 8192 rays, 1689 images, fp16 field mode; same step, same timing rules."""
+    B = Bench(args, rank, world, dev, config="trevi")
+    leg, _ = B.leg(0.3, "f16", True)
+    _, summ = B.leg(0.3, "f16", False, timer_only={"field_fwd", "field_bwd"}, steps=min(args.steps, 6), warmup=2)
+    nk = min(args.steps, 6)
+    kern = {n: dict(launches_per_step=v["launches"] / nk, avg_ms=v["avg_ms"], ms_per_step=v["total_ms"] / nk,
+                    units_per_launch=v["units_per_launch"]) for n, v in summ.items()}
+    mac = algorithmic_fwd_mac(leg["sched_mult"])
+    return {"value": leg["value"], "unit": "rays/s", "ms_per_step": leg["ms_per_step"], "dtype": DTYPE["f16"],
+            "config": {"workload": CONFIGS["trevi"]["workload"], "rays_per_gpu": B.rays, "n_images": B.n_images, "progress": 0.3,
+                       "field": "f16"},
+            "host_issue_ms_per_step": leg["host_issue_ms_per_step"],
+            "roofline": roofline_of(kern, "f16", mac, "peak = f16 dense MFMA 2516.6 TF; HIP events over eager steps")}
+
+
+def tto_object(args, dev):
+    """BASELINE.json configs[4]: test-time optimisation on frozen fields (per-image pose, then appearance; tto.py:100 batch of
+    1024 rays; one graph replay per step) and the no-grad render of a full held-out image (175 k rays in 4096-ray chunks,
+    density-only coarse pass)."""
+    import torch
+    from upnerf_amd import rendering, synth
+    from upnerf_amd.graph_step import GraphedTrainingStep
+    from upnerf_amd.nerf_system import SyntheticDataset
+    from upnerf_amd.nerf_system_optimize import NeRFSystemOptimize
+    rendering.FIELD_MODE, rendering.WGRAD_STORE = "f16x3", "f32"
+    trained = build_system(dev, 0.8)
+    out = {"field": "f16x3", "rays_per_step": 1024}
+    steps, warm = max(args.steps, 20), 5
+    for stage in ("pose", "appearance"):
+        tto = NeRFSystemOptimize(dict(trained.hparams), SyntheticDataset(763), pose_optimize=stage == "pose")
+        tto.model_setup(trained_state=trained.state_dict(), n_test_images=1)
+        tto = tto.to(dev)
+        batches = []
+        for i in range(4):
+            b = {k: v.to(dev) for k, v in synth.batch(1024, 1, seed=50 + i).items()}
+            b["img_idx"] = torch.zeros_like(b["img_idx"])
+            batches.append(b)
+        step = GraphedTrainingStep(tto)
+        for i in range(2 + warm):
+            step(batches[i % 4], i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(batches[i % 4], i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[stage + "_stage"] = {"value": 1024 / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "steps": steps}
+        if stage == "appearance":  # the evaluation render of the same system
+            pixels = 175104  # ~500 x 350 (SURVEY.md 8d config 5)
+            tto.hparams["val.chunk_size"] = 4096
+            tto.coarse_sigma_only = True
+            b = synth.batch(pixels, 1, seed=7)
+            b["img_idx"] = torch.zeros_like(b["img_idx"])
+            vb = {k: v.to(dev) for k, v in b.items()}
+            tto.validation_step(vb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                tto.validation_step(vb)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            out["render"] = {"value": pixels / dt, "unit": "rays/s", "ms_per_image": dt * 1e3, "pixels": pixels, "chunk": 4096,
+                             "no_grad": True, "coarse_sigma_only": True}
+        del tto, step, batches
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +313,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-extras", action="store_true", help="skip the `phases` and `strict_f32` legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs34", action="store_true", help="skip the `trevi` (configs[3]) and `tto` (configs[4]) objects")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-timing", choices=["field", "all"], default="field",
                     help="HIP-event leg: the two field kernels only (what `roofline` needs) or every instrumented class")
@@ -301,6 +384,10 @@ def main():
             f32, _ = B.leg(args.progress, "f32", graph)
             extras["strict_f32"] = {"value": f32["value"], "ms_per_step": f32["ms_per_step"], "dtype": "f32",
                                     "contraction": "fp32 MFMA (v_mfma_f32_32x32x2_f32) in every field contraction"}
+    if not args.no_extras and args.config == "brandenburg" and not args.no_configs34:
+        extras["trevi"] = trevi_object(args, rank, world, dev)  # BASELINE configs[3]
+        if world == 1:
+            extras["tto"] = tto_object(args, dev)               # BASELINE configs[4]
     summ = None
     if not args.no_kernel_timing:
         only = {"field_fwd", "field_bwd"} if args.kernel_timing == "field" else set()

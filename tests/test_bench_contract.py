@@ -44,6 +44,16 @@ def test_default_shape_bench_line():
     assert c["kind"] in ("port", "reference") and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0
     assert isinstance(c["sample"], str) and c["sample"]
     assert d["value"] / c["value"] > 10  # north_star: >= 10x the CPU path
+    # BASELINE.json configs[3] and configs[4] ride in the same line
+    t = d["trevi"]
+    assert t["config"]["rays_per_gpu"] == 8192 and t["config"]["n_images"] == 1689 and t["dtype"].startswith("f16")
+    assert abs(t["value"] - 8192 / (t["ms_per_step"] * 1e-3)) < 1e-6 * t["value"] and t["value"] > 100_000
+    assert t["roofline"]["peak"] > 2000 and 0.02 < t["roofline"]["frac"] < 1.0
+    o = d["tto"]
+    for st in ("pose_stage", "appearance_stage"):
+        assert o["rays_per_step"] == 1024 and abs(o[st]["value"] - 1024 / (o[st]["ms_per_step"] * 1e-3)) < 1e-6 * o[st]["value"]
+        assert o[st]["value"] > 20_000
+    assert o["render"]["no_grad"] is True and o["render"]["value"] > 100_000 and o["render"]["chunk"] == 4096
 
 
 def _run(args, env=None, timeout=300):

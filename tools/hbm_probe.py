@@ -9,3 +9,6 @@ def t(fn, n=5):
 r = t(lambda: x.sum())
 c = t(lambda: y.copy_(x))
 print(f"read (sum of 4 GiB): {x.numel() * 4 / r / 1e12:.2f} TB/s; copy: {2 * x.numel() * 4 / c / 1e12:.2f} TB/s (read + write)")
+w = t(lambda: y.fill_(1.5))
+z = t(lambda: y.zero_())
+print(f"write only (fill of 4 GiB): {y.numel() * 4 / w / 1e12:.2f} TB/s; zero_: {y.numel() * 4 / z / 1e12:.2f} TB/s")

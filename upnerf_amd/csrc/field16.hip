@@ -66,7 +66,16 @@ __device__ unsigned long long upnerf_stamp_acc[16];  // [0..7] forward trunk pha
       for (int _i = 0; _i < 8; ++_i) atomicAdd(&upnerf_stamp_acc[(base) + _i], _t_acc[_i]); \
   } while (0)
 #define STAMP_FLUSH STAMP_FLUSH_AT(0)
+#ifdef PL_EXP_FINE  // fine stamps inside the pipelined steps replace the coarse ones of the pipelined trunk (those -> slot 7)
+#define STAMP_F(i) STAMP(i)
+#define STAMP_C(i) STAMP(7)
 #else
+#define STAMP_F(i)
+#define STAMP_C(i) STAMP(i)
+#endif
+#else
+#define STAMP_F(i)
+#define STAMP_C(i)
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_FLUSH
@@ -295,10 +304,9 @@ __device__ __forceinline__ int fwd_trunk_pipelined(const upnerf_layout& L, const
   WPre<NP> wpre;
   if (D > 1) {
     const bool sk = 1 == L.skip;
-    const char* wp1 = wbase(1, sk ? (UPNERF_X0 + W) / 16 : W / 16, sk ? UPNERF_X0 / 16 : 0, lane);
-    pl_ldw<NP>(wpre.h[0], wpre.l[0], wp1, 0);
-    pl_ldw<NP>(wpre.h[1], wpre.l[1], wp1, 1);
+    pl_preload<NP>(wpre, wbase(1, sk ? (UPNERF_X0 + W) / 16 : W / 16, sk ? UPNERF_X0 / 16 : 0, lane));
   }
+
   unsigned int bitsB = 0u;
   float vmaxB = 0.0f;
 #pragma unroll 1
@@ -371,28 +379,28 @@ __device__ __forceinline__ int fwd_trunk_pipelined(const upnerf_layout& L, const
           if (sk) skip_part(std::integral_constant<int, 1>{}, eB_in);
         },
         /* endP1 */ [&]() {
-          STAMP(0);
+          STAMP_C(0);
           finish_half(l - 1, 1, bitsB, vmaxB, eB_in, lane);
           bitsB = 0u;
           vmaxB = 0.0f;
           pl_barrier();  // planes B hold h_{l-1}
-          STAMP(1);
+          STAMP_C(1);
         },
         /* endP2 */ [&]() {
-          STAMP(2);
+          STAMP_C(2);
           publish(smax, pl_absmax<0>(acc), eA_in, wel, bias_absmax(l, lane), lane);
           pl_barrier();  // every wave is done reading planes A; the bound of A is in LDS
-          STAMP(3);
+          STAMP_C(3);
           eAo = bound_exp(wg_max<NW>(smax));
           sA = pow2f(-(eA_in + wel));
           peA = pow2f(eAo);
         },
         /* endP3 */ [&]() {
-          STAMP(4);
+          STAMP_C(4);
           finish_half(l, 0, bitsA, vmaxA, eAo, lane);
           publish(smaxb, pl_absmax<1>(acc), eB_in, wel, bias_absmax(l, lane), lane);
           pl_barrier();  // planes A hold h_l; every wave is done reading planes B; the bound of B is in LDS
-          STAMP(5);
+          STAMP_C(5);
           eBo = bound_exp(wg_max<NW>(smaxb));
         });
     wel_prev = wel;
@@ -574,9 +582,10 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_fwd_kernel(
     STAMP(1);
     // h_{l-1} leaves from the planes this K loop has just read, in whole lines, behind the loop's last wait for a weight
     // fragment: the epilogue, two barriers and the plane write pass before the wave waits for a load again
-    if (l >= 1) store_h32(l - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
     f32x4 bl[TW::NT][4];
-    load_cols(bl, P + bl_off, n0, hh);
+    load_cols(bl, P + bl_off, n0, hh);  // requested BEFORE the stores: a wait for it behind them would wait for them too
+    asm volatile("" ::: "memory");
+    if (l >= 1) store_h32(l - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
     const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wel)), bl);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
@@ -624,6 +633,7 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_fwd_kernel(
     f32x4 be[TW::NT][4];
     load_cols(be, P + L.be, n0, hh);
     mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, lane);
+    asm volatile("" ::: "memory");  // the bias loads above stay above the stores below
     store_h32(D - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
     acc_fma_bias_h<false>(acc, pow2f(-(ehalf[0] + wexp[8])), pow2f(-(ehalf[1] + wexp[8])), be);
     const float wm = acc_absmax(acc);
@@ -768,12 +778,8 @@ __device__ __forceinline__ void bwd_trunk_pipelined(const upnerf_layout& L, cons
     track_wave(mx_s, l, ldexpf(wave_max_nn(vmax), -e_out), lane);
   };
   WPre<NP> wpre;
-  if (D > 1) {
-    const int lane = tid & 63;
-    const char* wp1 = wbase(D - 1, lane);
-    pl_ldw<NP>(wpre.h[0], wpre.l[0], wp1, 0);
-    pl_ldw<NP>(wpre.h[1], wpre.l[1], wp1, 1);
-  }
+  if (D > 1) pl_preload<NP>(wpre, wbase(D - 1, tid & 63));
+
   float vmaxB = 0.0f, spB = 0.0f;
   unsigned int bitsB = 0u;
   bool pendB = false;  // half B of the previous stage still has its epilogue to run
@@ -1093,7 +1099,9 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_bwd_kernel(
     f32x4 ws[TW::NT][4];
     load_cols(ws, P + L.wsig, n0, hh);
     mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)L.t_we, W / 16, n0, 0, lane);
-    // gz_e leaves from the planes this K loop has just read, in whole lines (see the forward kernel)
+    // gz_e leaves from the planes this K loop has just read, in whole lines (see the forward kernel); every load requested
+    // so far (ws, the sign bits) stays in front of the stores
+    asm volatile("" ::: "memory");
     tile_store16<NP, W, TILE, THREADS, W>(Ph, Pl, 0, pow2f(-ecur), a.gz_e, W, m0, M, tid);
     const float un = pow2f(-(ecur + wexp[8]));
 #pragma unroll
@@ -1148,6 +1156,7 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_bwd_kernel(
     acc_zero(acc);
     const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);  // wave-uniform; asked for before the contraction
     mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, PT16 + 4 * (size_t)__builtin_amdgcn_readfirstlane(loff_s[l]), W / 16, n0, 0, lane);
+    asm volatile("" ::: "memory");  // the sign-bit load stays in front of the stores
     store_gz32(l, pow2f(-ecur), pow2f(-ecur));  // gz_l: the planes this K loop has just read
     acc_scale(acc, pow2f(-(ecur + wel)));
     acc_apply_mask(acc, bits);

@@ -143,13 +143,13 @@ __device__ __forceinline__ float pl_absmax(const f32x16 (&acc)[4]) {
   return wave_max_nn(m);
 }
 
-// One PIECE of the activation stores of a stage: 16 rows x this wave's 32 columns of one row half, read back from the planes
-// and written as WHOLE 128-byte lines: lane j handles row j/8 of an 8-row group and the 16-byte chunk j%8 of the wave's
-// 128-byte row segment, so one store instruction covers 8 full lines (1 KiB contiguous per 8 rows).  Per-lane 32-byte row
-// pieces (what the MFMA layouts hand out naturally) touch 32 lines per instruction with 16-byte fragments: the vector memory
-// path then issues ~14 B/clk/CU (9k cycles per 128 KB stage) and HBM sees partial lines.
-//   fp32: (hi + lo) * un, two v_fma_mix_f32 per element;  fp16 storage: the hi plane as it stands (lane j: row j/4 of a
-//   16-row group, 16-byte chunk j%4 of the wave's 64-byte segment).
+// One PIECE of the activation stores of a stage: two whole rows (all 256 columns) of one row half per wave, read back
+// from the planes: lane j converts columns 4j .. 4j+3, so a store instruction writes one row = 1 KiB contiguous.  (Per-lane
+// row pieces -- what the MFMA layouts hand out naturally, 32 bytes in each of 32 rows per instruction -- were measured at
+// half the HBM write rate and ~14 B/clk/CU of issue.)  The eight waves share a half's 64 rows: wave w stores rows
+// 8 * piece... + w, four pieces of two rows per half and stage.
+//   fp32: (hi + lo) * un, two v_fma_mix_f32 per element;  fp16 storage: the hi plane as it stands (lane j: 16-byte chunk
+//   j % 32 of row j / 32 -> both rows of the piece in ONE instruction).
 // base32 / base16: tensor rows of this tile half (row 0 of the half), or nullptr; nrows: rows of the half inside the tensor.
 template <int NP, int W>
 __device__ __forceinline__ void pl_store_piece(const char* Ph, const char* Pl, int half_row0, int piece, int lane, int wave,
@@ -157,13 +157,12 @@ __device__ __forceinline__ void pl_store_piece(const char* Ph, const char* Pl, i
   if (base32) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = 16 * piece + 8 * i + (lane >> 3), c = lane & 7, k = 32 * wave + 4 * c;
+      const int r = 16 * piece + 8 * i + wave, k = 4 * lane;
       const int o = poff<W>(half_row0 + r, k);
-      const f32x2 ph = *(const f32x2*)(Ph + o);  // four fp16 values
-      const u32x2_t uh = __builtin_bit_cast(u32x2_t, ph);
+      const u32x2_t uh = *(const u32x2_t*)(Ph + o);  // four fp16 values
       f32x4 v;
       if constexpr (NP == 2) {
-        const u32x2_t ul = __builtin_bit_cast(u32x2_t, *(const f32x2*)(Pl + o));
+        const u32x2_t ul = *(const u32x2_t*)(Pl + o);
         v = f32x4{mix16<0>(uh[0], un, mix16<0>(ul[0], un, 0.f)), mix16<1>(uh[0], un, mix16<1>(ul[0], un, 0.f)),
                   mix16<0>(uh[1], un, mix16<0>(ul[1], un, 0.f)), mix16<1>(uh[1], un, mix16<1>(ul[1], un, 0.f))};
       } else {
@@ -172,7 +171,7 @@ __device__ __forceinline__ void pl_store_piece(const char* Ph, const char* Pl, i
       if (r < nrows) *(f32x4*)(base32 + (size_t)r * W + k) = v;
     }
   } else if (base16) {
-    const int r = 16 * piece + (lane >> 2), k = 32 * wave + 8 * (lane & 3);
+    const int r = 16 * piece + 8 * (lane >> 5) + wave, k = 8 * (lane & 31);
     const f32x4 v = *(const f32x4*)(Ph + poff<W>(half_row0 + r, k));
     if (r < nrows) *(f32x4*)(base16 + (size_t)r * W + k) = v;
   }
@@ -236,19 +235,25 @@ __device__ __forceinline__ void pl_epi_bwd_quad(f32x16 (&acc)[4], int c, float s
 //            of A hold the previous stage's output through phases 1 and 2, those of B through phases 2 and 3)
 //   preB()      start of phase 2, before B's first MFMA (accumulators of B are free from here on: zero / pre-load them)
 //   endP1() / endP2() / endP3()   publish maxima, barrier, read them back
-// wpre: the first two weight fragment pairs of this stage, requested during the previous stage's phase 3 (or just before
-// the call); wp_next: the next stage's fragment base (nullptr: none) whose first two pairs are requested here.
+//
+// Weight requests.  CDNA4 retires a wave's loads and stores through ONE in-order counter: a wait for a weight fragment is
+// also a wait for every older activation store of the wave.  The ring therefore runs FOUR steps ahead where steps are
+// short: phase 3 requests the next stage's fragments 0..3 (the ring has drained by then), phase 1 requests fragment t + 4
+// at step t (t = 0..5), phase 2 fragment t + 2 (its steps carry twelve MFMAs per wave).  Never more than ten pairs live.
+// wnext: in: this stage's fragments 0..3; out: the next stage's (wp_next; nullptr: none).
+#define PL_PRE 4
 template <int NP>
 struct WPre {
-  h8 h[2], l[2];
+  h8 h[PL_PRE], l[PL_PRE];
 };
 
+template <int NP>
+__device__ __forceinline__ void pl_preload(WPre<NP>& w, const char* __restrict__ wp) {
+#pragma unroll
+  for (int t = 0; t < PL_PRE; ++t) pl_ldw<NP>(w.h[t], w.l[t], wp, t);
+}
+
 // timing experiments (diagnostic builds only; results are wrong with any of them)
-#ifdef PL_EXP_NOLDW
-#define PL_LDW(h, l, p, t) do { (h) = wpre.h[0]; (l) = wpre.l[0]; } while (0)
-#else
-#define PL_LDW(h, l, p, t) pl_ldw<NP>(h, l, p, t)
-#endif
 #ifdef PL_EXP_NOLDX
 #define PL_LDX(x, rb, t) do { } while (0)
 #else
@@ -267,10 +272,10 @@ struct WPre {
 
 template <int NP, int W, class EpiB, class EpiA, class PieceA, class PieceB, class PreB, class End1, class End2, class End3>
 __device__ __forceinline__ void pl_stage(f32x16 (&acc)[4], const char* Ph, const char* Pl, int rbyteA, int rsw, int hh,
-                                         const char* __restrict__ wp, WPre<NP>& wpre, const char* __restrict__ wp_next,
+                                         const char* __restrict__ wp, WPre<NP>& wnext, const char* __restrict__ wp_next,
                                          EpiB&& epiB, EpiA&& epiA, PieceA&& pieceA, PieceB&& pieceB, PreB&& preB, End1&& endP1,
                                          End2&& endP2, End3&& endP3) {
-  constexpr int T = W / 16, LAG = PL_LAG, PF = 2;
+  constexpr int T = W / 16, LAG = PL_LAG, PRE = PL_PRE, PF2 = 2;
   static_assert(T == 16 && LAG == 8, "phase structure");
   // the per-k-block LDS addresses are invariant across the caller's layer loop: hipcc would hoist all of them out of it and
   // spill (sixteen live registers); an opaque redefinition per stage keeps them local to the step that uses them
@@ -278,34 +283,33 @@ __device__ __forceinline__ void pl_stage(f32x16 (&acc)[4], const char* Ph, const
   const int rbyteB = rbyteA + 64 * W * 2;
   h8 wh[T], wl[T];
   XFrag<NP> xa, xb;
-  wh[0] = wpre.h[0];
-  wh[1] = wpre.h[1];
-  if constexpr (NP == 2) {
-    wl[0] = wpre.l[0];
-    wl[1] = wpre.l[1];
+#pragma unroll
+  for (int t = 0; t < PRE; ++t) {
+    wh[t] = wnext.h[t];
+    if constexpr (NP == 2) wl[t] = wnext.l[t];
   }
   pl_ldx<NP, W>(xa, Ph, Pl, rbyteA, rsw, 0, hh);
-  // ---- phase 1: A(0..7) | epilogue of B (previous stage) | store pieces of A at steps 1, 5
+  // ---- phase 1: A(0..7) | epilogue of B (previous stage) | store pieces of A at steps 2, 6
 #pragma unroll
   for (int t = 0; t < LAG; ++t) {
-    PL_LDW(wh[t + PF], wl[t + PF], wp, t + PF);
+    if (t + PRE < LAG + PF2) pl_ldw<NP>(wh[t + PRE], wl[t + PRE], wp, t + PRE);
     pl_mma<NP, 0>(acc, xa, wh[t], wl[t]);
     PL_LDX(xa, rbyteA, t + 1);
     PL_EPI(epiB(t));
-    if (t == 1) PL_PIECE(pieceA(0));
-    if (t == 5) PL_PIECE(pieceA(1));
+    if (t == 2) PL_PIECE(pieceA(0));
+    if (t == 6) PL_PIECE(pieceA(1));
     __builtin_amdgcn_sched_barrier(0);
   }
   endP1();
   // ---- phase 2: A(8..15), B(0..7) | store pieces of A at steps 9, 13, of B at steps 11, 15.  B goes first in a step: its
-  // MFMAs retire the oldest fragment pair of the ring before the request for the newest one is issued (ten live pairs at most).
+  // MFMAs retire the oldest fragment pair of the ring before the request for the newest one is issued.
   pl_ldx<NP, W>(xb, Ph, Pl, rbyteB, rsw, 0, hh);
   preB();
 #pragma unroll
   for (int t = LAG; t < T; ++t) {
     pl_mma<NP, 1>(acc, xb, wh[t - LAG], wl[t - LAG]);
     PL_LDX(xb, rbyteB, t - LAG + 1);
-    if (t + PF < T) PL_LDW(wh[t + PF], wl[t + PF], wp, t + PF);
+    if (t + PF2 < T) pl_ldw<NP>(wh[t + PF2], wl[t + PF2], wp, t + PF2);
     pl_mma<NP, 0>(acc, xa, wh[t], wl[t]);
     if (t + 1 < T) PL_LDX(xa, rbyteA, t + 1);
     if (t == 9) PL_PIECE(pieceA(2));
@@ -315,12 +319,11 @@ __device__ __forceinline__ void pl_stage(f32x16 (&acc)[4], const char* Ph, const
     __builtin_amdgcn_sched_barrier(0);
   }
   endP2();
-  // ---- phase 3: B(8..15) | epilogue of A (this stage) | store pieces of B at steps 17, 21
+  // ---- phase 3: B(8..15) | epilogue of A (this stage) | store pieces of B at steps 17, 21 | the next stage's fragments
+  // 0..3 at steps 20..23 (short live ranges: the ring has drained)
 #pragma unroll
   for (int t = T; t < T + LAG; ++t) {
-    // the next stage's first fragments: asked for late in the phase, when the ring has drained (short live ranges)
-    if (wp_next && t - T >= LAG - 2 - PF && t - T < LAG - 2)
-      pl_ldw<NP>(wpre.h[t - T - (LAG - 2 - PF)], wpre.l[t - T - (LAG - 2 - PF)], wp_next, t - T - (LAG - 2 - PF));
+    if (wp_next && t - T >= LAG - PRE) pl_ldw<NP>(wnext.h[t - T - (LAG - PRE)], wnext.l[t - T - (LAG - PRE)], wp_next, t - T - (LAG - PRE));
     pl_mma<NP, 1>(acc, xb, wh[t - LAG], wl[t - LAG]);
     if (t + 1 < T + LAG) PL_LDX(xb, rbyteB, t - LAG + 1);
     PL_EPI(epiA(t - T));
