@@ -163,6 +163,10 @@ class Bench:
         self.args, self.rank, self.world, self.dev = args, rank, world, dev
         self.cfg = CONFIGS[config or args.config]
         self.rays, self.n_images = self.cfg["rays"], self.cfg["n_images"]
+        if getattr(args, "strong", False):
+            if self.rays % world:
+                raise SystemExit(f"--strong: {self.rays} rays do not split over {world} ranks")
+            self.rays //= world  # per rank; `value` stays whole-job rays/s
 
     def barrier(self):
         import torch
@@ -310,6 +314,9 @@ def main():
                     help="arithmetic of the field contractions: f16x3 = 3-term fp16 split on the f16 matrix cores "
                          "(fp32-level accuracy; default of --config brandenburg); f32 = fp32 MFMA kernels; f16 = fp16 weights "
                          "and activations, one MFMA per product (default of --config trevi)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (SURVEY.md 8d config 3): the configuration's rays per step are split over the ranks "
+                         "(4096 rays total = 512 per rank at --gpus 8) instead of every rank rendering a full batch")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-extras", action="store_true", help="skip the `phases` and `strict_f32` legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -350,8 +357,8 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "training rays/sec", "value": 0.0, "unit": "rays/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(dt) / args.steps * 1e3,
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[field],
-                              "data": "synthetic", "dry_run": True, "world_size_observed": observed, "backend": backend,
+                              "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+                              "dtype": DTYPE[field], "data": "synthetic", "dry_run": True, "world_size_observed": observed, "backend": backend,
                               "config": {"workload": cfg["workload"], "parallelism": f"dp{world}"}}))
         if world > 1:
             dist.destroy_process_group()
@@ -403,7 +410,8 @@ def main():
     rays = B.rays
     line = {
         "metric": "training rays/sec", "value": main_leg["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True,
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": DTYPE[field], "data": "synthetic",
         "config": {"workload": cfg["workload"], "rays_per_gpu": rays, "n_images": B.n_images, "N_samples": NC,
                    "N_importance": NF, "progress": args.progress, "sched_mult": sched, "parallelism": f"dp{world}",

@@ -56,12 +56,13 @@ int upnerf_sample_coarse(int R, int S, const float* near_far, const float* steps
                          float perturb, int use_disp, float* z_out, void* stream);
 
 /* ---- uniform draws for a5 / a11 (the reference calls torch.rand / rand_like, models/rendering.py:248, 29) --------------
- * out[r][c] = u(seed, step, row0 + r, draw, c) in [0, 1), c < n: Philox4x32-10 with counter (row0 + r, c / 4, step, draw) and
- * key seed, 24 bits per value.  row0 = GLOBAL row of this rank's first ray in the data-parallel batch, so the numbers do not
- * depend on how the batch is split over ranks; draw = 0 coarse jitter, 1, 2 = the sample_pdf sets in call
- * order.  step_dev (DEVICE [1] float or NULL) overrides `step` at execution time (graph replay). */
-int upnerf_uniform_keyed(int R, int n, uint64_t seed, int step, const float* step_dev, int row0, int draw, float* out,
-                         void* stream);
+ * out[r][c] = u(seed, step, row0 + r * row_stride, draw, c) in [0, 1), c < n: Philox4x32-10 with counter (global row, c / 4,
+ * step, draw) and key seed, 24 bits per value.  row0 + r * row_stride = GLOBAL row of local ray r in the data-parallel batch, so
+ * the numbers do not depend on how the batch is split over ranks: contiguous shards pass (rank * R, 1), shards
+ * dealt like DistributedSampler (local ray r = global ray r * world + rank) pass (rank, world).  draw = 0 coarse jitter, 1, 2 =
+ * the sample_pdf sets in call order.  step_dev (DEVICE [1] float or NULL) overrides `step` at execution time (graph replay). */
+int upnerf_uniform_keyed(int R, int n, uint64_t seed, int step, const float* step_dev, int row0, int row_stride, int draw,
+                         float* out, void* stream);
 
 /* ---- a11: inverse-CDF resampling (models/rendering.py:7-50 sample_pdf) ---------------------------
  * z [R][S] coarse depths (bins = midpoints, computed inside), weights [R][S] (only [1:S-1] used),

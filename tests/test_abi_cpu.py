@@ -3,6 +3,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -86,3 +87,42 @@ def test_host_wrappers_refuse_or_fall_back_cleanly_without_a_gpu():
     assert isinstance(opt, torch.optim.Adam) and not isinstance(opt, FlatAdam)
     with pytest.raises(ValueError):
         FlatAdam(lin.parameters())
+
+
+def test_no_inline_asm_reads_an_mfma_result_inside_the_hazard_window(tmp_path):
+    """hipcc does not pad an MFMA-result -> VALU-read hazard when the reader is an inline-asm statement (stale
+    lanes in a few rows per 65 536, different rows every run).  The rule of this code base -- inline asm (v_fma_mix_f32 in
+    resid16 / mix16) only reads values that went through a compiler-visible vector instruction first -- is checked on the
+    generated ISA: no v_fma_mix_f32 may read a register that a v_mfma wrote within the previous 12 instructions."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "upnerf_amd", "csrc")
+    bad = []
+    for src in ("field16.hip",):
+        out = tmp_path / (src + ".s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
+                            "--cuda-device-only", os.path.join(csrc, src), "-o", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        window = []  # (first, last) destination registers of recent v_mfma, one entry per instruction slot
+        n_mix = 0
+        for line in open(out):
+            t = line.strip()
+            if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+                continue
+            op = t.split()[0]
+            m = re.match(r"v_mfma\S*\s+v\[(\d+):(\d+)\]", t)
+            if op == "s_nop":  # an s_nop N stands for N + 1 wait states
+                window = (window + [None] * (int(t.split()[1]) + 1))[-12:]
+                continue
+            if op.startswith("v_fma_mix_f32"):
+                n_mix += 1
+                srcs = [int(x) for x in re.findall(r"v(\d+)", t.split(",", 1)[1])]
+                for w in window:
+                    if w and any(w[0] <= s <= w[1] for s in srcs):
+                        bad.append((src, t))
+            window = (window + [(int(m.group(1)), int(m.group(2))) if m else None])[-12:]
+        assert n_mix > 100, (src, n_mix)  # the check looked at something
+    assert not bad, bad[:5]

@@ -78,6 +78,17 @@ def test_gpus_n_without_torchrun_spawns_n_ranks():
     assert d["config"]["parallelism"] == "dp2" and d["steps"] == 3
 
 
+def test_strong_scaling_dry_run_splits_the_batch():
+    """--strong: the configuration's 4096 rays are split over the ranks; the line says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["UPNERF_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--dry-run", "--strong"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["world_size_observed"] == 2
+
+
 def test_world_size_mismatch_is_an_error():
     """A launcher environment that disagrees with --gpus must fail, not measure something else."""
     out = _run(["--gpus", "2", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})

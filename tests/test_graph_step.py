@@ -93,3 +93,54 @@ def test_replayed_steps_are_bitwise_the_eager_steps(perturb):
     for k, v in runs["eager"][2].items():
         w = runs["graph"][2][k]
         assert (torch.equal(v, w) if torch.is_tensor(v) else v == w), k
+
+
+@pytest.mark.gpu
+def test_captured_step_holds_no_memset_node(monkeypatch):
+    """A memset node once lost its order against the kernel nodes of a replayed step.  The library issues
+    none; this pins that nothing else in the captured step does either."""
+    from upnerf_amd import synth
+    from upnerf_amd.graph_step import GraphedTrainingStep
+    monkeypatch.setenv("UPNERF_GRAPH_CENSUS", "1")
+    s = _system(1.0, 120)
+    s.global_step = 72  # progress 0.3: all heads active
+    s.set_progress(s.global_step / 240)
+    step = GraphedTrainingStep(s)
+    batches = [{k: v.cuda() for k, v in synth.batch(192, 7, seed=60 + i).items()} for i in range(2)]
+    for i in range(4):
+        step(batches[i % 2], i)
+    torch.cuda.synchronize()
+    assert step.stats["captures"] >= 1 and step.stats["memset_nodes"] == 0, step.stats
+
+
+@pytest.mark.gpu
+def test_sgd_falls_back_to_eager_launches_and_follows_its_lr_schedule():
+    """An optimiser whose step() reads Python scalars (SGD: the learning rate) must not be captured: the replay would
+    freeze the value of the capture.  GraphedTrainingStep then launches eagerly -- same parameters as the plain loop."""
+    import warnings
+    from upnerf_amd import synth
+    from upnerf_amd.graph_step import GraphedTrainingStep
+    batches = [{k: v.cuda() for k, v in synth.batch(192, 7, seed=70 + i).items()} for i in range(2)]
+    out = {}
+    for mode in ("eager", "graph"):
+        from upnerf_amd.nerf_system import NeRFSystem, SyntheticDataset, default_hparams
+        hp = default_hparams(**{"nerf.N_samples": 32, "nerf.N_importance": 32, "train.batch_size": 192, "max_steps": 50,
+                                "nerf.perturb": 0.0, "optimizer.type": "sgd"})
+        torch.manual_seed(0)
+        s = NeRFSystem(hp, SyntheticDataset(7))
+        s.setup()
+        s = s.cuda()
+        s.set_progress(0.3)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            step = GraphedTrainingStep(s) if mode == "graph" else s.training_step
+        if mode == "graph":
+            assert step.eager_reason and any("eagerly" in str(x.message) for x in w)
+        for i in range(6):
+            step(batches[i % 2], i)
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert step.stats["captures"] == 0 and step.stats["eager"] == 6
+        out[mode] = {k: v.detach().clone() for k, v in s.state_dict().items()}
+    for k, v in out["eager"].items():
+        assert torch.equal(v, out["graph"][k]), k

@@ -763,7 +763,7 @@ def test_keyed_uniform_draws_follow_the_philox_spec_and_the_global_row(hip):
     lib, ptr, stream, check = hip["lib"].lib, hip["lib"].ptr, hip["lib"].stream, hip["lib"].check
     R, n, seed, step, draw = 37, 90, 0x1234567890ABCDEF, 4711, 2
     out = torch.empty(R, n, device="cuda")
-    check(lib.upnerf_uniform_keyed(R, n, seed, step, None, 100, draw, ptr(out), stream()), "uniform")
+    check(lib.upnerf_uniform_keyed(R, n, seed, step, None, 100, 1, draw, ptr(out), stream()), "uniform")
     q4 = (n + 3) // 4
     rr, qq = np.meshgrid(np.arange(R), np.arange(q4), indexing="ij")
     ctr = np.stack([100 + rr.ravel(), qq.ravel(), np.full(R * q4, step), np.full(R * q4, draw)], 1).astype(np.uint32)
@@ -773,9 +773,14 @@ def test_keyed_uniform_draws_follow_the_philox_spec_and_the_global_row(hip):
     assert 0.0 <= float(out.min()) and float(out.max()) < 1.0 and abs(float(out.mean()) - 0.5) < 0.03
     a, b = torch.empty(20, n, device="cuda"), torch.empty(17, n, device="cuda")
     step_dev = torch.tensor([float(step)], device="cuda")
-    check(lib.upnerf_uniform_keyed(20, n, seed, 0, ptr(step_dev), 100, draw, ptr(a), stream()), "uniform")
-    check(lib.upnerf_uniform_keyed(17, n, seed, 0, ptr(step_dev), 120, draw, ptr(b), stream()), "uniform")
+    check(lib.upnerf_uniform_keyed(20, n, seed, 0, ptr(step_dev), 100, 1, draw, ptr(a), stream()), "uniform")
+    check(lib.upnerf_uniform_keyed(17, n, seed, 0, ptr(step_dev), 120, 1, draw, ptr(b), stream()), "uniform")
     assert torch.equal(torch.cat([a, b]), out)
+    # shards dealt like DistributedSampler (local ray r of rank k = global ray r * world + k): stride = world
+    c0, c1 = torch.empty(19, n, device="cuda"), torch.empty(18, n, device="cuda")
+    check(lib.upnerf_uniform_keyed(19, n, seed, 0, ptr(step_dev), 100, 2, draw, ptr(c0), stream()), "uniform")
+    check(lib.upnerf_uniform_keyed(18, n, seed, 0, ptr(step_dev), 101, 2, draw, ptr(c1), stream()), "uniform")
+    assert torch.equal(c0, out[0::2]) and torch.equal(c1, out[1::2])
 
 
 def test_two_virtual_ranks_draw_what_one_rank_draws(hip):
@@ -792,8 +797,8 @@ def test_two_virtual_ranks_draw_what_one_rank_draws(hip):
     s.set_progress(0.3)
     batch = {k: v.cuda() for k, v in synth.batch(256, 5, seed=3).items()}
 
-    def depths(b, row0):
-        s._rng_row0 = row0
+    def depths(b, row0, stride=1):
+        s._rng_row0, s._rng_stride = row0, stride
         keep = {}
         with torch.no_grad():
             rays = s.rays_from_batch(b)
@@ -803,6 +808,10 @@ def test_two_virtual_ranks_draw_what_one_rank_draws(hip):
     zc, zf = depths(batch, 0)
     halves = [depths({k: v[lo:lo + 128] for k, v in batch.items()}, lo) for lo in (0, 128)]
     assert torch.equal(zc, torch.cat([h[0] for h in halves])) and torch.equal(zf, torch.cat([h[1] for h in halves]))
+    # the layout the ray sampler actually produces (ray_sampler.py: perm[rank::world]): rank k holds global rays k, k + 2, ...
+    for k in (0, 1):
+        zk = depths({kk: v[k::2].contiguous() for kk, v in batch.items()}, k, 2)
+        assert torch.equal(zk[0], zc[k::2]) and torch.equal(zk[1], zf[k::2])
     s.global_step = 62  # another step: other numbers
     zc2, _ = depths(batch, 0)
     assert not torch.equal(zc, zc2)

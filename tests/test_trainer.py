@@ -117,6 +117,21 @@ def test_fit_validates_checkpoints_and_resumes_bitwise(tmp_path):
         assert torch.equal(sa[k], sd[k]), k
     assert [h["val/psnr"] for h in td.history] == [h["val/psnr"] for h in ta.history]
 
+    # a file in the round-1 layout (resume state under the bare keys `loops` / `callbacks` / `rng_states`) still resumes at its
+    # position; a file with no resume position at all says so instead of silently replaying the epoch
+    ck = torch.load(str(tmp_path / "b" / "last.ckpt"), weights_only=False)
+    old = dict(ck)
+    old["loops"], old["callbacks"], old["rng_states"] = old.pop("upnerf_loops"), old.pop("upnerf_topk"), old.pop("upnerf_rng")
+    torch.save(old, str(tmp_path / "old.ckpt"))
+    te = Trainer(MAX, dirpath=None, seed=3)
+    te.resume(_system(I), str(tmp_path / "old.ckpt"))
+    assert (te.epoch, te.batch_in_epoch) == (int(ck["upnerf_loops"]["epoch"]), int(ck["upnerf_loops"]["batch_in_epoch"]))
+    for k in ("loops", "callbacks", "rng_states"):
+        old.pop(k)
+    torch.save(old, str(tmp_path / "bare.ckpt"))
+    with pytest.warns(UserWarning, match="no resume position"):
+        Trainer(MAX, dirpath=None, seed=3).resume(_system(I), str(tmp_path / "bare.ckpt"))
+
 
 @pytest.mark.gpu
 def test_fit_from_config_wires_yaml_to_run_directory(tmp_path):

@@ -129,7 +129,7 @@ _SIGNATURES = {
     "upnerf_pose_rays_fwd": [_i, _p, _p, _p, _p, _p, _p],
     "upnerf_pose_rays_bwd": [_i, _p, _p, _p, _p, _p, _p, _p],
     "upnerf_sample_coarse": [_i, _i, _p, _p, _p, _f, _i, _p, _p],
-    "upnerf_uniform_keyed": [_i, _i, C.c_uint64, _i, _p, _i, _i, _p, _p],
+    "upnerf_uniform_keyed": [_i, _i, C.c_uint64, _i, _p, _i, _i, _i, _p, _p],
     "upnerf_sample_pdf": [_i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     "upnerf_sort_rows": [_i, _i, _p, _p],
     "upnerf_ray_aux": [_i, _p, _p, C.POINTER(C.c_float), _p, _p, _p],

@@ -241,13 +241,14 @@ __device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int 
   c[2] = n2;
 }
 __global__ void uniform_keyed_kernel(int R, int n, unsigned int seed_lo, unsigned int seed_hi, int step,
-                                     const float* __restrict__ step_dev, int row0, int draw, float* __restrict__ out) {
+                                     const float* __restrict__ step_dev, int row0, int row_stride, int draw,
+                                     float* __restrict__ out) {
   const int q4 = (n + 3) >> 2;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * q4) return;
   const int r = idx / q4, q = idx - r * q4;
   if (step_dev) step = (int)step_dev[0];  // graph replay: the step counter lives in device memory (exact in fp32 below 2^24)
-  unsigned int c[4] = {(unsigned int)(row0 + r), (unsigned int)q, (unsigned int)step, (unsigned int)draw};
+  unsigned int c[4] = {(unsigned int)(row0 + r * row_stride), (unsigned int)q, (unsigned int)step, (unsigned int)draw};
   unsigned int k0 = seed_lo, k1 = seed_hi;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
@@ -553,12 +554,12 @@ extern "C" int upnerf_sample_coarse(int R, int S, const float* near_far, const f
   return (int)hipGetLastError();
 }
 
-extern "C" int upnerf_uniform_keyed(int R, int n, uint64_t seed, int step, const float* step_dev, int row0, int draw, float* out,
-                                    void* stream) {
-  if (R <= 0 || n <= 0 || !out || step < 0 || row0 < 0 || draw < 0) return UPNERF_EINVAL;
+extern "C" int upnerf_uniform_keyed(int R, int n, uint64_t seed, int step, const float* step_dev, int row0, int row_stride,
+                                    int draw, float* out, void* stream) {
+  if (R <= 0 || n <= 0 || !out || step < 0 || row0 < 0 || row_stride < 1 || draw < 0) return UPNERF_EINVAL;
   const long long total = (long long)R * ((n + 3) / 4);
   hipLaunchKernelGGL(uniform_keyed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R, n,
-                     (unsigned int)seed, (unsigned int)(seed >> 32), step, step_dev, row0, draw, out);
+                     (unsigned int)seed, (unsigned int)(seed >> 32), step, step_dev, row0, row_stride, draw, out);
   return (int)hipGetLastError();
 }
 

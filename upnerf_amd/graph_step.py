@@ -21,6 +21,7 @@ the flat gradient buffer, RCCL all-reduce issued eagerly, graph 2 = unpack + Ada
 capture support in the communication library."""
 from __future__ import annotations
 
+import warnings
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -52,9 +53,43 @@ class GraphedTrainingStep:
         self.seen: Dict[tuple, int] = {}
         self.max_graphs, self.eager_steps = max_graphs, eager_steps
         self.stats = {"eager": 0, "captures": 0, "replays": 0}
+        # UPNERF_GRAPH_CENSUS=1 (tests): count the memset nodes of every captured graph (stats["memset_nodes"])
+        self.census = bool(int(__import__("os").environ.get("UPNERF_GRAPH_CENSUS", "0")))
         nc, nf = system.nerf_coarse, getattr(system, "nerf_fine", None)
         if nf is not None and (nf.xyz_L, nf.dir_L, nf.c2f) != (nc.xyz_L, nc.dir_L, nc.c2f):
             raise ValueError("coarse and fine fields must share the encoding configuration")
+        # An optimiser whose step() reads Python scalars bakes them into the captured launches: SGD would replay the learning
+        # rate of the capture for ever (the LR scheduler silently ignored), torch's non-capturable Adam raises in the middle
+        # of the capture.  Only optimisers that split into step_device / step_host (FlatAdam) or are capturable with the
+        # learning rate on the device replay correctly; anything else runs eagerly (round-2 ADVICE).
+        self.eager_reason = self._not_capturable()
+        if self.eager_reason:
+            warnings.warn(f"GraphedTrainingStep: {self.eager_reason}; the step is launched eagerly instead of replayed")
+
+    def _not_capturable(self) -> Optional[str]:
+        opts, _ = self.system._opts_scheds()
+        for o in opts:
+            if hasattr(o, "step_device"):
+                continue
+            for g in o.param_groups:
+                if not g.get("capturable", False):
+                    return f"{type(o).__name__} is not capturable"
+                if not torch.is_tensor(g.get("lr")) and self._lr_moves(o):
+                    return f"{type(o).__name__} keeps its learning rate as a Python number under an LR schedule"
+        return None
+
+    def _lr_moves(self, opt) -> bool:
+        """Does an LR schedule change this optimiser's learning rate from step to step?"""
+        for sch in self.system._opts_scheds()[1]:
+            if getattr(sch, "optimizer", None) is not opt:
+                continue
+            name = type(sch).__name__
+            if name == "ConstantLR" and getattr(sch, "factor", None) == 1.0:
+                return False
+            if name == "ExponentialLR" and getattr(sch, "gamma", None) == 1.0:
+                return False
+            return True
+        return False
 
     # ---- signature ---------------------------------------------------------------------------------------------------
     def key(self, batch) -> tuple:
@@ -96,6 +131,8 @@ class GraphedTrainingStep:
         e = _Entry()
         e.scalars = StepScalars(self.device, self._providers())
         e.g1, e.g2, e.replays = torch.cuda.CUDAGraph(), None, 0
+        if self.census:
+            e.g1.enable_debug_mode()
         with e.scalars:
             with torch.cuda.graph(e.g1, pool=self.pool, stream=self.stream, capture_error_mode=mode):
                 e.loss, e.loss_d = s._step_backward(static)
@@ -106,15 +143,41 @@ class GraphedTrainingStep:
                     e.n_sync = sync.pack()
             if sync is not None:
                 e.g2 = torch.cuda.CUDAGraph()
+                if self.census:
+                    e.g2.enable_debug_mode()
                 with torch.cuda.graph(e.g2, pool=self.pool, stream=self.stream, capture_error_mode=mode):
                     sync.unpack()
                     e.done = s._step_update()
         e.grads = [(p, p.grad) for p in s.parameters()]
+        if self.census:
+            self.stats["memset_nodes"] = self._memset_nodes(e)
         self.stats["captures"] += 1
         self.graphs[key] = e
         while len(self.graphs) > self.max_graphs:
             self.graphs.popitem(last=False)
         return e
+
+    def _memset_nodes(self, e) -> int:
+        """Memset nodes in the captured graphs (a memset node once lost its order against kernel nodes after
+        null-stream work between replays; the library issues none, what is left comes from ATen).  -1: not inspectable."""
+        n = 0
+        for g in (e.g1, e.g2):
+            if g is None:
+                continue
+            path = f"/tmp/upnerf_graph_{id(g)}.dot"
+            try:
+                g.debug_dump(path)
+                with open(path) as f:
+                    n += f.read().upper().count("MEMSET")
+            except Exception:
+                return -1
+            finally:
+                try:
+                    import os
+                    os.remove(path)
+                except OSError:
+                    pass
+        return n
 
     # ---- one training step -------------------------------------------------------------------------------------------
     def __call__(self, batch, batch_nb: int = 0):
@@ -124,7 +187,7 @@ class GraphedTrainingStep:
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             e = self.graphs.get(key)
-            if e is None and self.seen.get(key, 0) < self.eager_steps:
+            if self.eager_reason or (e is None and self.seen.get(key, 0) < self.eager_steps):
                 self.seen[key] = self.seen.get(key, 0) + 1
                 self.stats["eager"] += 1
                 loss = s.training_step(batch, batch_nb)

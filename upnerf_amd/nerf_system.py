@@ -144,7 +144,8 @@ class NeRFSystem(_Base):
         if train and u_list is None and hp.get("rng.keyed", True) and hp["nerf.perturb"] > 0:
             # stratified-sampling draws keyed by (seed, optimisation step, GLOBAL row of the ray): the reference draws from the
             # process-wide generator (rendering.py:248, 29), whose numbers depend on the rank count
-            rng = {"seed": int(hp.get("seed", 0)), "step": int(self.global_step), "row0": self.rng_row0(rays.shape[0])}
+            row0, stride = self.rng_rows(rays.shape[0])
+            rng = {"seed": int(hp.get("seed", 0)), "step": int(self.global_step), "row0": row0, "stride": stride}
         sched_phase = 0 if sched_mult == 0 else (2 if sched_mult == 1 else 1)
         B = rays.shape[0]
         results = defaultdict(list)
@@ -172,7 +173,7 @@ class NeRFSystem(_Base):
                               perturb=hp["nerf.perturb"] if train else 0, N_importance=hp["nerf.N_importance"],
                               white_back=getattr(self.train_dataset, "white_back", False),
                               encode_feat=hp["nerf.feat_dim"] > 0, validation=not train, u_list=u_list, keep=keep,
-                              rng=None if rng is None else dict(rng, row0=rng["row0"] + i))
+                              rng=None if rng is None else dict(rng, row0=rng["row0"] + i * rng["stride"]))
             for k, v in out.items():
                 results[k] += [v]
         results = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in results.items()}
@@ -193,12 +194,16 @@ class NeRFSystem(_Base):
                 results["rgb_coarse"] = results["s_rgb_coarse"]
         return results
 
-    def rng_row0(self, rows: int) -> int:
-        """Global row of this rank's first ray in the data-parallel batch (`rows` rays per rank); tests may pin it."""
+    def rng_rows(self, rows: int):
+        """(row0, stride): global row of local ray r in the data-parallel batch = row0 + r * stride.  The ray sampler deals
+        the global batch like DistributedSampler (ray_sampler.py: perm[rank::world]), so local ray r of rank k is global ray
+        r * world + k -> (rank, world); `_rng_row0` / `_rng_stride` pin other layouts (tests: contiguous halves)."""
         if getattr(self, "_rng_row0", None) is not None:
-            return int(self._rng_row0)
+            return int(self._rng_row0), int(getattr(self, "_rng_stride", 1))
         import torch.distributed as dist
-        return dist.get_rank() * rows if dist.is_available() and dist.is_initialized() else 0
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
 
     # ---- pieces of training_step, exposed for tests and the benchmark ------------------------------------
     def rays_from_batch(self, batch):

@@ -431,7 +431,7 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
     R = rays.shape[0]
     st = stream()
 
-    rng = kwargs.get("rng")  # dict(seed, step, row0): keyed draws (upnerf_uniform_keyed); absent: torch.rand like the reference
+    rng = kwargs.get("rng")  # dict(seed, step, row0[, stride]): keyed draws (upnerf_uniform_keyed); absent: torch.rand like the reference
     n_drawn = [0]
 
     def draw(n):
@@ -450,7 +450,8 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
             return t
         dyn = step_scalars.current()
         check(lib.upnerf_uniform_keyed(R, n, int(rng["seed"]) & 0xFFFFFFFFFFFFFFFF, int(rng["step"]),
-                                       dyn.ptr_named("step", 1) if dyn else None, int(rng["row0"]), n_drawn[0] - 1, ptr(t), st),
+                                       dyn.ptr_named("step", 1) if dyn else None, int(rng["row0"]), int(rng.get("stride", 1)),
+                                       n_drawn[0] - 1, ptr(t), st),
               "upnerf_uniform_keyed")
         return t
 

@@ -129,12 +129,26 @@ class Trainer:
     def resume(self, system, ckpt_path: str) -> None:
         ck = read_checkpoint(ckpt_path)
         load_checkpoint(system, ck, resume=True)
-        loops = ck.get("upnerf_loops") or {}  # absent in a file written by the reference: start of the stored epoch
+        # Resume state lives under upnerf_* keys (a Lightning checkpoint of the reference carries its own, differently
+        # shaped `loops` / `callbacks`).  Files written by round 1 of this package kept it under the bare names: read those
+        # when the new keys are absent and the old ones have OUR shape; anything else resumes at the start of the stored
+        # epoch -- loudly, because batches already consumed will then be replayed.
+        loops, topk, rng = ck.get("upnerf_loops"), ck.get("upnerf_topk"), ck.get("upnerf_rng")
+        legacy = ck.get("loops")
+        if loops is None and isinstance(legacy, dict) and "batch_in_epoch" in legacy:
+            loops = legacy
+            topk = topk if topk is not None else (ck.get("callbacks") if isinstance(ck.get("callbacks"), dict) else None)
+            rng = rng if rng is not None else ck.get("rng_states")
+        if loops is None:
+            import warnings
+            warnings.warn(f"{ckpt_path}: no resume position (upnerf_loops) in the checkpoint: resuming at the start of epoch "
+                          f"{int(ck.get('epoch', 0))}; batches of that epoch already trained on will be seen again")
+            loops = {}
         self.epoch = int(loops.get("epoch", ck.get("epoch", 0)))
         self.batch_in_epoch = int(loops.get("batch_in_epoch", 0))
-        if self.ckpts is not None and isinstance(ck.get("upnerf_topk"), dict):
-            self.ckpts.load_state_dict(ck["upnerf_topk"])
-        rng = ck.get("upnerf_rng") or {}
+        if self.ckpts is not None and isinstance(topk, dict) and "best" in topk:
+            self.ckpts.load_state_dict(topk)
+        rng = rng or {}
         if rng.get("torch") is not None:
             torch.set_rng_state(rng["torch"])
         if rng.get("cuda") is not None and torch.cuda.is_available():
