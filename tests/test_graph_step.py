@@ -96,21 +96,26 @@ def test_replayed_steps_are_bitwise_the_eager_steps(perturb):
 
 
 @pytest.mark.gpu
-def test_captured_step_holds_no_memset_node(monkeypatch):
+def test_a_training_step_issues_no_memset():
     """A memset node once lost its order against the kernel nodes of a replayed step.  The library issues
-    none; this pins that nothing else in the captured step does either."""
+    none; this pins that nothing else in the step does either: the runtime calls of one eager step -- the call sequence a
+    capture records -- contain no hipMemset*.  (torch's CUDAGraph.debug_dump writes nothing on this ROCm build, so the
+    captured graph itself cannot be listed.)"""
+    from torch.profiler import ProfilerActivity, profile
     from upnerf_amd import synth
-    from upnerf_amd.graph_step import GraphedTrainingStep
-    monkeypatch.setenv("UPNERF_GRAPH_CENSUS", "1")
-    s = _system(1.0, 120)
-    s.global_step = 72  # progress 0.3: all heads active
-    s.set_progress(s.global_step / 240)
-    step = GraphedTrainingStep(s)
+    s = _system(1.0, 100000)
+    s.global_step = 60000  # progress 0.3: all heads active
+    s.set_progress(s.global_step / 200000)
     batches = [{k: v.cuda() for k, v in synth.batch(192, 7, seed=60 + i).items()} for i in range(2)]
-    for i in range(4):
-        step(batches[i % 2], i)
+    for i in range(2):
+        s.training_step(batches[i], i)
     torch.cuda.synchronize()
-    assert step.stats["captures"] >= 1 and step.stats["memset_nodes"] == 0, step.stats
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        s.training_step(batches[0], 2)
+        torch.cuda.synchronize()
+    names = [ev.name for ev in prof.events()]
+    assert any(n.startswith("hipLaunchKernel") or n.startswith("hipModuleLaunchKernel") or "LaunchKernel" in n for n in names)
+    assert not [n for n in names if "emset" in n], sorted({n for n in names if "emset" in n})
 
 
 @pytest.mark.gpu

@@ -15,6 +15,13 @@ from golden_util import CASES, Case, rel_err
 pytestmark = pytest.mark.gpu
 
 TOL_MAP, TOL_W, TOL_GRAD = 1e-4, 2e-4, 1e-3
+# Goldens in which at least one resampled depth of the GPU run sits an eps-bin away from the reference's (see
+# test_training_step_matches_reference_golden): those are compared loosely with the golden gradients and strictly with the
+# oracle at the GPU's own depths.  The set is PINNED: a change that makes another case flip fails
+# test_only_the_known_goldens_take_the_flipped_branch instead of quietly moving it to the loose gate.
+KNOWN_FLIPPED = frozenset({"cfg1_small_fine", "cfg2_det_phase1", "cfg2_phase0", "cfg2_phase1", "cfg2_phase2", "cfg2_trained_p045",
+                           "cfg2_trained_p08", "small_nocand"})  # round 3, both field tilings
+_FLIPPED_SEEN = {}
 
 
 def oracle_grads(c, dtype, z_fine=None):
@@ -196,6 +203,8 @@ def test_training_step_matches_reference_golden(name):
         dz = (keep["z_fine"].cpu() - okeep["z_fine"]).abs()
         assert float((dz < 1e-5).float().mean()) > 0.99, "resampled depths disagree beyond isolated eps-bin flips"
         flipped = bool(dz.max() > 1e-5)
+    _FLIPPED_SEEN[name] = flipped
+    print(f"[flipped] {name}: {flipped}" + (f" (max |dz| {float(dz.max()):.2e}, {float((dz > 1e-5).float().mean()):.2%} beyond 1e-5)" if c.fine else ""))
     bad = {}
 
     def gate(n):
@@ -240,6 +249,15 @@ def test_training_step_matches_reference_golden(name):
             if err >= max(TOL_GRAD, 4 * noise.get(n, worst_noise)):
                 bad[n] = (err, noise.get(n, 0.0))
         assert not bad, ("vs oracle at the GPU's fine depths", bad)
+
+
+def test_only_the_known_goldens_take_the_flipped_branch():
+    """Runs after the golden cases above (file order): the cases whose gradients were compared at the loose gate must be a
+    subset of the pinned set."""
+    if len(_FLIPPED_SEEN) < len(CASES):
+        pytest.skip("needs the full run of test_training_step_matches_reference_golden in this process")
+    took = {n for n, f in _FLIPPED_SEEN.items() if f}
+    assert took <= KNOWN_FLIPPED, f"new cases on the loose gradient gate: {sorted(took - KNOWN_FLIPPED)}"
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

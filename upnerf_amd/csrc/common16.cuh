@@ -118,7 +118,47 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
                                           const char* __restrict__ Wf, int Kp16, int n0, int kB0, int lane) {
   constexpr int SETS = (AHEAD + 1 > T) ? T : AHEAD + 1;  // ring size; the ring runs SETS - 1 blocks ahead
   constexpr int AH = SETS - 1;
-  static_assert(SETS % 2 == 0 && T % SETS == 0, "ring size: even, dividing the number of k-blocks");
+#ifndef F16_FORCE_UNROLLED_K
+#define F16_FORCE_UNROLLED_K 0
+#endif
+  if constexpr (F16_FORCE_UNROLLED_K || SETS % 2 != 0 || T % SETS != 0) {
+    // ring sizes that do not divide the loop (two blocks ahead = three sets): the whole K loop unrolled, every ring index a
+    // compile-time constant.  The lane's row offsets are made opaque first: hipcc would otherwise hoist all T LDS addresses
+    // out of the caller's layer loop and spill them.
+    int li = lane & 31, lh = lane >> 5;
+    asm volatile("" : "+v"(li), "+v"(lh));
+    const char* bpu[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bpu[nt] = Wf + ((size_t)((n0 >> 5) + nt) * Kp16 + (kB0 >> 4)) * 2048 + (li + 32 * lh) * 16;
+    h8 uwh[SETS][NT], uwl[SETS][NT], uxh[2][MT], uxl[2][MT];
+    auto ldw = [&](int t) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        uwh[t % SETS][nt] = *(const h8*)(bpu[nt] + (size_t)t * 2048);
+        if constexpr (NP == 2) uwl[t % SETS][nt] = *(const h8*)(bpu[nt] + (size_t)t * 2048 + 1024);
+      }
+    };
+    auto ldx = [&](int t) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int o = poff<W>(row0 + 32 * mt + li, kA0 + 16 * t + 8 * lh);
+        uxh[t & 1][mt] = *(const h8*)(Ph + o);
+        if constexpr (NP == 2) uxl[t & 1][mt] = *(const h8*)(Pl + o);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < AH; ++t) ldw(t);
+    ldx(0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + AH < T) ldw(t + AH);
+      if (t + 1 < T) ldx(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma16_step<NP>(acc, uxh[t & 1], uxl[t & 1], uwh[t % SETS], uwl[t % SETS]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   const int i = lane & 31, hh = lane >> 5;
   const char* bp[NT];
   int arow[MT];

@@ -37,10 +37,12 @@
 // Weight fragments are requested this many 16-deep k-blocks ahead of the MFMAs that consume them.  Measured with the stamps
 // build (per wave and trunk layer): f16 mode 10.4k cycles per K loop one block ahead = 650 cycles per k-block = the L2
 // latency, 8.1k three ahead and 8.3k seven ahead -- from there on the loop is bound by the bytes the CU can pull from L2
-// (~32 B/clk: 128 KB of fp16 weights per 64-row tile and layer).  The f16x3 mode moves twice the bytes (16.5k cycles per K
-// loop at every depth: bandwidth-bound already one block ahead), deeper rings only add register pressure there.
+// (~32 B/clk: 128 KB of fp16 weights per 64-row tile and layer).  f16x3 mode: TWO ahead (a ring of three fragment sets, the K
+// loop fully unrolled: common16.cuh) -- 2.57 / 2.50 ms per forward / backward launch against 2.66 / 2.58 one ahead and
+// 2.60 / 2.52 three ahead (round 3, same box, alternating runs): one block of twelve MFMAs does not cover the L2 latency
+// when the partner workgroup is in its epilogue, three blocks cost registers the epilogue needs.
 #ifndef F16_AHEAD_X3
-#define F16_AHEAD_X3 1
+#define F16_AHEAD_X3 2
 #endif
 #ifndef F16_AHEAD_F16
 #define F16_AHEAD_F16 3

@@ -53,8 +53,6 @@ class GraphedTrainingStep:
         self.seen: Dict[tuple, int] = {}
         self.max_graphs, self.eager_steps = max_graphs, eager_steps
         self.stats = {"eager": 0, "captures": 0, "replays": 0}
-        # UPNERF_GRAPH_CENSUS=1 (tests): count the memset nodes of every captured graph (stats["memset_nodes"])
-        self.census = bool(int(__import__("os").environ.get("UPNERF_GRAPH_CENSUS", "0")))
         nc, nf = system.nerf_coarse, getattr(system, "nerf_fine", None)
         if nf is not None and (nf.xyz_L, nf.dir_L, nf.c2f) != (nc.xyz_L, nc.dir_L, nc.c2f):
             raise ValueError("coarse and fine fields must share the encoding configuration")
@@ -131,8 +129,6 @@ class GraphedTrainingStep:
         e = _Entry()
         e.scalars = StepScalars(self.device, self._providers())
         e.g1, e.g2, e.replays = torch.cuda.CUDAGraph(), None, 0
-        if self.census:
-            e.g1.enable_debug_mode()
         with e.scalars:
             with torch.cuda.graph(e.g1, pool=self.pool, stream=self.stream, capture_error_mode=mode):
                 e.loss, e.loss_d = s._step_backward(static)
@@ -143,41 +139,15 @@ class GraphedTrainingStep:
                     e.n_sync = sync.pack()
             if sync is not None:
                 e.g2 = torch.cuda.CUDAGraph()
-                if self.census:
-                    e.g2.enable_debug_mode()
                 with torch.cuda.graph(e.g2, pool=self.pool, stream=self.stream, capture_error_mode=mode):
                     sync.unpack()
                     e.done = s._step_update()
         e.grads = [(p, p.grad) for p in s.parameters()]
-        if self.census:
-            self.stats["memset_nodes"] = self._memset_nodes(e)
         self.stats["captures"] += 1
         self.graphs[key] = e
         while len(self.graphs) > self.max_graphs:
             self.graphs.popitem(last=False)
         return e
-
-    def _memset_nodes(self, e) -> int:
-        """Memset nodes in the captured graphs (a memset node once lost its order against kernel nodes after
-        null-stream work between replays; the library issues none, what is left comes from ATen).  -1: not inspectable."""
-        n = 0
-        for g in (e.g1, e.g2):
-            if g is None:
-                continue
-            path = f"/tmp/upnerf_graph_{id(g)}.dot"
-            try:
-                g.debug_dump(path)
-                with open(path) as f:
-                    n += f.read().upper().count("MEMSET")
-            except Exception:
-                return -1
-            finally:
-                try:
-                    import os
-                    os.remove(path)
-                except OSError:
-                    pass
-        return n
 
     # ---- one training step -------------------------------------------------------------------------------------------
     def __call__(self, batch, batch_nb: int = 0):
