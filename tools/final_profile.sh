@@ -7,8 +7,8 @@ set -u
 OUT=$(realpath -m "${1:-gpurun_out/final}"); mkdir -p "$OUT"
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-kernel-timing > "$OUT/prof.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_trevi" -o k -- python3 "$R/bench.py" --config trevi --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-kernel-timing > "$OUT/prof_trevi.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-kernel-timing > "$OUT/prof.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_trevi" -o k -- python3 "$R/bench.py" --config trevi --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-kernel-timing > "$OUT/prof_trevi.log" 2>&1
 cd "$R"
 bash tools/pmc_collect.sh "$OUT/pmc" --no-extras > "$OUT/pmc.log" 2>&1
 bash tools/pmc_collect.sh "$OUT/pmc_trevi" --no-extras --config trevi > "$OUT/pmc_trevi.log" 2>&1

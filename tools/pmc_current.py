@@ -16,8 +16,8 @@ ap.add_argument("--progress", type=float, default=0.3)
 a = ap.parse_args()
 pmc = json.load(open(a.pmc_json))
 np_ = "1" if a.field == "f16" else "2"
-pick = {"field_fwd": (f"field16_fwd_kernel<{np_}, 64>" if a.field != "f32" else "field_fwd_kernel<256, 64>"),
-        "field_bwd": (f"field16_bwd_kernel<{np_}, 64>" if a.field != "f32" else "field_bwd_kernel<256, 64>"),
+pick = {"field_fwd": (f"field16_fwd_kernel<{np_}, 64, 4>" if a.field != "f32" else "field_fwd_kernel<256, 64>"),
+        "field_bwd": (f"field16_bwd_kernel<{np_}, 64, 4>" if a.field != "f32" else "field_bwd_kernel<256, 64>"),
         "wgrad16_256x256": f"wgrad_f16x3_kernel<{np_}, 4, 4>", "wgrad16p_256x256": "wgrad_f16p_kernel<4, 4, 1>",
         "wgrad_256x256": "wgrad_kernel<4, 4>"}
 kern = {}

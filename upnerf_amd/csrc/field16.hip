@@ -448,8 +448,8 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_fwd_kernel(
   // layer makes hipcc copy it to scratch and fetch the entry with a VMEM load + s_waitcnt vmcnt(0) -- a full drain of the
   // previous layer's activation stores at the top of every layer.
   __shared__ int loff_s[2 * UPNERF_MAX_D];
-  // trunk biases [D][W] for the pipelined trunk of the 128-sample tile (its epilogues read them from LDS)
-  __shared__ __attribute__((aligned(16))) float bias_s[TILE == F16_TILE_BIG ? UPNERF_MAX_D * W : 4];
+  // trunk biases [D][W]: the epilogues read them from LDS
+  __shared__ __attribute__((aligned(16))) float bias_s[UPNERF_MAX_D * W];
   char* Ph = planes;
   char* Pl = planes + (NP - 1) * TILE * W * 2;  // NP == 1: never dereferenced
   using TW = WaveTile16<W, TILE, NW>;
@@ -472,11 +472,10 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_fwd_kernel(
     }
   }
   if (tid < 16) mx_s[tid] = 0u;
-  if constexpr (TILE == F16_TILE_BIG) {
 #pragma unroll
-    for (int l = 0; l < UPNERF_MAX_D; ++l)
-      if (l < D && tid < W) bias_s[l * W + tid] = P[L.b[l] + tid];
-  }
+  for (int l = 0; l < UPNERF_MAX_D; ++l)
+    if (l < D)
+      for (int c = tid; c < W; c += THREADS) bias_s[l * W + c] = P[L.b[l] + c];
 
   // ---- sample positions (rendering.py:251 / 308) and the maxima that bound the side inputs of this tile
   {
@@ -565,7 +564,7 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_fwd_kernel(
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
     const int wel = __builtin_amdgcn_readfirstlane(wexp[l]);
-    const int wl = __builtin_amdgcn_readfirstlane(loff_s[l]), bl_off = __builtin_amdgcn_readfirstlane(loff_s[UPNERF_MAX_D + l]);
+    const int wl = __builtin_amdgcn_readfirstlane(loff_s[l]);
     if (l == 0) {
       mma16_lds<NP, W, UPNERF_X0 / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, UPNERF_X0 / 16, n0, 0, lane);
     } else if (l == L.skip) {
@@ -584,10 +583,11 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_fwd_kernel(
     STAMP(1);
     // h_{l-1} leaves from the planes this K loop has just read, in whole lines, behind the loop's last wait for a weight
     // fragment: the epilogue, two barriers and the plane write pass before the wave waits for a load again
-    f32x4 bl[TW::NT][4];
-    load_cols(bl, P + bl_off, n0, hh);  // requested BEFORE the stores: a wait for it behind them would wait for them too
-    asm volatile("" ::: "memory");
     if (l >= 1) store_h32(l - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
+    // the bias row comes from the LDS copy made at kernel start: a global load here would open every epilogue with an L2
+    // round trip, and its wait would also wait for the stores just issued (vmcnt retires in order)
+    f32x4 bl[TW::NT][4];
+    load_cols(bl, bias_s + l * W, n0, hh);
     const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wel)), bl);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
