@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UPNERF_ABI_VERSION 4
+#define UPNERF_ABI_VERSION 5
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
@@ -264,7 +264,20 @@ typedef struct {
   int32_t* gzexp;                /* [D][ceil(M/64)] */
   void* xs;                      /* 128-sample tiles with a skip layer and need_dxyz: scratch of ceil(M/128) * 32768 bytes (the
                                     forward pass's x0f may be reused: its content is dead by now) */
+  float* tile_part;              /* NULL, or [ceil(M/64)][UPNERF_TILE_PART_STRIDE] (f16x3 variant, tile_rows 0 / 64 only): per-tile
+                                    partial sums of what upnerf_vec_wgrad (dpre_sig_c x g2, dpre_rgb x r1) and upnerf_ray_sum
+                                    (gz_g1, gz_r1) would re-read M x W/2 tensors for; finished by upnerf_tile_part_finish */
 } upnerf_field_bwd_args;
+
+/* Layout of one row of tile_part (floats): d w_csig [W/2] | d w_r2 [3][W/2] | sum dpre_sig_c, sum dpre_rgb[0..2] | 4 pad |
+ * sums of gz_g1 over the tile's rows of ray slot 0, 1, 2 [3][W/2] | the same for gz_r1 [3][W/2]; ray slot of row i of tile t =
+ * (64 t + i) / S - (64 t) / S.  W/2 = 128. */
+#define UPNERF_TILE_PART_STRIDE 1288
+/* Finishes the per-tile partial sums: rs_g1 / rs_r1 [R][128] = per-ray sums of gz_g1 / gz_r1 (upnerf_ray_sum's result),
+ * d_wcsig [128], d_bcsig [1], d_wr2 [3][128], d_br2 [3] = upnerf_vec_wgrad's results; any output may be NULL.  Fixed summation
+ * order (bitwise reproducible).  scratch: 128 * 520 floats. */
+int upnerf_tile_part_finish(int R, int S, const float* tile_part, float* rs_g1, float* rs_r1, float* d_wcsig, float* d_bcsig,
+                            float* d_wr2, float* d_br2, float* scratch, void* stream);
 
 int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream);
 /* f16x3 variant: W = 256 and S >= 32 (at most 3 rays per 64-sample tile); hmask from upnerf_field_fwd_f16x3. */

@@ -509,6 +509,72 @@ def test_pipelined_128_sample_kernels_on_ragged_tiles(hip, R, S, mode, use_cand,
     _ragged_tiles(hip, R, S, mode, use_cand, use_rgb)
 
 
+@pytest.mark.parametrize("field_mode", ["f16x3", "f16"], indirect=True)
+@pytest.mark.parametrize("R,S,mode,use_cand,use_rgb", [(7, 40, 1, True, True), (5, 64, 0, True, False), (3, 256, 2, False, True),
+                                                         (6, 33, 1, True, True), (2, 200, 1, True, True)])
+def test_tile_partial_sums_match_the_separate_launches(hip, R, S, mode, use_cand, use_rgb, field_mode):
+    """upnerf_field_bwd_args.tile_part + upnerf_tile_part_finish (the backward kernel's per-tile partial sums of the 128-wide
+    vector heads and of the per-ray sums) against upnerf_vec_wgrad / upnerf_ray_sum on the stored tensors: the same sums in
+    another order (1e-5 of the tensor's scale), everything else bitwise; tiles that straddle up to three rays, ragged last tile."""
+    from upnerf_amd import synth
+    from upnerf_amd.nerf import NeRF
+    rd = hip["rendering"]
+    kw = dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    model = NeRF("coarse", c2f=None, **kw)
+    model.load_state_dict(synth.nerf_state("coarse", seed=3, **kw))
+    model = model.cuda()
+    pk, L = model.packer, model.packer.L
+    o = (gen((R, 3), 70) * 0.3).cuda()
+    d = torch.nn.functional.normalize(gen((R, 3), 71), dim=-1).cuda()
+    z = (torch.sort(gen((R, S), 72).abs() * 3 + 0.1, dim=-1).values).cuda()
+    c_rows, a_rows = gen((R, 16), 73).cuda(), gen((R, 48), 74).cuda()
+    cfg = rd._PassCfg(pk, mode, use_cand, use_rgb, [1.0] * 10, [1.0] * 4)
+    res = {}
+    old = rd.TILE_PARTIALS
+    try:
+        for tp in (0, 1):
+            rd.TILE_PARTIALS = tp
+            leaves = [t.clone().requires_grad_(True) for t in (o, d, c_rows, a_rows, model.packed().detach())]
+            outs = rd._FieldPass.apply(leaves[0], leaves[1], z, leaves[2], leaves[3], leaves[4], cfg)
+            sum((t * gen(tuple(t.shape), 80 + i).cuda()).sum() for i, t in enumerate(outs) if t.numel()).backward()
+            res[tp] = [cpu(t.grad) if t.grad is not None else None for t in leaves]
+    finally:
+        rd.TILE_PARTIALS = old
+    a, b = res[0], res[1]
+    W2 = pk.W2
+    moved = [(L.wcsig, W2), (L.bcsig, 1), (L.wr2, 3 * W2), (L.br2, 3),                 # the vector heads
+             (L.wc1 + pk.W, None), (L.wr1 + pk.W, None)]                                # consumers of the per-ray sums
+    dPa, dPb = a[4].clone(), b[4].clone()
+    bad = {}
+    for off, n in moved[:4]:
+        x, y = dPa[off:off + n].double(), dPb[off:off + n].double()
+        if x.abs().max() > 0:
+            e = float((x - y).abs().max() / x.abs().max())
+            if not e < (1e-5 if n > 3 else 2e-4):  # the bias sums are single numbers left over from cancelling terms
+                bad[f"dP[{off}:{off + n}]"] = e
+        dPa[off:off + n] = 0
+        dPb[off:off + n] = 0
+    # wc1[:, W:] and wr1[:, W:] (the per-ray inputs' columns) come from the ray sums: strided blocks of the two matrices
+    for off, ld, k in ((L.wc1, pk.W + 16, 16), (L.wr1, pk.W + 80, 80)):
+        va, vb = dPa[off:off + W2 * ld].view(W2, ld), dPb[off:off + W2 * ld].view(W2, ld)
+        x, y = va[:, pk.W:].double(), vb[:, pk.W:].double()
+        if x.abs().max() > 0:
+            e = float((x - y).abs().max() / x.abs().max())
+            if not e < 1e-5:
+                bad[f"ray-sum block of {off}"] = e
+        va[:, pk.W:] = 0
+        vb[:, pk.W:] = 0
+    assert torch.equal(dPa, dPb), "parameter gradients outside the re-ordered sums changed"
+    for i in (0, 1):
+        assert (a[i] is None and b[i] is None) or torch.equal(a[i], b[i])
+    for i in (2, 3):  # d c_rows, d a_rows = ray sums . W
+        if a[i] is not None and a[i].abs().max() > 0:
+            e = float((a[i].double() - b[i].double()).abs().max() / a[i].double().abs().max())
+            if not e < 1e-5:
+                bad[f"leaf {i}"] = e
+    assert not bad, bad
+
+
 def _ragged_tiles(hip, R, S, mode, use_cand, use_rgb):
     """f16x3 kernels against the fp32 kernels on shapes whose tiles are ragged (M % 64 != 0) and straddle up to three
     rays; large and tiny magnitudes mixed so that the per-tile exponents differ between tiles and stages."""

@@ -67,7 +67,7 @@ class FieldBwdArgs(C.Structure):
                 ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp), ("hmask", _fp), ("gmax", _fp),
                 ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp),
-                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("gz16", _fp), ("gzexp", _fp), ("xs", _fp)]
+                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("gz16", _fp), ("gzexp", _fp), ("xs", _fp), ("tile_part", _fp)]
 
 
 class LossArgs(C.Structure):
@@ -102,6 +102,7 @@ class WgradGroup(C.Structure):
 
 
 MAX_WGRAD_GROUPS = 32
+TILE_PART_STRIDE = 1288  # UPNERF_TILE_PART_STRIDE
 
 
 class EmbedGroup(C.Structure):
@@ -147,6 +148,7 @@ _SIGNATURES = {
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
+    "upnerf_tile_part_finish": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],
     "upnerf_pack": [_p, C.POINTER(PackDesc), _i, _i, _p],
     "upnerf_gather_rays": [C.POINTER(GatherRaysArgs), _p],
@@ -180,7 +182,7 @@ def _load():
 
 
 lib = _load()
-ABI_VERSION = 4
+ABI_VERSION = 5
 if lib.upnerf_abi_version() != ABI_VERSION:
     raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
 

@@ -144,6 +144,9 @@ __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int
                   mix16<0>(wh[j][1], un, mix16<0>(wl[j][1], un, 0.f)), mix16<1>(wh[j][1], un, mix16<1>(wl[j][1], un, 0.f))};
       else
         v = f32x4{mix16<0>(wh[j][0], un, 0.f), mix16<1>(wh[j][0], un, 0.f), mix16<0>(wh[j][1], un, 0.f), mix16<1>(wh[j][1], un, 0.f)};
+#ifdef UPNERF_EXP_HALFROW
+      if (NCOLS == 256 && g >= UPNERF_EXP_HALFROW) continue;
+#endif
       if (whole || m0 + row < M) *(f32x4*)&dst[(size_t)(m0 + row) * ldg + 4 * g] = v;
     }
   }
@@ -152,6 +155,44 @@ template <int NP, int W, int TILE, int THREADS, int NCOLS, int BATCH = 4>
 __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, float unscale, float* __restrict__ dst,
                                              int ldg, int m0, int M, int tid) {
   tile_store16<NP, W, TILE, THREADS, NCOLS, BATCH>(Ph, Pl, c0, unscale, unscale, dst, ldg, m0, M, tid);
+}
+
+// tile_store16 for a half-width tensor that also adds every stored row to the accumulator of the row's ray slot (sums[slot],
+// this thread's four columns; slot_s[row] < NS): the per-tile part of upnerf_ray_sum (see upnerf_field_bwd_args.tile_part).
+template <int NP, int W, int TILE, int THREADS, int NCOLS, int NS>
+__device__ __forceinline__ void tile_store16_sum(const char* Ph, const char* Pl, int c0, float un, float* __restrict__ dst,
+                                                 int ldg, int m0, int M, int tid, const int* slot_s, f32x4 (&sums)[NS]) {
+  constexpr int GPR = NCOLS >> 2, ITER = TILE * GPR / THREADS, B = 4;
+  static_assert(TILE * GPR % THREADS == 0 && ITER % B == 0, "whole batches of whole passes");
+#pragma unroll 1
+  for (int it0 = 0; it0 < ITER; it0 += B) {
+    u32x2_t wh[B], wl[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int idx = tid + (it0 + j) * THREADS, row = idx / GPR, g = idx % GPR;
+      const int o = poff<W>(row, c0 + 4 * g);
+      wh[j] = *(const u32x2_t*)(Ph + o);
+      if constexpr (NP == 2) wl[j] = *(const u32x2_t*)(Pl + o);
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int idx = tid + (it0 + j) * THREADS, row = idx / GPR, g = idx % GPR;
+      f32x4 v;
+      if constexpr (NP == 2)
+        v = f32x4{mix16<0>(wh[j][0], un, mix16<0>(wl[j][0], un, 0.f)), mix16<1>(wh[j][0], un, mix16<1>(wl[j][0], un, 0.f)),
+                  mix16<0>(wh[j][1], un, mix16<0>(wl[j][1], un, 0.f)), mix16<1>(wh[j][1], un, mix16<1>(wl[j][1], un, 0.f))};
+      else
+        v = f32x4{mix16<0>(wh[j][0], un, 0.f), mix16<1>(wh[j][0], un, 0.f), mix16<0>(wh[j][1], un, 0.f), mix16<1>(wh[j][1], un, 0.f)};
+      const bool in = m0 + row < M;
+      if (in) *(f32x4*)&dst[(size_t)(m0 + row) * ldg + 4 * g] = v;
+      const int sl = slot_s[row];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const float k = (in && sl == q) ? 1.0f : 0.0f;
+        sums[q] += v * k;
+      }
+    }
+  }
 }
 
 // The hi plane of the tile (columns [0, W)) -> row-major fp16 global tensor, as it stands (16 bytes per thread and step);
@@ -892,6 +933,14 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_bwd_kernel(
   __shared__ float dpc_s[TILE], cwj_s[TILE];
   __shared__ __attribute__((aligned(16))) float dprgb_s[TILE][4];
   __shared__ int loff_s[UPNERF_MAX_D];  // t_w[l] (see the forward kernel: no runtime index into the by-value struct)
+  // per-tile partial sums (a.tile_part, 64-sample tiles only): ray slot of every row; cross-wave reduction scratch
+  constexpr int TPW = TILE == F16_TILE ? NW : 1;
+  __shared__ int slot_s[TILE];
+  __shared__ __attribute__((aligned(16))) float red_s[TPW][32][24];
+  const bool tp = TILE == F16_TILE && a.tile_part != nullptr;
+  f32x4 tp_c = {0.f, 0.f, 0.f, 0.f}, tp_r[3], tp_sg[MAXRAYS], tp_sr[MAXRAYS];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) tp_r[q] = tp_sg[q] = tp_sr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   char* Ph = planes;
   char* Pl = planes + (NP - 1) * TILE * W * 2;
   using TW = WaveTile16<W, TILE, NW>;
@@ -944,6 +993,7 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_bwd_kernel(
     dpc_s[tid] = dpc;
     cwj_s[tid] = cwj;
     *(f32x4*)&dprgb_s[tid][0] = dprgb;
+    slot_s[tid] = j;
 #pragma unroll
     for (int q = 0; q < MAXRAYS; ++q) wfj[q][tid] = (q == j) ? wf : 0.0f;
   }
@@ -982,6 +1032,7 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_bwd_kernel(
 #pragma unroll
           for (int c = 0; c < 4; ++c) out[c] = (m < M && gv[q][c] > 0.f) ? wv[c] * dp + cw * gg[q][c] : 0.f;
           if (m < M) *(f32x4*)&a.gz_g2[(size_t)m * W2 + 4 * eg] = out;
+          tp_c += gv[q] * dp;  // d w_csig: dp is zero for rows past M (the clamped row is then ignored)
           vals[q] = out;
           lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
         }
@@ -1026,6 +1077,13 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_bwd_kernel(
           out[u] = (m < M && rv[q][u] > 0.f) ? t : 0.f;
         }
         if (m < M) *(f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * eg] = out;
+        if (tp) {
+          const int sl = slot_s[row];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) tp_r[c] += rv[q] * dp[c];
+#pragma unroll
+          for (int c = 0; c < MAXRAYS; ++c) tp_sr[c] += out * (sl == c ? 1.0f : 0.0f);
+        }
         valr[q] = out;
         mr1 = fmaxf(mr1, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
       }
@@ -1048,7 +1106,59 @@ __global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_bwd_kernel(
       for (int q = 0; q < EPT; ++q) put_quad<NP, W>(Ph, Pl, er0 + ERS * q, 4 * eg, valr[q], erg);
     }
     __syncthreads();
-    if (a.use_cand) tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
+    if (a.use_cand) {
+      if (tp) tile_store16_sum<NP, W, TILE, THREADS, W2, MAXRAYS>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid, slot_s, tp_sg);
+      else tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
+    }
+    if (tp) {
+      // A thread holds four columns (eg) of 2 * EPT rows' worth of sums; the two halves of a wave fold first, then the
+      // waves through LDS, in a fixed order (bitwise reproducible).  Two rounds of at most 24 floats per column group.
+      float* __restrict__ part = a.tile_part + (size_t)blockIdx.x * UPNERF_TILE_PART_STRIDE;
+      auto fold = [&](f32x4 v) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += __shfl_xor(v[c], 32);
+        return v;
+      };
+      const int g = tid & 31, k = tid >> 5;  // column group, vector index of the read-out
+      auto readout = [&](int kk) {
+        f32x4 sacc = *(const f32x4*)&red_s[0][g][4 * kk];
+#pragma unroll
+        for (int w = 1; w < TPW; ++w) sacc += *(const f32x4*)&red_s[w][g][4 * kk];
+        return sacc;
+      };
+      tp_c = fold(tp_c);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tp_r[c] = fold(tp_r[c]);
+      if (lane < 32) {
+        *(f32x4*)&red_s[wave % TPW][lane][0] = tp_c;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *(f32x4*)&red_s[wave % TPW][lane][4 + 4 * c] = tp_r[c];
+      }
+      __syncthreads();
+      if (k < 4) *(f32x4*)&part[(k == 0 ? 0 : W2 * k) + 4 * g] = readout(k);
+      if (tid >= THREADS - 4) {  // sums of the per-row scalars: d b_csig, d b_r2
+        const int c = tid - (THREADS - 4);
+        float sacc = 0.0f;
+        for (int r = 0; r < TILE; ++r) sacc += c == 0 ? dpc_s[r] : dprgb_s[r][c - 1];
+        part[4 * W2 + c] = sacc;
+        part[4 * W2 + 4 + c] = 0.0f;  // pad
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < MAXRAYS; ++c) {
+        tp_sr[c] = fold(tp_sr[c]);
+        tp_sg[c] = fold(tp_sg[c]);
+      }
+      if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < MAXRAYS; ++c) {
+          *(f32x4*)&red_s[wave % TPW][lane][4 * c] = tp_sg[c];
+          *(f32x4*)&red_s[wave % TPW][lane][12 + 4 * c] = tp_sr[c];
+        }
+      }
+      __syncthreads();
+      if (k < 6) *(f32x4*)&part[4 * W2 + 8 + W2 * k + 4 * g] = readout(k);
+    }
   }
 
   STAMP(0);  // head stages (elementwise d g2 / d r1, 128-wide contraction, plane writes)
@@ -1304,6 +1414,7 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   const int tile = tile_rows16(a->tile_rows, a->S);
   if (tile < 0) return UPNERF_EINVAL;
   if (tile == F16_TILE_BIG && a->need_dxyz && L->skip > 0 && !a->xs) return UPNERF_EINVAL;
+  if (a->tile_part && tile != F16_TILE) return UPNERF_EUNSUP;  // per-tile partial sums: 64-sample tiles only
   const int grid = (int)((M + tile - 1) / tile);
   const hipStream_t st = (hipStream_t)stream;
   if (tile == F16_TILE_BIG) {

@@ -796,6 +796,102 @@ extern "C" int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const 
   return (int)hipGetLastError();
 }
 
+// ---- finishing the per-tile partial sums of upnerf_field_bwd_f16x3 (upnerf_field_bwd_args.tile_part)
+#define TP_STRIDE UPNERF_TILE_PART_STRIDE
+#define TP_WCOLS 520   // weight part of a row: w_csig | w_r2 | 4 sums | 4 pad
+#define TP_NS 128      // first-stage splits
+namespace {
+// rs[which][r][:] = sum over the tiles that hold rows of ray r of the tile's sums for that ray's slot (ascending tile order)
+__global__ void tile_part_rays_kernel(int R, int S, const float* __restrict__ part, float* __restrict__ rs_g1,
+                                      float* __restrict__ rs_r1) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  float* __restrict__ out = blockIdx.y == 0 ? rs_g1 : rs_r1;
+  if (idx >= R * 32 || !out) return;
+  const int r = idx >> 5, g = idx & 31;
+  const long long b = (long long)r * S, e = b + S - 1;
+  const int t0 = (int)(b / 64), t1 = (int)(e / 64);
+  const int base = TP_WCOLS + (blockIdx.y == 0 ? 0 : 384) + 4 * g;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int t = t0; t <= t1; ++t) {
+    const int j = r - (int)(((long long)t * 64) / S);
+    s += *(const f32x4*)&part[(size_t)t * TP_STRIDE + base + 128 * j];
+  }
+  *(f32x4*)&out[(size_t)r * 128 + 4 * g] = s;
+}
+// out1[split][0..519] = sum of the weight part over the split's tiles: two row groups of 130 16-byte columns, 8 rows in flight
+__global__ __launch_bounds__(320) void tile_part_sum1_kernel(int ntiles, int per, const float* __restrict__ part,
+                                                             float* __restrict__ out1) {
+  __shared__ __attribute__((aligned(16))) float red[TP_WCOLS];
+  const int tid = threadIdx.x, c4 = tid % 130, rg = tid / 130;
+  const int tb = blockIdx.x * per, te = (tb + per < ntiles) ? tb + per : ntiles;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (rg < 2) {
+    constexpr int U = 8;
+    for (int t = tb + rg; t < te; t += 2 * U) {
+      f32x4 x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int tt = t + 2 * u;
+        x[u] = *(const f32x4*)&part[(size_t)(tt < te ? tt : te - 1) * TP_STRIDE + 4 * c4];
+        if (tt >= te) x[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += x[u];
+    }
+  }
+  if (rg == 1) *(f32x4*)&red[4 * c4] = acc;
+  __syncthreads();
+  if (rg == 0) *(f32x4*)&out1[(size_t)blockIdx.x * TP_WCOLS + 4 * c4] = acc + *(const f32x4*)&red[4 * c4];
+}
+// column c of the weight part summed over the splits (four groups of splits per column, folded in a fixed order)
+__global__ __launch_bounds__(256) void tile_part_sum2_kernel(int ns, const float* __restrict__ out1, float* __restrict__ d_wcsig,
+                                                             float* __restrict__ d_bcsig, float* __restrict__ d_wr2,
+                                                             float* __restrict__ d_br2) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, cl = tid & 63, sg = tid >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (ns + 3) / 4, sb = sg * per, se = (sb + per < ns) ? sb + per : ns;
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < TP_WCOLS) {
+    int sp = sb;
+    for (; sp + 8 <= se; sp += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += out1[(size_t)(sp + u) * TP_WCOLS + c];
+    }
+    for (; sp < se; ++sp) p[0] += out1[(size_t)sp * TP_WCOLS + c];
+  }
+  red[sg][cl] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  __syncthreads();
+  if (sg == 0 && c < TP_WCOLS) {
+    const float s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (c < 128) { if (d_wcsig) d_wcsig[c] = s; }
+    else if (c < 512) { if (d_wr2) d_wr2[c - 128] = s; }
+    else if (c == 512) { if (d_bcsig) d_bcsig[0] = s; }
+    else if (c < 516) { if (d_br2) d_br2[c - 513] = s; }
+  }
+}
+}  // namespace
+
+extern "C" int upnerf_tile_part_finish(int R, int S, const float* tile_part, float* rs_g1, float* rs_r1, float* d_wcsig,
+                                       float* d_bcsig, float* d_wr2, float* d_br2, float* scratch, void* stream) {
+  if (R <= 0 || S < 32 || !tile_part) return UPNERF_EINVAL;
+  const long long M = (long long)R * S;
+  if (M > 0x7fffffffLL) return UPNERF_EINVAL;
+  const int ntiles = (int)((M + 63) / 64);
+  const hipStream_t st = (hipStream_t)stream;
+  if (rs_g1 || rs_r1)
+    hipLaunchKernelGGL(tile_part_rays_kernel, dim3((R * 32 + 255) / 256, 2), dim3(256), 0, st, R, S, tile_part, rs_g1, rs_r1);
+  if (d_wcsig || d_bcsig || d_wr2 || d_br2) {
+    if (!scratch) return UPNERF_EINVAL;
+    const int ns = ntiles < TP_NS ? ntiles : TP_NS, per = (ntiles + ns - 1) / ns;
+    const int nsu = (ntiles + per - 1) / per;  // splits that hold at least one tile
+    hipLaunchKernelGGL(tile_part_sum1_kernel, dim3(nsu), dim3(320), 0, st, ntiles, per, tile_part, scratch);
+    hipLaunchKernelGGL(tile_part_sum2_kernel, dim3((TP_WCOLS + 63) / 64), dim3(256), 0, st, nsu, scratch, d_wcsig, d_bcsig, d_wr2,
+                       d_br2);
+  }
+  return (int)hipGetLastError();
+}
+
 extern "C" int upnerf_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
                              float* C, int ldc, int act, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 3) || (!(act & 2) && (ldb & 3)) || !A || !B || !C || (act & ~3))

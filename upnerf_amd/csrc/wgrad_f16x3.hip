@@ -45,6 +45,11 @@ __device__ __forceinline__ h4 tr_read(const char* base, int byteoff) {
 // NP = 2: f16x3 (hi/lo split of both operands, three MFMAs per block, fp32-level accuracy); NP = 1: f16 (operands rounded
 // to fp16, one MFMA per block, fp32 accumulate: the "f16" field mode of BASELINE.json configs[3]).
 #define FX_THREADS 512
+#ifdef UPNERF_EXP_HALFROW
+#define HALFROW_OK(T, c4) (!((T) == 256 && (c4) >= UPNERF_EXP_HALFROW))
+#else
+#define HALFROW_OK(T, c4) true
+#endif
 template <int NP, int MTW, int NTW>
 __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                                   const float* __restrict__ B, int ldb,
@@ -84,13 +89,13 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     for (int q = 0; q < A4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
       const int m = mc + row;
-      ra[q] = (m < mend && nblk + 4 * c4 < N) ? *(const f32x4*)&A[(size_t)m * lda + nblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[q] = (m < mend && nblk + 4 * c4 < N && HALFROW_OK(TN, c4)) ? *(const f32x4*)&A[(size_t)m * lda + nblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int q = 0; q < B4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
       const int m = mc + row;
-      rb[q] = (m < mend && kblk + 4 * c4 < K) ? *(const f32x4*)&B[(size_t)m * ldb + kblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      rb[q] = (m < mend && kblk + 4 * c4 < K && HALFROW_OK(TK, c4)) ? *(const f32x4*)&B[(size_t)m * ldb + kblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto split_store = [&](char* hi, char* lo, f32x4 v, float s, int row, int col) {

@@ -18,10 +18,10 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib, step_scalars
-from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, X0, check, lib, ptr,
-                   stream)
+from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, TILE_PART_STRIDE, X0, check, lib,
+                   ptr, stream)
 from .ops import (TIMER, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16p_into,
-                  wgrad_f16x3_into, wgrad_into)
+                  wgrad_f16x3_into, wgrad_into, workspace)
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
@@ -59,6 +59,9 @@ WGRAD_STORE = __import__("os").environ.get("UPNERF_WGRAD_STORE", "f32")
 # samples (default), 128 = the eight-wave software-pipelined kernels (rays of >= 64 samples; falls back to 64 below that).
 # Forward and backward pass always get the same value.
 FIELD_TILE = int(__import__("os").environ.get("UPNERF_FIELD_TILE", "0"))
+# Per-tile partial sums of the vector heads and per-ray sums from the backward field kernel (upnerf_field_bwd_args.tile_part);
+# 0 = the separate upnerf_vec_wgrad / upnerf_ray_sum launches (always used with 128-sample tiles and the fp32-MFMA kernels).
+TILE_PARTIALS = int(__import__("os").environ.get("UPNERF_TILE_PARTIALS", "1"))
 
 
 def _planes() -> int:
@@ -255,6 +258,11 @@ class _FieldPass(torch.autograd.Function):
         dpre_rgb = _empty(M, 4, device=dev) if cfg.use_rgb else None
         dxyz = _empty(M, 3, device=dev) if need_dxyz else None
         gmax = torch.zeros(16, device=dev)
+        # 64-sample f16 kernels: per-tile partial sums of the 128-wide vector heads and of the per-ray sums, written by the
+        # backward kernel (which holds those tiles anyway) and finished by three small launches -- instead of five kernels
+        # that read M x 128 tensors again
+        tile_part = (_empty((M + 63) // 64, TILE_PART_STRIDE, device=dev)
+                     if (use16 and ctx.tile_rows == 64 and TILE_PARTIALS and (cfg.use_cand or cfg.use_rgb)) else None)
         w_feat = (sv["w_sj"] if joint else sv["w_s"]) if gE is not None else None
         fb = FieldBwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), need_dxyz=int(need_dxyz),
                           PT=ptr(PT), P=ptr(P), d_sigma_s=ptr(d_sigma_s), d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb),
@@ -264,7 +272,7 @@ class _FieldPass(torch.autograd.Function):
                           r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, tile_rows=ctx.tile_rows, xs=ptr(sv.get("x0f")), gz16=ptr(gz16),
-                          gzexp=ptr(gzexp))
+                          gzexp=ptr(gzexp), tile_part=ptr(tile_part))
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
         check(TIMER.run("field_bwd", lambda: bwd_fn(C.byref(L), C.byref(fb), st), units=M), "upnerf_field_bwd")
 
@@ -319,25 +327,37 @@ class _FieldPass(torch.autograd.Function):
             h_last = h[0] if store16 else h[D - 1]
             wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
             vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
+        rs_c = _empty(R, W2, device=dev) if cfg.use_cand else None
+        rs_r = _empty(R, W2, device=dev) if cfg.use_rgb else None
+        if tile_part is not None:
+            want_w = dP is not None
+            ws = workspace("tile_part", 128 * 520, dev) if want_w else None
+            check(lib.upnerf_tile_part_finish(
+                R, S, ptr(tile_part), ptr(rs_c), ptr(rs_r),
+                at(L.wcsig) if (want_w and cfg.use_cand) else None, at(L.bcsig) if (want_w and cfg.use_cand) else None,
+                at(L.wr2) if (want_w and cfg.use_rgb) else None, at(L.br2) if (want_w and cfg.use_rgb) else None,
+                ptr(ws), st), "upnerf_tile_part_finish")
         if cfg.use_cand:
-            rs = _empty(R, W2, device=dev)
-            check(lib.upnerf_ray_sum(R, S, ptr(gz_g1), W2, ptr(rs), st), "upnerf_ray_sum")
+            if tile_part is None:
+                check(lib.upnerf_ray_sum(R, S, ptr(gz_g1), W2, ptr(rs_c), st), "upnerf_ray_sum")
             if dP is not None:
                 wg(gz_g1, W2, W2, sv["e"], W, W, L.wc1, W + CK, L.bc1, D + 1, D)
-                wgrad_into(R, rs, W2, W2, sv["c_rows"], CK, CK, at(L.wc1 + W), W + CK, None, dev)
+                wgrad_into(R, rs_c, W2, W2, sv["c_rows"], CK, CK, at(L.wc1 + W), W + CK, None, dev)
                 wg(gz_g2, W2, W2, sv["g1"], W2, W2, L.wc2, W2, L.bc2, D + 2, D + 1)
-                vec_wgrad_into(M, dpre_c, 1, 1, sv["g2"], W2, W2, at(L.wcsig), at(L.bcsig), dev)
+                if tile_part is None:
+                    vec_wgrad_into(M, dpre_c, 1, 1, sv["g2"], W2, W2, at(L.wcsig), at(L.bcsig), dev)
             if ctx.needs_input_grad[3]:
-                d_c_rows = linear_kn_view(rs, P, L.wc1 + W, W + CK, CK)  # rs . wc1[:, W:]
+                d_c_rows = linear_kn_view(rs_c, P, L.wc1 + W, W + CK, CK)  # rs . wc1[:, W:]
         if cfg.use_rgb:
-            rs = _empty(R, W2, device=dev)
-            check(lib.upnerf_ray_sum(R, S, ptr(gz_r1), W2, ptr(rs), st), "upnerf_ray_sum")
+            if tile_part is None:
+                check(lib.upnerf_ray_sum(R, S, ptr(gz_r1), W2, ptr(rs_r), st), "upnerf_ray_sum")
             if dP is not None:
                 wg(gz_r1, W2, W2, sv["e"], W, W, L.wr1, W + AUXK, L.br1, D + 3, D)
-                wgrad_into(R, rs, W2, W2, sv["aux"], AUXK, AUXK, at(L.wr1 + W), W + AUXK, None, dev)
-                vec_wgrad_into(M, dpre_rgb, 4, 3, sv["r1"], W2, W2, at(L.wr2), at(L.br2), dev)
+                wgrad_into(R, rs_r, W2, W2, sv["aux"], AUXK, AUXK, at(L.wr1 + W), W + AUXK, None, dev)
+                if tile_part is None:
+                    vec_wgrad_into(M, dpre_rgb, 4, 3, sv["r1"], W2, W2, at(L.wr2), at(L.br2), dev)
             if ctx.has_a and ctx.needs_input_grad[4]:
-                d_a_rows = linear_kn_view(rs, P, L.wr1 + W + 27, W + AUXK, 48)  # rs . wr1[:, W+27 : W+75]
+                d_a_rows = linear_kn_view(rs_r, P, L.wr1 + W + 27, W + AUXK, 48)  # rs . wr1[:, W+27 : W+75]
         d_o = d_d = None
         if need_dxyz:
             d_o, d_d = _empty(R, 3, device=dev), _empty(R, 3, device=dev)
