@@ -313,6 +313,13 @@ int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const float* B, in
                        float* dW, int ldo, float* db, float* slabs, int nsplit, const int* expo_a,
                        const int* expo_b, int planes, void* stream);
 
+/* upnerf_wgrad_f16x3 for N = K = 256 that also computes, in the same pass over B, what upnerf_vec_wgrad(M, vec, 1, 1, B, ldb, 256)
+ * would: dvec[k] = sum_m vec[m] B[m][k], *dbvec = sum_m vec[m] (the final trunk layer and the density head read the same
+ * activations, nerf.py:88-89).  vscratch: nsplit * 4 * 257 floats.  dbvec may be NULL. */
+int upnerf_wgrad_f16x3_vec(int M, const float* A, int lda, const float* B, int ldb, float* dW, int ldo, float* db, float* slabs,
+                           int nsplit, const int* expo_a, const int* expo_b, int planes, const float* vec, float* dvec,
+                           float* dbvec, float* vscratch, void* stream);
+
 /* Same contraction for the f16 field mode with fp16-STORED operands: A16 [M][lda] fp16 bits scaled per 64-row tile by
  * 2^aexp[m / 64] (upnerf_field_bwd_f16x3's gz16 / gzexp); B either fp16 the same way (b_is_f16 = 1: B16 / bexp, from h16 /
  * hexp) or fp32 row-major (b_is_f16 = 0: x0).  Operands are brought to the tensor-wide exponents *expo_a / *expo_b on load

@@ -143,6 +143,7 @@ _SIGNATURES = {
     "upnerf_frag16": [_p, _p, _p, C.POINTER(Frag16Desc), _i, C.POINTER(Frag16Desc), _i, _p, _p, _i, _i, _p, _p],
     "upnerf_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p],
+    "upnerf_wgrad_f16x3_vec": [_i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p],
     "upnerf_wgrad_f16p": [_i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p],
     "upnerf_wgrad_grouped_scratch": [C.POINTER(WgradGroup), _i, _i],
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],

@@ -710,6 +710,31 @@ extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const f
   return (int)hipGetLastError();
 }
 
+extern "C" int upnerf_wgrad_f16x3_partial_vec(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
+                                              const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows,
+                                              int planes, const float* vec, float* vslabs, void* stream);
+
+// upnerf_wgrad_f16x3 for a 256 x 256 block + upnerf_vec_wgrad(vec, B) in the same pass over B (nerf.py:88-89: the final trunk
+// layer and the density head read the same activations).
+extern "C" int upnerf_wgrad_f16x3_vec(int M, const float* A, int lda, const float* B, int ldb, float* dW, int ldo, float* db,
+                                      float* slabs, int nsplit, const int* expo_a, const int* expo_b, int planes, const float* vec,
+                                      float* dvec, float* dbvec, float* vscratch, void* stream) {
+  const int N = 256, K = 256;
+  if (M <= 0 || !A || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b || !vec || !dvec || !vscratch) return UPNERF_EINVAL;
+  if (planes != 0 && planes != 1 && planes != 2) return UPNERF_EINVAL;
+  if ((lda & 3) || (ldb & 3) || (ldo & 3)) return UPNERF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = (((M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  float* bslabs = slabs + (size_t)nsplit * N * K;
+  int rc = upnerf_wgrad_f16x3_partial_vec(M, A, lda, N, B, ldb, K, expo_a, expo_b, slabs, bslabs, nsplit, rows, planes, vec, vscratch,
+                                          stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N * (K / 4) + 63) / 64), dim3(RED_THREADS), 0, st, N, K, N, K, nsplit, slabs, bslabs,
+                     dW, ldo, db);
+  hipLaunchKernelGGL(vec_wgrad_reduce_kernel, dim3((K + 1 + 255) / 256), dim3(256), 0, st, 1, K, nsplit, vscratch, dvec, dbvec);
+  return (int)hipGetLastError();
+}
+
 extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, const int* aexp, int N, const void* B, int ldb,
                                          const int* bexp, int b_is_f16, int K, const int* expo_a, const int* expo_b, float* slabs,
                                          float* bslabs, int nsplit, int rows, int TN, int TK, void* stream);

@@ -199,6 +199,18 @@ def wgrad_f16x3_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor,
     check(rc, "upnerf_wgrad_f16x3")
 
 
+def wgrad_f16x3_vec_into(M: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int, dW_ptr: int, ldo: int, db_ptr: Optional[int],
+                         vec: torch.Tensor, dvec_ptr: int, dbvec_ptr: Optional[int], device, expo_a: int, expo_b: int, planes: int = 2):
+    """wgrad_f16x3_into for a 256 x 256 block plus, in the same pass over B, vec_wgrad_into(M, vec, 1, 1, B, ldb, 256, ...)."""
+    ns = nsplit_for(M)
+    ws = workspace("wgrad", ns * (256 * 256 + 256), device)
+    vs = workspace("vec_wgrad", ns * 4 * 257, device)
+    rc = TIMER.run("wgrad16v_256x256", lambda: lib.upnerf_wgrad_f16x3_vec(M, ptr(A), lda, ptr(B), ldb, dW_ptr, ldo, db_ptr, ptr(ws), ns,
+                                                                          expo_a, expo_b, planes, ptr(vec), dvec_ptr, dbvec_ptr,
+                                                                          ptr(vs), stream()), units=M)
+    check(rc, "upnerf_wgrad_f16x3_vec")
+
+
 def wgrad_f16p_into(M: int, A16: torch.Tensor, lda: int, aexp: torch.Tensor, N: int, B: torch.Tensor, ldb: int,
                     bexp: Optional[torch.Tensor], K: int, dW_ptr: int, ldo: int, db_ptr: Optional[int], device, expo_a: int,
                     expo_b: int):

@@ -21,7 +21,7 @@ from . import _lib, step_scalars
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, TILE_PART_STRIDE, X0, check, lib,
                    ptr, stream)
 from .ops import (TIMER, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16p_into,
-                  wgrad_f16x3_into, wgrad_into, workspace)
+                  wgrad_f16x3_into, wgrad_f16x3_vec_into, wgrad_into, workspace)
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
@@ -62,6 +62,8 @@ FIELD_TILE = int(__import__("os").environ.get("UPNERF_FIELD_TILE", "0"))
 # Per-tile partial sums of the vector heads and per-ray sums from the backward field kernel (upnerf_field_bwd_args.tile_part);
 # 0 = the separate upnerf_vec_wgrad / upnerf_ray_sum launches (always used with 128-sample tiles and the fp32-MFMA kernels).
 TILE_PARTIALS = int(__import__("os").environ.get("UPNERF_TILE_PARTIALS", "1"))
+# The density head's weight gradient computed inside the final trunk layer's weight-gradient launch (upnerf_wgrad_f16x3_vec).
+VEC_FOLD = int(__import__("os").environ.get("UPNERF_VEC_FOLD", "1"))
 
 
 def _planes() -> int:
@@ -325,8 +327,12 @@ class _FieldPass(torch.autograd.Function):
                 else:
                     wg(gz, W, W, h[l - 1], W, W, L.w[l], W, L.b[l], l, l - 1)
             h_last = h[0] if store16 else h[D - 1]
-            wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
-            vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
+            if VEC_FOLD and W == 256:  # the density head's weight gradient rides on the final layer's pass over h_last
+                wgrad_f16x3_vec_into(M, gz_e, W, h_last, W, at(L.we), W, at(L.be), dpre_s, at(L.wsig), at(L.bsig), dev,
+                                     EA(D), EB(D - 1), planes=ctx.planes)
+            else:
+                wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
+                vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
         rs_c = _empty(R, W2, device=dev) if cfg.use_cand else None
         rs_r = _empty(R, W2, device=dev) if cfg.use_rgb else None
         if tile_part is not None:
