@@ -34,6 +34,11 @@
 // two workgroups per CU = 2 waves per SIMD; hipcc takes the second __launch_bounds__ argument as the minimum number of
 // waves per SIMD
 #define F16_WAVES_PER_EU 2
+// f16 mode (one plane: 42-48 KB of LDS per 64-sample workgroup): a third workgroup per CU fits if a wave stays within 168 registers
+#ifndef F16_WAVES_PER_EU_F16
+#define F16_WAVES_PER_EU_F16 2
+#endif
+#define F16_EU(NP, TILE) ((NP) == 1 && (TILE) == 64 ? F16_WAVES_PER_EU_F16 : F16_WAVES_PER_EU)
 // Weight fragments are requested this many 16-deep k-blocks ahead of the MFMAs that consume them.  Measured with the stamps
 // build (per wave and trunk layer): f16 mode 10.4k cycles per K loop one block ahead = 650 cycles per k-block = the L2
 // latency, 8.1k three ahead and 8.3k seven ahead -- from there on the loop is bound by the bytes the CU can pull from L2
@@ -477,7 +482,7 @@ __device__ __forceinline__ int fwd_trunk_pipelined(const upnerf_layout& L, const
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int NP, int TILE, int NW>
-__global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
+__global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
   constexpr int W = 256, W2 = 128, THREADS = 64 * NW;
   constexpr int AH = NP == 2 ? F16_AHEAD_X3 : F16_AHEAD_F16;  // weight k-blocks in flight (common16.cuh:mma16_lds)
   constexpr int TPR = THREADS / TILE;
@@ -915,7 +920,7 @@ __device__ __forceinline__ void bwd_trunk_pipelined(const upnerf_layout& L, cons
 // ------------------------------------------------------------------------------------------------------------------
 // Backward data-gradient chain (autograd of nerf.py:80-124), stage for stage as field.hip:field_bwd_kernel.
 template <int NP, int TILE, int NW>
-__global__ __launch_bounds__(64 * NW, F16_WAVES_PER_EU) void field16_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
+__global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
   constexpr int W = 256, W2 = 128, THREADS = 64 * NW;
   constexpr int AH = NP == 2 ? F16_AHEAD_X3 : F16_AHEAD_F16;
   constexpr int MAXRAYS = 3;            // rays a 64-sample tile can touch when S >= 32

@@ -513,22 +513,40 @@ __global__ void zero_floats_kernel(float* __restrict__ p, int n) {
   if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
 }
 
-__global__ void frag16_amax_kernel(const float* __restrict__ src, Frag16Descs D, float* __restrict__ amax) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// Maxima per matrix id.  A thread walks AMAX_PER elements (stride 256: coalesced; a transposed descriptor is walked along
+// its source rows -- the maximum does not care about the order) and only touches the table when its id changes; a workgroup
+// whose elements all carry one id -- descriptors are long runs -- issues ONE atomic.  (One element per thread was 2 400
+// workgroups = 2 400 atomics on a handful of addresses: 32 us for 2.4 MB.)
+#define AMAX_PER 8
+__global__ __launch_bounds__(256) void frag16_amax_kernel(const float* __restrict__ src, Frag16Descs D, float* __restrict__ amax) {
+  const int total = D.start[D.n];
   float v = 0.0f;
-  int id = 0;
-  if (idx < D.start[D.n]) {
-    int j = 0;
-    while (idx >= D.start[j + 1]) ++j;
-    const upnerf_frag16_desc q = D.d[j];
-    const int e = idx - D.start[j];
-    const int r = e / q.cols, c = e - r * q.cols;
-    v = fabsf(frag16_src(src, q, r, c));
-    id = q.exp_id;
+  int id = -2;  // -2: nothing seen yet
+  int j = 0;
+#pragma unroll
+  for (int u = 0; u < AMAX_PER; ++u) {
+    const int idx = (blockIdx.x * AMAX_PER + u) * 256 + threadIdx.x;
+    if (idx < total) {
+      while (idx >= D.start[j + 1]) ++j;
+      const upnerf_frag16_desc q = D.d[j];
+      const int e = idx - D.start[j];
+      int r, c;
+      if (q.transpose) { c = e / q.rows; r = e - c * q.rows; }
+      else { r = e / q.cols; c = e - r * q.cols; }
+      const float x = fabsf(frag16_src(src, q, r, c));
+      if (q.exp_id != id) {
+        if (id >= 0) atomicMax((unsigned int*)&amax[id], __float_as_uint(v));
+        id = q.exp_id;
+        v = x;
+      } else {
+        v = fmaxf(v, x);
+      }
+    }
   }
-  // one atomic per workgroup when the whole group sits inside one matrix id (the common case: descriptors are long runs)
   __shared__ float wmax[4];
   __shared__ int wid[4];
+  const int myid = id;
+  const float myv = v;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     const float ov = __shfl_xor(v, d);
@@ -546,13 +564,8 @@ __global__ void frag16_amax_kernel(const float* __restrict__ src, Frag16Descs D,
   if (uniform) {
     if (threadIdx.x == 0)
       atomicMax((unsigned int*)&amax[wid[0]], __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
-  } else if (idx < D.start[D.n]) {
-    int j = 0;
-    while (idx >= D.start[j + 1]) ++j;
-    const upnerf_frag16_desc q = D.d[j];
-    const int e = idx - D.start[j];
-    const int r = e / q.cols, c = e - r * q.cols;
-    atomicMax((unsigned int*)&amax[q.exp_id], __float_as_uint(fabsf(frag16_src(src, q, r, c))));
+  } else if (myid >= 0) {
+    atomicMax((unsigned int*)&amax[myid], __float_as_uint(myv));
   }
 }
 // wnorm[j] = max over the rows r of descriptor j of sum_c |X[r][c]|  (the operator norm that bounds |X h|_inf by
@@ -989,8 +1002,10 @@ extern "C" int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, con
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, amax_scratch, 16);
   // maxima over the forward matrices and over the transposed ones (ids that exist only there, e.g. the fused head)
-  hipLaunchKernelGGL(frag16_amax_kernel, dim3((F.start[nfwd] + 255) / 256), dim3(256), 0, st, src, F, amax_scratch);
-  hipLaunchKernelGGL(frag16_amax_kernel, dim3((Bd.start[nbwd] + 255) / 256), dim3(256), 0, st, src, Bd, amax_scratch);
+  hipLaunchKernelGGL(frag16_amax_kernel, dim3((F.start[nfwd] + 256 * AMAX_PER - 1) / (256 * AMAX_PER)), dim3(256), 0, st, src, F,
+                     amax_scratch);
+  hipLaunchKernelGGL(frag16_amax_kernel, dim3((Bd.start[nbwd] + 256 * AMAX_PER - 1) / (256 * AMAX_PER)), dim3(256), 0, st, src, Bd,
+                     amax_scratch);
   hipLaunchKernelGGL(frag16_write_kernel, dim3((F.start[nfwd] + 255) / 256), dim3(256), 0, st, src, (char*)dst_fwd, F,
                      amax_scratch, wexp, perm_fwd);
   hipLaunchKernelGGL(frag16_write_kernel, dim3((Bd.start[nbwd] + 255) / 256), dim3(256), 0, st, src, (char*)dst_bwd, Bd,

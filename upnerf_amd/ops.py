@@ -81,6 +81,22 @@ def wgrad_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor, ldb: 
     check(rc, "upnerf_wgrad")
 
 
+def wgrad_blocks_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor, ldb: int, K: int, dW_ptr: int, ldo: int,
+                      db_ptr: Optional[int], device, a_off: int = 0, b_off: int = 0):
+    """wgrad_into for a small-M problem whose N or K exceeds one 256 x 256 block: ONE grouped launch + ONE reduction
+    (upnerf_wgrad_grouped cuts any N x K into 128 x 128 blocks) instead of a launch pair per block."""
+    g = _lib.WgradGroup(A=A.data_ptr() + 4 * a_off, B=B.data_ptr() + 4 * b_off, dW=dW_ptr, db=db_ptr, M=M, N=N, K=K, lda=lda,
+                        ldb=ldb, ldo=ldo)
+    arr = (_lib.WgradGroup * 1)(g)
+    nsplit = max(1, min(_DeferredWgrads.NSPLIT, M // 64))
+    n = lib.upnerf_wgrad_grouped_scratch(arr, 1, nsplit)
+    if n < 0:
+        check(n, "upnerf_wgrad_grouped_scratch")
+    ws = workspace("wgrad_blocks", n, device)
+    check(TIMER.run(f"wgrad_blocks_{N}x{K}", lambda: lib.upnerf_wgrad_grouped(arr, 1, ptr(ws), nsplit, stream())),
+          "upnerf_wgrad_grouped")
+
+
 class _DeferredWgrads:
     """Small (per-ray, M = rays) weight gradients of HipLinear, collected during a backward pass and computed by ONE
     grouped launch + ONE reduction when the autograd engine finishes that pass (`queue_callback`, the hook DDP's reducer
@@ -311,12 +327,15 @@ class HipLinear(torch.autograd.Function):
                     DEFERRED_WGRADS.add(M, gy, N, N, xc, K, K, gw, gb if ctx.has_bias else None,
                                         owners=((ctx.owners[0], gw), (ctx.owners[1], gb if ctx.has_bias else None)))
                     return gx, gw, gb if ctx.has_bias else None, None, None
-                for n0 in range(0, N, 256):
-                    nn_ = min(256, N - n0)
-                    for k0 in range(0, K, 256):
-                        kk = min(256, K - k0)
-                        wgrad_into(M, gy, N, nn_, xc, K, kk, gw.data_ptr() + 4 * (n0 * K + k0), K,
-                                   gb.data_ptr() + 4 * n0 if k0 == 0 else None, x.device, a_off=n0, b_off=k0)
+                if (N > 256 or K > 256) and M <= DEFERRED_WGRADS.MAX_M:
+                    wgrad_blocks_into(M, gy, N, N, xc, K, K, gw.data_ptr(), K, gb.data_ptr(), x.device)
+                else:
+                    for n0 in range(0, N, 256):
+                        nn_ = min(256, N - n0)
+                        for k0 in range(0, K, 256):
+                            kk = min(256, K - k0)
+                            wgrad_into(M, gy, N, nn_, xc, K, kk, gw.data_ptr() + 4 * (n0 * K + k0), K,
+                                       gb.data_ptr() + 4 * n0 if k0 == 0 else None, x.device, a_off=n0, b_off=k0)
             if not ctx.has_bias:
                 gb = None
         return gx, gw, gb, None, None

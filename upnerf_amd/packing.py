@@ -53,7 +53,7 @@ class _PackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dP):
         from ._lib import PackDesc, check, lib, ptr, stream
-        from .ops import wgrad_into
+        from .ops import wgrad_blocks_into, wgrad_into
         packer, names, buf = ctx.packer, ctx.names, ctx.buf
         L, W, W2, Fd = packer.L, packer.W, packer.W2, packer.feat_dim
         feat_w, feat_b = ctx.saved_tensors
@@ -81,9 +81,10 @@ class _PackFn(torch.autograd.Function):
         # d W_feat = W_r1[:, :F]^T . gfold ; d b_feat = W_r1[:, :F]^T . gbr1 ; d b_r1 = gbr1
         wrF = buf[L.total:].view(W2, Fd)
         g_fw = grads["feat_share_layer.weight"]
-        for n0 in range(0, Fd, 256):
-            nn_ = min(256, Fd - n0)
-            wgrad_into(W2, wrF, Fd, nn_, dP, W + AUXK, W, g_fw.data_ptr() + 4 * n0 * W, W, None, dev, a_off=n0, b_off=L.wr1)
+        if Fd > 256:
+            wgrad_blocks_into(W2, wrF, Fd, Fd, dP, W + AUXK, W, g_fw.data_ptr(), W, None, dev, b_off=L.wr1)
+        else:
+            wgrad_into(W2, wrF, Fd, Fd, dP, W + AUXK, W, g_fw.data_ptr(), W, None, dev, b_off=L.wr1)
         grads["feat_share_layer.bias"].copy_(torch.mv(wrF.t(), gbr1))
         grads["rgb_share_layer.0.bias"].copy_(gbr1)
         return (None, None) + tuple(grads[n] for n in names)
