@@ -313,12 +313,21 @@ int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const float* B, in
                        float* dW, int ldo, float* db, float* slabs, int nsplit, const int* expo_a,
                        const int* expo_b, int planes, void* stream);
 
-/* upnerf_wgrad_f16x3 for N = K = 256 that also computes, in the same pass over B, what upnerf_vec_wgrad(M, vec, 1, 1, B, ldb, 256)
- * would: dvec[k] = sum_m vec[m] B[m][k], *dbvec = sum_m vec[m] (the final trunk layer and the density head read the same
- * activations, nerf.py:88-89).  vscratch: nsplit * 4 * 257 floats.  dbvec may be NULL. */
-int upnerf_wgrad_f16x3_vec(int M, const float* A, int lda, const float* B, int ldb, float* dW, int ldo, float* db, float* slabs,
-                           int nsplit, const int* expo_a, const int* expo_b, int planes, const float* vec, float* dvec,
-                           float* dbvec, float* vscratch, void* stream);
+/* Chained form of upnerf_wgrad_f16x3: the slabs of one weight gradient are summed by the first workgroups of the NEXT
+ * weight-gradient launch (a prologue that costs it a few microseconds) instead of a reduction launch of their own (20+ us
+ * each, 40 per step).  `pending` describes the problem whose slabs are written but not summed (nsplit == 0: none): the call
+ * sums it -- in its kernel's prologue when the grid is large enough, by a reduction launch otherwise -- and replaces it by
+ * the description of ITS problem.  upnerf_wgrad_finish sums what is pending and clears it.  The caller alternates between two
+ * slab buffers: `slabs` must differ from pending->slabs.  Same arithmetic and summation order as upnerf_wgrad_f16x3. */
+typedef struct {
+  const float* slabs; const float* bslabs;
+  float* dW; float* db;
+  int32_t N, K, TN, TK, nsplit, ldo, rblocks, pad;
+} upnerf_wgrad_pending;
+int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
+                             float* db, float* slabs, int nsplit, const int* expo_a, const int* expo_b, int planes,
+                             upnerf_wgrad_pending* pending, void* stream);
+int upnerf_wgrad_finish(upnerf_wgrad_pending* pending, void* stream);
 
 /* Same contraction for the f16 field mode with fp16-STORED operands: A16 [M][lda] fp16 bits scaled per 64-row tile by
  * 2^aexp[m / 64] (upnerf_field_bwd_f16x3's gz16 / gzexp); B either fp16 the same way (b_is_f16 = 1: B16 / bexp, from h16 /

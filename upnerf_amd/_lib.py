@@ -96,6 +96,11 @@ class PackDesc(C.Structure):
                 ("dst_ld", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class WgradPending(C.Structure):
+    _fields_ = [("slabs", _fp), ("bslabs", _fp), ("dW", _fp), ("db", _fp), ("N", C.c_int32), ("K", C.c_int32), ("TN", C.c_int32),
+                ("TK", C.c_int32), ("nsplit", C.c_int32), ("ldo", C.c_int32), ("rblocks", C.c_int32), ("pad", C.c_int32)]
+
+
 class WgradGroup(C.Structure):
     _fields_ = [("A", _fp), ("B", _fp), ("dW", _fp), ("db", _fp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("ldo", C.c_int32)]
@@ -143,7 +148,8 @@ _SIGNATURES = {
     "upnerf_frag16": [_p, _p, _p, C.POINTER(Frag16Desc), _i, C.POINTER(Frag16Desc), _i, _p, _p, _i, _i, _p, _p],
     "upnerf_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p],
-    "upnerf_wgrad_f16x3_vec": [_i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p],
+    "upnerf_wgrad_f16x3_chain": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p],
+    "upnerf_wgrad_finish": [_p, _p],
     "upnerf_wgrad_f16p": [_i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p],
     "upnerf_wgrad_grouped_scratch": [C.POINTER(WgradGroup), _i, _i],
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],

@@ -363,3 +363,62 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
+
+// ---- fixed-order reduction of weight-gradient slabs (upnerf_wgrad*): the work of ONE 512-thread block `bid` of the reduce
+// grid, callable from the reduce kernel and from the prologue of the NEXT weight-gradient kernel (upnerf_wgrad_f16x3_chain).
+// dW[n][k] = sum_split slab[split][by][bz][n%TN][k%TK]; one thread per 4 consecutive k (16-byte loads); the splits are dealt
+// round-robin to 8 thread groups whose partial sums meet in LDS (`part`, 8 KiB); each group keeps 8 loads in flight.
+#define RED_RG 8
+#define RED_THREADS (64 * RED_RG)
+__device__ __forceinline__ void wgrad_reduce_body(int bid, int tid, int N, int K, int TN, int TK, int nsplit,
+                                                  const float* __restrict__ slabs, const float* __restrict__ bslabs,
+                                                  float* __restrict__ dW, int ldo, float* __restrict__ db, f32x4 (*part)[64]) {
+  const int lane = tid & 63, rg = tid >> 6;
+  const int q = bid * 64 + lane;  // index of a group of 4 consecutive k
+  const int K4 = K >> 2;
+  const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
+  const bool ok = q < N * K4;
+  const int n = ok ? q / K4 : 0, k = ok ? (q - n * K4) * 4 : 0;
+  const int by = n / TN, bz = k / TK;
+  const size_t off = ((size_t)by * gz + bz) * TN * TK + (size_t)(n - by * TN) * TK + (k - bz * TK);
+  const size_t stride = (size_t)gy * gz * TN * TK;
+  // 8 waves x 8 loads of 16 bytes per lane = 64 KiB in flight per workgroup (one workgroup per CU at 256 x 256): at 16 KiB
+  // the 67 MB of slabs of a 256 x 256 layer came in at 2.7 TB/s
+  f32x4 s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    int sp = rg;
+    for (; sp + 7 * RED_RG < nsplit; sp += 8 * RED_RG) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)&slabs[off + (size_t)(sp + u * RED_RG) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += v[u];
+    }
+    for (; sp < nsplit; sp += RED_RG) s[0] += *(const f32x4*)&slabs[off + (size_t)sp * stride];
+  }
+  part[rg][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (rg == 0 && ok) {
+    const f32x4 t = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+                    ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
+    *(f32x4*)&dW[(size_t)n * ldo + k] = t;
+  }
+  if (db) {
+    const int idx = bid * RED_THREADS + tid;
+    if (idx < N) {
+      const int bby = idx / TN;
+      float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* src = bslabs + (size_t)bby * TN + (idx - bby * TN);
+      const size_t bst = (size_t)gy * TN;
+      int sp = 0;
+      for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] += src[(size_t)(sp + u) * bst];
+      }
+      for (; sp < nsplit; ++sp) p[0] += src[(size_t)sp * bst];
+      db[idx] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    }
+  }
+}

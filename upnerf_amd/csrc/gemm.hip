@@ -198,65 +198,13 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_grouped_reduce_kernel(WgradGro
   }
 }
 
-// dW[n][k] = sum_split slab[split][by][bz][n%TN][k%TK]   (fixed order -> bitwise reproducible)
-// One thread per 4 consecutive k (16-byte loads); the splits are dealt round-robin to RG = 4 thread groups whose
-// partial sums meet in LDS; each group keeps 4 loads in flight.  The reduction is a pure HBM stream (nsplit x N x K x 4
-// bytes), so what matters is bytes in flight, not arithmetic.
-#define RED_RG 8
-#define RED_THREADS (64 * RED_RG)
+// dW[n][k] = sum_split slab[split][by][bz][n%TN][k%TK]   (fixed order -> bitwise reproducible; common.cuh:wgrad_reduce_body)
 __global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_kernel(int N, int K, int TN, int TK, int nsplit,
                                                                  const float* __restrict__ slabs,
                                                                  const float* __restrict__ bslabs, float* __restrict__ dW,
                                                                  int ldo, float* __restrict__ db) {
   __shared__ f32x4 part[RED_RG][64];
-  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int q = blockIdx.x * 64 + lane;  // index of a group of 4 consecutive k
-  const int K4 = K >> 2;
-  const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
-  const bool ok = q < N * K4;
-  const int n = ok ? q / K4 : 0, k = ok ? (q - n * K4) * 4 : 0;
-  const int by = n / TN, bz = k / TK;
-  const size_t off = ((size_t)by * gz + bz) * TN * TK + (size_t)(n - by * TN) * TK + (k - bz * TK);
-  const size_t stride = (size_t)gy * gz * TN * TK;
-  // 8 waves x 8 loads of 16 bytes per lane = 64 KiB in flight per workgroup (one workgroup per CU at 256 x 256): at 16 KiB
-  // the 67 MB of slabs of a 256 x 256 layer came in at 2.7 TB/s
-  f32x4 s[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (ok) {
-    int sp = rg;
-    for (; sp + 7 * RED_RG < nsplit; sp += 8 * RED_RG) {
-      f32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)&slabs[off + (size_t)(sp + u * RED_RG) * stride];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s[u] += v[u];
-    }
-    for (; sp < nsplit; sp += RED_RG) s[0] += *(const f32x4*)&slabs[off + (size_t)sp * stride];
-  }
-  part[rg][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-  __syncthreads();
-  if (rg == 0 && ok) {
-    const f32x4 t = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
-                    ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
-    *(f32x4*)&dW[(size_t)n * ldo + k] = t;
-  }
-  if (db) {
-    const int idx = blockIdx.x * RED_THREADS + threadIdx.x;
-    if (idx < N) {
-      const int bby = idx / TN;
-      float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const float* src = bslabs + (size_t)bby * TN + (idx - bby * TN);
-      const size_t bst = (size_t)gy * TN;
-      int sp = 0;
-      for (; sp + 8 <= nsplit; sp += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] += src[(size_t)(sp + u) * bst];
-      }
-      for (; sp < nsplit; ++sp) p[0] += src[(size_t)sp * bst];
-      db[idx] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-    }
-  }
+  wgrad_reduce_body(blockIdx.x, threadIdx.x, N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db, part);
 }
 
 // ---- N = 1 / 3 heads: dw[c][k] = sum_m v[m][c] X[m][k].  HBM-bound stream of X: every lane owns 4 columns
@@ -694,7 +642,8 @@ extern "C" int upnerf_wgrad(int M, const float* A, int lda, int N, const float* 
 
 extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
                                           const int* expo_a, const int* expo_b, float* slabs, float* bslabs,
-                                          int nsplit, int rows, int TN, int TK, int planes, void* stream);
+                                          int nsplit, int rows, int TN, int TK, int planes, const upnerf_wgrad_pending* prev,
+                                          void* stream);
 
 // Same contract as upnerf_wgrad, contraction on the f16 matrix cores (wgrad_f16x3.hip): planes 0 / 2 = 3-term hi/lo
 // split (fp32-level accuracy), planes 1 = operands rounded to fp16, one MFMA per block.
@@ -713,7 +662,7 @@ extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const f
   const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
   float* bslabs = slabs + (size_t)nsplit * gy * gz * TN * TK;
   int rc = upnerf_wgrad_f16x3_partial(M, A, lda, N, B, ldb, K, expo_a, expo_b, slabs, bslabs, nsplit, rows, TN, TK,
-                                      planes, stream);
+                                      planes, nullptr, stream);
   if (rc) return rc;
   const int quads = N * (K / 4);
   int rblocks = (quads + 63) / 64;
@@ -723,29 +672,41 @@ extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const f
   return (int)hipGetLastError();
 }
 
-extern "C" int upnerf_wgrad_f16x3_partial_vec(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
-                                              const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows,
-                                              int planes, const float* vec, float* vslabs, void* stream);
-
-// upnerf_wgrad_f16x3 for a 256 x 256 block + upnerf_vec_wgrad(vec, B) in the same pass over B (nerf.py:88-89: the final trunk
-// layer and the density head read the same activations).
-extern "C" int upnerf_wgrad_f16x3_vec(int M, const float* A, int lda, const float* B, int ldb, float* dW, int ldo, float* db,
-                                      float* slabs, int nsplit, const int* expo_a, const int* expo_b, int planes, const float* vec,
-                                      float* dvec, float* dbvec, float* vscratch, void* stream) {
-  const int N = 256, K = 256;
-  if (M <= 0 || !A || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b || !vec || !dvec || !vscratch) return UPNERF_EINVAL;
-  if (planes != 0 && planes != 1 && planes != 2) return UPNERF_EINVAL;
-  if ((lda & 3) || (ldb & 3) || (ldo & 3)) return UPNERF_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int rows = (((M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
-  float* bslabs = slabs + (size_t)nsplit * N * K;
-  int rc = upnerf_wgrad_f16x3_partial_vec(M, A, lda, N, B, ldb, K, expo_a, expo_b, slabs, bslabs, nsplit, rows, planes, vec, vscratch,
-                                          stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N * (K / 4) + 63) / 64), dim3(RED_THREADS), 0, st, N, K, N, K, nsplit, slabs, bslabs,
-                     dW, ldo, db);
-  hipLaunchKernelGGL(vec_wgrad_reduce_kernel, dim3((K + 1 + 255) / 256), dim3(256), 0, st, 1, K, nsplit, vscratch, dvec, dbvec);
+extern "C" int upnerf_wgrad_finish(upnerf_wgrad_pending* p, void* stream) {
+  if (!p) return UPNERF_EINVAL;
+  if (p->nsplit <= 0) return 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p->rblocks), dim3(RED_THREADS), 0, (hipStream_t)stream, p->N, p->K, p->TN, p->TK,
+                     p->nsplit, p->slabs, p->bslabs, p->dW, p->ldo, p->db);
+  p->nsplit = 0;
   return (int)hipGetLastError();
+}
+
+// Chained upnerf_wgrad_f16x3 (include/upnerf_hip.h): the previous problem's slabs are summed by this launch's first workgroups.
+extern "C" int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
+                                        float* db, float* slabs, int nsplit, const int* expo_a, const int* expo_b, int planes,
+                                        upnerf_wgrad_pending* pending, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b || !pending)
+    return UPNERF_EINVAL;
+  if (planes != 0 && planes != 1 && planes != 2) return UPNERF_EINVAL;
+  if ((N & 3) || (K & 3) || (lda & 3) || (ldb & 3) || (ldo & 3)) return UPNERF_EINVAL;
+  if (pending->nsplit > 0 && pending->slabs == slabs) return UPNERF_EINVAL;  // the pending slabs would be overwritten
+  int TN, TK;
+  wgrad_shape(N, K, &TN, &TK);
+  const int rows = (((M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
+  float* bslabs = slabs + (size_t)nsplit * gy * gz * TN * TK;
+  if (pending->nsplit > 0 && pending->rblocks > nsplit * gy * gz) {  // grid too small to carry the previous reduction
+    int rc = upnerf_wgrad_finish(pending, stream);
+    if (rc) return rc;
+  }
+  int rc = upnerf_wgrad_f16x3_partial(M, A, lda, N, B, ldb, K, expo_a, expo_b, slabs, bslabs, nsplit, rows, TN, TK, planes,
+                                      pending->nsplit > 0 ? pending : nullptr, stream);
+  if (rc) return rc;
+  const int quads = N * (K / 4);
+  int rblocks = (quads + 63) / 64;
+  if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
+  *pending = upnerf_wgrad_pending{slabs, bslabs, dW, db, N, K, TN, TK, nsplit, ldo, rblocks, 0};
+  return 0;
 }
 
 extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, const int* aexp, int N, const void* B, int ldb,

@@ -73,8 +73,40 @@ __global__ __launch_bounds__(NTHREADS) void loss_fwd_kernel(upnerf_loss_args a, 
   }
   if (p0) {
     const int n = (r1 - r0) * a.F;
-    for (int i = tid; i < n; i += NTHREADS) {
-      const size_t off = (size_t)r0 * a.F + i;
+    const size_t base = (size_t)r0 * a.F;
+    int i0 = 0;
+    if ((a.F & 3) == 0) {
+      // 16-byte loads, four pieces per thread in flight: with 64 workgroups this loop is a chain of L2 round trips (96 of them
+      // per thread at 4 bytes and one in flight: 75 us for 19 MB)
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const int n4 = n >> 2;
+      constexpr int U = 4;
+      for (int i = tid; i < n4; i += U * NTHREADS) {
+        f4 g[U], c[U], f[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = i + u * NTHREADS;
+          const size_t off = base + 4 * (size_t)(j < n4 ? j : n4 - 1);
+          g[u] = *(const f4*)&a.feat_gt[off];
+          c[u] = *(const f4*)&a.feat_c[off];
+          f[u] = a.fine ? *(const f4*)&a.feat_f[off] : g[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (i + u * NTHREADS < n4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float e = c[u][q] - g[u][q], ef = f[u][q] - g[u][q];
+              acc[T_FEAT_C] += e * e;
+              acc[T_FEAT_F] += ef * ef;  // zero without a fine pass
+            }
+          }
+        }
+      }
+      i0 = n;
+    }
+    for (int i = i0 + tid; i < n; i += NTHREADS) {
+      const size_t off = base + i;
       const float g = a.feat_gt[off];
       const float e = a.feat_c[off] - g;
       acc[T_FEAT_C] += e * e;

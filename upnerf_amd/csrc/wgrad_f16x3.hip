@@ -50,16 +50,12 @@ __device__ __forceinline__ h4 tr_read(const char* base, int byteoff) {
 #else
 #define HALFROW_OK(T, c4) true
 #endif
-// VEC: additionally dvec[k] = sum_m vec[m] B[m][k] and sum_m vec[m] (a one-output head that reads the same B rows -- the
-// density head beside the final trunk layer -- costs one scalar load and four FMAs per 16-byte piece of B instead of a pass of
-// its own over B); partial sums per split in upnerf_vec_wgrad's scratch layout [split][4][K + 1], row 0.
-template <int NP, int MTW, int NTW, bool VEC = false>
+template <int NP, int MTW, int NTW>
 __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                                   const float* __restrict__ B, int ldb,
                                                                   const int* __restrict__ expo_a, const int* __restrict__ expo_b,
                                                                   float* __restrict__ slabs, float* __restrict__ bslabs,
-                                                                  int rows_per_split, const float* __restrict__ vec = nullptr,
-                                                                  float* __restrict__ vslabs = nullptr) {
+                                                                  int rows_per_split, upnerf_wgrad_pending prev) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   constexpr int FX_CHUNK = (MTW * NTW == 16) ? FX_CHUNK_BIG : 32;
   constexpr int PN = (TN + 127) / 128, PK = (TK + 127) / 128;           // 128-column panels per plane
@@ -80,6 +76,15 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
   const int nblk = blockIdx.y * TN, kblk = blockIdx.z * TK;
   const int mbeg = split * rows_per_split;
   const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  // Prologue: the first prev.rblocks workgroups sum the slabs the PREVIOUS weight-gradient launch left (upnerf_wgrad_f16x3_chain)
+  if (prev.nsplit > 0) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < prev.rblocks) {
+      wgrad_reduce_body(wg, tid, prev.N, prev.K, prev.TN, prev.TK, prev.nsplit, prev.slabs, prev.bslabs, prev.dW, prev.ldo, prev.db,
+                        (f32x4(*)[64])lds);
+      __syncthreads();
+    }
+  }
   const int ea = expo_a[0], eb = expo_b[0];
   const float sa = ldexpf(1.0f, ea), sb = ldexpf(1.0f, eb);
 
@@ -88,29 +93,6 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // this thread's 4 columns of A, summed over its rows (fp32, unscaled)
 
   f32x4 ra0[A4], rb0[B4], ra1[A4], rb1[B4];
-  float rv0[B4], rv1[B4];  // VEC: vec[m] of the B rows in flight
-  f32x4 vsum = {0.f, 0.f, 0.f, 0.f};
-  float vb = 0.f;
-  auto vload = [&](float (&rv)[B4], int mc) {
-    if constexpr (VEC) {
-#pragma unroll
-      for (int q = 0; q < B4; ++q) {
-        // a wave's 64 lanes hold one row of B (TK / 4 = 64 pieces): the row index is wave-uniform, the load a scalar one
-        static_assert(!VEC || TK == 256, "VEC is built for 256-column blocks of B");
-        const int m = __builtin_amdgcn_readfirstlane(mc + (tid + q * FX_THREADS) / (TK / 4));
-        rv[q] = m < mend ? vec[m] : 0.f;
-      }
-    }
-  };
-  auto vacc = [&](const f32x4 (&rb)[B4], const float (&rv)[B4]) {
-    if constexpr (VEC) {
-#pragma unroll
-      for (int q = 0; q < B4; ++q) {
-        vsum += rb[q] * rv[q];
-        vb += rv[q];
-      }
-    }
-  };
   auto gload = [&](f32x4 (&ra)[A4], f32x4 (&rb)[B4], int mc) {
 #pragma unroll
     for (int q = 0; q < A4; ++q) {
@@ -196,39 +178,30 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
   };
   // Two register sets (loads of chunk c+2 in flight while chunk c is contracted) where the accumulators leave room for
   // them; the 256x256 block (128 accumulator registers per wave) keeps one set.
-  constexpr bool TWO_SETS = (MT * NT * 16 <= 64 || FX_CHUNK == 16) && !VEC;  // VEC: one set (two spill)
+  constexpr bool TWO_SETS = MT * NT * 16 <= 64 || FX_CHUNK == 16;
   if constexpr (TWO_SETS) {
     // rows beyond mend load as zeros, so an odd number of chunks simply contracts one all-zero chunk
     gload(ra0, rb0, mbeg);
-    vload(rv0, mbeg);
     gload(ra1, rb1, mbeg + FX_CHUNK);
-    vload(rv1, mbeg + FX_CHUNK);
 #pragma unroll 1
     for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
       lstore(ra0, rb0, 0);
-      vacc(rb0, rv0);
       __syncthreads();
       gload(ra0, rb0, mc + 2 * FX_CHUNK);
-      vload(rv0, mc + 2 * FX_CHUNK);
       contract(0);
       lstore(ra1, rb1, 1);
-      vacc(rb1, rv1);
       __syncthreads();
       gload(ra1, rb1, mc + 3 * FX_CHUNK);
-      vload(rv1, mc + 3 * FX_CHUNK);
       contract(1);
     }
   } else {
     int buf = 0;
     gload(ra0, rb0, mbeg);
-    vload(rv0, mbeg);
 #pragma unroll 1
     for (int mc = mbeg; mc < mend; mc += FX_CHUNK) {
       lstore(ra0, rb0, buf);
-      vacc(rb0, rv0);
       __syncthreads();
       gload(ra0, rb0, mc + FX_CHUNK);
-      vload(rv0, mc + FX_CHUNK);
       contract(buf);
       buf ^= 1;
     }
@@ -260,32 +233,6 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
 #pragma unroll
       for (int j = 1; j < G; ++j) s += red[tid + j * Q];
       *(f32x4*)&bslabs[((size_t)split * gridDim.y + blockIdx.y) * TN + 4 * tid] = s;
-    }
-  }
-  if constexpr (VEC) {
-    if (vslabs && blockIdx.y == 0) {
-      // the same fold for the B-side sums: thread t owns columns 4*(t % (TK/4)) ..+3 of B
-      __syncthreads();
-      f32x4* red = (f32x4*)lds;
-      float* redb = (float*)(lds + FX_THREADS * 16);
-      red[tid] = vsum;
-      redb[tid] = vb;
-      __syncthreads();
-      constexpr int Q = TK / 4, G = FX_THREADS / Q;
-      float* __restrict__ row = vslabs + (size_t)split * 4 * (K + 1);
-      if (tid < Q && kblk + 4 * tid < K) {
-        f32x4 sv = red[tid];
-#pragma unroll
-        for (int j = 1; j < G; ++j) sv += red[tid + j * Q];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) row[kblk + 4 * tid + c] = sv[c];  // (K + 1)-float rows: no 16-byte alignment
-      }
-      if (tid == 0 && blockIdx.z == 0) {
-        float sb2 = redb[0];
-#pragma unroll
-        for (int j = 1; j < G; ++j) sb2 += redb[j * Q];
-        row[K] = sb2;
-      }
     }
   }
 }
@@ -479,28 +426,17 @@ int launch_p(int M, int N, int K, const uint16_t* A, int lda, const int* aexp, c
 
 template <int MTW, int NTW>
 int launch(int planes, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const int* expo_a, const int* expo_b,
-           float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st, const float* vec = nullptr, float* vslabs = nullptr) {
+           float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st, const upnerf_wgrad_pending* prevp = nullptr) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   dim3 grid(nsplit, (N + TN - 1) / TN, (K + TK - 1) / TK);
-  if (vec) {
-    if constexpr (MTW == 4 && NTW == 4) {
-      if (planes == 1)
-        hipLaunchKernelGGL((wgrad_f16x3_kernel<1, 4, 4, true>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b,
-                           slabs, bslabs, rows, vec, vslabs);
-      else
-        hipLaunchKernelGGL((wgrad_f16x3_kernel<2, 4, 4, true>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b,
-                           slabs, bslabs, rows, vec, vslabs);
-      return (int)hipGetLastError();
-    } else {
-      return UPNERF_EUNSUP;  // built for the 256 x 256 block (the final trunk layer beside the density head)
-    }
-  }
+  upnerf_wgrad_pending prev = {};
+  if (prevp) prev = *prevp;
   if (planes == 1)
     hipLaunchKernelGGL((wgrad_f16x3_kernel<1, MTW, NTW>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b,
-                       slabs, bslabs, rows);
+                       slabs, bslabs, rows, prev);
   else
     hipLaunchKernelGGL((wgrad_f16x3_kernel<2, MTW, NTW>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b,
-                       slabs, bslabs, rows);
+                       slabs, bslabs, rows, prev);
   return (int)hipGetLastError();
 }
 
@@ -508,25 +444,21 @@ int launch(int planes, int M, int N, int K, const float* A, int lda, const float
 
 // Same contract as upnerf_wgrad_partial in gemm.hip: writes nsplit slabs (+ bias slabs) that upnerf_wgrad's reduce
 // kernel sums.  expo_a, expo_b: DEVICE pointers to the two exponents.  Returns the block shape through TN/TK.
-extern "C" int upnerf_wgrad_f16x3_partial_vec(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
-                                              const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows,
-                                              int planes, const float* vec, float* vslabs, void* stream) {
-  return launch<4, 4>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, (hipStream_t)stream, vec, vslabs);
-}
-
 extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N, const float* B, int ldb, int K,
                                           const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows, int TN,
-                                          int TK, int planes, void* stream) {
+                                          int TK, int planes, const upnerf_wgrad_pending* prev, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (TN == 256 && TK == 256) return launch<4, 4>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 256 && TK == 128) return launch<4, 2>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 256 && TK == 64) return launch<4, 1>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 128 && TK == 256) return launch<2, 4>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 128 && TK == 128) return launch<2, 2>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 128 && TK == 64) return launch<2, 1>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 64 && TK == 256) return launch<1, 4>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  if (TN == 64 && TK == 128) return launch<1, 2>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
-  return launch<1, 1>(planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+#define WG_ARGS planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev
+  if (TN == 256 && TK == 256) return launch<4, 4>(WG_ARGS);
+  if (TN == 256 && TK == 128) return launch<4, 2>(WG_ARGS);
+  if (TN == 256 && TK == 64) return launch<4, 1>(WG_ARGS);
+  if (TN == 128 && TK == 256) return launch<2, 4>(WG_ARGS);
+  if (TN == 128 && TK == 128) return launch<2, 2>(WG_ARGS);
+  if (TN == 128 && TK == 64) return launch<2, 1>(WG_ARGS);
+  if (TN == 64 && TK == 256) return launch<1, 4>(WG_ARGS);
+  if (TN == 64 && TK == 128) return launch<1, 2>(WG_ARGS);
+  return launch<1, 1>(WG_ARGS);
+#undef WG_ARGS
 }
 
 // Packed-operand variant behind upnerf_wgrad_f16p (gemm.hip): blocks of 256 x 256 (both operands fp16-stored) and

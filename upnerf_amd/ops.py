@@ -215,16 +215,28 @@ def wgrad_f16x3_into(M: int, A: torch.Tensor, lda: int, N: int, B: torch.Tensor,
     check(rc, "upnerf_wgrad_f16x3")
 
 
-def wgrad_f16x3_vec_into(M: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int, dW_ptr: int, ldo: int, db_ptr: Optional[int],
-                         vec: torch.Tensor, dvec_ptr: int, dbvec_ptr: Optional[int], device, expo_a: int, expo_b: int, planes: int = 2):
-    """wgrad_f16x3_into for a 256 x 256 block plus, in the same pass over B, vec_wgrad_into(M, vec, 1, 1, B, ldb, 256, ...)."""
-    ns = nsplit_for(M)
-    ws = workspace("wgrad", ns * (256 * 256 + 256), device)
-    vs = workspace("vec_wgrad", ns * 4 * 257, device)
-    rc = TIMER.run("wgrad16v_256x256", lambda: lib.upnerf_wgrad_f16x3_vec(M, ptr(A), lda, ptr(B), ldb, dW_ptr, ldo, db_ptr, ptr(ws), ns,
-                                                                          expo_a, expo_b, planes, ptr(vec), dvec_ptr, dbvec_ptr,
-                                                                          ptr(vs), stream()), units=M)
-    check(rc, "upnerf_wgrad_f16x3_vec")
+class WgradChain:
+    """A run of f16x3 weight gradients whose slab reductions ride on the NEXT launch (upnerf_wgrad_f16x3_chain): each kernel's
+    first workgroups sum the previous problem's slabs before their own work, the last problem is summed by `finish()`.
+    Nothing may read a gradient of the run before `finish()`; the slabs alternate between two workspaces."""
+
+    def __init__(self, device):
+        self.device, self.pending, self.flip = device, _lib.WgradPending(), 0
+
+    def _slabs(self, ns):
+        self.flip ^= 1
+        return workspace(f"wgrad_chain{self.flip}", ns * (256 * 256 + 256), self.device)
+
+    def wgrad(self, M, A, lda, N, B, ldb, K, dW_ptr, ldo, db_ptr, expo_a, expo_b, a_off=0, b_off=0, planes=2):
+        ns = nsplit_for(M)
+        ws = self._slabs(ns)
+        rc = TIMER.run(f"wgrad16_{N}x{K}", lambda: lib.upnerf_wgrad_f16x3_chain(
+            M, A.data_ptr() + 4 * a_off, lda, N, B.data_ptr() + 4 * b_off, ldb, K, dW_ptr, ldo, db_ptr, ptr(ws), ns, expo_a, expo_b,
+            planes, C.byref(self.pending), stream()), units=M)
+        check(rc, "upnerf_wgrad_f16x3_chain")
+
+    def finish(self):
+        check(lib.upnerf_wgrad_finish(C.byref(self.pending), stream()), "upnerf_wgrad_finish")
 
 
 def wgrad_f16p_into(M: int, A16: torch.Tensor, lda: int, aexp: torch.Tensor, N: int, B: torch.Tensor, ldb: int,

@@ -20,8 +20,8 @@ import torch
 from . import _lib, step_scalars
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, TILE_PART_STRIDE, X0, check, lib,
                    ptr, stream)
-from .ops import (TIMER, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16p_into,
-                  wgrad_f16x3_into, wgrad_f16x3_vec_into, wgrad_into, workspace)
+from .ops import (TIMER, WgradChain, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16p_into,
+                  wgrad_f16x3_into, wgrad_into, workspace)
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
 
@@ -62,8 +62,8 @@ FIELD_TILE = int(__import__("os").environ.get("UPNERF_FIELD_TILE", "0"))
 # Per-tile partial sums of the vector heads and per-ray sums from the backward field kernel (upnerf_field_bwd_args.tile_part);
 # 0 = the separate upnerf_vec_wgrad / upnerf_ray_sum launches (always used with 128-sample tiles and the fp32-MFMA kernels).
 TILE_PARTIALS = int(__import__("os").environ.get("UPNERF_TILE_PARTIALS", "1"))
-# The density head's weight gradient computed inside the final trunk layer's weight-gradient launch (upnerf_wgrad_f16x3_vec).
-VEC_FOLD = int(__import__("os").environ.get("UPNERF_VEC_FOLD", "1"))
+# Slab reductions of the f16x3 weight gradients inside the next weight-gradient launch (upnerf_wgrad_f16x3_chain).
+WGRAD_CHAIN = int(__import__("os").environ.get("UPNERF_WGRAD_CHAIN", "1"))
 
 
 def _planes() -> int:
@@ -298,9 +298,16 @@ class _FieldPass(torch.autograd.Function):
             EB = lambda i: eb.data_ptr() + 4 * i
             ctx_keep = (ea, eb)
 
+            # WGRAD_CHAIN: the slab reduction of every f16x3 weight gradient rides on the next one's launch (ops.WgradChain)
+            chain = WgradChain(dev) if WGRAD_CHAIN else None
+
             def wg(gz, lda, N, Bt, ldb, K, off, ldo, boff, ia, ib, b_off=0):
-                wgrad_f16x3_into(M, gz, lda, N, Bt, ldb, K, at(off), ldo, None if boff is None else at(boff), dev,
-                                 expo_a=EA(ia), expo_b=EB(ib), b_off=b_off, planes=ctx.planes)
+                if chain is not None:
+                    chain.wgrad(M, gz, lda, N, Bt, ldb, K, at(off), ldo, None if boff is None else at(boff), EA(ia), EB(ib),
+                                b_off=b_off, planes=ctx.planes)
+                else:
+                    wgrad_f16x3_into(M, gz, lda, N, Bt, ldb, K, at(off), ldo, None if boff is None else at(boff), dev,
+                                     expo_a=EA(ia), expo_b=EB(ib), b_off=b_off, planes=ctx.planes)
 
             if store16:  # fp16-stored operands (1 KB per sample and layer instead of 2)
                 h16, hexp = sv["h16"], sv["hexp"]
@@ -327,12 +334,8 @@ class _FieldPass(torch.autograd.Function):
                 else:
                     wg(gz, W, W, h[l - 1], W, W, L.w[l], W, L.b[l], l, l - 1)
             h_last = h[0] if store16 else h[D - 1]
-            if VEC_FOLD and W == 256:  # the density head's weight gradient rides on the final layer's pass over h_last
-                wgrad_f16x3_vec_into(M, gz_e, W, h_last, W, at(L.we), W, at(L.be), dpre_s, at(L.wsig), at(L.bsig), dev,
-                                     EA(D), EB(D - 1), planes=ctx.planes)
-            else:
-                wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
-                vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
+            wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
+            vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
         rs_c = _empty(R, W2, device=dev) if cfg.use_cand else None
         rs_r = _empty(R, W2, device=dev) if cfg.use_rgb else None
         if tile_part is not None:
@@ -364,6 +367,8 @@ class _FieldPass(torch.autograd.Function):
                     vec_wgrad_into(M, dpre_rgb, 4, 3, sv["r1"], W2, W2, at(L.wr2), at(L.br2), dev)
             if ctx.has_a and ctx.needs_input_grad[4]:
                 d_a_rows = linear_kn_view(rs_r, P, L.wr1 + W + 27, W + AUXK, 48)  # rs . wr1[:, W+27 : W+75]
+        if dP is not None and chain is not None:
+            chain.finish()
         d_o = d_d = None
         if need_dxyz:
             d_o, d_d = _empty(R, 3, device=dev), _empty(R, 3, device=dev)
