@@ -118,6 +118,9 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
                                           const char* __restrict__ Wf, int Kp16, int n0, int kB0, int lane) {
   constexpr int SETS = (AHEAD + 1 > T) ? T : AHEAD + 1;  // ring size; the ring runs SETS - 1 blocks ahead
   constexpr int AH = SETS - 1;
+#ifdef UPNERF_EXP_SETPRIO
+  struct Prio { __device__ Prio() { __builtin_amdgcn_s_setprio(UPNERF_EXP_SETPRIO); } __device__ ~Prio() { __builtin_amdgcn_s_setprio(0); } } prio_;
+#endif
 #ifndef F16_FORCE_UNROLLED_K
 #define F16_FORCE_UNROLLED_K 0
 #endif

@@ -141,13 +141,13 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
         const float wj = __shfl(wf, j);
         const size_t m = base + c0 + j;
         if (laneE) {
-          const f32x4 ev = *(const f32x4*)&a.e[m * W + 4 * lane];
+          const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
           accE.x += wj * ev.x; accE.y += wj * ev.y; accE.z += wj * ev.z; accE.w += wj * ev.w;
         }
         if (joint) {
           const float cj = __shfl(w_cj, j);
           if (laneG) {
-            const f32x4 gv = *(const f32x4*)&a.g2[m * W2 + 4 * lane];
+            const f32x4 gv = NT_LOAD((const f32x4*)&a.g2[m * W2 + 4 * lane]);
             accG.x += cj * gv.x; accG.y += cj * gv.y; accG.z += cj * gv.z; accG.w += cj * gv.w;
           }
         }
@@ -229,11 +229,11 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
         const size_t m = base + c0 + j;
         float pe = 0.f, pg = 0.f;
         if (laneE) {
-          const f32x4 ev = *(const f32x4*)&a.e[m * W + 4 * lane];
+          const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
           pe = gE.x * ev.x + gE.y * ev.y + gE.z * ev.z + gE.w * ev.w;
         }
         if (joint && laneG) {
-          const f32x4 gv = *(const f32x4*)&a.g2[m * W2 + 4 * lane];
+          const f32x4 gv = NT_LOAD((const f32x4*)&a.g2[m * W2 + 4 * lane]);
           pg = gG.x * gv.x + gG.y * gv.y + gG.z * gv.z + gG.w * gv.w;
         }
         pe = wave_sum(pe);

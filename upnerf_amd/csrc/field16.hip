@@ -27,6 +27,7 @@
 //                         n-tile for all 128 rows (MT = 4, NT = 1), so each weight fragment enters the CU once per 128
 //                         rows -- half the L2 -> CU weight stream per sample -- and no two waves of the CU ever ask for
 //                         the same fragment.
+#define ACT_STORE(p, v) NT_STORE(p, v)  // activations / gradients for a later kernel (common.cuh: streaming accesses)
 #define F16_TILE 64
 #define F16_WAVES 4
 #define F16_TILE_BIG 128
@@ -121,7 +122,7 @@ __device__ __forceinline__ float pow2f(int n) { return ldexpf(1.0f, n); }
 // row, 16 or 32 bytes of it) touch 32 lines per instruction: the vector memory path then moves ~14 B/clk/CU and HBM takes
 // partial lines at ~3.5 TB/s; whole lines were measured at about twice that (round 3).  The LDS reads of BATCH
 // iterations are issued before the first conversion.
-template <int NP, int W, int TILE, int THREADS, int NCOLS, int BATCH = 4>
+template <int NP, int W, int TILE, int THREADS, int NCOLS, int BATCH = 4, bool STREAM = true>
 __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, float unscale, float unscale2,
                                              float* __restrict__ dst, int ldg, int m0, int M, int tid) {
   constexpr int GPR = NCOLS >> 2, ITER = TILE * GPR / THREADS;
@@ -152,14 +153,17 @@ __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int
 #ifdef UPNERF_EXP_HALFROW
       if (NCOLS == 256 && g >= UPNERF_EXP_HALFROW) continue;
 #endif
-      if (whole || m0 + row < M) *(f32x4*)&dst[(size_t)(m0 + row) * ldg + 4 * g] = v;
+      if (whole || m0 + row < M) {
+        if constexpr (STREAM) ACT_STORE((f32x4*)&dst[(size_t)(m0 + row) * ldg + 4 * g], v);
+        else *(f32x4*)&dst[(size_t)(m0 + row) * ldg + 4 * g] = v;  // re-read by this workgroup soon (x0 at the skip layer)
+      }
     }
   }
 }
-template <int NP, int W, int TILE, int THREADS, int NCOLS, int BATCH = 4>
+template <int NP, int W, int TILE, int THREADS, int NCOLS, int BATCH = 4, bool STREAM = true>
 __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int c0, float unscale, float* __restrict__ dst,
                                              int ldg, int m0, int M, int tid) {
-  tile_store16<NP, W, TILE, THREADS, NCOLS, BATCH>(Ph, Pl, c0, unscale, unscale, dst, ldg, m0, M, tid);
+  tile_store16<NP, W, TILE, THREADS, NCOLS, BATCH, STREAM>(Ph, Pl, c0, unscale, unscale, dst, ldg, m0, M, tid);
 }
 
 // tile_store16 for a half-width tensor that also adds every stored row to the accumulator of the row's ray slot (sums[slot],
@@ -189,7 +193,7 @@ __device__ __forceinline__ void tile_store16_sum(const char* Ph, const char* Pl,
       else
         v = f32x4{mix16<0>(wh[j][0], un, 0.f), mix16<1>(wh[j][0], un, 0.f), mix16<0>(wh[j][1], un, 0.f), mix16<1>(wh[j][1], un, 0.f)};
       const bool in = m0 + row < M;
-      if (in) *(f32x4*)&dst[(size_t)(m0 + row) * ldg + 4 * g] = v;
+      if (in) ACT_STORE((f32x4*)&dst[(size_t)(m0 + row) * ldg + 4 * g], v);
       const int sl = slot_s[row];
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
@@ -212,7 +216,7 @@ __device__ __forceinline__ void tile_copy16(const char* Ph, int e, int e2, uint1
   for (int it = 0; it < ITER; ++it) {
     const int idx = tid + it * THREADS, row = idx / GPR, g = idx % GPR;
     const f32x4 v = *(const f32x4*)(Ph + poff<W>(row, 8 * g));
-    if (m0 + row < M) *(f32x4*)((char*)dst + ((size_t)(m0 + row) * W + 8 * g) * 2) = v;
+    if (m0 + row < M) ACT_STORE((f32x4*)((char*)dst + ((size_t)(m0 + row) * W + 8 * g) * 2), v);
   }
 }
 template <int W, int TILE, int THREADS>
@@ -307,7 +311,7 @@ __device__ __forceinline__ int fwd_trunk_pipelined(const upnerf_layout& L, const
   };
   auto finish_half = [&](int l, int half, unsigned int bits, float vmax, int e_out, int lane) {
     if (a.hmask)
-      ((unsigned int*)a.hmask)[(size_t)l * hm_stride32 + ((size_t)blockIdx.x * THREADS + wave * 64 + lane) * 2 + half] = bits;
+      NT_STORE(&((unsigned int*)a.hmask)[(size_t)l * hm_stride32 + ((size_t)blockIdx.x * THREADS + wave * 64 + lane) * 2 + half], bits);
     track_wave(mx_s, l, ldexpf(wave_max_nn(vmax), -e_out), lane);
   };
 
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     }
   }
   __syncthreads();
-  tile_store16<NP, W, TILE, THREADS, UPNERF_X0>(Ph, Pl, 0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
+  tile_store16<NP, W, TILE, THREADS, UPNERF_X0, 4, false>(Ph, Pl, 0, pow2f(-ecur), a.x0, UPNERF_X0, m0, M, tid);
 
   // fp32 copy of trunk activation h_lidx for the weight gradients, from the planes (with fp16 storage only the last layer)
   auto store_h32 = [&](int lidx, float un0, float un1) {
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     const unsigned long long bits = acc_fma_relu_pack(acc, pow2f(-(ecur + wel)), bl);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
-    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * THREADS + tid] = bits;
+    if (a.hmask) NT_STORE(&((unsigned long long*)a.hmask)[((size_t)l * gridDim.x + blockIdx.x) * THREADS + tid], bits);
     STAMP(2);
     __syncthreads();
     STAMP(3);
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.c_rows + (size_t)rayrow[mt] * UPNERF_CK + 8 * hh;
     mma16_glb<NP>(accc, ap, ecur, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, UPNERF_CK, lane);
     const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), bc);
-    if (a.hmask) ((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * THREADS + tid] = bits;
+    if (a.hmask) NT_STORE(&((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * THREADS + tid], bits);
     mc = acc_absmax(accc);
   }
   if (lane == 0) {
@@ -817,7 +821,7 @@ __device__ __forceinline__ void bwd_trunk_pipelined(const upnerf_layout& L, cons
     return PT16 + 4 * (size_t)wl + (size_t)wave * (W / 16) * 2048 + lane * 16;
   };
   auto mask32 = [&](int l, int half, int lane) -> unsigned int {
-    return ((const unsigned int*)a.hmask)[(size_t)l * hm_stride32 + ((size_t)blockIdx.x * THREADS + wave * 64 + lane) * 2 + half];
+    return NT_LOAD(&((const unsigned int*)a.hmask)[(size_t)l * hm_stride32 + ((size_t)blockIdx.x * THREADS + wave * 64 + lane) * 2 + half]);
   };
   auto publish = [&](float* slot, float accmax, int e_in, int wel, int lane) {
     if (lane == 0) slot[wave] = accmax * pow2f(-(e_in + wel));
@@ -1026,7 +1030,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
         for (int q = 0; q < EPT; ++q) {
           int m = m0 + er0 + ERS * q;
           m = m < M ? m : M - 1;
-          gv[q] = *(const f32x4*)&a.g2[(size_t)m * W2 + 4 * eg];
+          gv[q] = NT_LOAD((const f32x4*)&a.g2[(size_t)m * W2 + 4 * eg]);
           gg[q] = a.g_G_c ? *(const f32x4*)&a.g_G_c[(size_t)(m / S) * W2 + 4 * eg] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
@@ -1036,7 +1040,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
           f32x4 out;
 #pragma unroll
           for (int c = 0; c < 4; ++c) out[c] = (m < M && gv[q][c] > 0.f) ? wv[c] * dp + cw * gg[q][c] : 0.f;
-          if (m < M) *(f32x4*)&a.gz_g2[(size_t)m * W2 + 4 * eg] = out;
+          if (m < M) ACT_STORE((f32x4*)&a.gz_g2[(size_t)m * W2 + 4 * eg], out);
           tp_c += gv[q] * dp;  // d w_csig: dp is zero for rows past M (the clamped row is then ignored)
           vals[q] = out;
           lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
@@ -1053,7 +1057,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
       __syncthreads();
       mma16_lds<NP, W, W2 / 16, AH>(accg, Ph, Pl, hrow0, W2, PT16 + 4 * (size_t)L.t_wc2, W2 / 16, hn0, 0, lane);
       acc_scale(accg, pow2f(-(eg2 + wexp[10])));
-      acc_apply_mask(accg, hm[(size_t)D * hm_stride]);
+      acc_apply_mask(accg, NT_LOAD(&hm[(size_t)D * hm_stride]));
       mg1 = acc_absmax(accg);
     }
     f32x4 valr[EPT];
@@ -1067,7 +1071,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
       for (int q = 0; q < EPT; ++q) {
         int m = m0 + er0 + ERS * q;
         m = m < M ? m : M - 1;
-        rv[q] = *(const f32x4*)&a.r1[(size_t)m * W2 + 4 * eg];
+        rv[q] = NT_LOAD((const f32x4*)&a.r1[(size_t)m * W2 + 4 * eg]);
       }
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
@@ -1081,7 +1085,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
           for (int c = 0; c < 3; ++c) t += wr[c][u] * dp[c];
           out[u] = (m < M && rv[q][u] > 0.f) ? t : 0.f;
         }
-        if (m < M) *(f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * eg] = out;
+        if (m < M) ACT_STORE((f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * eg], out);
         if (tp) {
           const int sl = slot_s[row];
 #pragma unroll
@@ -1210,7 +1214,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
   STAMP(1);  // d e
   // ---- d h_{D-1} = gz_e . W_e + w_sig * dpre_s, masked by relu (sign bits from the forward, in this lane's layout)
   {
-    const unsigned long long bits = hm[(size_t)(D - 1) * hm_stride];
+    const unsigned long long bits = NT_LOAD(&hm[(size_t)(D - 1) * hm_stride]);
     f32x16 acc[TW::MT][TW::NT];
     acc_zero(acc);
     f32x4 ws[TW::NT][4];
@@ -1264,7 +1268,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     }
   } else {
   for (int l = D - 1; l >= 1; --l) {
-    const unsigned long long bits = hm[(size_t)(l - 1) * hm_stride];  // arrives under the contraction below
+    const unsigned long long bits = NT_LOAD(&hm[(size_t)(l - 1) * hm_stride]);  // arrives under the contraction below
     if (a.need_dxyz && l == L.skip) {
       mma16_lds<NP, W, W / 16, AH>(accx, Ph, Pl, xrow0, 0, PT16 + 4 * (size_t)L.t_skipx, W / 16, xn0, 0, lane);
       acc_scale(accx, pow2f(-(ecur + wexp[l])));  // natural units: the layer-0 term arrives at another exponent

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NTHREADS) void vec_wgrad_kernel(int M, const float*
       const int mm = m + u * RG;
       const bool ok = mm < mend;
       const int mc = ok ? mm : mend - 1;  // loads first (clamped), masks after: no branch around a load
-      x[u] = *(const f32x4*)&X[(size_t)mc * ldx + 4 * c4];
+      x[u] = NT_LOAD((const f32x4*)&X[(size_t)mc * ldx + 4 * c4]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) vv[u][c] = (c < nvec) ? v[(size_t)mc * ldv + c] : 0.f;
       if (!ok) {

@@ -45,6 +45,7 @@ __device__ __forceinline__ h4 tr_read(const char* base, int byteoff) {
 // NP = 2: f16x3 (hi/lo split of both operands, three MFMAs per block, fp32-level accuracy); NP = 1: f16 (operands rounded
 // to fp16, one MFMA per block, fp32 accumulate: the "f16" field mode of BASELINE.json configs[3]).
 #define FX_THREADS 512
+#define WG_LOAD(p) NT_LOAD(p)  // operand rows: read once per step (common.cuh: streaming accesses)
 #ifdef UPNERF_EXP_HALFROW
 #define HALFROW_OK(T, c4) (!((T) == 256 && (c4) >= UPNERF_EXP_HALFROW))
 #else
@@ -98,13 +99,13 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     for (int q = 0; q < A4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
       const int m = mc + row;
-      ra[q] = (m < mend && nblk + 4 * c4 < N && HALFROW_OK(TN, c4)) ? *(const f32x4*)&A[(size_t)m * lda + nblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[q] = (m < mend && nblk + 4 * c4 < N && HALFROW_OK(TN, c4)) ? WG_LOAD((const f32x4*)&A[(size_t)m * lda + nblk + 4 * c4]) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int q = 0; q < B4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
       const int m = mc + row;
-      rb[q] = (m < mend && kblk + 4 * c4 < K && HALFROW_OK(TK, c4)) ? *(const f32x4*)&B[(size_t)m * ldb + kblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      rb[q] = (m < mend && kblk + 4 * c4 < K && HALFROW_OK(TK, c4)) ? WG_LOAD((const f32x4*)&B[(size_t)m * ldb + kblk + 4 * c4]) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto split_store = [&](char* hi, char* lo, f32x4 v, float s, int row, int col) {
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
       const int idx = tid + q * FX_THREADS, row = idx / (TN / 8), c8 = idx - row * (TN / 8);
       const int m = mc + row;
       const bool ok = m < mend && nblk + 8 * c8 < N;
-      ra[q] = ok ? *(const h8*)&A[(size_t)m * lda + nblk + 8 * c8] : zero8;
+      ra[q] = ok ? NT_LOAD((const h8*)&A[(size_t)m * lda + nblk + 8 * c8]) : zero8;
       xa[q] = ok ? aexp[m >> 6] : 0;
     }
     if constexpr (PKB) {
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
         const int idx = tid + q * FX_THREADS, row = idx / (TK / 8), c8 = idx - row * (TK / 8);
         const int m = mc + row;
         const bool ok = m < mend && kblk + 8 * c8 < K;
-        rbp[q] = ok ? *(const h8*)&Bh[(size_t)m * ldb + kblk + 8 * c8] : zero8;
+        rbp[q] = ok ? NT_LOAD((const h8*)&Bh[(size_t)m * ldb + kblk + 8 * c8]) : zero8;
         xb[q] = ok ? bexp[m >> 6] : 0;
       }
     } else {
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
       for (int q = 0; q < B4; ++q) {
         const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
         const int m = mc + row;
-        rbf[q] = (m < mend && kblk + 4 * c4 < K) ? *(const f32x4*)&Bf[(size_t)m * ldb + kblk + 4 * c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        rbf[q] = (m < mend && kblk + 4 * c4 < K) ? NT_LOAD((const f32x4*)&Bf[(size_t)m * ldb + kblk + 4 * c4]) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
