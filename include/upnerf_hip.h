@@ -313,6 +313,41 @@ int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const float* B, in
                        float* dW, int ldo, float* db, float* slabs, int nsplit, const int* expo_a,
                        const int* expo_b, int planes, void* stream);
 
+/* ---- TransientNet (models/transient_net.py:5-38) as one forward and one backward launch: feat_dim 384, hidden width 256,
+ * transient embedding width 128 (the reference's defaults), one row per ray.  Weights in the nn.Linear layout ([out][in],
+ * row-major); fp32 MFMA, fp32 accumulate.  The forward pass stores what the backward pass and the weight gradients read. */
+typedef struct {
+  int32_t R; float beta_min;
+  const float* feat;             /* [R][384] */
+  const float* t_emb;            /* [R][128] rows of embedding_t */
+  const float* w0; const float* b0;   /* feat_encoder.0  [256][384], [256] */
+  const float* w1; const float* b1;   /* feat_encoder.2  [256][256] */
+  const float* w2; const float* b2;   /* feat_encoder.4 */
+  const float* w3; const float* b3;   /* feat_encoder.6 */
+  const float* wf; const float* bf;   /* final_encoder   [256][256] */
+  const float* wt; const float* bt;   /* t_encoder.0     [128][384] over [final_encoding | t_emb] */
+  const float* wa; const float* ba;   /* alpha_layer.0   [1][256] */
+  const float* wb; const float* bb;   /* beta_layer.0    [1][128] */
+  const float* wr; const float* br;   /* rgb_layer.0     [3][128] */
+  float* h;                      /* [4][R][256] post-ReLU outputs of the four feat_encoder layers */
+  float* e;                      /* [R][256] final_encoding */
+  float* t;                      /* [R][128] post-ReLU output of t_encoder */
+  float* alpha; float* rgb; float* beta;   /* [R], [R][3], [R]: the module's outputs */
+  float* spre;                   /* [R] pre-activation of the beta head */
+} upnerf_transient_args;
+typedef struct {
+  const float* d_alpha; const float* d_rgb; const float* d_beta;   /* [R], [R][3], [R]; NULL = zero */
+  float* dz_heads;               /* [R][8]: pre-activation gradients of alpha, beta, rgb[3] (3 unused) */
+  float* gz_t;                   /* [R][128] */
+  float* gz_e;                   /* [R][256] */
+  float* gz_h;                   /* [4][R][256] */
+  float* g_temb;                 /* [R][128] or NULL */
+  float* g_feat;                 /* [R][384] or NULL */
+} upnerf_transient_grads;
+int upnerf_transient_fwd(const upnerf_transient_args* a, void* stream);
+/* data gradients only; the weight gradients are upnerf_wgrad_grouped over (gz_*, stored inputs) */
+int upnerf_transient_bwd(const upnerf_transient_args* a, const upnerf_transient_grads* g, void* stream);
+
 /* Chained form of upnerf_wgrad_f16x3: the slabs of one weight gradient are summed by the first workgroups of the NEXT
  * weight-gradient launch (a prologue that costs it a few microseconds) instead of a reduction launch of their own (20+ us
  * each, 40 per step).  `pending` describes the problem whose slabs are written but not summed (nsplit == 0: none): the call

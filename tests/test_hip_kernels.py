@@ -575,6 +575,70 @@ def test_tile_partial_sums_match_the_separate_launches(hip, R, S, mode, use_cand
     assert not bad, bad
 
 
+@pytest.mark.parametrize("R", [37, 1024])
+def test_fused_transient_net_matches_torch(hip, R):
+    """csrc/transient.hip (the whole TransientNet as one forward and one backward launch + one grouped weight-gradient launch)
+    against the same module evaluated by plain torch ops in fp64 on the CPU (models/transient_net.py:27-38): outputs and every
+    gradient, a ragged last tile (R % 16 != 0), and against the per-layer HIP path it replaces."""
+    import upnerf_amd.transient_net as tn
+    from upnerf_amd import synth
+    torch.manual_seed(5)
+    NI = 11
+    net = tn.TransientNet(NI).cuda()
+    net.load_state_dict({k: v.cuda() for k, v in synth.transient_state(NI, seed=4).items()})
+    feat = gen((R, 384), 91).cuda()
+    ts = (torch.arange(R) * 7 % NI).cuda()
+    up = [gen((R, 1), 92).cuda(), gen((R, 3), 93).cuda(), gen((R, 1), 94).cuda()]
+
+    def run(fused, want_feat_grad):
+        old = tn.FUSED
+        tn.FUSED = fused
+        try:
+            net.zero_grad(set_to_none=True)
+            f = feat.clone().requires_grad_(want_feat_grad)
+            out = net(f, ts)
+            (out["alpha"] * up[0]).sum().add((out["rgb"] * up[1]).sum()).add((out["beta"] * up[2]).sum()).backward()
+            torch.cuda.synchronize()
+            return ({k: cpu(v) for k, v in out.items()}, {n: cpu(q.grad) for n, q in net.named_parameters()},
+                    cpu(f.grad) if want_feat_grad else None)
+        finally:
+            tn.FUSED = old
+
+    # fp64 reference with plain torch modules
+    import copy
+    net64 = copy.deepcopy(net).cpu().double()
+    f64 = cpu(feat).double().requires_grad_(True)
+    h = net64.feat_encoder(f64)
+    e = net64.final_encoder(h)
+    t = net64.t_encoder(torch.cat([e, net64.embedding_t(cpu(ts))], -1))
+    o64 = {"alpha": net64.alpha_layer(h), "rgb": net64.rgb_layer(t)}
+    o64["beta"] = net64.beta_layer(t) * o64["alpha"] + net64.beta_min
+    (o64["alpha"] * cpu(up[0]).double()).sum().add((o64["rgb"] * cpu(up[1]).double()).sum()).add(
+        (o64["beta"] * cpu(up[2]).double()).sum()).backward()
+    g64 = {n: q.grad for n, q in net64.named_parameters()}
+
+    bad = {}
+
+    def chk(tag, x, y, tol):
+        x, y = x.double().reshape(-1), y.double().reshape(-1)
+        err = float((x - y).abs().max() / max(float(y.abs().max()), 1e-30))
+        if not err < tol:
+            bad[tag] = err
+
+    for fused in (True, False):
+        out, grads, gf = run(fused, True)
+        for k in out:
+            chk(f"{fused} {k}", out[k], o64[k].detach(), 2e-6)
+        for n in grads:
+            chk(f"{fused} d {n}", grads[n], g64[n], 2e-5)
+        chk(f"{fused} d feat", gf, f64.grad, 2e-5)
+    out, grads, gf = run(True, False)  # without a gradient for the features (the training step: they are data)
+    assert gf is None
+    for n in grads:
+        chk(f"nofeat d {n}", grads[n], g64[n], 2e-5)
+    assert not bad, bad
+
+
 def _ragged_tiles(hip, R, S, mode, use_cand, use_rgb):
     """f16x3 kernels against the fp32 kernels on shapes whose tiles are ragged (M % 64 != 0) and straddle up to three
     rays; large and tiny magnitudes mixed so that the per-tile exponents differ between tiles and stages."""

@@ -96,6 +96,16 @@ class PackDesc(C.Structure):
                 ("dst_ld", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class TransientArgs(C.Structure):
+    _fields_ = ([("R", C.c_int32), ("beta_min", C.c_float), ("feat", _fp), ("t_emb", _fp)]
+                + [(n, _fp) for n in ("w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3", "wf", "bf", "wt", "bt", "wa", "ba", "wb", "bb",
+                                      "wr", "br", "h", "e", "t", "alpha", "rgb", "beta", "spre")])
+
+
+class TransientGrads(C.Structure):
+    _fields_ = [(n, _fp) for n in ("d_alpha", "d_rgb", "d_beta", "dz_heads", "gz_t", "gz_e", "gz_h", "g_temb", "g_feat")]
+
+
 class WgradPending(C.Structure):
     _fields_ = [("slabs", _fp), ("bslabs", _fp), ("dW", _fp), ("db", _fp), ("N", C.c_int32), ("K", C.c_int32), ("TN", C.c_int32),
                 ("TK", C.c_int32), ("nsplit", C.c_int32), ("ldo", C.c_int32), ("rblocks", C.c_int32), ("pad", C.c_int32)]
@@ -150,6 +160,8 @@ _SIGNATURES = {
     "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3_chain": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p],
     "upnerf_wgrad_finish": [_p, _p],
+    "upnerf_transient_fwd": [_p, _p],
+    "upnerf_transient_bwd": [_p, _p, _p],
     "upnerf_wgrad_f16p": [_i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p],
     "upnerf_wgrad_grouped_scratch": [C.POINTER(WgradGroup), _i, _i],
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],
