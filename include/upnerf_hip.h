@@ -267,6 +267,11 @@ typedef struct {
   float* tile_part;              /* NULL, or [ceil(M/64)][UPNERF_TILE_PART_STRIDE] (f16x3 variant, tile_rows 0 / 64 only): per-tile
                                     partial sums of what upnerf_vec_wgrad (dpre_sig_c x g2, dpre_rgb x r1) and upnerf_ray_sum
                                     (gz_g1, gz_r1) would re-read M x W/2 tensors for; finished by upnerf_tile_part_finish */
+  int32_t gz_rg_ld;              /* f16x3 variant: row stride (floats) of gz_r1 and gz_g1; 0 = W/2 (two dense tensors).  With
+                                    gz_g1 = gz_r1 + W/2 and a stride of W the two form ONE [M][W] tensor [gz_r1 | gz_g1], whose
+                                    weight gradient against e is one launch (upnerf_wgrad_f16x3_chain2); its running maximum is
+                                    tracked in gmax slot D+4 */
+  int32_t reserved_;
 } upnerf_field_bwd_args;
 
 /* Layout of one row of tile_part (floats): d w_csig [W/2] | d w_r2 [3][W/2] | sum dpre_sig_c, sum dpre_rgb[0..2] | 4 pad |
@@ -357,11 +362,19 @@ int upnerf_transient_bwd(const upnerf_transient_args* a, const upnerf_transient_
 typedef struct {
   const float* slabs; const float* bslabs;
   float* dW; float* db;
-  int32_t N, K, TN, TK, nsplit, ldo, rblocks, pad;
+  int32_t N, K, TN, TK, nsplit, ldo, rblocks;
+  int32_t n2;                    /* > 0: rows n >= n2 of the result go to dW2[(n - n2) * ldo2 + k], db2[n - n2] */
+  float* dW2; float* db2;
+  int32_t ldo2, pad;
 } upnerf_wgrad_pending;
 int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
                              float* db, float* slabs, int nsplit, const int* expo_a, const int* expo_b, int planes,
                              upnerf_wgrad_pending* pending, void* stream);
+/* the same with a result split by rows between two destinations (two layers that share B and whose A operands sit side by
+ * side in one tensor: the colour and candidate heads' first layers, both fed by e) */
+int upnerf_wgrad_f16x3_chain2(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
+                              float* db, int n2, float* dW2, int ldo2, float* db2, float* slabs, int nsplit, const int* expo_a,
+                              const int* expo_b, int planes, upnerf_wgrad_pending* pending, void* stream);
 int upnerf_wgrad_finish(upnerf_wgrad_pending* pending, void* stream);
 
 /* Same contraction for the f16 field mode with fp16-STORED operands: A16 [M][lda] fp16 bits scaled per 64-row tile by

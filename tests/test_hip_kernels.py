@@ -530,7 +530,8 @@ def test_tile_partial_sums_match_the_separate_launches(hip, R, S, mode, use_cand
     c_rows, a_rows = gen((R, 16), 73).cuda(), gen((R, 48), 74).cuda()
     cfg = rd._PassCfg(pk, mode, use_cand, use_rgb, [1.0] * 10, [1.0] * 4)
     res = {}
-    old = rd.TILE_PARTIALS
+    old, old_join = rd.TILE_PARTIALS, rd.JOIN_HEADS
+    rd.JOIN_HEADS = 0  # (the joined [gz_r1 | gz_g1] weight gradient needs the partial sums: it would differ between the two runs)
     try:
         for tp in (0, 1):
             rd.TILE_PARTIALS = tp
@@ -539,7 +540,7 @@ def test_tile_partial_sums_match_the_separate_launches(hip, R, S, mode, use_cand
             sum((t * gen(tuple(t.shape), 80 + i).cuda()).sum() for i, t in enumerate(outs) if t.numel()).backward()
             res[tp] = [cpu(t.grad) if t.grad is not None else None for t in leaves]
     finally:
-        rd.TILE_PARTIALS = old
+        rd.TILE_PARTIALS, rd.JOIN_HEADS = old, old_join
     a, b = res[0], res[1]
     W2 = pk.W2
     moved = [(L.wcsig, W2), (L.bcsig, 1), (L.wr2, 3 * W2), (L.br2, 3),                 # the vector heads
@@ -637,6 +638,55 @@ def test_fused_transient_net_matches_torch(hip, R):
     for n in grads:
         chk(f"nofeat d {n}", grads[n], g64[n], 2e-5)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("field_mode", ["f16x3", "f16"], indirect=True)
+@pytest.mark.parametrize("R,S", [(7, 40), (3, 256)])
+def test_joined_head_gradients_match_the_separate_launches(hip, R, S, field_mode):
+    """[gz_r1 | gz_g1] stored as one tensor and contracted against e in ONE launch (upnerf_wgrad_f16x3_chain2, rows split
+    between the colour and the candidate head) against one launch per head: the same sums under one joint power-of-two scale
+    instead of two (differences at the 2^-22 level of the f16x3 split, 1e-2 in the f16 mode), everything else bitwise."""
+    from upnerf_amd import synth
+    from upnerf_amd.nerf import NeRF
+    rd = hip["rendering"]
+    kw = dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    model = NeRF("coarse", c2f=None, **kw)
+    model.load_state_dict(synth.nerf_state("coarse", seed=3, **kw))
+    model = model.cuda()
+    pk, L = model.packer, model.packer.L
+    o = (gen((R, 3), 70) * 0.3).cuda()
+    d = torch.nn.functional.normalize(gen((R, 3), 71), dim=-1).cuda()
+    z = (torch.sort(gen((R, S), 72).abs() * 3 + 0.1, dim=-1).values).cuda()
+    c_rows, a_rows = gen((R, 16), 73).cuda(), gen((R, 48), 74).cuda()
+    cfg = rd._PassCfg(pk, 1, True, True, [1.0] * 10, [1.0] * 4)
+    res = {}
+    old = rd.JOIN_HEADS
+    try:
+        for j in (0, 1):
+            rd.JOIN_HEADS = j
+            leaves = [t.clone().requires_grad_(True) for t in (o, d, c_rows, a_rows, model.packed().detach())]
+            outs = rd._FieldPass.apply(leaves[0], leaves[1], z, leaves[2], leaves[3], leaves[4], cfg)
+            sum((t * gen(tuple(t.shape), 80 + i).cuda()).sum() for i, t in enumerate(outs) if t.numel()).backward()
+            res[j] = [cpu(t.grad) for t in leaves]
+    finally:
+        rd.JOIN_HEADS = old
+    a, b = res[0], res[1]
+    for i in range(4):
+        assert torch.equal(a[i], b[i]), i
+    dPa, dPb = a[4].clone(), b[4].clone()
+    W, W2 = pk.W, pk.W2
+    tol = 1e-2 if field_mode == "f16" else 2e-6
+    for off, ld, nb in ((L.wr1, W + 80, L.br1), (L.wc1, W + 16, L.bc1)):
+        va, vb = dPa[off:off + W2 * ld].view(W2, ld), dPb[off:off + W2 * ld].view(W2, ld)
+        x, y = va[:, :W].double(), vb[:, :W].double()
+        assert float((x - y).abs().max() / x.abs().max()) < tol
+        va[:, :W] = 0
+        vb[:, :W] = 0
+        xb, yb = dPa[nb:nb + W2].double(), dPb[nb:nb + W2].double()
+        assert float((xb - yb).abs().max() / xb.abs().max()) < 1e-6  # bias = plain column sums, another order
+        dPa[nb:nb + W2] = 0
+        dPb[nb:nb + W2] = 0
+    assert torch.equal(dPa, dPb)
 
 
 def _ragged_tiles(hip, R, S, mode, use_cand, use_rgb):

@@ -67,7 +67,7 @@ class FieldBwdArgs(C.Structure):
                 ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp), ("hmask", _fp), ("gmax", _fp),
                 ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp),
-                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("gz16", _fp), ("gzexp", _fp), ("xs", _fp), ("tile_part", _fp)]
+                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("gz16", _fp), ("gzexp", _fp), ("xs", _fp), ("tile_part", _fp), ("gz_rg_ld", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class LossArgs(C.Structure):
@@ -108,7 +108,8 @@ class TransientGrads(C.Structure):
 
 class WgradPending(C.Structure):
     _fields_ = [("slabs", _fp), ("bslabs", _fp), ("dW", _fp), ("db", _fp), ("N", C.c_int32), ("K", C.c_int32), ("TN", C.c_int32),
-                ("TK", C.c_int32), ("nsplit", C.c_int32), ("ldo", C.c_int32), ("rblocks", C.c_int32), ("pad", C.c_int32)]
+                ("TK", C.c_int32), ("nsplit", C.c_int32), ("ldo", C.c_int32), ("rblocks", C.c_int32), ("n2", C.c_int32),
+                ("dW2", _fp), ("db2", _fp), ("ldo2", C.c_int32), ("pad", C.c_int32)]
 
 
 class WgradGroup(C.Structure):
@@ -159,6 +160,7 @@ _SIGNATURES = {
     "upnerf_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3_chain": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p],
+    "upnerf_wgrad_f16x3_chain2": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p],
     "upnerf_wgrad_finish": [_p, _p],
     "upnerf_transient_fwd": [_p, _p],
     "upnerf_transient_bwd": [_p, _p, _p],

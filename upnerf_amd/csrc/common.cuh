@@ -383,9 +383,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // round-robin to 8 thread groups whose partial sums meet in LDS (`part`, 8 KiB); each group keeps 8 loads in flight.
 #define RED_RG 8
 #define RED_THREADS (64 * RED_RG)
-__device__ __forceinline__ void wgrad_reduce_body(int bid, int tid, int N, int K, int TN, int TK, int nsplit,
-                                                  const float* __restrict__ slabs, const float* __restrict__ bslabs,
-                                                  float* __restrict__ dW, int ldo, float* __restrict__ db, f32x4 (*part)[64]) {
+__device__ __forceinline__ void wgrad_reduce_body(int bid, int tid, const upnerf_wgrad_pending& P, f32x4 (*part)[64]) {
+  const int N = P.N, K = P.K, TN = P.TN, TK = P.TK, nsplit = P.nsplit;
+  const float* __restrict__ slabs = P.slabs;
+  const float* __restrict__ bslabs = P.bslabs;
   const int lane = tid & 63, rg = tid >> 6;
   const int q = bid * 64 + lane;  // index of a group of 4 consecutive k
   const int K4 = K >> 2;
@@ -416,9 +417,10 @@ __device__ __forceinline__ void wgrad_reduce_body(int bid, int tid, int N, int K
   if (rg == 0 && ok) {
     const f32x4 t = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
                     ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
-    *(f32x4*)&dW[(size_t)n * ldo + k] = t;
+    if (P.n2 > 0 && n >= P.n2) *(f32x4*)&P.dW2[(size_t)(n - P.n2) * P.ldo2 + k] = t;
+    else *(f32x4*)&P.dW[(size_t)n * P.ldo + k] = t;
   }
-  if (db) {
+  if (P.db || (P.n2 > 0 && P.db2)) {
     const int idx = bid * RED_THREADS + tid;
     if (idx < N) {
       const int bby = idx / TN;
@@ -431,7 +433,9 @@ __device__ __forceinline__ void wgrad_reduce_body(int bid, int tid, int N, int K
         for (int u = 0; u < 8; ++u) p[u] += src[(size_t)(sp + u) * bst];
       }
       for (; sp < nsplit; ++sp) p[0] += src[(size_t)sp * bst];
-      db[idx] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      const float sb = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      if (P.n2 > 0 && idx >= P.n2) { if (P.db2) P.db2[idx - P.n2] = sb; }
+      else if (P.db) P.db[idx] = sb;
     }
   }
 }

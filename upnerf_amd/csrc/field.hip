@@ -440,7 +440,7 @@ extern "C" int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_a
   if (a->use_rgb && (!a->d_rgb || !a->rgb || !a->r1 || !a->gz_r1 || !a->dpre_rgb)) return UPNERF_EINVAL;
   if (a->g_E_s && !a->w_feat_s) return UPNERF_EINVAL;
   if (a->need_dxyz && (!a->dxyz || !a->x0)) return UPNERF_EINVAL;
-  if (a->tile_part) return UPNERF_EUNSUP;  // per-tile partial sums: f16x3 variant only
+  if (a->tile_part || a->gz_rg_ld) return UPNERF_EUNSUP;  // per-tile partial sums, joined gz_r1 / gz_g1: f16x3 variant only
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int grid = (int)((M + FIELD_TILE - 1) / FIELD_TILE);

@@ -947,6 +947,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
   __shared__ int slot_s[TILE];
   __shared__ __attribute__((aligned(16))) float red_s[TPW][32][24];
   const bool tp = TILE == F16_TILE && a.tile_part != nullptr;
+  const int gld = a.gz_rg_ld > 0 ? a.gz_rg_ld : W2;  // row stride of gz_r1 / gz_g1
   f32x4 tp_c = {0.f, 0.f, 0.f, 0.f}, tp_r[3], tp_sg[MAXRAYS], tp_sr[MAXRAYS];
 #pragma unroll
   for (int q = 0; q < 3; ++q) tp_r[q] = tp_sg[q] = tp_sr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
           for (int c = 0; c < 3; ++c) t += wr[c][u] * dp[c];
           out[u] = (m < M && rv[q][u] > 0.f) ? t : 0.f;
         }
-        if (m < M) ACT_STORE((f32x4*)&a.gz_r1[(size_t)m * W2 + 4 * eg], out);
+        if (m < M) ACT_STORE((f32x4*)&a.gz_r1[(size_t)m * gld + 4 * eg], out);
         if (tp) {
           const int sl = slot_s[row];
 #pragma unroll
@@ -1107,6 +1108,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
       const float mxg = wg_max<NW>(smax), mxr = wg_max<NW>(smaxb);
       if (a.use_cand) track(mx_s, D + 1, mxg, tid);
       if (a.use_rgb) track(mx_s, D + 3, mxr, tid);
+      if (a.use_cand && a.use_rgb) track(mx_s, D + 4, fmaxf(mxg, mxr), tid);  // of [gz_r1 | gz_g1] as one tensor (gz_rg_ld)
       erg = scale_exp(fmaxf(mxg, mxr));
     }
     if (a.use_cand) acc_to_planes<NP, W>(accg, Ph, Pl, hrow0, hn0, W2, erg, lane);
@@ -1116,8 +1118,8 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     }
     __syncthreads();
     if (a.use_cand) {
-      if (tp) tile_store16_sum<NP, W, TILE, THREADS, W2, MAXRAYS>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid, slot_s, tp_sg);
-      else tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, W2, m0, M, tid);
+      if (tp) tile_store16_sum<NP, W, TILE, THREADS, W2, MAXRAYS>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, gld, m0, M, tid, slot_s, tp_sg);
+      else tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, gld, m0, M, tid);
     }
     if (tp) {
       // A thread holds four columns (eg) of 2 * EPT rows' worth of sums; the two halves of a wave fold first, then the

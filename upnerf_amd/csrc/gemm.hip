@@ -199,12 +199,19 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_grouped_reduce_kernel(WgradGro
 }
 
 // dW[n][k] = sum_split slab[split][by][bz][n%TN][k%TK]   (fixed order -> bitwise reproducible; common.cuh:wgrad_reduce_body)
-__global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_kernel(int N, int K, int TN, int TK, int nsplit,
-                                                                 const float* __restrict__ slabs,
-                                                                 const float* __restrict__ bslabs, float* __restrict__ dW,
-                                                                 int ldo, float* __restrict__ db) {
+__global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_kernel(upnerf_wgrad_pending P) {
   __shared__ f32x4 part[RED_RG][64];
-  wgrad_reduce_body(blockIdx.x, threadIdx.x, N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db, part);
+  wgrad_reduce_body(blockIdx.x, threadIdx.x, P, part);
+}
+static upnerf_wgrad_pending reduce_desc(int N, int K, int TN, int TK, int nsplit, const float* slabs, const float* bslabs, float* dW,
+                                        int ldo, float* db) {
+  const int quads = N * (K / 4);
+  int rblocks = (quads + 63) / 64;
+  if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
+  return upnerf_wgrad_pending{slabs, bslabs, dW, db, N, K, TN, TK, nsplit, ldo, rblocks, 0, nullptr, nullptr, 0, 0};
+}
+static void launch_reduce(hipStream_t st, const upnerf_wgrad_pending& P) {
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(P.rblocks), dim3(RED_THREADS), 0, st, P);
 }
 
 // ---- N = 1 / 3 heads: dw[c][k] = sum_m v[m][c] X[m][k].  HBM-bound stream of X: every lane owns 4 columns
@@ -632,11 +639,7 @@ extern "C" int upnerf_wgrad(int M, const float* A, int lda, int N, const float* 
   else rc = launch_wgrad<1, 1>(M, A, lda, N, B, ldb, K, slabs, bslabs, nsplit, rows, st);
   if (rc) return rc;
   if (ldo & 3) return UPNERF_EINVAL;  // 16-byte stores into dW
-  const int quads = N * (K / 4);
-  int rblocks = (quads + 63) / 64;
-  if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;  // the bias sum needs one thread per row
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(RED_THREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
-                     ldo, db);
+  launch_reduce(st, reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db));  // (the bias sum needs one thread per row)
   return (int)hipGetLastError();
 }
 
@@ -664,31 +667,28 @@ extern "C" int upnerf_wgrad_f16x3(int M, const float* A, int lda, int N, const f
   int rc = upnerf_wgrad_f16x3_partial(M, A, lda, N, B, ldb, K, expo_a, expo_b, slabs, bslabs, nsplit, rows, TN, TK,
                                       planes, nullptr, stream);
   if (rc) return rc;
-  const int quads = N * (K / 4);
-  int rblocks = (quads + 63) / 64;
-  if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(RED_THREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
-                     ldo, db);
+  launch_reduce(st, reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db));
   return (int)hipGetLastError();
 }
 
 extern "C" int upnerf_wgrad_finish(upnerf_wgrad_pending* p, void* stream) {
   if (!p) return UPNERF_EINVAL;
   if (p->nsplit <= 0) return 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p->rblocks), dim3(RED_THREADS), 0, (hipStream_t)stream, p->N, p->K, p->TN, p->TK,
-                     p->nsplit, p->slabs, p->bslabs, p->dW, p->ldo, p->db);
+  launch_reduce((hipStream_t)stream, *p);
   p->nsplit = 0;
   return (int)hipGetLastError();
 }
 
 // Chained upnerf_wgrad_f16x3 (include/upnerf_hip.h): the previous problem's slabs are summed by this launch's first workgroups.
-extern "C" int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
-                                        float* db, float* slabs, int nsplit, const int* expo_a, const int* expo_b, int planes,
-                                        upnerf_wgrad_pending* pending, void* stream) {
+extern "C" int upnerf_wgrad_f16x3_chain2(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
+                                         float* db, int n2, float* dW2, int ldo2, float* db2, float* slabs, int nsplit,
+                                         const int* expo_a, const int* expo_b, int planes, upnerf_wgrad_pending* pending,
+                                         void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b || !pending)
     return UPNERF_EINVAL;
   if (planes != 0 && planes != 1 && planes != 2) return UPNERF_EINVAL;
   if ((N & 3) || (K & 3) || (lda & 3) || (ldb & 3) || (ldo & 3)) return UPNERF_EINVAL;
+  if (n2 < 0 || n2 >= N || (n2 > 0 && (!dW2 || (ldo2 & 3)))) return UPNERF_EINVAL;
   if (pending->nsplit > 0 && pending->slabs == slabs) return UPNERF_EINVAL;  // the pending slabs would be overwritten
   int TN, TK;
   wgrad_shape(N, K, &TN, &TK);
@@ -702,11 +702,20 @@ extern "C" int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, c
   int rc = upnerf_wgrad_f16x3_partial(M, A, lda, N, B, ldb, K, expo_a, expo_b, slabs, bslabs, nsplit, rows, TN, TK, planes,
                                       pending->nsplit > 0 ? pending : nullptr, stream);
   if (rc) return rc;
-  const int quads = N * (K / 4);
-  int rblocks = (quads + 63) / 64;
-  if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
-  *pending = upnerf_wgrad_pending{slabs, bslabs, dW, db, N, K, TN, TK, nsplit, ldo, rblocks, 0};
+  upnerf_wgrad_pending P = reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db);
+  P.n2 = n2;
+  P.dW2 = dW2;
+  P.db2 = db2;
+  P.ldo2 = ldo2;
+  *pending = P;
   return 0;
+}
+
+extern "C" int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
+                                        float* db, float* slabs, int nsplit, const int* expo_a, const int* expo_b, int planes,
+                                        upnerf_wgrad_pending* pending, void* stream) {
+  return upnerf_wgrad_f16x3_chain2(M, A, lda, N, B, ldb, K, dW, ldo, db, 0, nullptr, 0, nullptr, slabs, nsplit, expo_a, expo_b, planes,
+                                   pending, stream);
 }
 
 extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, const int* aexp, int N, const void* B, int ldb,
@@ -730,11 +739,7 @@ extern "C" int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int3
   int rc = upnerf_wgrad_f16p_partial(M, A16, lda, aexp, N, B, ldb, bexp, b_is_f16, K, expo_a, expo_b, slabs, bslabs, nsplit, rows,
                                      TN, TK, stream);
   if (rc) return rc;
-  const int quads = N * (K / 4);
-  int rblocks = (quads + 63) / 64;
-  if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(RED_THREADS), 0, st, N, K, TN, TK, nsplit, slabs, bslabs, dW,
-                     ldo, db);
+  launch_reduce(st, reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db));
   return (int)hipGetLastError();
 }
 

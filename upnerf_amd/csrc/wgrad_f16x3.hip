@@ -81,8 +81,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
   if (prev.nsplit > 0) {
     const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (wg < prev.rblocks) {
-      wgrad_reduce_body(wg, tid, prev.N, prev.K, prev.TN, prev.TK, prev.nsplit, prev.slabs, prev.bslabs, prev.dW, prev.ldo, prev.db,
-                        (f32x4(*)[64])lds);
+      wgrad_reduce_body(wg, tid, prev, (f32x4(*)[64])lds);
       __syncthreads();
     }
   }

@@ -235,6 +235,15 @@ class WgradChain:
             planes, C.byref(self.pending), stream()), units=M)
         check(rc, "upnerf_wgrad_f16x3_chain")
 
+    def wgrad2(self, M, A, lda, N, B, ldb, K, dW_ptr, ldo, db_ptr, n2, dW2_ptr, ldo2, db2_ptr, expo_a, expo_b, planes=2):
+        """Rows [0, n2) of the result go to dW / db, rows [n2, N) to dW2 / db2 (two layers fed by the same B, A side by side)."""
+        ns = nsplit_for(M)
+        ws = self._slabs(ns)
+        rc = TIMER.run(f"wgrad16_{N}x{K}", lambda: lib.upnerf_wgrad_f16x3_chain2(
+            M, ptr(A), lda, N, ptr(B), ldb, K, dW_ptr, ldo, db_ptr, n2, dW2_ptr, ldo2, db2_ptr, ptr(ws), ns, expo_a, expo_b, planes,
+            C.byref(self.pending), stream()), units=M)
+        check(rc, "upnerf_wgrad_f16x3_chain2")
+
     def finish(self):
         check(lib.upnerf_wgrad_finish(C.byref(self.pending), stream()), "upnerf_wgrad_finish")
 

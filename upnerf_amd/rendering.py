@@ -64,6 +64,8 @@ FIELD_TILE = int(__import__("os").environ.get("UPNERF_FIELD_TILE", "0"))
 TILE_PARTIALS = int(__import__("os").environ.get("UPNERF_TILE_PARTIALS", "1"))
 # Slab reductions of the f16x3 weight gradients inside the next weight-gradient launch (upnerf_wgrad_f16x3_chain).
 WGRAD_CHAIN = int(__import__("os").environ.get("UPNERF_WGRAD_CHAIN", "1"))
+# Colour and candidate heads: [gz_r1 | gz_g1] stored as one tensor, one weight-gradient launch against e for both first layers.
+JOIN_HEADS = int(__import__("os").environ.get("UPNERF_JOIN_HEADS", "1"))
 
 
 def _planes() -> int:
@@ -252,9 +254,14 @@ class _FieldPass(torch.autograd.Function):
         gz_h = None if store16 else _empty(D, M, W, device=dev)
         gz16 = torch.empty(D, M, W, device=dev, dtype=torch.float16) if store16 else None
         gzexp = torch.empty(D, sv["hexp"].shape[1], device=dev, dtype=torch.int32) if store16 else None
-        gz_g1 = _empty(M, W2, device=dev) if cfg.use_cand else None
+        # [gz_r1 | gz_g1] as ONE [M][W] tensor when both heads are on and the chained f16x3 weight gradients run: the two first
+        # layers of the heads are both fed by e, so their weight gradients are one launch that reads e once (chain.wgrad2)
+        joined = bool(use16 and cfg.use_cand and cfg.use_rgb and JOIN_HEADS and WGRAD_CHAIN and W == 256
+                      and ctx.tile_rows == 64 and TILE_PARTIALS)  # (upnerf_ray_sum, the fallback, wants dense tensors)
+        gz_rg = _empty(M, W, device=dev) if joined else None
+        gz_g1 = (gz_rg[:, W2:] if joined else _empty(M, W2, device=dev)) if cfg.use_cand else None
         gz_g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
-        gz_r1 = _empty(M, W2, device=dev) if cfg.use_rgb else None
+        gz_r1 = (gz_rg[:, :W2] if joined else _empty(M, W2, device=dev)) if cfg.use_rgb else None
         dpre_s = _empty(M, device=dev)
         dpre_c = _empty(M, device=dev) if cfg.use_cand else None
         dpre_rgb = _empty(M, 4, device=dev) if cfg.use_rgb else None
@@ -271,8 +278,9 @@ class _FieldPass(torch.autograd.Function):
                           sigma_s=ptr(sv["sigma_s"]), sigma_c=ptr(sv["sigma_c"]), rgb=ptr(sv["rgb"]),
                           w_feat_s=ptr(w_feat), w_cj=ptr(sv["w_cj"]) if gG is not None else None, g_E_s=ptr(gE),
                           g_G_c=ptr(gG), x0=ptr(sv["x0"]), h=ptr(sv["h"]), g1=ptr(sv["g1"]), g2=ptr(sv["g2"]),
-                          r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e), gz_g1=ptr(gz_g1), gz_g2=ptr(gz_g2),
-                          gz_r1=ptr(gz_r1), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
+                          r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e),
+                          gz_g1=(gz_rg.data_ptr() + 4 * W2) if joined else ptr(gz_g1), gz_g2=ptr(gz_g2),
+                          gz_r1=ptr(gz_rg) if joined else ptr(gz_r1), gz_rg_ld=W if joined else 0, dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, tile_rows=ctx.tile_rows, xs=ptr(sv.get("x0f")), gz16=ptr(gz16),
                           gzexp=ptr(gzexp), tile_part=ptr(tile_part))
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
@@ -350,7 +358,11 @@ class _FieldPass(torch.autograd.Function):
             if tile_part is None:
                 check(lib.upnerf_ray_sum(R, S, ptr(gz_g1), W2, ptr(rs_c), st), "upnerf_ray_sum")
             if dP is not None:
-                wg(gz_g1, W2, W2, sv["e"], W, W, L.wc1, W + CK, L.bc1, D + 1, D)
+                if joined:  # rows [0, W2) -> wr1 / br1 (colour head), rows [W2, W) -> wc1 / bc1 (candidate head)
+                    chain.wgrad2(M, gz_rg, W, W, sv["e"], W, W, at(L.wr1), W + AUXK, at(L.br1), W2, at(L.wc1), W + CK, at(L.bc1),
+                                 EA(D + 4), EB(D), planes=ctx.planes)
+                else:
+                    wg(gz_g1, W2, W2, sv["e"], W, W, L.wc1, W + CK, L.bc1, D + 1, D)
                 wgrad_into(R, rs_c, W2, W2, sv["c_rows"], CK, CK, at(L.wc1 + W), W + CK, None, dev)
                 wg(gz_g2, W2, W2, sv["g1"], W2, W2, L.wc2, W2, L.bc2, D + 2, D + 1)
                 if tile_part is None:
@@ -361,7 +373,8 @@ class _FieldPass(torch.autograd.Function):
             if tile_part is None:
                 check(lib.upnerf_ray_sum(R, S, ptr(gz_r1), W2, ptr(rs_r), st), "upnerf_ray_sum")
             if dP is not None:
-                wg(gz_r1, W2, W2, sv["e"], W, W, L.wr1, W + AUXK, L.br1, D + 3, D)
+                if not joined:
+                    wg(gz_r1, W2, W2, sv["e"], W, W, L.wr1, W + AUXK, L.br1, D + 3, D)
                 wgrad_into(R, rs_r, W2, W2, sv["aux"], AUXK, AUXK, at(L.wr1 + W), W + AUXK, None, dev)
                 if tile_part is None:
                     vec_wgrad_into(M, dpre_rgb, 4, 3, sv["r1"], W2, W2, at(L.wr2), at(L.br2), dev)
