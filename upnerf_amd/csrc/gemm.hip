@@ -473,8 +473,12 @@ __global__ void zero_floats_kernel(float* __restrict__ p, int n) {
 // whose elements all carry one id -- descriptors are long runs -- issues ONE atomic.  (One element per thread was 2 400
 // workgroups = 2 400 atomics on a handful of addresses: 32 us for 2.4 MB.)
 #define AMAX_PER 8
-__global__ __launch_bounds__(256) void frag16_amax_kernel(const float* __restrict__ src, Frag16Descs D, float* __restrict__ amax) {
+// (both descriptor sets of upnerf_frag16 -- forward and transposed -- in one launch: blockIdx.y picks the set)
+__global__ __launch_bounds__(256) void frag16_amax_kernel(const float* __restrict__ src, Frag16Descs D0, Frag16Descs D1,
+                                                          float* __restrict__ amax) {
+  const Frag16Descs& D = blockIdx.y ? D1 : D0;
   const int total = D.start[D.n];
+  if ((int)(blockIdx.x * AMAX_PER * 256) >= total) return;
   float v = 0.0f;
   int id = -2;  // -2: nothing seen yet
   int j = 0;
@@ -541,10 +545,13 @@ __global__ void frag16_rownorm_kernel(const float* __restrict__ src, Frag16Descs
 // perm: k order inside a 16-deep block.  0: element j of lane half h holds k = 8h + j (operands read from memory);
 // 1: k = 8(j>>2) + 4h + (j&3) -- the order in which a 32x32 MFMA result, converted in place, presents its rows as the next
 // product's operand (cdna_hip_programming.md "An accumulator tile as the next MFMA's operand").
-__global__ void frag16_write_kernel(const float* __restrict__ src, char* __restrict__ dst, Frag16Descs D,
-                                    const float* __restrict__ amax, int* __restrict__ wexp, int perm) {
+__global__ void frag16_write_kernel(const float* __restrict__ src, char* __restrict__ dst0, char* __restrict__ dst1, Frag16Descs D0,
+                                    Frag16Descs D1, const float* __restrict__ amax, int* __restrict__ wexp, int perm0, int perm1) {
+  const Frag16Descs& D = blockIdx.y ? D1 : D0;
+  char* __restrict__ dst = blockIdx.y ? dst1 : dst0;
+  const int perm = blockIdx.y ? perm1 : perm0;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (wexp && blockIdx.x == 0 && threadIdx.x < 16) wexp[threadIdx.x] = frag16_exp(amax[threadIdx.x]);
+  if (wexp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) wexp[threadIdx.x] = frag16_exp(amax[threadIdx.x]);
   if (idx >= D.start[D.n]) return;
   int j = 0;
   while (idx >= D.start[j + 1]) ++j;
@@ -968,14 +975,11 @@ extern "C" int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, con
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, amax_scratch, 16);
   // maxima over the forward matrices and over the transposed ones (ids that exist only there, e.g. the fused head)
-  hipLaunchKernelGGL(frag16_amax_kernel, dim3((F.start[nfwd] + 256 * AMAX_PER - 1) / (256 * AMAX_PER)), dim3(256), 0, st, src, F,
+  const int tmax = F.start[nfwd] > Bd.start[nbwd] ? F.start[nfwd] : Bd.start[nbwd];
+  hipLaunchKernelGGL(frag16_amax_kernel, dim3((tmax + 256 * AMAX_PER - 1) / (256 * AMAX_PER), 2), dim3(256), 0, st, src, F, Bd,
                      amax_scratch);
-  hipLaunchKernelGGL(frag16_amax_kernel, dim3((Bd.start[nbwd] + 256 * AMAX_PER - 1) / (256 * AMAX_PER)), dim3(256), 0, st, src, Bd,
-                     amax_scratch);
-  hipLaunchKernelGGL(frag16_write_kernel, dim3((F.start[nfwd] + 255) / 256), dim3(256), 0, st, src, (char*)dst_fwd, F,
-                     amax_scratch, wexp, perm_fwd);
-  hipLaunchKernelGGL(frag16_write_kernel, dim3((Bd.start[nbwd] + 255) / 256), dim3(256), 0, st, src, (char*)dst_bwd, Bd,
-                     amax_scratch, (int*)nullptr, perm_bwd);
+  hipLaunchKernelGGL(frag16_write_kernel, dim3((tmax + 255) / 256, 2), dim3(256), 0, st, src, (char*)dst_fwd, (char*)dst_bwd, F, Bd,
+                     amax_scratch, wexp, perm_fwd, perm_bwd);
   if (wnorm) {  // [64]: forward descriptors at 0.., transposed ones at 32..
     hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, wnorm, 64);
     int rf = 0, rb = 0;

@@ -65,6 +65,56 @@ except Exception:
             loss.backward()
 
 
+class _LazyResults(dict):
+    """The results dict of NeRFSystem.forward with entries that are computed on first access (`lazy(key, thunk)`): present
+    for `in`, `keys()`, `get`, `[]`, `items()` like any other entry."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._thunks = {}
+
+    def lazy(self, key, thunk):
+        self._thunks[key] = thunk
+
+    def _force(self, key=None):
+        for k in ([key] if key is not None else list(self._thunks)):
+            if k in self._thunks:
+                super().__setitem__(k, self._thunks.pop(k)())
+
+    def __contains__(self, key):
+        return key in self._thunks or super().__contains__(key)
+
+    def __getitem__(self, key):
+        self._force(key)
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __setitem__(self, key, value):
+        self._thunks.pop(key, None)
+        super().__setitem__(key, value)
+
+    def __iter__(self):
+        self._force()
+        return super().__iter__()
+
+    def __len__(self):
+        return super().__len__() + len(self._thunks)
+
+    def keys(self):
+        self._force()
+        return super().keys()
+
+    def items(self):
+        self._force()
+        return super().items()
+
+    def values(self):
+        self._force()
+        return super().values()
+
+
 class NeRFSystem(_Base):
     supports_graph_step = True  # training_step splits into _step_backward / _step_update / _step_host (graph_step.py)
 
@@ -185,10 +235,14 @@ class NeRFSystem(_Base):
                 else:
                     t = self.transient_net(feats, img_idx)
                 t_rgbs, t_alphas, t_betas = t["rgb"], t["alpha"], t["beta"]
-                results["rgb_coarse"] = results["s_rgb_coarse"] * (1 - t_alphas.detach()) \
-                    + t_rgbs.detach() * t_alphas.detach()
+                # the blended colours (models/nerf_system.py:136-142) have one reader, the validation PSNR (:268): they are
+                # evaluated when somebody asks for them -- the training step never does (its loss reads s_rgb_*, losses.py:38,59)
+                results = _LazyResults(results)
+                s_c = results["s_rgb_coarse"]
+                results.lazy("rgb_coarse", lambda: s_c * (1 - t_alphas.detach()) + t_rgbs.detach() * t_alphas.detach())
                 if "s_rgb_fine" in results:
-                    results["rgb_fine"] = results["s_rgb_fine"] * (1 - t_alphas) + t_rgbs * t_alphas
+                    s_f = results["s_rgb_fine"]
+                    results.lazy("rgb_fine", lambda: s_f * (1 - t_alphas) + t_rgbs * t_alphas)
                 results["t_beta"], results["t_alpha"] = t_betas, t_alphas
             else:
                 results["rgb_coarse"] = results["s_rgb_coarse"]

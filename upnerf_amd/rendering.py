@@ -168,7 +168,10 @@ class _FieldPass(torch.autograd.Function):
         e = _empty(M, W, device=dev) if (train or want_feat) else None
         hmask = torch.empty((D + 1) * ((M + 127) // 128) * 512, device=dev,  # 64 bits per lane and tile, either tiling
                             dtype=torch.int64) if train else None
-        amax = torch.zeros(16, device=dev) if train else None  # running max|.| (scales of the f16x3 weight gradients)
+        # running max|.| of the stored tensors (scales of the f16x3 weight gradients): slots [0, 16) filled by this pass, [16, 32)
+        # by the backward kernel -- one zero fill and, later, one exponent launch for both
+        mx32 = torch.zeros(32, device=dev) if train else None
+        amax = mx32[:16] if train else None
         g1 = _empty(M, W2, device=dev) if (cfg.use_cand and train) else None
         g2 = _empty(M, W2, device=dev) if (cfg.use_cand and (train or joint)) else None
         r1 = _empty(M, W2, device=dev) if (cfg.use_rgb and train) else None
@@ -208,7 +211,7 @@ class _FieldPass(torch.autograd.Function):
         ctx.cfg, ctx.dims, ctx.planes, ctx.tile_rows = cfg, (R, S), _planes(), tile
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, mx32=mx32, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
                          w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s)
         z0 = torch.zeros(0, device=dev)
@@ -266,7 +269,7 @@ class _FieldPass(torch.autograd.Function):
         dpre_c = _empty(M, device=dev) if cfg.use_cand else None
         dpre_rgb = _empty(M, 4, device=dev) if cfg.use_rgb else None
         dxyz = _empty(M, 3, device=dev) if need_dxyz else None
-        gmax = torch.zeros(16, device=dev)
+        gmax = sv["mx32"][16:]
         # 64-sample f16 kernels: per-tile partial sums of the 128-wide vector heads and of the per-ray sums, written by the
         # backward kernel (which holds those tiles anyway) and finished by three small launches -- instead of five kernels
         # that read M x 128 tensors again
@@ -299,12 +302,11 @@ class _FieldPass(torch.autograd.Function):
             h, x0 = sv["h"], sv["x0"]
             # power-of-two scales of the f16x3 contraction: 2^14 / max|.| per tensor, from the maxima the field kernels
             # tracked (device side, no host sync).  ea[i] pairs with gmax slot i, eb[i] with amax slot i.
-            ea, eb = torch.empty(16, device=dev, dtype=torch.int32), torch.empty(16, device=dev, dtype=torch.int32)
-            check(lib.upnerf_scale_exponents(ptr(gmax), 16, ptr(ea), st), "upnerf_scale_exponents")
-            check(lib.upnerf_scale_exponents(ptr(sv["amax"]), 16, ptr(eb), st), "upnerf_scale_exponents")
-            EA = lambda i: ea.data_ptr() + 4 * i
-            EB = lambda i: eb.data_ptr() + 4 * i
-            ctx_keep = (ea, eb)
+            e32 = torch.empty(32, device=dev, dtype=torch.int32)
+            check(lib.upnerf_scale_exponents(ptr(sv["mx32"]), 32, ptr(e32), st), "upnerf_scale_exponents")
+            EA = lambda i: e32.data_ptr() + 4 * (16 + i)
+            EB = lambda i: e32.data_ptr() + 4 * i
+            ctx_keep = (e32,)
 
             # WGRAD_CHAIN: the slab reduction of every f16x3 weight gradient rides on the next one's launch (ops.WgradChain)
             chain = WgradChain(dev) if WGRAD_CHAIN else None
@@ -429,23 +431,77 @@ def _zeros(rows, cols, device):
     return _ZEROS[key]
 
 
+class _ProjectFeat(torch.autograd.Function):
+    """feat = [x_0 | x_1 | ... | 0] . [w_0 | w_1 | ... | 0]^T with the pieces gathered by ONE pack launch and every gradient
+    handed back contiguous by ONE unpack launch (torch.cat + autograd's slices cost a copy launch per piece: the compositing
+    backward wants dense [R][W] rows, AccumulateGrad clones a strided weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, n, *tensors):
+        from ._lib import PackDesc
+        xs, ws = tensors[:n], tensors[n:]
+        R, N, dev = xs[0].shape[0], ws[0].shape[0], xs[0].device
+        cols = [x.shape[1] for x in xs]
+        K = sum(cols)
+        Kp = (K + 31) // 32 * 32
+        st = stream()
+        keep = [t.detach().contiguous() for t in tensors]
+        buf = torch.empty((R + N) * Kp, device=dev)
+        descs, k0 = [], 0
+        for j, c in enumerate(cols):
+            descs.append(PackDesc(ptr(keep[j]), R, c, c, k0, Kp, 0))
+            descs.append(PackDesc(ptr(keep[n + j]), N, c, c, R * Kp + k0, Kp, 0))
+            k0 += c
+        if Kp != K:  # the padding columns come from a cached zero block: no fill launch
+            descs.append(PackDesc(ptr(_zeros(R, Kp - K, dev)), R, Kp - K, Kp - K, K, Kp, 0))
+            descs.append(PackDesc(ptr(_zeros(N, Kp - K, dev)), N, Kp - K, Kp - K, R * Kp + K, Kp, 0))
+        arr = (PackDesc * len(descs))(*descs)
+        check(lib.upnerf_pack(ptr(buf), arr, len(descs), 0, st), "upnerf_pack")
+        X, Wc = buf[:R * Kp].view(R, Kp), buf[R * Kp:].view(N, Kp)
+        y = _empty(R, N, device=dev)
+        check(lib.upnerf_linear(R, N, Kp, ptr(X), Kp, ptr(Wc), Kp, None, ptr(y), N, 0, st), "upnerf_linear")
+        ctx.n, ctx.cols, ctx.dims, ctx.buf = n, cols, (R, N, K, Kp), buf
+        ctx.shapes = [tuple(t.shape) for t in tensors]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from ._lib import PackDesc
+        from .ops import wgrad_blocks_into
+        n, cols, (R, N, K, Kp), buf = ctx.n, ctx.cols, ctx.dims, ctx.buf
+        dev = gy.device
+        st = stream()
+        gy = gy.contiguous()
+        X, Wc = buf[:R * Kp].view(R, Kp), buf[R * Kp:].view(N, Kp)
+        g = torch.empty((R + N) * Kp, device=dev)
+        gX, gW = g[:R * Kp].view(R, Kp), g[R * Kp:].view(N, Kp)
+        check(lib.upnerf_linear(R, Kp, N, ptr(gy), N, ptr(Wc), Kp, None, ptr(gX), Kp, 2, st), "upnerf_linear")  # gy . Wc
+        wgrad_blocks_into(R, gy, N, N, X, Kp, Kp, ptr(gW), Kp, None, dev)                                        # gy^T . X
+        outs = [torch.empty(sh, device=dev) for sh in ctx.shapes]
+        descs, k0 = [], 0
+        for j, c in enumerate(cols):
+            if ctx.needs_input_grad[1 + j]:
+                descs.append(PackDesc(ptr(outs[j]), R, c, c, k0, Kp, 0))
+            if ctx.needs_input_grad[1 + n + j]:
+                descs.append(PackDesc(ptr(outs[n + j]), N, c, c, R * Kp + k0, Kp, 0))
+            k0 += c
+        if descs:
+            arr = (PackDesc * len(descs))(*descs)
+            check(lib.upnerf_pack(ptr(g), arr, len(descs), 1, st), "upnerf_pack")
+        return (None,) + tuple(o if ctx.needs_input_grad[1 + i] else None for i, o in enumerate(outs))
+
+
 def _project_feat(model, E_s, sum_sfeat, G_c=None, t_weight=None):
     """feat map = W_f (sum w e) + b_f sum w  [+ W_cf (sum w_c g) + b_cf sum w_c]  (nerf.py:95,100 composited by
     rendering.py:166-177) as ONE product [E_s | sum w | G_c | sum w_c | 0] . [W_f | b_f | W_cf | b_cf | 0]^T: the bias terms
-    ride along as one more input column each (three launches forward and a handful backward instead of ~35 elementwise
-    and reduction launches; K padded to the next multiple of 32 for the weight-gradient kernel)."""
+    ride along as one more input column each (K padded to the next multiple of 32 for the weight-gradient kernel)."""
     fs = model.feat_share_layer
     xs, ws = [E_s, sum_sfeat[:, None]], [fs.weight, fs.bias[:, None]]
     if G_c is not None:
         fc = model.feat_candidate_layer
         xs += [G_c, t_weight[:, None]]
         ws += [fc.weight, fc.bias[:, None]]
-    K = sum(x.shape[1] for x in xs)
-    pad = (-K) % 32
-    if pad:
-        xs.append(_zeros(E_s.shape[0], pad, E_s.device))
-        ws.append(_zeros(fs.weight.shape[0], pad, E_s.device))
-    return hip_linear(torch.cat(xs, 1), torch.cat(ws, 1))
+    return _ProjectFeat.apply(len(xs), *xs, *ws)
 
 
 def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use_disp=False, perturb=0,
