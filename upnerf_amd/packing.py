@@ -328,8 +328,9 @@ class NerfPacker:
         forward set in the k order of the register-resident forward kernel, plus the row norms it bounds its exponents with."""
         from ._lib import check, lib, ptr, stream
         fd, nf, bd, nb = self._descs16()
-        P16 = torch.zeros(self.L.total, device=P.device, dtype=torch.float32)
-        PT16 = torch.zeros(self.L.t_total, device=P.device, dtype=torch.float32)
+        t0 = (self.L.total + 63) // 64 * 64  # the transposed set starts on a 256-byte boundary
+        both = torch.zeros(t0 + self.L.t_total, device=P.device, dtype=torch.float32)  # one fill for the two sets
+        P16, PT16 = both[:self.L.total], both[t0:]
         scratch = torch.empty(16, device=P.device, dtype=torch.float32)
         wexp = torch.empty(16, device=P.device, dtype=torch.int32)
         wnorm = torch.empty(64, device=P.device, dtype=torch.float32) if perm_fwd else None

@@ -555,7 +555,7 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
               "upnerf_uniform_keyed")
         return t
 
-    rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
+    rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()  # once, not once per field pass
     near_far = rays[:, 6:8].detach().contiguous()
     z = _empty(R, N_samples, device=dev)
     u0 = draw(N_samples) if perturb > 0 else None
