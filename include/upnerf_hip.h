@@ -522,6 +522,12 @@ int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, const upnerf_f
  * time: a captured graph follows the step count and the learning-rate schedule from one replay to the next. */
 int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float beta1, float beta2, float eps,
                 float step_size, float bc2_sqrt, const float* dyn2, void* stream);
+/* The same update over ndesc pieces of the flat buffers, each with its gradient wherever autograd left it: piece j covers
+ * elements [off, off + n) of p / m / v and reads the n floats at g.  Bitwise the result of gathering the gradients first. */
+#define UPNERF_MAX_ADAM_DESC 96
+typedef struct { const float* g; int32_t off, n; } upnerf_adam_desc;
+int upnerf_adam_gather(float* p, float* m, float* v, const upnerf_adam_desc* descs /*host*/, int ndesc, float beta1, float beta2,
+                       float eps, float step_size, float bc2_sqrt, const float* dyn2, void* stream);
 
 /* ---- per-step scalars for captured HIP graphs: dst[i] = vals[i], i < n <= UPNERF_MAX_SCALARS --------------------------
  * `vals` is HOST memory, copied into the kernel arguments at call time (no staging buffer whose lifetime the caller would

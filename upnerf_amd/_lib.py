@@ -106,6 +106,13 @@ class TransientGrads(C.Structure):
     _fields_ = [(n, _fp) for n in ("d_alpha", "d_rgb", "d_beta", "dz_heads", "gz_t", "gz_e", "gz_h", "g_temb", "g_feat")]
 
 
+class AdamDesc(C.Structure):
+    _fields_ = [("g", _fp), ("off", C.c_int32), ("n", C.c_int32)]
+
+
+MAX_ADAM_DESC = 96
+
+
 class WgradPending(C.Structure):
     _fields_ = [("slabs", _fp), ("bslabs", _fp), ("dW", _fp), ("db", _fp), ("N", C.c_int32), ("K", C.c_int32), ("TN", C.c_int32),
                 ("TK", C.c_int32), ("nsplit", C.c_int32), ("ldo", C.c_int32), ("rblocks", C.c_int32), ("n2", C.c_int32),
@@ -180,6 +187,7 @@ _SIGNATURES = {
     "upnerf_loss_bwd": [C.POINTER(LossArgs), _p, C.POINTER(LossGrads), _p],
     "upnerf_frag_copy": [_p, _p, C.POINTER(FragDesc), _i, _p],
     "upnerf_adam": [C.c_int64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p],
+    "upnerf_adam_gather": [_p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p],
     "upnerf_set_scalars": [_p, _i, C.POINTER(C.c_float), _p],
     "upnerf_scale_exponents": [_p, _i, _p, _p],
 }

@@ -991,6 +991,56 @@ extern "C" int upnerf_frag16(const float* src, void* dst_fwd, void* dst_bwd, con
   return (int)hipGetLastError();
 }
 
+// The same update with the gradients read where autograd left them: descriptor j covers flat elements [off, off + n) of p / m / v
+// and the n floats at g (no gather of ~70 gradient tensors into a flat buffer first: two multi-tensor copy launches per step).
+struct AdamDescs {
+  upnerf_adam_desc d[UPNERF_MAX_ADAM_DESC];
+  int bstart[UPNERF_MAX_ADAM_DESC + 1];  // first 1024-element block of every descriptor
+  int n;
+};
+__global__ __launch_bounds__(256) void adam_gather_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                          AdamDescs D, float b1, float b2, float eps, float step_size, float bc2_sqrt,
+                                                          const float* __restrict__ dyn2) {
+  int j = 0;
+  while ((int)blockIdx.x >= D.bstart[j + 1]) ++j;  // uniform per workgroup
+  const upnerf_adam_desc q = D.d[j];
+  const int e0 = ((int)blockIdx.x - D.bstart[j]) * 1024 + threadIdx.x;
+  if (dyn2) {
+    step_size = dyn2[0];
+    bc2_sqrt = dyn2[1];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = e0 + 256 * u;
+    if (e < q.n) {
+      const size_t i = (size_t)q.off + e;
+      const float gi = q.g[e];
+      const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+      const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      const float denom = sqrtf(vi) / bc2_sqrt + eps;
+      p[i] = p[i] - step_size * (mi / denom);
+    }
+  }
+}
+
+extern "C" int upnerf_adam_gather(float* p, float* m, float* v, const upnerf_adam_desc* descs, int ndesc, float beta1, float beta2,
+                                  float eps, float step_size, float bc2_sqrt, const float* dyn2, void* stream) {
+  if (!p || !m || !v || !descs || ndesc <= 0 || ndesc > UPNERF_MAX_ADAM_DESC) return UPNERF_EINVAL;
+  AdamDescs D;
+  D.n = ndesc;
+  D.bstart[0] = 0;
+  for (int j = 0; j < ndesc; ++j) {
+    if (!descs[j].g || descs[j].n <= 0 || descs[j].off < 0) return UPNERF_EINVAL;
+    D.d[j] = descs[j];
+    D.bstart[j + 1] = D.bstart[j] + (descs[j].n + 1023) / 1024;
+  }
+  hipLaunchKernelGGL(adam_gather_kernel, dim3(D.bstart[ndesc]), dim3(256), 0, (hipStream_t)stream, p, m, v, D, beta1, beta2, eps,
+                     step_size, bc2_sqrt, dyn2);
+  return (int)hipGetLastError();
+}
+
 extern "C" int upnerf_adam(int64_t n, float* p, const float* g, float* m, float* v, float beta1, float beta2, float eps,
                            float step_size, float bc2_sqrt, const float* dyn2, void* stream) {
   if (n <= 0 || !p || !g || !m || !v) return UPNERF_EINVAL;

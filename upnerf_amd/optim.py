@@ -77,14 +77,25 @@ class FlatAdam(torch.optim.Optimizer):
         live, runs = self._plan()
         if not live:
             return []
-        torch._foreach_copy_([self.flat_g[self._spans[i][1]:self._spans[i][1] + self._spans[i][2]].view_as(self._spans[i][0])
-                              for i in live], [self._spans[i][0].grad for i in live])
+        from ._lib import MAX_ADAM_DESC, AdamDesc
         dyn = step_scalars.current()
+        grads = {i: self._spans[i][0].grad for i in live}
+        in_place = all(g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda for g in grads.values())
+        if not in_place:  # (strided or foreign gradients: gather them into the flat buffer first)
+            torch._foreach_copy_([self.flat_g[self._spans[i][1]:self._spans[i][1] + self._spans[i][2]].view_as(self._spans[i][0])
+                                  for i in live], [grads[i] for i in live])
         for run in runs:
-            a, b = self._spans[run[0]][1], self._spans[run[-1]][1] + self._spans[run[-1]][2]
-            p, g, m, v = self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b]
             step_size, bc2s = self._scalars(run[0])
             dyn2 = dyn.ptr_fn(2, lambda first=run[0]: self._scalars(first)) if dyn is not None else None
+            if in_place:  # the update reads every gradient where autograd left it: one launch per run of <= 96 tensors
+                for c0 in range(0, len(run), MAX_ADAM_DESC):
+                    part = run[c0:c0 + MAX_ADAM_DESC]
+                    arr = (AdamDesc * len(part))(*[AdamDesc(grads[i].data_ptr(), self._spans[i][1], self._spans[i][2]) for i in part])
+                    check(lib.upnerf_adam_gather(ptr(self.flat_p), ptr(self.flat_m), ptr(self.flat_v), arr, len(part), b1, b2, eps,
+                                                 step_size, bc2s, dyn2, stream()), "upnerf_adam_gather")
+                continue
+            a, b = self._spans[run[0]][1], self._spans[run[-1]][1] + self._spans[run[-1]][2]
+            p, g, m, v = self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b]
             check(lib.upnerf_adam(b - a, ptr(p), ptr(g), ptr(m), ptr(v), b1, b2, eps, step_size, bc2s, dyn2, stream()),
                   "upnerf_adam")
         return runs
