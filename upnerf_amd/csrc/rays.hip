@@ -454,21 +454,32 @@ __global__ void embed_bwd_grouped_kernel(int R, int N, const long long* __restri
   for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[t][q] = 0.f;
-  for (int base = 0; base < R; base += 64) {
-    const int r = base + lane;
-    const bool hit = r < R && idx[r] == (long long)n;
-    unsigned long long m = __ballot(hit);
-    while (m) {
-      const int j = __ffsll((long long)m) - 1;
-      m &= m - 1;
+  // the index scan runs eight 64-ray groups ahead of the accumulation (one load per group would be a chain of 64 L2 round
+  // trips for a table row that, typically, no ray of the batch hits)
+  constexpr int U = 8;
+  for (int base0 = 0; base0 < R; base0 += 64 * U) {
+    long long iv[U];
 #pragma unroll
-      for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t) {
-        if (t < T.n) {
-          const int dim = T.dim[t];
-          const float* __restrict__ row = T.g[t] + (size_t)(base + j) * dim;
+    for (int u = 0; u < U; ++u) {
+      const int r = base0 + 64 * u + lane;
+      iv[u] = r < R ? idx[r] : -1;
+    }
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (lane + 64 * q < dim) acc[t][q] += row[lane + 64 * q];
+    for (int u = 0; u < U; ++u) {
+      const int base = base0 + 64 * u;
+      unsigned long long m = __ballot(iv[u] == (long long)n);
+      while (m) {
+        const int j = __ffsll((long long)m) - 1;
+        m &= m - 1;
+#pragma unroll
+        for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t) {
+          if (t < T.n) {
+            const int dim = T.dim[t];
+            const float* __restrict__ row = T.g[t] + (size_t)(base + j) * dim;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (lane + 64 * q < dim) acc[t][q] += row[lane + 64 * q];
+          }
         }
       }
     }

@@ -41,8 +41,8 @@ class _PackFn(torch.autograd.Function):
         # folded colour layer: W_r1[:, :F] . W_feat -> wr1[:, :W];  W_r1[:, :F] . b_feat + b_r1 -> br1
         check(lib.upnerf_linear(W2, W, Fd, wrF, Fd, ptr(p["feat_share_layer.weight"]), W, None, base + 4 * L.wr1, W + AUXK, 2,
                                 st), "upnerf_linear")
-        check(lib.upnerf_linear(W2, 1, Fd, wrF, Fd, ptr(p["feat_share_layer.bias"]), 1, None, base + 4 * L.br1, 1, 2, st),
-              "upnerf_linear")
+        # (a 128 x 384 matrix-vector product: rocBLAS gemv, 6 us; the 64 x 64-tile GEMM kernel took 25 us for it)
+        torch.mv(buf[L.total:].view(W2, Fd), p["feat_share_layer.bias"], out=buf[L.br1:L.br1 + W2])
         acc = (PackDesc * 1)(PackDesc(ptr(p["rgb_share_layer.0.bias"]), 1, W2, W2, L.br1, W2, 1))
         check(lib.upnerf_pack(ptr(buf), acc, 1, 0, st), "upnerf_pack")
         ctx.packer, ctx.names, ctx.buf = packer, names, buf
