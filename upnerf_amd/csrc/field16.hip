@@ -29,7 +29,9 @@
 //                         the same fragment.
 #define ACT_STORE(p, v) NT_STORE(p, v)  // activations / gradients for a later kernel (common.cuh: streaming accesses)
 #define F16_TILE 64
-#define F16_WAVES 4
+#ifndef F16_WAVES
+#define F16_WAVES 4  // waves of a 64-sample workgroup (experiment: 8 = one 32-column tile per wave, four waves per SIMD)
+#endif
 #define F16_TILE_BIG 128
 #define F16_WAVES_BIG 8
 // two workgroups per CU = 2 waves per SIMD; hipcc takes the second __launch_bounds__ argument as the minimum number of
@@ -39,7 +41,7 @@
 #ifndef F16_WAVES_PER_EU_F16
 #define F16_WAVES_PER_EU_F16 2
 #endif
-#define F16_EU(NP, TILE) ((NP) == 1 && (TILE) == 64 ? F16_WAVES_PER_EU_F16 : F16_WAVES_PER_EU)
+#define F16_EU(NP, TILE) ((TILE) == 64 && F16_WAVES == 8 ? 4 : ((NP) == 1 && (TILE) == 64 ? F16_WAVES_PER_EU_F16 : F16_WAVES_PER_EU))
 // Weight fragments are requested this many 16-deep k-blocks ahead of the MFMAs that consume them.  Measured with the stamps
 // build (per wave and trunk layer): f16 mode 10.4k cycles per K loop one block ahead = 650 cycles per k-block = the L2
 // latency, 8.1k three ahead and 8.3k seven ahead -- from there on the loop is bound by the bytes the CU can pull from L2
@@ -943,10 +945,10 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
   __shared__ __attribute__((aligned(16))) float dprgb_s[TILE][4];
   __shared__ int loff_s[UPNERF_MAX_D];  // t_w[l] (see the forward kernel: no runtime index into the by-value struct)
   // per-tile partial sums (a.tile_part, 64-sample tiles only): ray slot of every row; cross-wave reduction scratch
-  constexpr int TPW = TILE == F16_TILE ? NW : 1;
+  constexpr int TPW = (TILE == F16_TILE && NW == 4) ? NW : 1;  // (the 8-wave experiment of the 64-sample tile: no partial sums)
   __shared__ int slot_s[TILE];
   __shared__ __attribute__((aligned(16))) float red_s[TPW][32][24];
-  const bool tp = TILE == F16_TILE && a.tile_part != nullptr;
+  const bool tp = TILE == F16_TILE && NW == 4 && a.tile_part != nullptr;
   const int gld = a.gz_rg_ld > 0 ? a.gz_rg_ld : W2;  // row stride of gz_r1 / gz_g1
   f32x4 tp_c = {0.f, 0.f, 0.f, 0.f}, tp_r[3], tp_sg[MAXRAYS], tp_sr[MAXRAYS];
 #pragma unroll

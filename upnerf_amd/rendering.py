@@ -66,6 +66,7 @@ TILE_PARTIALS = int(__import__("os").environ.get("UPNERF_TILE_PARTIALS", "1"))
 WGRAD_CHAIN = int(__import__("os").environ.get("UPNERF_WGRAD_CHAIN", "1"))
 # Colour and candidate heads: [gz_r1 | gz_g1] stored as one tensor, one weight-gradient launch against e for both first layers.
 JOIN_HEADS = int(__import__("os").environ.get("UPNERF_JOIN_HEADS", "1"))
+HMASK_SCALE = int(__import__("os").environ.get("UPNERF_HMASK_SCALE", "1"))  # experiment builds with more threads per tile
 
 
 def _planes() -> int:
@@ -166,7 +167,7 @@ class _FieldPass(torch.autograd.Function):
         hexp = torch.empty(D, ntile, device=dev, dtype=torch.int32) if store16 else None
         h = (_empty(1, M, W, device=dev) if store16 else _empty(D, M, W, device=dev)) if train else None
         e = _empty(M, W, device=dev) if (train or want_feat) else None
-        hmask = torch.empty((D + 1) * ((M + 127) // 128) * 512, device=dev,  # 64 bits per lane and tile, either tiling
+        hmask = torch.empty((D + 1) * ((M + 127) // 128) * 512 * HMASK_SCALE, device=dev,  # 64 bits per lane and tile, either tiling
                             dtype=torch.int64) if train else None
         # running max|.| of the stored tensors (scales of the f16x3 weight gradients): slots [0, 16) filled by this pass, [16, 32)
         # by the backward kernel -- one zero fill and, later, one exponent launch for both
