@@ -131,6 +131,9 @@ __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int
   static_assert(TILE * GPR % THREADS == 0, "whole passes of the workgroup");
   constexpr int B = (BATCH == 0 || BATCH > ITER) ? ITER : BATCH;
   static_assert(ITER % B == 0, "whole batches");
+#if F16_WAVES == 8 || defined(F16_OPAQUE_STORE)
+  asm volatile("" : "+v"(tid));  // (128-register build: keep hipcc from hoisting every row address out of the caller's layer loop)
+#endif
   const bool whole = m0 + TILE <= M;
 #pragma unroll 1
   for (int it0 = 0; it0 < ITER; it0 += B) {
@@ -214,6 +217,9 @@ __device__ __forceinline__ void tile_copy16(const char* Ph, int e, int e2, uint1
                                             int m0, int M, int tid) {
   constexpr int GPR = W >> 3, ITER = TILE * GPR / THREADS;
   if (tid < TILE / 64 && m0 + 64 * tid < M) dexp[m0 / 64 + tid] = tid == 0 ? e : e2;
+#if F16_WAVES == 8  // (128-register build; in the default build the hoisted, partly spilled offsets measured FASTER than recomputing them)
+  asm volatile("" : "+v"(tid));
+#endif
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
     const int idx = tid + it * THREADS, row = idx / GPR, g = idx % GPR;
@@ -506,7 +512,11 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   char* Pl = planes + (NP - 1) * TILE * W * 2;  // NP == 1: never dereferenced
   using TW = WaveTile16<W, TILE, NW>;
   using TH = WaveTile16<W2, TILE, NW>;
+#if F16_WAVES == 8 || defined(F16_SCALAR_WAVE)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: no 64-bit per-lane bases)
+#else
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#endif
   const int li = lane & 31, hh = lane >> 5;
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE;
   const float* __restrict__ P = a.P;
@@ -958,7 +968,11 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
   using TW = WaveTile16<W, TILE, NW>;
   using TH = WaveTile16<W2, TILE, NW>;
   using TX = WaveTile16<UPNERF_X0, TILE, NW>;
+#if F16_WAVES == 8 || defined(F16_SCALAR_WAVE)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: no 64-bit per-lane bases)
+#else
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#endif
   const int li = lane & 31, hh = lane >> 5;
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE, D = L.D;
   const float* __restrict__ P = a.P;
