@@ -689,6 +689,65 @@ def test_joined_head_gradients_match_the_separate_launches(hip, R, S, field_mode
     assert torch.equal(dPa, dPb)
 
 
+@pytest.mark.parametrize("field_mode", ["f16x3", "f16"], indirect=True)
+def test_chained_slab_reductions_are_bitwise_the_separate_ones(hip, field_mode):
+    """upnerf_wgrad_f16x3_chain (the slabs of one weight gradient summed by the first workgroups of the next launch) against
+    one reduction launch per weight gradient: same slabs, same summation order -- every parameter gradient bit for bit."""
+    from upnerf_amd import synth
+    from upnerf_amd.nerf import NeRF
+    rd = hip["rendering"]
+    kw = dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    model = NeRF("coarse", c2f=None, **kw)
+    model.load_state_dict(synth.nerf_state("coarse", seed=3, **kw))
+    model = model.cuda()
+    pk = model.packer
+    R, S = 9, 72
+    o = (gen((R, 3), 70) * 0.3).cuda()
+    d = torch.nn.functional.normalize(gen((R, 3), 71), dim=-1).cuda()
+    z = (torch.sort(gen((R, S), 72).abs() * 3 + 0.1, dim=-1).values).cuda()
+    c_rows, a_rows = gen((R, 16), 73).cuda(), gen((R, 48), 74).cuda()
+    cfg = rd._PassCfg(pk, 1, True, True, [1.0] * 10, [1.0] * 4)
+    res = {}
+    old, old_join = rd.WGRAD_CHAIN, rd.JOIN_HEADS
+    rd.JOIN_HEADS = 0  # (the joined launch exists only in the chained form)
+    try:
+        for ch in (0, 1):
+            rd.WGRAD_CHAIN = ch
+            leaves = [t.clone().requires_grad_(True) for t in (o, d, c_rows, a_rows, model.packed().detach())]
+            outs = rd._FieldPass.apply(leaves[0], leaves[1], z, leaves[2], leaves[3], leaves[4], cfg)
+            sum((t * gen(tuple(t.shape), 80 + i).cuda()).sum() for i, t in enumerate(outs) if t.numel()).backward()
+            res[ch] = [cpu(t.grad) for t in leaves]
+    finally:
+        rd.WGRAD_CHAIN, rd.JOIN_HEADS = old, old_join
+    for i in range(5):
+        assert torch.equal(res[0][i], res[1][i]), i
+
+
+def test_adam_update_with_gradients_in_place_is_bitwise_the_flat_one(hip):
+    """upnerf_adam_gather (every piece reads its gradient where autograd left it) against upnerf_adam on gathered gradients."""
+    from upnerf_amd import _lib
+    import ctypes as C
+    lib, ptr = _lib.lib, _lib.ptr
+    sizes = [1, 3, 1024, 1025, 7, 65536 + 5, 256 * 320]
+    n = sum(sizes)
+    p0, m0, v0 = gen((n,), 31).cuda(), gen((n,), 32).cuda() * 0.01, gen((n,), 33).cuda().abs() * 1e-4
+    grads = [gen((k,), 40 + i).cuda() for i, k in enumerate(sizes)]
+    flat_g = torch.cat(grads)
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    args = (0.9, 0.999, 1e-8, 1e-3 / (1 - 0.9 ** 3), (1 - 0.999 ** 3) ** 0.5)
+    assert lib.upnerf_adam(n, ptr(pa), ptr(flat_g), ptr(ma), ptr(va), *args, None, None) == 0
+    descs, off = [], 0
+    for g in grads:
+        descs.append(_lib.AdamDesc(g.data_ptr(), off, g.numel()))
+        off += g.numel()
+    arr = (_lib.AdamDesc * len(descs))(*descs)
+    assert lib.upnerf_adam_gather(ptr(pb), ptr(mb), ptr(vb), arr, len(descs), *args, None, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert not torch.equal(pa, p0)
+
+
 def _ragged_tiles(hip, R, S, mode, use_cand, use_rgb):
     """f16x3 kernels against the fp32 kernels on shapes whose tiles are ragged (M % 64 != 0) and straddle up to three
     rays; large and tiny magnitudes mixed so that the per-tile exponents differ between tiles and stages."""

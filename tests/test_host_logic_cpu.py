@@ -1,0 +1,22 @@
+"""Host-side logic that needs no GPU."""
+import pytest
+
+
+
+def test_lazy_results_behave_like_a_dict():
+    """NeRFSystem.forward returns the blended colours as entries that are computed on first access (models/nerf_system.py:
+    136-142 have one reader, the validation PSNR): every way of reading the dict sees them, nothing runs before that."""
+    from upnerf_amd.nerf_system import _LazyResults
+    calls = []
+    r = _LazyResults({"a": 1})
+    r.lazy("b", lambda: calls.append("b") or 2)
+    r.lazy("c", lambda: calls.append("c") or 3)
+    assert "b" in r and "c" in r and "z" not in r and len(r) == 3 and not calls
+    assert r.get("z", 7) == 7 and not calls
+    assert r["b"] == 2 and calls == ["b"]
+    assert r["b"] == 2 and calls == ["b"]          # once
+    assert dict(r.items()) == {"a": 1, "b": 2, "c": 3} and calls == ["b", "c"]
+    r2 = _LazyResults({"a": 1})
+    r2.lazy("b", lambda: 5)
+    r2["b"] = 9                                     # an explicit value replaces the thunk
+    assert r2["b"] == 9 and sorted(r2.keys()) == ["a", "b"] and list(r2.values()).count(9) == 1

@@ -572,6 +572,17 @@ __global__ void frag16_write_kernel(const float* __restrict__ src, char* __restr
 // ---- Adam (torch.optim.Adam, no weight decay / amsgrad): same op order as torch's single-tensor path.  step_size =
 // lr / bias_corr1 and bc2_sqrt = sqrt(bias_corr2) are formed by the host in double precision and rounded to fp32, as
 // torch forms its Python scalars; dyn2 (device, [step_size, bc2_sqrt]) overrides the by-value pair under graph replay.
+// One element's update, shared by the flat and the gathering kernel (one expression tree, one set of roundings: no contraction)
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float gi, float b1, float b2, float eps, float step_size,
+                                            float bc2_sqrt) {
+#pragma clang fp contract(off)
+  const float mi = m + (gi - m) * (1.f - b1);        // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = v * b2 + (1.f - b2) * gi * gi;    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+  m = mi;
+  v = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p = p - step_size * (mi / denom);
+}
 __global__ void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float b1, float b2, float eps, float step_size, float bc2_sqrt,
                             const float* __restrict__ dyn2) {
@@ -581,13 +592,7 @@ __global__ void adam_kernel(long long n, float* __restrict__ p, const float* __r
     step_size = dyn2[0];
     bc2_sqrt = dyn2[1];
   }
-  const float gi = g[i];
-  const float mi = m[i] + (gi - m[i]) * (1.f - b1);       // exp_avg.lerp_(grad, 1-beta1)
-  const float vi = v[i] * b2 + (1.f - b2) * gi * gi;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
-  m[i] = mi;
-  v[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  p[i] = p[i] - step_size * (mi / denom);
+  adam_update(p[i], m[i], v[i], g[i], b1, b2, eps, step_size, bc2_sqrt);
 }
 
 struct ScalarPack {
@@ -1014,13 +1019,7 @@ __global__ __launch_bounds__(256) void adam_gather_kernel(float* __restrict__ p,
     const int e = e0 + 256 * u;
     if (e < q.n) {
       const size_t i = (size_t)q.off + e;
-      const float gi = q.g[e];
-      const float mi = m[i] + (gi - m[i]) * (1.f - b1);
-      const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-      m[i] = mi;
-      v[i] = vi;
-      const float denom = sqrtf(vi) / bc2_sqrt + eps;
-      p[i] = p[i] - step_size * (mi / denom);
+      adam_update(p[i], m[i], v[i], q.g[e], b1, b2, eps, step_size, bc2_sqrt);
     }
   }
 }
