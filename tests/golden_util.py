@@ -38,6 +38,8 @@ class Case:
             self.sched = int(self.sched)
         self.u_list = [torch.from_numpy(self.g[f"u_{i}"]) for i in range(int(self.g["n_draws"]))]
         self.fine = self.Nf > 0
+        # the reference's own fine depths (render_rays kwargs["z_fine"] / the oracle's z_fine_override evaluate the fine pass AT them)
+        self.z_fine = torch.from_numpy(self.g["z_fine"]) if "z_fine" in self.g else None
 
     def nerf_kw(self):
         return dict(D=self.D, W=self.W, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)

@@ -24,10 +24,10 @@ pytestmark = pytest.mark.gpu
 class SynthCase(Case):
     """A Case without a fixture file: same closed-form weights / batch generators, draws from a seeded generator."""
 
-    def __init__(self, name, R, progress, seed=7, n_img=9, trunk_gain=1.0, sigma_gain=1.0):
+    def __init__(self, name, R, progress, seed=7, n_img=9, trunk_gain=1.0, sigma_gain=1.0, Nc=64, Nf=128):
         self.name, self.g = name, {}
         self.R, self.n_img, self.seed = R, n_img, seed
-        self.D, self.W, self.Nc, self.Nf = 8, 256, 64, 128
+        self.D, self.W, self.Nc, self.Nf = 8, 256, Nc, Nf
         self.progress, self.perturb, self.pose_opt, self.use_disp, self.identity_c2w = progress, 1.0, True, False, False
         self.sigma_bias, self.sigma_gain, self.trunk_gain = 0.0, sigma_gain, trunk_gain
         self.c2f, self.encode_candidate, self.fine = (0.1, 0.5), None, True
@@ -36,11 +36,15 @@ class SynthCase(Case):
         n_s = round(self.sched * self.Nf)
         shapes = [self.Nc] + ([self.Nf] if self.sched in (0, 1) else [self.Nf - n_s, n_s])  # the draw order
         self.u_list = [torch.rand(R, n, generator=g) for n in shapes]
+        self.z_fine = None
 
 
 RAYS = 301
 CASES = {"phase0": dict(progress=0.05), "phase1": dict(progress=0.3), "phase2": dict(progress=0.8),
-         "trained_p045": dict(progress=0.45, trunk_gain=1.6, sigma_gain=24.0)}
+         "trained_p045": dict(progress=0.45, trunk_gain=1.6, sigma_gain=24.0),
+         # the reference's shipped sampling shape (configs/default.yaml:8-9): 128 + 128 samples, the fine pass at S = 256
+         "yaml_phase0": dict(progress=0.05, Nc=128, Nf=128), "yaml_phase1": dict(progress=0.3, Nc=128, Nf=128),
+         "yaml_phase2": dict(progress=0.8, Nc=128, Nf=128)}
 
 
 def oracle_at(c, z_fine, dtype):

@@ -251,6 +251,65 @@ def test_training_step_matches_reference_golden(name):
         assert not bad, ("vs oracle at the GPU's fine depths", bad)
 
 
+@pytest.mark.parametrize("name", [n for n in CASES if Case(n).fine])
+def test_training_step_matches_reference_golden_at_the_reference_depths(name):
+    """strict reference-vs-HIP comparison of EVERY golden gradient, with no loose branch.  The fine pass
+    of the HIP path is evaluated at the reference's own fine depths (golden key `z_fine`, injected through render_rays'
+    test-only `z_fine` argument; the resampling itself carries no gradient, rendering.py:271-306, and stays pinned by the
+    test above and by test_sample_pdf_*).  Gates: maps / loss terms 1e-4, per-sample weights 2e-4, every parameter and ray
+    gradient max(1e-3, 4 x the reference's own fp32-vs-fp64 noise at the same depths)."""
+    c = Case(name)
+    sysm = build_system(c)
+    batch = {k: v.cuda() for k, v in c.batch().items()}
+    keep = {}
+    loss, loss_d, res = sysm.compute_loss(batch, u_list=[u.clone() for u in c.u_list], keep=keep, z_fine=c.z_fine.cuda())
+    assert torch.equal(keep["z_fine"].cpu(), c.z_fine)
+    exp = c.expected_results()
+    assert set(res.keys()) == set(exp.keys())
+    errs = {k: e for k, v in exp.items()
+            if (e := rel_err(res[k].detach().cpu().numpy().reshape(v.shape), v)) >= (TOL_W if "weights" in k else TOL_MAP)}
+    assert not errs, errs
+    el = c.expected_losses()
+    for k, v in loss_d.items():
+        assert abs(float(v) - float(el[k])) <= TOL_MAP * max(abs(float(el[k])), 1e-2), (k, float(v), float(el[k]))
+    if sysm._last_rays.requires_grad:
+        sysm._last_rays.retain_grad()
+    loss.backward()
+    got = {n: p.grad for n, p in sysm.named_parameters()}
+    g32, _ = oracle_grads(c, torch.float32, z_fine=c.z_fine)
+    g64, _ = oracle_grads(c, torch.float64, z_fine=c.z_fine)
+    noise = {k: float((a.double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-30))
+             for k, a in g32.items() if a is not None and g64[k] is not None}
+    worst_noise = max(noise.values()) if noise else 0.0
+    bad = {}
+    if sysm._last_rays.requires_grad:
+        gr, er = sysm._last_rays.grad.cpu().numpy(), c.g["grad_rays"]
+        for tag, sl in (("rays_o", slice(0, 3)), ("rays_d", slice(3, 6))):
+            e = rel_err(gr[:, sl], er[:, sl])
+            if e >= max(TOL_GRAD, 4 * worst_noise):
+                bad["grad_" + tag] = e
+    for n, e in c.expected_grads().items():
+        if n.endswith(".progress"):
+            continue
+        g = got[n]
+        if e is None:
+            if g is not None and float(g.abs().max()) != 0.0:
+                bad[n] = "expected no gradient"
+            continue
+        vals, stride, sums = e
+        if g is None:
+            if sums[1] > 0:
+                bad[n] = "missing gradient"
+            continue
+        flat = g.detach().reshape(-1).cpu()
+        sub = (flat[::stride] if stride else flat).numpy()[: len(vals)]
+        scale = max(float(np.abs(vals).max()), sums[1] / flat.numel(), 1e-12)
+        err = float(np.abs(sub - vals).max()) / scale
+        if err >= max(TOL_GRAD, 4 * noise.get(n, worst_noise)):
+            bad[n] = (err, noise.get(n, 0.0))
+    assert not bad, ("vs reference golden at the reference's fine depths", bad)
+
+
 def test_only_the_known_goldens_take_the_flipped_branch():
     """Runs after the golden cases above (file order): the cases whose gradients were compared at the loose gate must be a
     subset of the pinned set."""

@@ -51,13 +51,39 @@ def test_training_forward_backward_matches_reference(name):
         assert float(np.abs(got_.astype(np.float64) - vals).max()) <= max(TOL_GRAD * float(np.abs(vals).max()), 1e-9), n
 
 
-def _forward_with_sched(c, st):
+@pytest.mark.parametrize("name", [n for n in CASES if Case(n).fine])
+def test_oracle_fine_depths_are_the_reference_fine_depths(name):
+    """The goldens carry the reference's own z_vals of the fine pass (the one torch.sort of rendering.py:277-307, recorded by
+    tools/make_goldens.py): the oracle resamples the same depths -- all but isolated draws that land in a bin of mass ~eps
+    (rendering.py:44-46 `denom < eps -> 1`), where 1e-7 of the coarse weights moves a depth by a bin width."""
+    c = Case(name)
+    keep = {}
+    with torch.no_grad():
+        (orc.training_forward(c.state(requires_grad=False), c.cfgs(), c.batch(), c.hparams(), c.progress, u_list=c.u_list, keep=keep)
+         if "cfg_sched" not in c.g else _forward_with_sched(c, c.state(requires_grad=False), keep))
+    assert c.z_fine is not None and keep["z_fine"].shape == c.z_fine.shape
+    dz = (keep["z_fine"] - c.z_fine).abs()
+    assert float((dz < 1e-5).float().mean()) > 0.995, float((dz < 1e-5).float().mean())
+    # and evaluated AT the reference's depths the oracle's fine maps are the golden's
+    with torch.no_grad():
+        real = orc.schedule_mult
+        orc.schedule_mult = (lambda p, s: c.sched) if "cfg_sched" in c.g else real
+        try:
+            _, res = orc.training_forward(c.state(requires_grad=False), c.cfgs(), c.batch(), c.hparams(), c.progress, u_list=c.u_list,
+                                          z_fine_override=c.z_fine)
+        finally:
+            orc.schedule_mult = real
+    for k, v in c.expected_results().items():
+        assert rel_err(res[k].numpy(), v) < TOL_FWD, k
+
+
+def _forward_with_sched(c, st, keep=None):
     """Fixtures that force sched_mult directly (not through the progress schedule)."""
     hp = dict(c.hparams())
     real = orc.schedule_mult
     orc.schedule_mult = lambda p, s: c.sched
     try:
-        return orc.training_forward(st, c.cfgs(), c.batch(), hp, c.progress, u_list=c.u_list)
+        return orc.training_forward(st, c.cfgs(), c.batch(), hp, c.progress, u_list=c.u_list, keep=keep)
     finally:
         orc.schedule_mult = real
 

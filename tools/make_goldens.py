@@ -51,11 +51,13 @@ MAX_GRAD_ELEMS = 384
 
 
 class RecordRand:
-    """Record every uniform draw the reference makes inside render_rays."""
+    """Record every uniform draw the reference makes inside render_rays, and every tensor torch.sort returns there (the
+    only sort of render_rays is the merge of the coarse and the resampled depths, rendering.py:277-307: its output is the
+    reference's own z_vals of the fine pass)."""
 
     def __enter__(self):
-        self.draws = []
-        self._rand, self._rand_like = torch.rand, torch.rand_like
+        self.draws, self.sorted = [], []
+        self._rand, self._rand_like, self._sort = torch.rand, torch.rand_like, torch.sort
 
         def rand(*a, **k):
             t = self._rand(*a, **k); self.draws.append(t.clone()); return t
@@ -63,11 +65,14 @@ class RecordRand:
         def rand_like(x, **k):
             t = self._rand_like(x, **k); self.draws.append(t.clone()); return t
 
-        torch.rand, torch.rand_like = rand, rand_like
+        def sort(*a, **k):
+            r = self._sort(*a, **k); self.sorted.append(r[0].detach().clone()); return r
+
+        torch.rand, torch.rand_like, torch.sort = rand, rand_like, sort
         return self
 
     def __exit__(self, *exc):
-        torch.rand, torch.rand_like = self._rand, self._rand_like
+        torch.rand, torch.rand_like, torch.sort = self._rand, self._rand_like, self._sort
 
 
 def schedule_mult(progress, sched):  # nerf_system.py:452-461 (cannot import: needs pytorch_lightning)
@@ -148,6 +153,10 @@ def run_case(name, case):
     for i, u in enumerate(rec.draws):
         out[f"u_{i}"] = u.numpy()
     out["n_draws"] = np.int64(len(rec.draws))
+    if fine:  # the reference's own fine depths: the HIP path can be evaluated AT them (render_rays z_fine=)
+        zf = [t for t in rec.sorted if tuple(t.shape) == (case["R"], case["Nc"] + case["Nf"])]
+        assert len(zf) == 1, [tuple(t.shape) for t in rec.sorted]
+        out["z_fine"] = zf[0].numpy()
     out["in_rays"] = rays.detach().numpy()
     out["in_depth"] = depth.detach().numpy()
     for k, v in res.items():
@@ -199,6 +208,11 @@ CASES = {
                              sigma_gain=24.0, trunk_gain=1.6),
     "cfg2_trained_p045": dict(BASE, R=6, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.45, perturb=1.0, pose_opt=True,
                               sigma_gain=24.0, trunk_gain=1.6),
+    # the reference's SHIPPED sampling shape (configs/default.yaml:8-9: N_samples 128, N_importance 128 -> the fine pass runs 256
+    # samples per ray at W = 256), the three schedule phases
+    "yaml_phase0": dict(BASE, R=4, D=8, W=256, Nc=128, Nf=128, c2f=(0.1, 0.5), progress=0.05, perturb=1.0, pose_opt=True),
+    "yaml_phase1": dict(BASE, R=4, D=8, W=256, Nc=128, Nf=128, c2f=(0.1, 0.5), progress=0.3, perturb=1.0, pose_opt=True),
+    "yaml_phase2": dict(BASE, R=4, D=8, W=256, Nc=128, Nf=128, c2f=(0.1, 0.5), progress=0.8, perturb=1.0, pose_opt=True),
     # deterministic resampling (validation path: perturb=0 -> det=True), non-identity c2w
     "cfg2_det_phase1": dict(BASE, R=5, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.25, perturb=0.0,
                             pose_opt=True, identity_c2w=False),

@@ -369,6 +369,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // data that IS re-read out of the 4 MB L2s and the Infinity Cache -- the weight fragments every field workgroup streams, the
 // weight-gradient slabs the next launch sums.  Measured (round 3, graph-replayed step, three alternating runs): 18.27 -> 17.79 ms.
 // -DUPNERF_NO_NT restores plain accesses.
+//
+// Experiment switches that change RESULTS (timing-only builds: wrong or missing outputs) compile only in a build that says it is
+// an experiment (`make variant` passes -DUPNERF_EXPERIMENT); a stray -D in the product build is a compile error, not a silently
+// wrong library.
+#if (defined(UPNERF_EXP_HALFROW) || defined(UPNERF_EXP_NOSTORE) || defined(UPNERF_EXP_SAMEB) || defined(RR_EXP_NOSTORE) || \
+     defined(RR_EXP_NODMA) || defined(RR_EXP_NOEPI)) && !defined(UPNERF_EXPERIMENT)
+#error "UPNERF_EXP_* / RR_EXP_* switches produce wrong results: build them with -DUPNERF_EXPERIMENT (make variant), never into libupnerf_hip.so"
+#endif
 #ifdef UPNERF_NO_NT
 #define NT_LOAD(p) (*(p))
 #define NT_STORE(p, v) (*(p) = (v))

@@ -188,7 +188,7 @@ class NeRFSystem(_Base):
         nn.init.zeros_(self.depth_scale.weight)
 
     # ---- forward (nerf_system.py:93-148) -------------------------------------------------------------
-    def forward(self, rays, feats, img_idx, sched_mult, train=True, u_list=None, keep=None):
+    def forward(self, rays, feats, img_idx, sched_mult, train=True, u_list=None, keep=None, z_fine=None):
         hp = self.hparams
         rng = None
         if train and u_list is None and hp.get("rng.keyed", True) and hp["nerf.perturb"] > 0:
@@ -223,6 +223,7 @@ class NeRFSystem(_Base):
                               perturb=hp["nerf.perturb"] if train else 0, N_importance=hp["nerf.N_importance"],
                               white_back=getattr(self.train_dataset, "white_back", False),
                               encode_feat=hp["nerf.feat_dim"] > 0, validation=not train, u_list=u_list, keep=keep,
+                              z_fine=None if z_fine is None else z_fine[i:i + chunk],
                               rng=None if rng is None else dict(rng, row0=rng["row0"] + i * rng["stride"]))
             for k, v in out.items():
                 results[k] += [v]
@@ -275,12 +276,12 @@ class NeRFSystem(_Base):
         d = 1.0 / p
         return torch.where(d < near, torch.full_like(d, near), d)
 
-    def compute_loss(self, batch, u_list=None, keep=None):
+    def compute_loss(self, batch, u_list=None, keep=None, z_fine=None):
         reset_deferred()  # nothing pending from a backward pass that raised
         rays = self.rays_from_batch(batch)
         self._last_rays = rays  # kept for tests (gradient w.r.t. the rays)
         sched_mult = self.get_schedule_mult(self._host_progress)
-        results = self(rays, batch["feats"], batch["img_idx"], sched_mult, u_list=u_list, keep=keep)
+        results = self(rays, batch["feats"], batch["img_idx"], sched_mult, u_list=u_list, keep=keep, z_fine=z_fine)
         loss_d, _depth = self.loss.forward_with_prior(results, batch["rgbs"], batch["feats"], batch["inv_depths"],
                                                       embed_rows(self.depth_scale, batch["img_idx"], defer_grad=True), sched_mult)
         return self.loss.total(), loss_d, results

@@ -517,7 +517,9 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
 
     Extensions used by the parity tests: kwargs["u_list"] = explicit uniform draws consumed in the reference's RNG
     call order (coarse jitter [R,Nc], then the sample_pdf draws); kwargs["keep"] = dict that receives the sampled
-    depths (z_coarse, z_fine).
+    depths (z_coarse, z_fine); kwargs["z_fine"] = [R, N_samples + N_importance] sorted depths the fine pass is evaluated
+    at INSTEAD of resampling (the resampling carries no gradient, rendering.py:271-306: with the reference's own depths
+    from a golden every fine-pass output and gradient compares strictly, whatever an eps-mass bin of the inverse CDF did).
 
     Extension for the eval / test-time-optimisation callers (nerf_system_optmize.py:84-111 read `s_rgb_fine` only):
     kwargs["coarse_sigma_only"] = True evaluates the coarse field up to its density head only, without gradient (the
@@ -616,8 +618,11 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
         S = N_samples + N_importance
         zf = _empty(R, S, device=dev)
         zf[:, :N_samples] = z
+        z_inject = kwargs.get("z_fine")
 
         def resample(key, n, col0):
+            if z_inject is not None:
+                return
             sample_pdf(z, results[key].detach().contiguous(), n, det, zf, col0, None if det else draw(n))
 
         if model.encode_candidate:  # rendering.py:267-300
@@ -631,7 +636,12 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
                 resample("s_weights_coarse", N_importance, N_samples)
         else:  # rendering.py:300-307
             resample("s_weights_coarse", N_importance, N_samples)
-        check(lib.upnerf_sort_rows(R, S, ptr(zf), st), "upnerf_sort_rows")
+        if z_inject is not None:
+            if tuple(z_inject.shape) != (R, S):
+                raise ValueError(f"z_fine has shape {tuple(z_inject.shape)}, expected {(R, S)}")
+            zf.copy_(z_inject.detach().to(dev, torch.float32))
+        else:
+            check(lib.upnerf_sort_rows(R, S, ptr(zf), st), "upnerf_sort_rows")
         if keep is not None:
             keep["z_fine"] = zf
         inference(model, zf)
