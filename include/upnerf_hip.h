@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UPNERF_ABI_VERSION 5
+#define UPNERF_ABI_VERSION 6
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
@@ -151,9 +151,19 @@ typedef struct {
   int32_t tile_rows;             /* upnerf_field_fwd_f16x3 only: samples per workgroup.  0 or 64: four waves, two workgroups per CU.
                                     128 (needs S >= 64): eight waves, software-pipelined trunk, each weight fragment enters the
                                     CU once per 128 samples; needs x0f when the field has a skip layer.  The backward pass of the
-                                    same evaluation must be given the same value (the hmask layout follows the tile) */
-  const float* wnorm;            /* reserved, must be NULL (selected a register-resident forward kernel that left the library:
-                                    tools/repro/field16r.hip) */
+                                    same evaluation must be given the same value (the hmask layout follows the tile).
+                                    256 (planes = 1 only, S >= 32): the REGISTER-RESIDENT kernels of csrc/field16rr.hip -- eight waves
+                                    of 32 samples whose activations stay in registers, every weight slab staged once per workgroup
+                                    in an LDS ring by LDS-DMA.  Contract of that variant: P16 / PT16 from upnerf_frag16 with
+                                    perm_fwd = perm_bwd = 1 and `wnorm` from the same call; EVERY per-sample tensor with more than
+                                    4 floats per sample (x0, e, g1, g2, r1, h, h16, hmask and the backward pass's gz_*, gz16) has room
+                                    for Mp = ceil(M / 256) * 256 rows (rows >= M are written with padding values); h16 / gz16 are in
+                                    FRAGMENT order -- [layer][Mp / 32][k-block 0..15][lane 0..63][8] fp16, feature of element j of
+                                    lane l in k-block s = 16 s + 8 (j / 4) + 4 (l / 32) + j % 4, row = 32 tile + l % 32 -- with one
+                                    exponent per 32 rows (hexp / gzexp [D][Mp / 32]); hmask holds (D + 3) * Mp * 4 words in the
+                                    kernel pair's own layout; `h` is [Mp][W] (last layer, h_last_only = 1) */
+  const float* wnorm;            /* [64] row 1-norms from upnerf_frag16 (forward set at 0.., transposed set at 32..): required by the
+                                    register-resident kernels (tile_rows = 256), must be NULL otherwise */
   /* fp16 STORAGE of the trunk activations (always in the f16 mode; an option in the f16x3 mode, where it rounds only the
    * operands of the weight gradients): halves what the pass writes and what the weight-gradient kernels read back
    * (upnerf_wgrad_f16p).  h16[l][m][k] = fp16(h_l[m][k] * 2^hexp[l][m / 64]): the content of the
@@ -272,6 +282,7 @@ typedef struct {
                                     weight gradient against e is one launch (upnerf_wgrad_f16x3_chain2); its running maximum is
                                     tracked in gmax slot D+4 */
   int32_t reserved_;
+  const float* wnorm;            /* as in upnerf_field_fwd_args (tile_rows = 256: required; else NULL) */
 } upnerf_field_bwd_args;
 
 /* Layout of one row of tile_part (floats): d w_csig [W/2] | d w_r2 [3][W/2] | sum dpre_sig_c, sum dpre_rgb[0..2] | 4 pad |
@@ -379,7 +390,9 @@ int upnerf_wgrad_finish(upnerf_wgrad_pending* pending, void* stream);
 
 /* Same contraction for the f16 field mode with fp16-STORED operands: A16 [M][lda] fp16 bits scaled per 64-row tile by
  * 2^aexp[m / 64] (upnerf_field_bwd_f16x3's gz16 / gzexp); B either fp16 the same way (b_is_f16 = 1: B16 / bexp, from h16 /
- * hexp) or fp32 row-major (b_is_f16 = 0: x0).  Operands are brought to the tensor-wide exponents *expo_a / *expo_b on load
+ * hexp) or fp32 row-major (b_is_f16 = 0: x0).  b_is_f16 | 2: the fp16 operands (A16, and B16 when bit 0 is set) are the operand
+ * FRAGMENTS of the register-resident field kernels (upnerf_field_fwd_args.tile_rows = 256: [32-row tile][k-block][lane][8], one
+ * exponent per 32 rows, N = 256 and, for a fp16 B, K = 256; lda / ldb are ignored for them).  Operands are brought to the tensor-wide exponents *expo_a / *expo_b on load
  * (exact power-of-two scaling in fp16), one MFMA per block, fp32 accumulate.  Reads 1 KB per sample and layer instead of 2. */
 int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
                       const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, float* slabs, int nsplit,

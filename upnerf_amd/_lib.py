@@ -67,7 +67,7 @@ class FieldBwdArgs(C.Structure):
                 ("x0", _fp), ("h", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp), ("hmask", _fp), ("gmax", _fp),
                 ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp),
-                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("gz16", _fp), ("gzexp", _fp), ("xs", _fp), ("tile_part", _fp), ("gz_rg_ld", C.c_int32), ("reserved_", C.c_int32)]
+                ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("gz16", _fp), ("gzexp", _fp), ("xs", _fp), ("tile_part", _fp), ("gz_rg_ld", C.c_int32), ("reserved_", C.c_int32), ("wnorm", _fp)]
 
 
 class LossArgs(C.Structure):
@@ -211,7 +211,7 @@ def _load():
 
 
 lib = _load()
-ABI_VERSION = 5
+ABI_VERSION = 6
 if lib.upnerf_abi_version() != ABI_VERSION:
     raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
 

@@ -1389,6 +1389,9 @@ extern "C" int upnerf_stamps_read(unsigned long long* out16, int reset) {
 }
 #endif
 
+int upnerf_rr16_fwd_launch(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);  // csrc/field16rr.hip
+int upnerf_rr16_bwd_launch(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream);
+
 extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream) {
   int rc = check_layout16(L);
   if (rc) return rc;
@@ -1401,7 +1404,16 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   if (a->h16 && !a->hexp) return UPNERF_EINVAL;
-  if (a->wnorm) return UPNERF_EUNSUP;  // the register-resident forward kernel left the library (tools/repro/field16r.hip)
+  if (a->tile_rows == 256) {  // register-resident kernels (csrc/field16rr.hip): fp16 mode, weights staged in LDS once per 256 samples
+    if (a->planes != 1) return UPNERF_EUNSUP;
+    if (a->S < 32) return UPNERF_EUNSUP;  // at most 9 rays per 256-sample tile
+    if (!a->wnorm) return UPNERF_EINVAL;
+    if (a->h16 && !a->hmask) return UPNERF_EINVAL;
+    if (a->use_cand && !a->g2) return UPNERF_EINVAL;
+    if (a->h16 && ((a->use_cand && !a->g1) || (a->use_rgb && !a->r1))) return UPNERF_EINVAL;
+    return upnerf_rr16_fwd_launch(L, a, stream);
+  }
+  if (a->wnorm) return UPNERF_EUNSUP;  // only the register-resident kernels read the row norms
   const int tile = tile_rows16(a->tile_rows, a->S);
   if (tile < 0) return UPNERF_EINVAL;
   if (tile == F16_TILE_BIG && L->skip > 0 && !a->x0f) return UPNERF_EINVAL;
@@ -1438,6 +1450,12 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->gz16 && !a->gzexp) return UPNERF_EINVAL;
   const long long M = (long long)a->R * a->S;
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
+  if (a->tile_rows == 256) {  // register-resident kernels (csrc/field16rr.hip)
+    if (a->planes != 1) return UPNERF_EUNSUP;
+    if (!a->wnorm || !a->gz16 || a->tile_part) return UPNERF_EINVAL;
+    return upnerf_rr16_bwd_launch(L, a, stream);
+  }
+  if (a->wnorm) return UPNERF_EUNSUP;
   const int tile = tile_rows16(a->tile_rows, a->S);
   if (tile < 0) return UPNERF_EINVAL;
   if (tile == F16_TILE_BIG && a->need_dxyz && L->skip > 0 && !a->xs) return UPNERF_EINVAL;

@@ -740,7 +740,7 @@ extern "C" int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int3
                                  const int* expo_a, const int* expo_b, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A16 || !aexp || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b)
     return UPNERF_EINVAL;
-  if (b_is_f16 && !bexp) return UPNERF_EINVAL;
+  if ((b_is_f16 & 1) && !bexp) return UPNERF_EINVAL;
   if ((N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || (ldo & 3)) return UPNERF_EINVAL;
   int TN, TK;
   wgrad_shape(N, K, &TN, &TK);

@@ -241,7 +241,11 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
 // 64-row tile by 2^exp[m / 64] (the LDS planes of the field kernels, copied out as they stood).  A thread moves 8 columns
 // (16 bytes) at a time, brings them to the tensor-wide exponent with an exact fp16 power-of-two multiply and drops them into
 // the same LDS image the fp32 path builds; one MFMA per block.  Half the HBM bytes of the fp32-stored operands.
-template <int MTW, int NTW, int PKB>
+// FRAG: the fp16 operands are the operand fragments of the register-resident field kernels (csrc/field16rr.hip) -- [32-row tile]
+// [k-block 16][lane 64][8], feature 16 s + 8 (j / 4) + 4 (lane / 32) + j % 4, one exponent per 32 rows.  A thread moves the 16 bytes
+// of one lane: sixteen consecutive threads read sixteen consecutive rows of one (k-block, lane half) = 256 contiguous bytes, and
+// the two 8-byte halves of the piece land at their natural columns of the same LDS image.  256-wide operands only.
+template <int MTW, int NTW, int PKB, int FRAG>
 __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N, int K, const uint16_t* __restrict__ A, int lda,
                                                                  const int* __restrict__ aexp, const void* __restrict__ Bv, int ldb,
                                                                  const int* __restrict__ bexp, const int* __restrict__ expo_a,
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   constexpr int WK = (TK >= 128) ? 4 : 2, WN = 8 / WK;
   constexpr int MT = (TN / WN >= 32) ? TN / WN / 32 : 1, NT = TK / WK / 32;
   static_assert(TN / WN >= 32, "packed variant is built for 256-row blocks");
+  static_assert(!FRAG || (TN == 256 && (!PKB || TK == 256) && FX_CHUNK % 16 == 0), "fragment-ordered operands are 256 wide");
   __shared__ __attribute__((aligned(16))) char lds[2 * (SZA + SZB)];  // [buffer][A | B], one plane each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
@@ -282,20 +287,34 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   auto gload = [&](h8 (&ra)[A8], int (&xa)[A8], h8 (&rbp)[B8 ? B8 : 1], int (&xb)[B8 ? B8 : 1], f32x4 (&rbf)[B4 ? B4 : 1], int mc) {
 #pragma unroll
     for (int q = 0; q < A8; ++q) {
-      const int idx = tid + q * FX_THREADS, row = idx / (TN / 8), c8 = idx - row * (TN / 8);
-      const int m = mc + row;
-      const bool ok = m < mend && nblk + 8 * c8 < N;
-      ra[q] = ok ? NT_LOAD((const h8*)&A[(size_t)m * lda + nblk + 8 * c8]) : zero8;
-      xa[q] = ok ? aexp[m >> 6] : 0;
+      if constexpr (FRAG) {
+        const int m = mc + (tid & 15) + 16 * q, s2 = tid >> 4;  // row of the chunk; (k-block, lane half) of this thread
+        const bool ok = m < mend;
+        ra[q] = ok ? NT_LOAD((const h8*)((const char*)A + (((size_t)(m >> 5) * 16 + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16)) : zero8;
+        xa[q] = ok ? aexp[m >> 5] : 0;
+      } else {
+        const int idx = tid + q * FX_THREADS, row = idx / (TN / 8), c8 = idx - row * (TN / 8);
+        const int m = mc + row;
+        const bool ok = m < mend && nblk + 8 * c8 < N;
+        ra[q] = ok ? NT_LOAD((const h8*)&A[(size_t)m * lda + nblk + 8 * c8]) : zero8;
+        xa[q] = ok ? aexp[m >> 6] : 0;
+      }
     }
     if constexpr (PKB) {
 #pragma unroll
       for (int q = 0; q < B8; ++q) {
-        const int idx = tid + q * FX_THREADS, row = idx / (TK / 8), c8 = idx - row * (TK / 8);
-        const int m = mc + row;
-        const bool ok = m < mend && kblk + 8 * c8 < K;
-        rbp[q] = ok ? NT_LOAD((const h8*)&Bh[(size_t)m * ldb + kblk + 8 * c8]) : zero8;
-        xb[q] = ok ? bexp[m >> 6] : 0;
+        if constexpr (FRAG) {
+          const int m = mc + (tid & 15) + 16 * q, s2 = tid >> 4;
+          const bool ok = m < mend;
+          rbp[q] = ok ? NT_LOAD((const h8*)((const char*)Bh + (((size_t)(m >> 5) * 16 + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16)) : zero8;
+          xb[q] = ok ? bexp[m >> 5] : 0;
+        } else {
+          const int idx = tid + q * FX_THREADS, row = idx / (TK / 8), c8 = idx - row * (TK / 8);
+          const int m = mc + row;
+          const bool ok = m < mend && kblk + 8 * c8 < K;
+          rbp[q] = ok ? NT_LOAD((const h8*)&Bh[(size_t)m * ldb + kblk + 8 * c8]) : zero8;
+          xb[q] = ok ? bexp[m >> 6] : 0;
+        }
       }
     } else {
 #pragma unroll
@@ -323,7 +342,13 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
       h8 v = ra[q];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * f;
-      *(h8*)(base + himg<FX_CHUNK>(row, 8 * c8)) = v;
+      if constexpr (FRAG) {
+        const int r = (tid & 15) + 16 * q, s2 = tid >> 4, col = 16 * (s2 >> 1) + 4 * (s2 & 1);
+        *(h4*)(base + himg<FX_CHUNK>(r, col)) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+        *(h4*)(base + himg<FX_CHUNK>(r, col + 8)) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+      } else {
+        *(h8*)(base + himg<FX_CHUNK>(row, 8 * c8)) = v;
+      }
     }
     if constexpr (PKB) {
 #pragma unroll
@@ -333,7 +358,13 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
         h8 v = rbp[q];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] * f;
-        *(h8*)(base + SZA + himg<FX_CHUNK>(row, 8 * c8)) = v;
+        if constexpr (FRAG) {
+          const int r = (tid & 15) + 16 * q, s2 = tid >> 4, col = 16 * (s2 >> 1) + 4 * (s2 & 1);
+          *(h4*)(base + SZA + himg<FX_CHUNK>(r, col)) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+          *(h4*)(base + SZA + himg<FX_CHUNK>(r, col + 8)) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+        } else {
+          *(h8*)(base + SZA + himg<FX_CHUNK>(row, 8 * c8)) = v;
+        }
       }
     } else {
       const float sb = ldexpf(1.0f, eb);
@@ -405,21 +436,27 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
     __syncthreads();
     constexpr int Q = TN / 8, G = FX_THREADS / Q;
     if (tid < TN) {
-      const int grp = tid >> 3, j = tid & 7;
       float sacc = 0.0f;
+      if constexpr (FRAG) {  // column tid = 16 s + 8 (j / 4) + 4 hh + j % 4 is held, as element j, by the 16 threads with tid / 16 = 2 s + hh
+        const int s2 = 2 * (tid >> 4) + ((tid >> 2) & 1), j = 4 * ((tid >> 3) & 1) + (tid & 3);
 #pragma unroll
-      for (int t = 0; t < G; ++t) sacc += red[(grp + t * Q) * 8 + j];
+        for (int t = 0; t < 16; ++t) sacc += red[(s2 * 16 + t) * 8 + j];
+      } else {
+        const int grp = tid >> 3, j = tid & 7;
+#pragma unroll
+        for (int t = 0; t < G; ++t) sacc += red[(grp + t * Q) * 8 + j];
+      }
       bslabs[((size_t)split * gridDim.y + blockIdx.y) * TN + tid] = sacc;
     }
   }
 }
 
-template <int MTW, int NTW, int PKB>
+template <int MTW, int NTW, int PKB, int FRAG>
 int launch_p(int M, int N, int K, const uint16_t* A, int lda, const int* aexp, const void* B, int ldb, const int* bexp,
              const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   dim3 grid(nsplit, (N + TN - 1) / TN, (K + TK - 1) / TK);
-  hipLaunchKernelGGL((wgrad_f16p_kernel<MTW, NTW, PKB>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, aexp, B, ldb, bexp, expo_a,
+  hipLaunchKernelGGL((wgrad_f16p_kernel<MTW, NTW, PKB, FRAG>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, aexp, B, ldb, bexp, expo_a,
                      expo_b, slabs, bslabs, rows);
   return (int)hipGetLastError();
 }
@@ -467,9 +504,14 @@ extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, co
                                          const int* bexp, int b_is_f16, int K, const int* expo_a, const int* expo_b, float* slabs,
                                          float* bslabs, int nsplit, int rows, int TN, int TK, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  const bool frag = (b_is_f16 & 2) != 0;  // bit 1: fp16 operands in the fragment order of the register-resident field kernels
+  b_is_f16 &= 1;
+  if (frag && (N != 256 || (b_is_f16 && K != 256))) return UPNERF_EUNSUP;
   if (TN == 256 && TK == 256 && b_is_f16)
-    return launch_p<4, 4, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+    return frag ? launch_p<4, 4, 1, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st)
+                : launch_p<4, 4, 1, 0>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
   if (TN == 256 && TK == 64 && !b_is_f16)
-    return launch_p<4, 1, 0>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+    return frag ? launch_p<4, 1, 0, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st)
+                : launch_p<4, 1, 0, 0>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
   return UPNERF_EUNSUP;
 }

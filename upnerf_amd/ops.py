@@ -250,13 +250,14 @@ class WgradChain:
 
 def wgrad_f16p_into(M: int, A16: torch.Tensor, lda: int, aexp: torch.Tensor, N: int, B: torch.Tensor, ldb: int,
                     bexp: Optional[torch.Tensor], K: int, dW_ptr: int, ldo: int, db_ptr: Optional[int], device, expo_a: int,
-                    expo_b: int):
+                    expo_b: int, frag: bool = False):
     """upnerf_wgrad for the f16 field mode's fp16-STORED operands: A16 [M][lda] fp16 scaled per 64-row tile by 2^aexp[tile]
-    (gz16 / gzexp), B the same (fp16, bexp) or fp32 rows (bexp None: the encoding x0)."""
+    (gz16 / gzexp), B the same (fp16, bexp) or fp32 rows (bexp None: the encoding x0).  frag: the fp16 operands are the
+    operand fragments of the register-resident field kernels (one exponent per 32 rows; include/upnerf_hip.h, tile_rows = 256)."""
     ns = nsplit_for(M)
     ws = workspace("wgrad", ns * (256 * 256 + 256), device)
     rc = TIMER.run(f"wgrad16p_{N}x{K}", lambda: lib.upnerf_wgrad_f16p(M, ptr(A16), lda, ptr(aexp), N, ptr(B), ldb, ptr(bexp),
-                                                                     int(bexp is not None), K, dW_ptr, ldo, db_ptr, ptr(ws), ns,
+                                                                     int(bexp is not None) | (2 if frag else 0), K, dW_ptr, ldo, db_ptr, ptr(ws), ns,
                                                                      expo_a, expo_b, stream()), units=M)
     check(rc, "upnerf_wgrad_f16p")
 

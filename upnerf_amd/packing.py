@@ -322,10 +322,11 @@ class NerfPacker:
         return self._desc16_cache
 
     @torch.no_grad()
-    def frag16_hip(self, P: torch.Tensor, perm_fwd: bool = False):
+    def frag16_hip(self, P: torch.Tensor, perm: bool = False):
         """(P16, PT16, wexp, wnorm): every matrix of P (and its transposed copy) as scaled fp16 (hi, lo) MFMA fragments with
-        one power-of-two exponent per matrix id -- what upnerf_field_fwd_f16x3 / upnerf_field_bwd_f16x3 read.  perm_fwd: the
-        forward set in the k order of the register-resident forward kernel, plus the row norms it bounds its exponents with."""
+        one power-of-two exponent per matrix id -- what upnerf_field_fwd_f16x3 / upnerf_field_bwd_f16x3 read.  perm: both
+        sets in the k order of the register-resident kernels (csrc/field16rr.hip: include/upnerf_hip.h, tile_rows = 256), plus
+        the row 1-norms they bound their exponents with (wnorm [64]: forward matrices at 0.., transposed ones at 32..)."""
         from ._lib import check, lib, ptr, stream
         fd, nf, bd, nb = self._descs16()
         t0 = (self.L.total + 63) // 64 * 64  # the transposed set starts on a 256-byte boundary
@@ -333,8 +334,8 @@ class NerfPacker:
         P16, PT16 = both[:self.L.total], both[t0:]
         scratch = torch.empty(16, device=P.device, dtype=torch.float32)
         wexp = torch.empty(16, device=P.device, dtype=torch.int32)
-        wnorm = torch.empty(64, device=P.device, dtype=torch.float32) if perm_fwd else None
-        check(lib.upnerf_frag16(ptr(P), ptr(P16), ptr(PT16), fd, nf, bd, nb, ptr(scratch), ptr(wexp), int(perm_fwd), 0,
+        wnorm = torch.empty(64, device=P.device, dtype=torch.float32) if perm else None
+        check(lib.upnerf_frag16(ptr(P), ptr(P16), ptr(PT16), fd, nf, bd, nb, ptr(scratch), ptr(wexp), int(perm), int(perm),
                                 ptr(wnorm), stream()), "upnerf_frag16")
         return P16, PT16, wexp, wnorm
 

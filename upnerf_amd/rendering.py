@@ -67,6 +67,14 @@ WGRAD_CHAIN = int(__import__("os").environ.get("UPNERF_WGRAD_CHAIN", "1"))
 # Colour and candidate heads: [gz_r1 | gz_g1] stored as one tensor, one weight-gradient launch against e for both first layers.
 JOIN_HEADS = int(__import__("os").environ.get("UPNERF_JOIN_HEADS", "1"))
 HMASK_SCALE = int(__import__("os").environ.get("UPNERF_HMASK_SCALE", "1"))  # experiment builds with more threads per tile
+# fp16 mode: the register-resident kernels (csrc/field16rr.hip; include/upnerf_hip.h tile_rows = 256) -- weights staged once per
+# 256 samples in an LDS ring, trunk activations / gradients stored as operand fragments.  0 = the 64-sample tile-in-LDS kernels.
+FIELD_RR = int(__import__("os").environ.get("UPNERF_FIELD_RR", "1"))
+RR_TILE = 256
+
+
+def _rr_ok(S: int) -> bool:
+    return bool(FIELD_RR) and FIELD_MODE == "f16" and S >= 32
 
 
 def _planes() -> int:
@@ -133,8 +141,10 @@ class _FieldPass(torch.autograd.Function):
         P = P.detach().contiguous()
         use16 = _field16_ok(pk, S)
         P16 = PT16 = wexp = wnorm = None
+        rr = use16 and _rr_ok(S)  # register-resident fp16 kernels: per-sample tensors padded to whole 256-sample tiles
+        Mp = (M + RR_TILE - 1) // RR_TILE * RR_TILE if rr else M
         if use16:  # matrices as scaled fp16 (hi, lo) fragments, forward and transposed sets in one pass
-            P16, PT16, wexp, wnorm = pk.frag16_hip(P)
+            P16, PT16, wexp, wnorm = pk.frag16_hip(P, perm=rr)
             PF = P  # the kernel reads only the vectors from it
         else:
             PF = pk.frag_hip(P)  # what the kernels read: matrices in MFMA fragment order
@@ -157,27 +167,27 @@ class _FieldPass(torch.autograd.Function):
         # No gradient wanted (validation / test renders under torch.no_grad()): the kernels skip every store that only
         # the backward pass reads -- 8 of the 11 KB per sample -- and keep what compositing needs (e, g2) plus x0.
         train = cfg.grad and any(ctx.needs_input_grad)
-        x0 = _empty(M, X0, device=dev)
+        x0 = _empty(Mp, X0, device=dev)[:M]
         # f16 mode: trunk activations are STORED as fp16 (the kernel's LDS plane per 64-sample tile + the tile's exponent):
         # half the bytes written here and read back by the weight-gradient kernels; fp32 only for the last layer (its
         # consumers are the density-head and final-layer weight gradients)
-        store16 = train and use16 and (FIELD_MODE == "f16" or WGRAD_STORE == "f16") and wnorm is None
-        ntile = (M + 63) // 64  # exponent tables: one entry per 64 rows whatever the kernel's tile
-        h16 = torch.empty(D, M, W, device=dev, dtype=torch.float16) if store16 else None
+        store16 = train and use16 and (FIELD_MODE == "f16" or WGRAD_STORE == "f16")
+        ntile = Mp // 32 if rr else (M + 63) // 64  # exponent tables: one entry per 64 rows whatever the kernel's tile (rr: per 32)
+        h16 = torch.empty(D, Mp, W, device=dev, dtype=torch.float16) if store16 else None  # (rr: fragment order, see dequant16)
         hexp = torch.empty(D, ntile, device=dev, dtype=torch.int32) if store16 else None
-        h = (_empty(1, M, W, device=dev) if store16 else _empty(D, M, W, device=dev)) if train else None
-        e = _empty(M, W, device=dev) if (train or want_feat) else None
-        hmask = torch.empty((D + 1) * ((M + 127) // 128) * 512 * HMASK_SCALE, device=dev,  # 64 bits per lane and tile, either tiling
-                            dtype=torch.int64) if train else None
+        h = (_empty(1, Mp, W, device=dev)[:, :M] if store16 else _empty(D, M, W, device=dev)) if train else None
+        e = _empty(Mp, W, device=dev)[:M] if (train or want_feat) else None
+        hmask = (torch.empty((D + 3) * Mp * 4 if rr else (D + 1) * ((M + 127) // 128) * 512 * HMASK_SCALE, device=dev,
+                             dtype=torch.int64) if train else None)  # 64 bits per lane and tile, either tiling (rr: 128 per lane)
         # running max|.| of the stored tensors (scales of the f16x3 weight gradients): slots [0, 16) filled by this pass, [16, 32)
         # by the backward kernel -- one zero fill and, later, one exponent launch for both
         mx32 = torch.zeros(32, device=dev) if train else None
         amax = mx32[:16] if train else None
-        g1 = _empty(M, W2, device=dev) if (cfg.use_cand and train) else None
-        g2 = _empty(M, W2, device=dev) if (cfg.use_cand and (train or joint)) else None
-        r1 = _empty(M, W2, device=dev) if (cfg.use_rgb and train) else None
+        g1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and train) else None
+        g2 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and (train or joint)) else None
+        r1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_rgb and train) else None
         # 128-sample tiles (S >= 64): scratch for the encoding as operand fragments, read back at the skip layer
-        tile = 128 if (FIELD_TILE == 128 and S >= 64) else 64
+        tile = RR_TILE if rr else (128 if (FIELD_TILE == 128 and S >= 64) else 64)
         x0f = (torch.empty(((M + 127) // 128) * 32768, device=dev, dtype=torch.uint8)
                if (use16 and pk.skip > 0 and tile == 128) else None)
         fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
@@ -210,11 +220,12 @@ class _FieldPass(torch.autograd.Function):
               "upnerf_composite_fwd")
 
         ctx.cfg, ctx.dims, ctx.planes, ctx.tile_rows = cfg, (R, S), _planes(), tile
+        ctx.rr, ctx.Mp = rr, Mp
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
                          sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, mx32=mx32, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
                          w_all=w_all, w_sj=w_sj,
-                         w_cj=w_cj, w_s=w_s)
+                         w_cj=w_cj, w_s=w_s, wnorm=wnorm)
         z0 = torch.zeros(0, device=dev)
         outs = (E_s, G_c, sum_sfeat, t_weight, c_depth, s_depth, rgb_map, w_all, w_s)
         return tuple(o if o is not None else z0 for o in outs)
@@ -254,18 +265,19 @@ class _FieldPass(torch.autograd.Function):
         use16 = sv["PT16"] is not None
         PT = None if use16 else pk.frag_t_hip(P)
         store16 = sv.get("h16") is not None
-        gz_e = _empty(M, W, device=dev)
+        rr, Mp = ctx.rr, ctx.Mp  # register-resident fp16 kernels: per-sample tensors padded to whole 256-sample tiles
+        gz_e = _empty(Mp, W, device=dev)[:M]
         gz_h = None if store16 else _empty(D, M, W, device=dev)
-        gz16 = torch.empty(D, M, W, device=dev, dtype=torch.float16) if store16 else None
+        gz16 = torch.empty(D, Mp, W, device=dev, dtype=torch.float16) if store16 else None  # (rr: fragment order)
         gzexp = torch.empty(D, sv["hexp"].shape[1], device=dev, dtype=torch.int32) if store16 else None
         # [gz_r1 | gz_g1] as ONE [M][W] tensor when both heads are on and the chained f16x3 weight gradients run: the two first
         # layers of the heads are both fed by e, so their weight gradients are one launch that reads e once (chain.wgrad2)
         joined = bool(use16 and cfg.use_cand and cfg.use_rgb and JOIN_HEADS and WGRAD_CHAIN and W == 256
                       and ctx.tile_rows == 64 and TILE_PARTIALS)  # (upnerf_ray_sum, the fallback, wants dense tensors)
         gz_rg = _empty(M, W, device=dev) if joined else None
-        gz_g1 = (gz_rg[:, W2:] if joined else _empty(M, W2, device=dev)) if cfg.use_cand else None
-        gz_g2 = _empty(M, W2, device=dev) if cfg.use_cand else None
-        gz_r1 = (gz_rg[:, :W2] if joined else _empty(M, W2, device=dev)) if cfg.use_rgb else None
+        gz_g1 = (gz_rg[:, W2:] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_cand else None
+        gz_g2 = _empty(Mp, W2, device=dev)[:M] if cfg.use_cand else None
+        gz_r1 = (gz_rg[:, :W2] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_rgb else None
         dpre_s = _empty(M, device=dev)
         dpre_c = _empty(M, device=dev) if cfg.use_cand else None
         dpre_rgb = _empty(M, 4, device=dev) if cfg.use_rgb else None
@@ -286,13 +298,13 @@ class _FieldPass(torch.autograd.Function):
                           gz_g1=(gz_rg.data_ptr() + 4 * W2) if joined else ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_rg) if joined else ptr(gz_r1), gz_rg_ld=W if joined else 0, dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, tile_rows=ctx.tile_rows, xs=ptr(sv.get("x0f")), gz16=ptr(gz16),
-                          gzexp=ptr(gzexp), tile_part=ptr(tile_part))
+                          gzexp=ptr(gzexp), tile_part=ptr(tile_part), wnorm=ptr(sv.get("wnorm")))
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
         check(TIMER.run("field_bwd", lambda: bwd_fn(C.byref(L), C.byref(fb), st), units=M), "upnerf_field_bwd")
 
         if _DEBUG_SINK is not None:
             _DEBUG_SINK.update(d_sigma_s=d_sigma_s, d_sigma_c=d_sigma_c, d_rgb=d_rgb,
-                               gz_h=gz_h if gz_h is not None else dequant16(gz16, gzexp), gz_e=gz_e, gz_g1=gz_g1,
+                               gz_h=gz_h if gz_h is not None else dequant16(gz16, gzexp, frag=rr)[:, :M], gz_e=gz_e, gz_g1=gz_g1,
                                gz_g2=gz_g2, gz_r1=gz_r1, dpre_s=dpre_s, dpre_c=dpre_c, dpre_rgb=dpre_rgb, dxyz=dxyz)
         # ---- weight gradients, written straight into a buffer with P's layout
         dP = torch.zeros(L.total, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
@@ -325,7 +337,7 @@ class _FieldPass(torch.autograd.Function):
 
                 def wgp(l, B, ldb, bexp, K, off, ldo, boff, ib):
                     wgrad_f16p_into(M, gz16[l], W, gzexp[l], W, B, ldb, bexp, K, at(off), ldo, None if boff is None else at(boff),
-                                    dev, EA(l), EB(ib))
+                                    dev, EA(l), EB(ib), frag=rr)
 
                 for l in range(D):
                     if l == 0:
@@ -393,9 +405,16 @@ class _FieldPass(torch.autograd.Function):
         return d_o, d_d, None, d_c_rows, d_a_rows, dP, None
 
 
-def dequant16(t16: torch.Tensor, texp: torch.Tensor) -> torch.Tensor:
-    """fp32 view of an fp16-stored, tile-scaled tensor [D][M][W] with exponents [D][ceil(M/64)] (tests, debugging)."""
+def dequant16(t16: torch.Tensor, texp: torch.Tensor, frag: bool = False) -> torch.Tensor:
+    """fp32 view of an fp16-stored, tile-scaled tensor [D][M][W] with exponents [D][ceil(M/64)] (tests, debugging).
+    frag: the register-resident kernels' layout (include/upnerf_hip.h, tile_rows = 256) -- [D][M/32][k-block 16][lane 64][8]
+    with feature 16 s + 8 (j / 4) + 4 (lane / 32) + j % 4, row 32 tile + lane % 32, one exponent per 32 rows."""
     D, M, W = t16.shape
+    if frag:
+        t = t16.view(D, M // 32, W // 16, 2, 32, 2, 4)        # [D][tile][s][hh][li][j>>2][j&3]
+        rows = t.permute(0, 1, 4, 2, 5, 3, 6).reshape(D, M, W)  # [D][tile][li][s][j>>2][hh][j&3]
+        scale = torch.ldexp(torch.ones((), device=t16.device), -texp.float()).repeat_interleave(32, dim=1)[:, :M]
+        return rows.float() * scale[:, :, None]
     scale = torch.ldexp(torch.ones((), device=t16.device), -texp.float()).repeat_interleave(64, dim=1)[:, :M]
     return t16.float() * scale[:, :, None]
 
