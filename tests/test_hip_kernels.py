@@ -421,7 +421,8 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
 
     ok = True
     ok &= cmp("x0", sv["x0"], f["x0"], 1e-3 if field_mode == "f16" else 2e-6)  # f16: stored from the fp16 plane the layers read
-    hs = sv["h"] if sv.get("h16") is None else rd.dequant16(sv["h16"], sv["hexp"])  # f16 mode stores fp16 tiles + exponents
+    # f16 mode stores fp16 tiles + exponents (the register-resident kernels: operand fragments, one exponent per 32 rows)
+    hs = sv["h"] if sv.get("h16") is None else rd.dequant16(sv["h16"], sv["hexp"], frag=getattr(node, "rr", False))[:, :M]
     for l in range(pk.D):
         ok &= cmp(f"h{l}", hs[l], f["h"][l], TOL_ACT)
     if sv.get("h16") is not None:
@@ -480,32 +481,9 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     assert ok, "BWD over tolerance: " + repr(errs)
 
 
-@pytest.mark.parametrize("field_mode", ["f16x3", "f16"], indirect=True)
-@pytest.mark.parametrize("name,typ", STAGE_CASES)
-def test_pipelined_128_sample_kernels_stage_by_stage(hip, name, typ, field_mode, monkeypatch):
-    """The eight-wave, software-pipelined kernels of the 128-sample tile (csrc/pipe16.cuh; rendering.FIELD_TILE = 128, opt-in)
-    against the same fp32 restatement at the same gates as the default 64-sample kernels: every activation, every
-    pre-activation gradient, every parameter gradient."""
-    c = Case(name)
-    if c.cfgs()["nerf_coarse"].W != 256:
-        pytest.skip("64-wide fields run the fp32 kernels")
-    monkeypatch.setattr(hip["rendering"], "FIELD_TILE", 128)
-    fn = getattr(test_field_pass_stage_by_stage, "__wrapped__", test_field_pass_stage_by_stage)
-    fn(hip, name, typ, field_mode)
-
-
 @pytest.mark.parametrize("R,S,mode,use_cand,use_rgb", [(7, 40, 1, True, True), (5, 33, 0, True, False),
                                                          (3, 200, 2, False, True), (9, 32, 3, False, False)])
 def test_field_f16x3_matches_fp32_kernels_on_ragged_tiles(hip, R, S, mode, use_cand, use_rgb):
-    _ragged_tiles(hip, R, S, mode, use_cand, use_rgb)
-
-
-@pytest.mark.parametrize("R,S,mode,use_cand,use_rgb", [(5, 70, 1, True, True), (3, 200, 2, False, True),
-                                                         (2, 129, 0, True, False), (1, 64, 3, False, False)])
-def test_pipelined_128_sample_kernels_on_ragged_tiles(hip, R, S, mode, use_cand, use_rgb, monkeypatch):
-    """The same comparison for the 128-sample kernels: last tile ragged (M % 128 != 0, also M < 128 and a tile whose second
-    row half is empty), tiles straddling up to three rays, per-half exponents that differ."""
-    monkeypatch.setattr(hip["rendering"], "FIELD_TILE", 128)
     _ragged_tiles(hip, R, S, mode, use_cand, use_rgb)
 
 

@@ -125,3 +125,12 @@ if args.time:
                 sum(t.sum() for t in outs if t.numel()).backward()
         ev[1].record(); torch.cuda.synchronize()
         print(f"{tag}: {ev[0].elapsed_time(ev[1]) / 5:.3f} ms per pass (R {R2} S {S2}, fwd{'+bwd' if args.bwd else ''} incl. compositing / weight gradients)")
+if "h_last" in res["rr"] and bad:
+    a, b = res["rr"]["h_last"], ref["h_last"]
+    d = (a - b).abs()
+    print("h_last debug: rr nonzero frac", float((a != 0).float().mean()), "ref nonzero frac", float((b != 0).float().mean()))
+    rows = d.max(dim=1).values
+    print("rows with error > 1e-2 of max:", int((rows > 1e-2 * float(b.abs().max())).sum()), "of", rows.numel(), "first bad rows", torch.nonzero(rows > 1e-2 * float(b.abs().max()))[:8].flatten().tolist())
+    cols = d.max(dim=0).values
+    print("bad cols", torch.nonzero(cols > 1e-2 * float(b.abs().max()))[:16].flatten().tolist())
+    print("ratio sample", (a[0, :8] / b[0, :8].clamp_min(1e-9)).tolist())

@@ -25,6 +25,19 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+// (fp16 half HALF of `pair`) * s + c in one instruction
+template <int HALF>
+__device__ __forceinline__ float mix16(unsigned int pair, float s, float c) {
+  float r;
+  if constexpr (HALF == 0)
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(s), "v"(c));
+  else
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(s), "v"(c));
+  return r;
+}
+
 #define WEXP_SLOTS 16  // exponent table: trunk layers 0..7, 8 = final, 9 = cand1, 10 = cand2, 11 = rgb1, 12 = head^T
 
 // exponent that brings a positive maximum into [2^13, 2^14); 0 for an all-zero tile

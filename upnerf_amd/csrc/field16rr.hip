@@ -42,12 +42,12 @@
 #include <type_traits>
 
 #define RR_NSLOT 4                 // ring slots
-#define RR_AHEAD 3                 // slabs in flight ahead of the one being contracted
+#define RR_AHEAD 2                 // slabs travel in pairs: the next pair is in flight while a pair is contracted
 #define RR_MAXKB 21                // k-blocks of the widest matrix row (colour head: 256 + 80)
 #define RR_SLOT (RR_MAXKB * 1024)  // bytes per ring slot
 #define RR_STG 4096                // per-wave transposer: 32 rows x 32 fp32
 #ifndef RR_PF
-#define RR_PF 2                    // weight fragments requested from LDS this many k-blocks ahead
+#define RR_PF 3                    // weight fragments requested from LDS this many k-blocks ahead
 #endif
 #ifndef RR_FILL_VALU
 #define RR_FILL_VALU 7
@@ -79,8 +79,10 @@ struct RRCfg {
   static constexpr int VEC0 = STG0 + NW * RR_STG;
   static constexpr int ROW0 = VEC0 + RR_V_TOTAL * 4;          // per-ray side rows
   static constexpr int ROWF = 256 + 128;                      // floats per ray slot (fwd: aux 80 + cand 16; bwd: g_E_s 256 + g_G_c 128)
-  static constexpr int INT0 = ROW0 + MAXR * ROWF * 4;         // small integer tables
-  static constexpr int LDS = INT0 + 64 * 4;
+  static constexpr int BSW0 = ROW0 + MAXR * ROWF * 4;         // per-wave copy of the running layer's bias, times 2^eo (1 KiB each)
+  static constexpr int INT0 = BSW0 + NW * 1024;               // small integer tables
+  static constexpr int SLB0 = INT0 + 96 * 4;                  // slab list of the pass (<= 96 entries of 8 bytes)
+  static constexpr int LDS = SLB0 + 96 * 8;
   static_assert(NW * 32 * RR_PE_LD * 4 <= RING, "encoding exchange scratch lives in the ring");
 };
 
@@ -98,141 +100,220 @@ __device__ __forceinline__ float wave_max_rr(float m) {
   return __builtin_bit_cast(float, max(max(a, b), max(c, d)));
 }
 
-// s_waitcnt vmcnt(n), n wave-uniform (values above 62 wait for 62); expcnt / lgkmcnt untouched.  gfx9 encoding:
-// vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
+// s_waitcnt vmcnt(n) for a wave-uniform RUN-TIME n (the instruction takes an immediate): a computed jump into a table of 32
+// {s_waitcnt vmcnt(k); s_branch end} pairs.  n above 31 waits for 31 -- a stronger wait, always safe.  expcnt / lgkmcnt untouched
+// (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]).  A switch statement here compiled into a chain of
+// ~10 taken branches per call (round 4 stamps: ~400 cycles per slab).
 __device__ __forceinline__ void wait_vmcnt(int n) {
 #ifdef RR_SAFE_WAIT  // diagnostic: drain everything (A/B against the counted waits)
   __builtin_amdgcn_s_waitcnt(0x0F70);
   return;
 #endif
-#define RR_W(N) case N: __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14)); break;
-  switch (n) {
-    RR_W(0) RR_W(1) RR_W(2) RR_W(3) RR_W(4) RR_W(5) RR_W(6) RR_W(7) RR_W(8) RR_W(9) RR_W(10) RR_W(11) RR_W(12) RR_W(13) RR_W(14)
-    RR_W(15) RR_W(16) RR_W(17) RR_W(18) RR_W(19) RR_W(20) RR_W(21) RR_W(22) RR_W(23) RR_W(24) RR_W(25) RR_W(26) RR_W(27) RR_W(28)
-    RR_W(29) RR_W(30) RR_W(31) RR_W(32) RR_W(33) RR_W(34) RR_W(35) RR_W(36) RR_W(37) RR_W(38) RR_W(39) RR_W(40) RR_W(41) RR_W(42)
-    RR_W(43) RR_W(44) RR_W(45) RR_W(46) RR_W(47)
-    default: __builtin_amdgcn_s_waitcnt(0x0F70 | (48 & 15) | ((48 >> 4) << 14)); break;
-  }
-#undef RR_W
+  n = __builtin_amdgcn_readfirstlane(n > 31 ? 31 : (n < 0 ? 0 : n));
+#define RR_WE(N) "s_waitcnt vmcnt(" #N ")\n\ts_branch 1f\n\t"
+  asm volatile(
+      "s_getpc_b64 s[92:93]\n\t"      // address of the next instruction
+      "s_lshl_b32 s94, %0, 3\n\t"     // 8 bytes per table entry
+      "s_add_u32 s92, s92, s94\n\t"
+      "s_addc_u32 s93, s93, 0\n\t"
+      "s_add_u32 s92, s92, 24\n\t"    // the six 4-byte instructions between the s_getpc and the table
+      "s_addc_u32 s93, s93, 0\n\t"
+      "s_setpc_b64 s[92:93]\n\t" RR_WE(0) RR_WE(1) RR_WE(2) RR_WE(3) RR_WE(4) RR_WE(5) RR_WE(6) RR_WE(7) RR_WE(8) RR_WE(9) RR_WE(10)
+          RR_WE(11) RR_WE(12) RR_WE(13) RR_WE(14) RR_WE(15) RR_WE(16) RR_WE(17) RR_WE(18) RR_WE(19) RR_WE(20) RR_WE(21) RR_WE(22)
+              RR_WE(23) RR_WE(24) RR_WE(25) RR_WE(26) RR_WE(27) RR_WE(28) RR_WE(29) RR_WE(30) RR_WE(31) "1:\n\t"
+      :
+      : "s"(n)
+      : "memory", "scc", "s92", "s93", "s94");
+#undef RR_WE
 }
 
 // ---- slab sequence -------------------------------------------------------------------------------------------------------
 // A pass is a list of STAGES (one weight matrix each) of `tiles` 32-feature slabs; every stage has a multiple of RR_NSLOT
 // tiles, so slab i of a stage always sits in ring slot i % RR_NSLOT (compile-time in the unrolled tile loops).  The tables
 // live in LDS (sq_*): byte offset of the matrix in the fragment buffer, k-blocks per row, tiles.
-struct SlabIt {
-  int stage, tile;
-};
 #define RR_MAXSTAGE 16
 
-// ---- per-wave ring state -------------------------------------------------------------------------------------------------
-// vmc: vector-memory instructions this wave has issued in the slab loop so far (DMA + counted stores); mark[s]: its value
-// right after the DMA into slot s was issued.  vmc - mark[s] instructions are younger than that DMA.
-template <int NW>
-struct Ring {
-  const char* src;       // fragment buffer (P16 or PT16)
-  const int* sq_off;     // [stages] byte offsets (LDS table)
-  const int* sq_kb;      // [stages] k-blocks per tile row
-  const int* sq_tiles;   // [stages]
-  const int* sq_wrap;    // [stages] or nullptr: source tile = tile % wrap (a 2-tile stage issued twice keeps the slots aligned)
-  int nstage;
-  int wave, lane;
-  int vmc;
-  int mark[RR_NSLOT];    // (every index below is a compile-time constant: the struct lives in scalar registers)
-  SlabIt pre;            // next slab to request
+// Diagnostic build only (-DUPNERF_STAMPS): shader-clock sums per phase of the slab loop (tools/stamps_rr16.py):
+// 0 wait for the slab's DMA, 1 barrier, 2 DMA issue, 3 everything between two slab tops (MFMAs, epilogues, stores)
+#ifdef UPNERF_STAMPS
+__device__ unsigned long long upnerf_stamp_acc_rr[24];  // [0..7] forward, [8..15] backward, [16..23] forward epilogue detail
+#define RR_STAMP(i)                                              \
+  do {                                                           \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                          \
+    st_acc[i] += _t - st_prev;                                   \
+    st_prev = _t;                                                \
+  } while (0)
+#define RR_STAMP_RG(rg, i)                                       \
+  do {                                                           \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                          \
+    (rg).st_acc[i] += _t - (rg).st_prev;                         \
+    (rg).st_prev = _t;                                           \
+  } while (0)
+#else
+#define RR_STAMP(i)
+#define RR_STAMP_RG(rg, i)
+#endif
 
-  // request the next slab of the sequence into ring slot SLOT (`ring`: the kernel's LDS array, passed in so that the compiler
-  // keeps the address space)
-  template <int SLOT>
-  __device__ __forceinline__ void issue_next(char* ring) {
-    if (pre.stage < nstage) {
-      const int kb = __builtin_amdgcn_readfirstlane(sq_kb[pre.stage]);
-      const int off = __builtin_amdgcn_readfirstlane(sq_off[pre.stage]);
-      const int per = (kb + NW - 1) / NW;
-      const int gt = sq_wrap ? pre.tile % __builtin_amdgcn_readfirstlane(sq_wrap[pre.stage]) : pre.tile;
-      const char* g = src + (size_t)off + (size_t)gt * kb * 2048 + lane * 16;
-      char* d = ring + SLOT * RR_SLOT;
-      asm volatile("" ::: "memory");
-      for (int q = 0; q < per; ++q) {
-        int ch = wave + NW * q;
-        ch = ch < kb ? ch : kb - 1;  // surplus waves repeat the last chunk (same bytes to the same place)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)ch * 2048),
-                                         (__attribute__((address_space(3))) void*)(d + ch * 1024), 16, 0, 0);
-      }
-      asm volatile("" ::: "memory");
-      vmc += per;
-      if (++pre.tile >= __builtin_amdgcn_readfirstlane(sq_tiles[pre.stage])) {
-        pre.tile = 0;
-        do ++pre.stage;
-        while (pre.stage < nstage && __builtin_amdgcn_readfirstlane(sq_tiles[pre.stage]) == 0);
-      }
+// The slab list of a pass, built once per workgroup from its stage tables (offsets in bytes, k-blocks, tiles, wrap: a 2-tile stage
+// issued twice keeps the ring slots aligned): thread i writes entry i.  Returns the number of slabs.
+__device__ __forceinline__ int build_slab_table(int2* slab_s, const int* st_off, const int* st_kb, const int* st_tiles, const int* st_wrap,
+                                                int nstage, int tid) {
+  int total = 0, mine = -1, mt = 0;
+  for (int st = 0; st < nstage; ++st) {
+    const int t = st_tiles[st];
+    if (mine < 0 && tid < total + t) {
+      mine = st;
+      mt = tid - total;
     }
-    mark[SLOT] = vmc;
+    total += t;
   }
-
-  __device__ __forceinline__ void start(char* ring) {
-    vmc = 0;
-    pre.stage = 0;
-    pre.tile = 0;
-    static_assert(RR_AHEAD == 3, "start() requests slabs 0, 1, 2");
-    issue_next<0>(ring);
-    issue_next<1>(ring);
-    issue_next<2>(ring);
+  if (mine >= 0) {
+    const int kb = st_kb[mine], wr = st_wrap ? st_wrap[mine] : st_tiles[mine];
+    const int gt = mt >= wr ? mt - wr : mt;
+    slab_s[tid] = int2{st_off[mine] + gt * kb * 2048, kb};
   }
-
-  // top of a slab whose data sits in slot SLOT: wait for its DMA (this wave's part), meet the other waves (their parts have
-  // landed too, and everybody is done with the slot refilled next), request the slab RR_AHEAD further on
-  template <int SLOT>
-  __device__ __forceinline__ void begin(char* ring) {
-    __builtin_amdgcn_sched_barrier(0);
-    wait_vmcnt(vmc - mark[SLOT]);
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS traffic (transposer, previous fragments) is done
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_next<(SLOT + RR_AHEAD) % RR_NSLOT>(ring);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __device__ __forceinline__ void count(int n) { vmc += n; }
-};
-
-// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
+  return total;
 }
 
+// ---- per-wave ring state -------------------------------------------------------------------------------------------------
+// vmc: vector-memory instructions this wave has issued in the slab loop so far (DMA + counted stores); mark of slot s: its
+// value right after the DMA into slot s was issued.  vmc - mark instructions are younger than that DMA.  The tile loops are
+// RUN-TIME loops (the unrolled form of round 4's first build was 60 KB of code per trunk layer against a 64 KB instruction
+// cache shared by two CUs: every phase of it ran at a third of its speed), so the slot index is a run-time scalar: four
+// scalars and selects, never an indexed array (hipcc would put it in scratch).
+template <int NW>
+struct Ring {
+  const char* src;     // fragment buffer (P16 or PT16)
+  const int2* slab_s;  // LDS table of the pass's slabs in consumption order: {byte offset of the tile's first k-block, k-blocks}
+  int nslab, nreq;     // slabs of the pass; next slab to request
+  int wave, lane;
+  int vmc;
+  int mk0, mk1, mk2, mk3;
+#ifdef UPNERF_STAMPS
+  unsigned long long st_acc[10], st_prev;
+#endif
+
+  __device__ __forceinline__ int mark(int slot) const { return slot == 0 ? mk0 : (slot == 1 ? mk1 : (slot == 2 ? mk2 : mk3)); }
+
+  // request the next slab of the sequence into ring slot `slot` (`ring`: the kernel's LDS array, passed in so that the compiler
+  // keeps the address space).  Everything about the slab comes from ONE table entry: no stage logic in the tile loops (round 4:
+  // with the stage bookkeeping inlined at every request site a tile iteration was 750 instructions, and at two waves per
+  // SIMD a wave issues an instruction about every four cycles -- the loop was bound by its instruction COUNT).
+  __device__ __forceinline__ void issue(char* ring, int slot) {
+    // Only the LAGGING half of the waves (w >= NW/2) requests slabs: a 1 KiB request blocks its wave until the CU's one
+    // vector-memory path takes it (~60 cycles each when eight waves issue together), and a blocked wave issues no MFMA.  The
+    // lagging waves start a tile with the previous tile's epilogue anyway; their SIMD partners go straight to the matrix
+    // work.  A leading wave waits for nothing of its own: the barrier behind the lagging waves' counted wait covers it.
+    if (nreq < nslab && wave >= NW / 2) {
+      constexpr int ND = NW / 2;
+      const int2 e = slab_s[nreq];
+      const int off = __builtin_amdgcn_readfirstlane(e.x), kb = __builtin_amdgcn_readfirstlane(e.y);
+      const int per = (kb + ND - 1) / ND;
+      const char* g = src + (size_t)off + lane * 16;
+      char* d = ring + slot * RR_SLOT;
+      asm volatile("" ::: "memory");
+#ifndef RR_EXP_NODMA
+#pragma unroll 1
+      for (int q = 0; q < per; ++q) {
+        int ch = (wave - ND) + ND * q;
+        ch = ch < kb ? ch : kb - 1;  // surplus waves repeat the last chunk (same bytes to the same place)
+#ifdef RR_EXP_PLAINLOAD  // timing experiment (wrong results): the same bytes by ordinary loads whose results are dropped
+        const f32x4 v = *(const volatile f32x4*)(g + (size_t)ch * 2048);
+        asm volatile("" ::"v"(v));
+#else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)ch * 2048),
+                                         (__attribute__((address_space(3))) void*)(d + ch * 1024), 16, 0, 0);
+#endif
+      }
+      vmc += per;
+#else
+      (void)g;
+      (void)d;
+#endif
+      asm volatile("" ::: "memory");
+    }
+    if (nreq < nslab) ++nreq;
+    mk0 = slot == 0 ? vmc : mk0;
+    mk1 = slot == 1 ? vmc : mk1;
+    mk2 = slot == 2 ? vmc : mk2;
+    mk3 = slot == 3 ? vmc : mk3;
+  }
+
+  // first pair of slabs of the sequence
+  __device__ __forceinline__ void start(char* ring) {
+    vmc = 0;
+    nreq = 0;
+    mk0 = mk1 = mk2 = mk3 = 0;
+    static_assert(RR_NSLOT == 4, "slot of slab i = i % 4; slabs travel in pairs");
+    issue(ring, 0);
+    issue(ring, 1);
+  }
+
+  // Slabs are consumed in PAIRS (every stage has a multiple of four tiles): at the top of an even tile -- data in `slot`, slot + 1
+  // -- wait for the pair's DMA (the lagging waves' own parts), meet the other waves (everybody's parts have landed, and everybody
+  // is done with the previous pair's slots), request the next pair into those slots.  An odd tile needs nothing: ONE barrier per
+  // two tiles (round 4 stamps: with one per tile a wave spent a third of a tile in the wait + barrier + request sequence --
+  // the two halves of the waves run half a tile apart by design, and the barrier re-aligned them every tile).
+  __device__ __forceinline__ void begin(char* ring, int slot) {
+    if (slot & 1) return;
+    __builtin_amdgcn_sched_barrier(0);
+    RR_STAMP(3);  // everything since the previous pair's top that has no stamp of its own
+    wait_vmcnt(vmc - mark(slot + 1));
+    RR_STAMP(0);  // wait for the pair's DMA (and, in order, for every older store)
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS traffic (transposer, previous fragments) is done
+#ifndef RR_EXP_NOBARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+    RR_STAMP(1);  // barrier
+    asm volatile("" ::: "memory");
+    issue(ring, (slot + 2) & 3);
+    issue(ring, (slot + 3) & 3);
+    RR_STAMP(2);  // DMA issue
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void count(int n) {
+#ifdef RR_EXP_NOSTORE
+    (void)n;  // (the experiment issues no stores; the sign-bit DMAs count themselves through count_dma)
+#else
+    vmc += n;
+#endif
+  }
+  __device__ __forceinline__ void count_dma(int n) { vmc += n; }
+};
+
 // acc (32 features x 32 samples, transposed) += slab k-blocks [p, p + T KiB) . o[0 .. T)
-// Weight fragments come from the LDS slot through a ring RR_PF k-blocks ahead of their MFMAs.  With FILL, `fill(g)` -- a quarter
-// of the PREVIOUS tile's epilogue -- is called once in each of the first four regions of four k-blocks, and sched_group_barrier
-// lays a region out as LDS read, MFMA, a few vector instructions, ... so that the vector work issues in the shadow of the
-// matrix pipe.
-template <int T, bool FILL, int N, class F>
-__device__ __forceinline__ void kpart(f32x16& acc, const char* p, const h8 (&o)[N], F fill) {
+// Weight fragments come from the LDS slot through a ring PF k-blocks ahead of their MFMAs; the order is pinned (hipcc otherwise
+// sinks the reads to just before their use and waits lgkmcnt(0) every other MFMA).
+template <int T, int N, bool FIRST = false, int PF = RR_PF>
+__device__ __forceinline__ void kpart(f32x16& acc, const char* p, const h8 (&o)[N]) {
   static_assert(T <= N, "operand array");
-  constexpr int SETS = RR_PF + 1, G = (T + 3) / 4;
+  constexpr int SETS = PF + 1;
   h8 af[SETS];
+#ifdef RR_EXP_NOLDS  // timing experiment: no weight-fragment reads
 #pragma unroll
-  for (int t = 0; t < RR_PF && t < T; ++t) af[t] = *(const h8*)(p + t * 1024);
-  __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < SETS; ++t) af[t] = o[0];
+#define RR_LDSREAD(dst, addr) asm volatile("" ::"v"(addr))
+#else
+#define RR_LDSREAD(dst, addr) dst = *(const h8*)(addr)
+#endif
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
+  for (int t = 0; t < PF && t < T; ++t) RR_LDSREAD(af[t], p + t * 1024);
 #pragma unroll
-    for (int t = 4 * g; t < 4 * g + 4 && t < T; ++t) {
-      if (t + RR_PF < T) af[(t + RR_PF) % SETS] = *(const h8*)(p + (t + RR_PF) * 1024);
+  for (int t = 0; t < T; ++t) {
+    if (t + PF < T) RR_LDSREAD(af[(t + PF) % SETS], p + (t + PF) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef RR_EXP_NOMMA
+    if (FIRST && t == 0) {  // C = 0 as an inline constant: no 16-register clear in front of the tile
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % SETS], o[t], z, 0, 0, 0);
+    } else {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % SETS], o[t], acc, 0, 0, 0);
     }
-    if constexpr (FILL) {
-      if (g < 4) fill(g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // one LDS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, RR_FILL_VALU, 0);  // vector instructions in its shadow
-      }
-    }
+#else
+    asm volatile("" ::"v"(af[t % SETS]), "v"(o[t]));
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -269,56 +350,197 @@ __device__ __forceinline__ void stg_flush(const char* stg, int lane, float* __re
   for (int i = 0; i < 4; ++i) {
     const int row = 8 * i + (lane >> 3);
     const f32x4 v = *(const f32x4*)(stg + row * 128 + ((c ^ (row & 7)) << 4));
+#ifndef RR_EXP_NOSTORE
     NT_STORE((f32x4*)(dst + (size_t)row * ld + col0 + 4 * c), v);
+#else
+    asm volatile("" ::"v"(v));
+#endif
   }
 }
 
-enum { EP_RELU = 1, EP_MASK = 2, EP_CONV = 4 };
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
-// Epilogue of register quad q of the 32-feature tile j of a stage: v = act(fma(acc, un, bias)); optional sign bits (word
-// j / 2 of bits[4], bit 16 (j % 2) + 4 q + u), running maximum, fp32 copy into the transposer, conversion into the next
-// operand fragments (k-blocks 2j, 2j + 1) at exponent eo, up to three dot products with LDS-staged vectors.
-template <int FLAGS, int NDOT, int NB>
-__device__ __forceinline__ void quad_epilogue(const f32x16& acc, int j, int q, float un, const float* bias_s, unsigned int (&bits)[4],
-                                              float& vmax, char* stg /* transposer, or nullptr: no fp32 copy */, int eo, h8 (&nx)[NB],
-                                              const float* dotw_s, int dot_ld, float (&dot)[3], int li, int hh) {
-  const int col = 32 * j + 8 * q + 4 * hh;
-  const f32x4 b = *(const f32x4*)&bias_s[col];
-  float v[4];
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+// ---- epilogue of one 32-feature tile, forward and backward.  What an epilogue costs decides the kernel: with two waves per SIMD
+// a wave's vector instructions take ~4 cycles each, the 16 MFMAs of a tile 512 -- an epilogue of 200 instructions (round 4's
+// first builds) ran 2.7x longer than the contraction it follows and the two never overlapped (elimination runs: 0.8 ms per
+// launch without epilogues, 2.2 ms without MFMAs, 2.85 ms with both).  So everything is done on register PAIRS (two consecutive
+// features of the lane's sample), in as few instructions as the ISA allows:
+//   FAST form (SCALED = true; the trunk): the addend arrives pre-multiplied by 2^eo (a per-wave, per-layer copy of the bias in LDS)
+//     s = acc * (un 2^eo) + add'             v_pk_fma_f32                 h = fp16(s)   v_cvt_pk_f16_f32
+//     [ReLU]  v_pk_max_f16                   [sign bits out]  v_pk_min_u16 + v_lshl_or_b32
+//     [sign-bit mask in]  4 integer ops      running maximum  v_pk_max_f16 (in units of 2^-eo: vmax2)
+//   EXACT form (SCALED = false; stages whose fp32 rows leave through the transposer): v = acc * un + add in natural units
+//     (v_pk_fma_f32), ReLU / sign-bit mask in fp32, rows to the transposer, then h = fp16(v 2^eo).
+// A pair IS one register of the next operand's fragment: blk[q / 2] register 2 (q % 2) + t.  Sign bits of a tile = one word `tw`:
+// element r of the tile at bit 16 (r % 2) + r / 2 (the halves of a pair 16 bits apart); tiles 2 w and 2 w + 1 share word w of the
+// lane's four words per stage (tile 2 w + 1 shifted left by 8).  A positive pre-activation that underflows fp16 (below 2^-38 of
+// the stage's bound) counts as inactive.
+template <bool SCALED, int ADD /*0 none, 1 add_s[col], 2 add_s[col] * add_sc*/, int MASKIN /*0, 1*/, bool RELU, bool MASKOUT>
+__device__ __forceinline__ void tile_epilogue(const f32x16& acc, int jp, float un, float pe, const float* add_s, float add_sc, unsigned int tw_in,
+                                              unsigned int& tw_out, float& vmax, h2& vmax2, char* stg, u32x4_t (&blk)[2], int li, int hh) {
+  f32x4 aq[4];
+  if constexpr (ADD != 0) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    v[u] = fmaf(acc[4 * q + u], un, b[u]);
-    if (FLAGS & EP_RELU) v[u] = fmaxf(v[u], 0.0f);
-    if (FLAGS & EP_MASK) {
-      const unsigned int one = min(__float_as_uint(v[u]), 1u);  // v >= 0 after the ReLU: positive <=> non-zero bit pattern
-      bits[(j >> 1) & 3] |= one << (16 * (j & 1) + 4 * q + u);
+    for (int q = 0; q < 4; ++q) aq[q] = *(const f32x4*)&add_s[32 * jp + 8 * q + 4 * hh];  // requested together: one LDS wait per tile
+  }
+  const float s1 = SCALED ? un * pe : un;
+  const f32x2 un2 = {s1, s1}, pe2 = {pe, pe}, sc2 = {add_sc, add_sc};
+  tw_out = 0u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x2 vv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x2 av = {acc[4 * q + 2 * t], acc[4 * q + 2 * t + 1]};
+      const int bit = 2 * q + t;
+      f32x2 v;
+      if constexpr (ADD == 1) v = __builtin_elementwise_fma(av, un2, f32x2{aq[q][2 * t], aq[q][2 * t + 1]});
+      else if constexpr (ADD == 2) v = __builtin_elementwise_fma(f32x2{aq[q][2 * t], aq[q][2 * t + 1]}, sc2, av * un2);
+      else v = av * un2;
+      h2 h;
+      if constexpr (SCALED) {
+        h = __builtin_convertvector(v, h2);
+        if constexpr (RELU) h = __builtin_elementwise_max(h, h2{(_Float16)0, (_Float16)0});
+      } else {
+        if constexpr (RELU) v = f32x2{fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
+        if constexpr (MASKIN == 1) {
+          v[0] = __uint_as_float(__float_as_uint(v[0]) & (unsigned int)(((int)(tw_in << (31 - bit))) >> 31));
+          v[1] = __uint_as_float(__float_as_uint(v[1]) & (unsigned int)(((int)(tw_in << (15 - bit))) >> 31));
+        }
+        vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+        h = __builtin_convertvector(v * pe2, h2);
+      }
+      if constexpr (SCALED && MASKIN == 1) {
+        const unsigned int m = (tw_in >> bit) & 0x00010001u;
+        const u16x2_t full = u16x2_t{0, 0} - __builtin_bit_cast(u16x2_t, m);  // 0xffff where the bit is set
+        h = __builtin_bit_cast(h2, __builtin_bit_cast(unsigned int, h) & __builtin_bit_cast(unsigned int, full));
+      }
+      if constexpr (SCALED) vmax2 = __builtin_elementwise_max(vmax2, MASKIN == 1 ? __builtin_elementwise_abs(h) : h);
+      if constexpr (MASKOUT) {
+        // (in C -- min(bits, 1) per half -- hipcc "knows" the operand is a float and emits ~30 compare / select instructions
+        // per pair; the operand is a conversion result, never an MFMA destination: DESIGN 4.4)
+        unsigned int one;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(one) : "v"(__builtin_bit_cast(unsigned int, h)), "v"(0x00010001u));
+        tw_out |= one << bit;
+      }
+      blk[q >> 1][2 * (q & 1) + t] = __builtin_bit_cast(unsigned int, h);
+      vv[t] = v;
+    }
+    if constexpr (!SCALED) {
+      if (stg) stg_put(stg, li, hh, q, f32x4{vv[0][0], vv[0][1], vv[1][0], vv[1][1]});
     }
   }
-  vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-  if (stg) stg_put(stg, li, hh, q, f32x4{v[0], v[1], v[2], v[3]});
-  if constexpr (NDOT > 0) {
+}
+__device__ __forceinline__ float pk_hmax(h2 v) { return fmaxf((float)v[0], (float)v[1]); }
+// NV dot products of this lane's sample row, held as KB operand fragments at exponent e, with LDS-staged fp32 vectors w_s[c * ld ..]:
+// the 1- and 3-wide heads (density, colour).  Outside the slab loop: inside it, three running sums per tile made hipcc spill
+// 200 registers around the colour head.
+template <int KB, int NV, int N>
+__device__ __forceinline__ void operand_dots(const h8 (&op)[N], int e, const float* w_s, int ld, int hh, float (&out)[3]) {
+  float acc[NV];
 #pragma unroll
-    for (int c = 0; c < NDOT; ++c) {
-      const f32x4 w = *(const f32x4*)&dotw_s[c * dot_ld + col];
-      dot[c] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+  for (int c = 0; c < NV; ++c) acc[c] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < KB; ++s) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = (float)op[s][u];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const f32x4 w0 = *(const f32x4*)&w_s[c * ld + 16 * s + 4 * hh], w1 = *(const f32x4*)&w_s[c * ld + 16 * s + 8 + 4 * hh];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[c] = fmaf(x[u], w0[u], fmaf(x[4 + u], w1[u], acc[c]));
     }
   }
-  if constexpr ((FLAGS & EP_CONV) != 0) {
-    h4 hi, lo;
-    split_quad<1>(ldexpf(v[0], eo), ldexpf(v[1], eo), ldexpf(v[2], eo), ldexpf(v[3], eo), hi, lo);
-    const int blk = 2 * j + (q >> 1);
-    if (q & 1) nx[blk] = __builtin_shufflevector(nx[blk], __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3), 0, 1, 2, 3, 12, 13, 14, 15);
-    else nx[blk] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3);
+  const float un = ldexpf(1.0f, -e);
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    acc[c] += __shfl_xor(acc[c], 32);
+    out[c] = acc[c] * un;
   }
 }
 
 // one operand fragment (k-block blk of this wave's 32-row tile) -> the fragment-ordered fp16 tensor: 1 KiB per instruction
 __device__ __forceinline__ void frag_store(uint16_t* __restrict__ base, size_t tile32, int blk, int lane, const h8& v) {
+#ifdef RR_EXP_NOSTORE  // timing experiment (wrong results): no activation / gradient stores at all
+  return;
+#endif
   NT_STORE((f32x4*)((char*)base + (tile32 * 16 + blk) * 1024 + lane * 16), __builtin_bit_cast(f32x4, v));
 }
 
 __device__ __forceinline__ void track_lds(unsigned int* mx_s, int slot, float wave_mx, int lane) {
   if (lane == 0) atomicMax(&mx_s[slot], __float_as_uint(wave_mx));
+}
+
+// ---- what a stage does with a finished tile besides the arithmetic: its operand fragments leave (frag != nullptr) and enter the
+// next operand, its fp32 rows leave through the transposer (rows != nullptr)
+struct TileOut {
+  uint16_t* frag;   // fragment-ordered fp16 tensor of this stage, or nullptr
+  float* rows;      // row-major fp32 tensor (this wave's first row), or nullptr
+  int ld;           // its row stride
+};
+template <int NW, int BLK0, int JP, int NB>
+__device__ __forceinline__ void tile_out(Ring<NW>& rg, const TileOut& o, const u32x4_t (&blk)[2], h8 (&nx)[NB], char* stg, size_t t32, int lane) {
+  nx[BLK0 + 2 * JP] = __builtin_bit_cast(h8, blk[0]);
+  nx[BLK0 + 2 * JP + 1] = __builtin_bit_cast(h8, blk[1]);
+  if (o.frag) {
+    frag_store(o.frag, t32, 2 * JP, lane, nx[BLK0 + 2 * JP]);
+    frag_store(o.frag, t32, 2 * JP + 1, lane, nx[BLK0 + 2 * JP + 1]);
+    rg.count(2);
+  }
+  if (o.rows) {
+    stg_flush(stg, lane, o.rows, o.ld, 32 * JP);
+    rg.count(4);
+  }
+}
+// sign-bit words of a stage: tiles 2 w, 2 w + 1 -> word w
+template <int JP>
+__device__ __forceinline__ void mask_add(u32x4_t& words, unsigned int tw) {
+  if constexpr ((JP & 1) == 0) words[JP >> 1] = tw;
+  else words[JP >> 1] |= tw << 8;
+}
+template <int JP>
+__device__ __forceinline__ unsigned int mask_tile(const u32x4_t& words) {
+  return words[JP >> 1] >> (8 * (JP & 1));
+}
+
+// ---- the tile loop of a stage, unrolled (NT tiles: every register index of the operand being built is a compile-time constant;
+// a run-time loop over dynamically indexed 32-register vectors was built and measured slower: hipcc copies the whole vector
+// around every insertion).  Slab j sits in ring slot j % 4 (every stage has a multiple of four tiles).  The two waves of a
+// SIMD (w and w + NW/2) run it half a tile apart: the leading half contracts tile j and then runs its epilogue, the lagging
+// half runs the epilogue of tile j - 1 and then contracts tile j -- one wave's vector work beside the other's matrix work on
+// every SIMD, one accumulator per wave (MI355X_MICROARCH.md, "try a stagger").  mma(p): the contraction of the slab at LDS
+// address p; epi(J): epilogue + outputs of tile J.
+template <int NW, int NT, class MMA, class EPI>
+__device__ __forceinline__ void run_tiles(Ring<NW>& rg, char* lds, bool lag, MMA mma, EPI epi) {
+  static_for<0, NT>([&](auto J) {
+    constexpr int j = decltype(J)::value, slot = j & 3;
+    rg.begin(lds, slot);
+#ifndef RR_EXP_NOEPI
+    if constexpr (j > 0) {
+      if (lag) epi(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{});
+    }
+#endif
+    RR_STAMP_RG(rg, 5);
+    mma(lds + slot * RR_SLOT + rg.lane * 16);
+    RR_STAMP_RG(rg, 4);
+#ifndef RR_EXP_NOEPI
+    if (!lag) epi(J);
+#endif
+    RR_STAMP_RG(rg, 5);
+  });
+#ifndef RR_EXP_NOEPI
+  if (lag) epi(std::integral_constant<int, NT - 1>{});
+#endif
 }
 
 // ================================================================================================================================
@@ -347,8 +569,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
   const size_t t32 = (size_t)blockIdx.x * NW + wave; // 32-row tile index
   const size_t nt32 = (size_t)gridDim.x * NW;
   const float* __restrict__ P = a.P;
-  const int* __restrict__ wexp = a.wexp;
-  const float* __restrict__ wnorm = a.wnorm;
+  // exponents and row norms of the matrices: copied to LDS once (read through the pointers inside the slab loop they are
+  // vector-memory loads -- the kernel stores, so hipcc cannot prove them read-only -- and every one drains the DMA queue)
+  const int* wexp = int_s + 64;
+  const float* wnorm = (const float*)(int_s + 80);
   const bool use_rgb = a.use_rgb != 0, use_cand = a.use_cand != 0;
   const bool train = a.h16 != nullptr;
   const int last_stage = (!a.e && !use_rgb && !use_cand) ? D - 1 : ((!use_rgb && !use_cand) ? D : D + 3);
@@ -378,6 +602,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
     int_s[16 + st] = kb;
     int_s[32 + st] = tiles;
     mx_s[st] = 0u;
+    int_s[64 + st] = a.wexp[st];
+    ((float*)int_s)[80 + st] = a.wnorm[st];
   }
 #pragma unroll
   for (int l = 0; l < UPNERF_MAX_D; ++l)
@@ -440,6 +666,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
     }
   }
   __syncthreads();
+  int2* slab_s = (int2*)(lds + C::SLB0);
+  const int nslab = build_slab_table(slab_s, int_s, int_s + 16, int_s + 32, nullptr, D + 4, tid);  // (visible after the next barrier)
   const float x0max = wave_max_rr(xm);
   const int e0 = scale_exp(x0max);
   {
@@ -488,13 +716,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
 
   Ring<NW> rg;
   rg.src = (const char*)a.P16;
-  rg.sq_off = int_s;
-  rg.sq_kb = int_s + 16;
-  rg.sq_tiles = int_s + 32;
-  rg.sq_wrap = nullptr;
-  rg.nstage = D + 4;
+  rg.slab_s = slab_s;
+  rg.nslab = nslab;
   rg.wave = wave;
   rg.lane = lane;
+#ifdef UPNERF_STAMPS
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < 10; ++i) rg.st_acc[i] = 0;
+  rg.st_prev = st_t0;
+#endif
   rg.start(lds);
 
   h8 Bh[16];  // operand of the running stage (previous stage's outputs)
@@ -502,11 +732,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
   float dot3[3] = {0.f, 0.f, 0.f};
   int e_in = e0;          // exponent of the operand the running stage reads
   float amax_in = x0max;  // its exact largest magnitude in this wave
-  auto nofill = [](int) {};
-  // The two waves of a SIMD (w and w + NW/2) run the tile loop half a tile apart: the leading half contracts tile j and then
-  // runs its epilogue, the lagging half runs the epilogue of tile j - 1 and then contracts tile j -- one wave's vector work
-  // beside the other's matrix work on every SIMD, one accumulator per wave (MI355X_MICROARCH.md, "try a stagger").
   const bool lag = wave >= NW / 2;
+  f32x16 acc;
+  float* bsw = (float*)(lds + C::BSW0 + wave * 1024);
 
   // ---- trunk (nerf.py:84-87)
 #pragma unroll 1
@@ -530,49 +758,53 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
     float bound = wnorm[l] * amax_in + vec_s[RR_V_BMAX + l];
     if (l + 1 == L.skip) bound = fmaxf(bound, x0max);
     const int eo = scale_exp(bound);
-    const float* bias_s = vec_s + 256 * l;
+    const float pe = pow2r(eo);
+    // this wave's copy of the layer's bias in units of 2^-eo: the epilogue then is ONE packed fma per pair (LDS traffic of a
+    // wave is ordered: no barrier)
+    *(f32x4*)&bsw[4 * lane] = *(const f32x4*)&vec_s[256 * l + 4 * lane] * pe;
     const bool rows32 = train && a.h != nullptr && l == D - 1;  // fp32 copy of the last trunk layer (density-head / final-layer gradients)
-    char* stg_l = rows32 ? stg : nullptr;
     const int xkb = (has_x && has_h) ? UPNERF_X0 / 16 : 0;  // k-blocks of the encoding part in front of the h part
-    unsigned int bits[4] = {0u, 0u, 0u, 0u};
+    TileOut to;
+    to.frag = train ? a.h16 + (size_t)l * nt32 * 16 * 512 : nullptr;
+    to.rows = rows32 ? a.h + (size_t)m0 * W : nullptr;
+    to.ld = W;
+    u32x4_t words = {0u, 0u, 0u, 0u};
     float vmax = 0.0f;
-    f32x16 acc;
-    // epilogue of tile jp, then its two operand fragments and (last layer) its fp32 rows leave
-    auto tile_epi = [&](auto JP) {
-      constexpr int jp = decltype(JP)::value;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        quad_epilogue<EP_RELU | EP_MASK | EP_CONV, 0>(acc, jp, q, un, bias_s, bits, vmax, stg_l, eo, Nh, nullptr, 0, dot3, li, hh);
-      if (train) {
-        uint16_t* __restrict__ h16l = a.h16 + (size_t)l * nt32 * 16 * 512;
-        frag_store(h16l, t32, 2 * jp, lane, Nh[2 * jp]);
-        frag_store(h16l, t32, 2 * jp + 1, lane, Nh[2 * jp + 1]);
-        rg.count(2);
-      }
-      if (rows32) {
-        stg_flush(stg, lane, a.h + (size_t)m0 * W, W, 32 * jp);
-        rg.count(4);
-      }
-    };
-    static_for<0, 8>([&](auto J) {
-      constexpr int j = decltype(J)::value;
-      rg.template begin<(j & 3)>(lds);
-      const char* p = lds + (j & 3) * RR_SLOT + lane * 16;
-      if constexpr (j > 0) {
-        if (lag) tile_epi(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{});
-      }
-      acc_clear(acc);
-      if (has_x) kpart<4, false>(acc, p, Xh, nofill);
-      if (has_h) kpart<16, false>(acc, p + xkb * 1024, Bh, nofill);
-      if (!lag) tile_epi(J);
-    });
-    if (lag) tile_epi(std::integral_constant<int, 7>{});
+    h2 vmax2 = {(_Float16)0, (_Float16)0};
+    const float inv_pe = pow2r(-eo);
+    run_tiles<NW, 8>(
+        rg, lds, lag,
+        [&](const char* p) {
+          if (has_x) {
+            kpart<4, 4, true>(acc, p, Xh);
+            if (has_h) kpart<16>(acc, p + xkb * 1024, Bh);
+          } else {
+            kpart<16, 16, true>(acc, p, Bh);
+          }
+        },
+        [&](auto JP) {
+          constexpr int jp = decltype(JP)::value;
+          u32x4_t blk[2];
+          unsigned int tw;
+          // (last layer: the exact form, whose fp32 rows -- the operand of the density head's and the final layer's weight
+          // gradients -- leave through the transposer; every other layer: the scaled form, one packed fma per pair)
+          RR_STAMP_RG(rg, 6);  // (whatever precedes the epilogue since the last stamp)
+          if (rows32) tile_epilogue<false, 1, 0, true, true>(acc, jp, un, pe, vec_s + 256 * l, 1.0f, 0u, tw, vmax, vmax2, stg, blk, li, hh);
+          else tile_epilogue<true, 1, 0, true, true>(acc, jp, un, pe, bsw, 1.0f, 0u, tw, vmax, vmax2, nullptr, blk, li, hh);
+          mask_add<jp>(words, tw);
+          asm volatile("" ::"v"(blk[0]), "v"(blk[1]));
+          RR_STAMP_RG(rg, 7);  // epilogue arithmetic (incl. the wait for the tile's last MFMA and for the bias quads)
+          tile_out<NW, 0, jp>(rg, to, blk, Nh, stg, t32, lane);
+          RR_STAMP_RG(rg, 8);  // fragment / row stores
+        });
     if (train) {
-      NT_STORE((u32x4_t*)((char*)a.hmask + (((size_t)l * nt32 + t32) * 64 + lane) * 16), (u32x4_t{bits[0], bits[1], bits[2], bits[3]}));
+#ifndef RR_EXP_NOSTORE
+      NT_STORE((u32x4_t*)((char*)a.hmask + (((size_t)l * nt32 + t32) * 64 + lane) * 16), words);
+#endif
       rg.count(1);
       if (lane == 0) a.hexp[(size_t)l * nt32 + t32] = eo;  // (one lane: not counted)
     }
-    amax_in = wave_max_rr(vmax);
+    amax_in = wave_max_rr(fmaxf(vmax, pk_hmax(vmax2) * inv_pe));
     track_lds(mx_s, l, amax_in, lane);
     e_in = eo;
 #pragma unroll
@@ -581,17 +813,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
 
   // ---- shared density head (nerf.py:89): softplus(w . h + b), from the operand fragments
   {
-    float sdot = 0.0f;
-    const float* wsig_s = vec_s + RR_V_WSIG;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const f32x4 w0 = *(const f32x4*)&wsig_s[16 * s + 4 * hh], w1 = *(const f32x4*)&wsig_s[16 * s + 8 + 4 * hh];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) sdot += (float)Bh[s][u] * w0[u] + (float)Bh[s][4 + u] * w1[u];
-    }
-    sdot += __shfl_xor(sdot, 32);
-    if (hh == 0 && valid) a.sigma_s[m] = softplus_f(sdot * pow2r(-e_in) + bsig);
+    operand_dots<16, 1>(Bh, e_in, vec_s + RR_V_WSIG, W, hh, dot3);
+    if (hh == 0 && valid) a.sigma_s[m] = softplus_f(dot3[0] + bsig);
   }
+  h2 novmax2 = {(_Float16)0, (_Float16)0};
   if (last_stage >= D) {
     // ---- xyz_encoding_final (nerf.py:93), no activation; its operand form E feeds both heads
     float amax_e;
@@ -600,32 +825,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
       const float un = pow2r(-(e_in + wexp[8]));
       const float bound = fmaxf(wnorm[D] * amax_in + vec_s[RR_V_BMAX + 8], sidemax);  // the heads add per-ray rows at E's exponent
       e_E = scale_exp(bound);
+      const float pe = pow2r(e_E);
+      TileOut to;
+      to.frag = nullptr;
+      to.rows = a.e ? a.e + (size_t)m0 * W : nullptr;
+      to.ld = W;
       char* stg_e = a.e ? stg : nullptr;
-      unsigned int nobits[4] = {0u, 0u, 0u, 0u};
       float vmax = 0.0f;
-      f32x16 acc;
-      auto tile_epi = [&](auto JP) {
-        constexpr int jp = decltype(JP)::value;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          quad_epilogue<EP_CONV, 0>(acc, jp, q, un, vec_s + RR_V_BE, nobits, vmax, stg_e, e_E, Nh, nullptr, 0, dot3, li, hh);
-        if (a.e) {
-          stg_flush(stg, lane, a.e + (size_t)m0 * W, W, 32 * jp);
-          rg.count(4);
-        }
-      };
-      static_for<0, 8>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        rg.template begin<(j & 3)>(lds);
-      const char* p = lds + (j & 3) * RR_SLOT + lane * 16;
-        if constexpr (j > 0) {
-          if (lag) tile_epi(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{});
-        }
-        acc_clear(acc);
-        kpart<16, false>(acc, p, Bh, nofill);
-        if (!lag) tile_epi(J);
-      });
-      if (lag) tile_epi(std::integral_constant<int, 7>{});
+      run_tiles<NW, 8>(
+          rg, lds, lag,
+          [&](const char* p) {
+            kpart<16, 16, true>(acc, p, Bh);
+          },
+          [&](auto JP) {
+            constexpr int jp = decltype(JP)::value;
+            u32x4_t blk[2];
+            unsigned int tw;
+            tile_epilogue<false, 1, 0, false, false>(acc, jp, un, pe, vec_s + RR_V_BE, 1.0f, 0u, tw, vmax, novmax2, stg_e, blk, li, hh);
+            tile_out<NW, 0, jp>(rg, to, blk, Nh, stg, t32, lane);
+          });
       amax_e = wave_max_rr(vmax);
       track_lds(mx_s, D, amax_e, lane);
 #pragma unroll
@@ -637,100 +855,126 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
 #pragma unroll
       for (int s = 0; s < 5; ++s) Ah[s] = row_op(rows_s + rs * C::ROWF, s, hh, e_E);
       const float un = pow2r(-(e_E + wexp[11]));
+      const int e_R = scale_exp(wnorm[D + 3] * fmaxf(amax_e, sidemax) + vec_s[RR_V_BMAX + 9]);  // r1 as an operand: feeds the colour dots
+      const float pe = pow2r(e_R);
+      TileOut to;
+      to.frag = nullptr;
+      to.rows = train ? a.r1 + (size_t)m0 * W2 : nullptr;
+      to.ld = W2;
       char* stg_r = train ? stg : nullptr;
-      float* __restrict__ rdst = train ? a.r1 + (size_t)m0 * W2 : nullptr;
-      unsigned int bits[4] = {0u, 0u, 0u, 0u};
+      u32x4_t words = {0u, 0u, 0u, 0u};
       float vmax = 0.0f;
-      dot3[0] = dot3[1] = dot3[2] = 0.0f;
-      static_for<0, 4>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        rg.template begin<(j & 3)>(lds);
-      const char* p = lds + (j & 3) * RR_SLOT + lane * 16;
-        f32x16 acc;
-        acc_clear(acc);
-        kpart<16, false>(acc, p, Bh, nofill);
-        kpart<5, false>(acc, p + 16 * 1024, Ah, nofill);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          quad_epilogue<EP_RELU | EP_MASK, 3>(acc, j, q, un, vec_s + RR_V_BR1, bits, vmax, stg_r, 0, Nh, vec_s + RR_V_WR2, W2, dot3, li, hh);
-        if (train) {
-          stg_flush(stg, lane, rdst, W2, 32 * j);
-          rg.count(4);
-        }
-      });
+      run_tiles<NW, 4>(
+          rg, lds, lag,
+          [&](const char* p) {
+            kpart<16, 16, true>(acc, p, Bh);
+            kpart<5>(acc, p + 16 * 1024, Ah);
+          },
+          [&](auto JP) {
+            constexpr int jp = decltype(JP)::value;
+            u32x4_t blk[2];
+            unsigned int tw;
+            tile_epilogue<false, 1, 0, true, true>(acc, jp, un, pe, vec_s + RR_V_BR1, 1.0f, 0u, tw, vmax, novmax2, stg_r, blk, li, hh);
+            mask_add<jp>(words, tw);
+            tile_out<NW, 0, jp>(rg, to, blk, Nh, stg, t32, lane);
+          });
       if (train) {
-        NT_STORE((u32x4_t*)((char*)a.hmask + (((size_t)(D + 2) * nt32 + t32) * 64 + lane) * 16), (u32x4_t{bits[0], bits[1], 0u, 0u}));
+#ifndef RR_EXP_NOSTORE
+        NT_STORE((u32x4_t*)((char*)a.hmask + (((size_t)(D + 2) * nt32 + t32) * 64 + lane) * 16), words);
+#endif
         rg.count(1);
       }
       track_lds(mx_s, D + 3, wave_max_rr(vmax), lane);
+      operand_dots<8, 3>(Nh, e_R, vec_s + RR_V_WR2, W2, hh, dot3);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float d = dot3[c] + __shfl_xor(dot3[c], 32);
-        if (hh == 0 && valid) a.rgb[(size_t)m * 3 + c] = sigmoid_f(d + br2[c]);
-      }
+      for (int c = 0; c < 3; ++c)
+        if (hh == 0 && valid) a.rgb[(size_t)m * 3 + c] = sigmoid_f(dot3[c] + br2[c]);
     }
     // ---- candidate head (nerf.py:97-100)
     if (last_stage > D && use_cand) {
       h8 Ch[1];
       Ch[0] = row_op(rows_s + rs * C::ROWF + 96, 0, hh, e_E);
       int e_G;
+      float amax_g1;
       {
         const float un = pow2r(-(e_E + wexp[9]));
         e_G = scale_exp(wnorm[D + 1] * fmaxf(amax_e, sidemax) + vec_s[RR_V_BMAX + 10]);
+        const float pe = pow2r(e_G);
+        TileOut to;
+        to.frag = nullptr;
+        to.rows = train ? a.g1 + (size_t)m0 * W2 : nullptr;
+        to.ld = W2;
         char* stg_g = train ? stg : nullptr;
-        float* __restrict__ gdst = train ? a.g1 + (size_t)m0 * W2 : nullptr;
-        unsigned int bits[4] = {0u, 0u, 0u, 0u};
+        u32x4_t words = {0u, 0u, 0u, 0u};
         float vmax = 0.0f;
-        static_for<0, 4>([&](auto J) {
-          constexpr int j = decltype(J)::value;
-          rg.template begin<(j & 3)>(lds);
-      const char* p = lds + (j & 3) * RR_SLOT + lane * 16;
-          f32x16 acc;
-          acc_clear(acc);
-          kpart<16, false>(acc, p, Bh, nofill);
-          kpart<1, false>(acc, p + 16 * 1024, Ch, nofill);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            quad_epilogue<EP_RELU | EP_MASK | EP_CONV, 0>(acc, j, q, un, vec_s + RR_V_BC1, bits, vmax, stg_g, e_G, Nh, nullptr, 0, dot3, li, hh);
-          if (train) {
-            stg_flush(stg, lane, gdst, W2, 32 * j);
-            rg.count(4);
-          }
-        });
+        run_tiles<NW, 4>(
+            rg, lds, lag,
+            [&](const char* p) {
+              kpart<16, 16, true>(acc, p, Bh);
+              kpart<1>(acc, p + 16 * 1024, Ch);
+            },
+            [&](auto JP) {
+              constexpr int jp = decltype(JP)::value;
+              u32x4_t blk[2];
+              unsigned int tw;
+              tile_epilogue<false, 1, 0, true, true>(acc, jp, un, pe, vec_s + RR_V_BC1, 1.0f, 0u, tw, vmax, novmax2, stg_g, blk, li, hh);
+              mask_add<jp>(words, tw);
+              tile_out<NW, 0, jp>(rg, to, blk, Nh, stg, t32, lane);
+            });
         if (train) {
-          NT_STORE((u32x4_t*)((char*)a.hmask + (((size_t)D * nt32 + t32) * 64 + lane) * 16), (u32x4_t{bits[0], bits[1], 0u, 0u}));
+#ifndef RR_EXP_NOSTORE
+          NT_STORE((u32x4_t*)((char*)a.hmask + (((size_t)D * nt32 + t32) * 64 + lane) * 16), words);
+#endif
           rg.count(1);
         }
-        track_lds(mx_s, D + 1, wave_max_rr(vmax), lane);
+        amax_g1 = wave_max_rr(vmax);
+        track_lds(mx_s, D + 1, amax_g1, lane);
       }
       {
         const float un = pow2r(-(e_G + wexp[10]));
-        float* __restrict__ gdst = a.g2 + (size_t)m0 * W2;  // compositing reads g2 in inference too
-        unsigned int bits[4] = {0u, 0u, 0u, 0u};
+        const int e_G2 = scale_exp(wnorm[D + 2] * amax_g1 + vec_s[RR_V_BMAX + 11]);  // g2 as an operand: feeds the candidate density dot
+        const float pe = pow2r(e_G2);
+        TileOut to;
+        to.frag = nullptr;
+        to.rows = a.g2 + (size_t)m0 * W2;  // compositing reads g2 in inference too
+        to.ld = W2;
+        u32x4_t words = {0u, 0u, 0u, 0u};
         float vmax = 0.0f;
-        dot3[0] = 0.0f;
-        static_for<0, 4>([&](auto J) {
-          constexpr int j = decltype(J)::value;
-          rg.template begin<(j & 3)>(lds);
-      const char* p = lds + (j & 3) * RR_SLOT + lane * 16;
-          f32x16 acc;
-          acc_clear(acc);
-          kpart<8, false>(acc, p, Nh, nofill);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            quad_epilogue<EP_RELU | EP_MASK, 1>(acc, j, q, un, vec_s + RR_V_BC2, bits, vmax, stg, 0, Bh, vec_s + RR_V_WCSIG, W2, dot3, li, hh);
-          stg_flush(stg, lane, gdst, W2, 32 * j);
-          rg.count(4);
-        });
+        // (operand: g1 in Nh[0..8); result: g2 into Bh[0..8) -- E is no longer needed)
+        run_tiles<NW, 4>(
+            rg, lds, lag,
+            [&](const char* p) {
+              kpart<8, 16, true>(acc, p, Nh);
+            },
+            [&](auto JP) {
+              constexpr int jp = decltype(JP)::value;
+              u32x4_t blk[2];
+              unsigned int tw;
+              tile_epilogue<false, 1, 0, true, true>(acc, jp, un, pe, vec_s + RR_V_BC2, 1.0f, 0u, tw, vmax, novmax2, stg, blk, li, hh);
+              mask_add<jp>(words, tw);
+              tile_out<NW, 0, jp>(rg, to, blk, Bh, stg, t32, lane);
+            });
         if (train) {
-          NT_STORE((u32x4_t*)((char*)a.hmask + (((size_t)(D + 1) * nt32 + t32) * 64 + lane) * 16), (u32x4_t{bits[0], bits[1], 0u, 0u}));
+#ifndef RR_EXP_NOSTORE
+          NT_STORE((u32x4_t*)((char*)a.hmask + (((size_t)(D + 1) * nt32 + t32) * 64 + lane) * 16), words);
+#endif
           rg.count(1);
         }
-        const float d = dot3[0] + __shfl_xor(dot3[0], 32);
-        if (hh == 0 && valid) a.sigma_c[m] = softplus_f(d + bcsig);
+        operand_dots<8, 1>(Bh, e_G2, vec_s + RR_V_WCSIG, W2, hh, dot3);
+        if (hh == 0 && valid) a.sigma_c[m] = softplus_f(dot3[0] + bcsig);
       }
     }
   }
+#ifdef UPNERF_STAMPS
+  if (lane == 0 && (blockIdx.x & 15) == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&upnerf_stamp_acc_rr[i], rg.st_acc[i]);
+    atomicAdd(&upnerf_stamp_acc_rr[4], __builtin_amdgcn_s_memtime() - st_t0);  // slab loop, whole
+    atomicAdd(&upnerf_stamp_acc_rr[5], 1ull);                                   // waves sampled
+    atomicAdd(&upnerf_stamp_acc_rr[6], rg.st_acc[4]);                           // trunk: contraction
+    atomicAdd(&upnerf_stamp_acc_rr[7], rg.st_acc[5]);                           // trunk: epilogue + stores
+    for (int i = 6; i < 10; ++i) atomicAdd(&upnerf_stamp_acc_rr[16 + i - 6], rg.st_acc[i]);
+  }
+#endif
   // running maxima -> global table (scales of the weight-gradient contraction), once per workgroup
   __syncthreads();
   if (a.amax && tid < 16) {
@@ -761,56 +1005,10 @@ struct RBCfg {
   static constexpr int ROWF = 256 + 128;
   static constexpr int MSK0 = ROW0 + MAXR * ROWF * 4;
   static constexpr int INT0 = MSK0 + NW * 2048;
-  static constexpr int LDS = INT0 + (4 * RB_NSTAGE + 16) * 4;
+  static constexpr int SLB0 = INT0 + (4 * RB_NSTAGE + 48) * 4;  // slab list of the pass (<= 96 entries of 8 bytes)
+  static constexpr int LDS = SLB0 + 96 * 8;
   static_assert(NW * 32 * 64 * 4 <= RING, "d x0 exchange scratch lives in the ring");
 };
-
-// the sign bit of accumulator element (tile j, register 4 q + u) as an all-ones / all-zeros word
-__device__ __forceinline__ unsigned int mask_word(const unsigned int (&bits)[4], int j, int q, int u) {
-  return (unsigned int)(((int)(bits[(j >> 1) & 3] << (31 - (16 * (j & 1) + 4 * q + u)))) >> 31);
-}
-
-enum { EB_MASK = 1, EB_CONV = 2 };
-// Epilogue of register quad q of tile j of a backward stage: v = acc * un + add, masked by the forward pass's sign bits;
-// running maximum, fp32 copy into the transposer (stg != nullptr), conversion into the next operand's fragments
-// nx[blk0 + 2 j], nx[blk0 + 2 j + 1] at exponent eo.
-template <int FLAGS, int NB>
-__device__ __forceinline__ void quad_epilogue_b(const f32x16& acc, int j, int q, float un, const f32x4& add, const unsigned int (&bits)[4],
-                                                float& vmax, char* stg, int eo, h8 (&nx)[NB], int blk0, int li, int hh) {
-  float v[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    v[u] = fmaf(acc[4 * q + u], un, add[u]);
-    if (FLAGS & EB_MASK) v[u] = __uint_as_float(__float_as_uint(v[u]) & mask_word(bits, j, q, u));
-  }
-  vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-  if (stg) stg_put(stg, li, hh, q, f32x4{v[0], v[1], v[2], v[3]});
-  if constexpr ((FLAGS & EB_CONV) != 0) {
-    h4 hi, lo;
-    split_quad<1>(ldexpf(v[0], eo), ldexpf(v[1], eo), ldexpf(v[2], eo), ldexpf(v[3], eo), hi, lo);
-    const int blk = blk0 + 2 * j + (q >> 1);
-    if (q & 1) nx[blk] = __builtin_shufflevector(nx[blk], __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3), 0, 1, 2, 3, 12, 13, 14, 15);
-    else nx[blk] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3);
-  }
-}
-
-// NT tiles of one stage: slab j sits in ring slot j % 4; the two waves of a SIMD run half a tile apart (see the forward kernel)
-template <int NW, int NT, int KB, int NOP, class EPI>
-__device__ __forceinline__ void run_stage(Ring<NW>& rg, char* lds, int lane, bool lag, f32x16& acc, const h8 (&op)[NOP], EPI epi) {
-  auto nofill = [](int) {};
-  static_for<0, NT>([&](auto J) {
-    constexpr int j = decltype(J)::value;
-    rg.template begin<(j & 3)>(lds);
-    const char* p = lds + (j & 3) * RR_SLOT + lane * 16;
-    if constexpr (j > 0) {
-      if (lag) epi(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{});
-    }
-    acc_clear(acc);
-    kpart<KB, false>(acc, p, op, nofill);
-    if (!lag) epi(J);
-  });
-  if (lag) epi(std::integral_constant<int, NT - 1>{});
-}
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout L, upnerf_field_bwd_args a) {
@@ -835,11 +1033,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
   const size_t t32 = (size_t)blockIdx.x * NW + wave;
   const size_t nt32 = (size_t)gridDim.x * NW;
   const float* __restrict__ P = a.P;
-  const int* __restrict__ wexp = a.wexp;
+  const int* wexp = int_s + 4 * RB_NSTAGE + 16;                      // LDS copies (see the forward kernel)
+  const float* wnt = (const float*)(int_s + 4 * RB_NSTAGE + 32);     // row norms of the transposed set, in descriptor order
   const bool use_rgb = a.use_rgb != 0, use_cand = a.use_cand != 0, heads = use_rgb || use_cand;
   const bool need_dxyz = a.need_dxyz != 0;
   const int hs = L.skip > 0 ? 1 : 0;                 // the skip layer has two transposed descriptors (row norms: descriptor order)
-  const float* __restrict__ wnt = a.wnorm + 32;      // row norms of the transposed set
   const int gld = a.gz_rg_ld > 0 ? a.gz_rg_ld : W2;  // row stride of gz_r1 / gz_g1
   const bool lag = wave >= NW / 2;
 
@@ -871,7 +1069,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
     int_s[RB_NSTAGE + st] = kb;
     int_s[2 * RB_NSTAGE + st] = tiles;
     int_s[3 * RB_NSTAGE + st] = wrap;
-    if (st < 16) mx_s[st] = 0u;
+    if (st < 16) {
+      mx_s[st] = 0u;
+      int_s[4 * RB_NSTAGE + 16 + st] = a.wexp[st];
+      ((float*)int_s)[4 * RB_NSTAGE + 32 + st] = a.wnorm[32 + st];
+    }
   }
   for (int c = tid; c < W; c += C::THREADS) vec_s[RB_V_WSIG + c] = P[L.wsig + c];
   for (int c = tid; c < W2; c += C::THREADS) vec_s[RB_V_WCSIG + c] = use_cand ? P[L.wcsig + c] : 0.0f;
@@ -916,18 +1118,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
     }
   }
   // sign bits of g2 / r1 (forward slots D + 1, D + 2): ordinary loads, nothing is in flight yet
-  unsigned int bits_g2[4] = {0u, 0u, 0u, 0u}, bits_r1[4] = {0u, 0u, 0u, 0u};
-  if (use_cand) {
-    const u32x4_t w = *(const u32x4_t*)((const char*)a.hmask + (((size_t)(D + 1) * nt32 + t32) * 64 + lane) * 16);
-    bits_g2[0] = w[0], bits_g2[1] = w[1];
-  }
-  if (use_rgb) {
-    const u32x4_t w = *(const u32x4_t*)((const char*)a.hmask + (((size_t)(D + 2) * nt32 + t32) * 64 + lane) * 16);
-    bits_r1[0] = w[0], bits_r1[1] = w[1];
-  }
+  u32x4_t bits_g2 = {0u, 0u, 0u, 0u}, bits_r1 = {0u, 0u, 0u, 0u};
+  if (use_cand) bits_g2 = *(const u32x4_t*)((const char*)a.hmask + (((size_t)(D + 1) * nt32 + t32) * 64 + lane) * 16);
+  if (use_rgb) bits_r1 = *(const u32x4_t*)((const char*)a.hmask + (((size_t)(D + 2) * nt32 + t32) * 64 + lane) * 16);
   gEmax = wave_max_rr(gEmax);
   gGmax = wave_max_rr(gGmax);
-  __syncthreads();  // tables zeroed
+  __syncthreads();  // tables written
+  int2* slab_s = (int2*)(lds + C::SLB0);
+  const int nslab = build_slab_table(slab_s, int_s, int_s + RB_NSTAGE, int_s + 2 * RB_NSTAGE, int_s + 3 * RB_NSTAGE, 3 + 2 * (D - 1) + 1, tid);
   if (lane == 0) {
     atomicMax(&mx_s[14], __float_as_uint(gEmax));
     atomicMax(&mx_s[15], __float_as_uint(gGmax));
@@ -939,21 +1137,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
 
   Ring<NW> rg;
   rg.src = (const char*)a.PT16;
-  rg.sq_off = int_s;
-  rg.sq_kb = int_s + RB_NSTAGE;
-  rg.sq_tiles = int_s + 2 * RB_NSTAGE;
-  rg.sq_wrap = int_s + 3 * RB_NSTAGE;
-  rg.nstage = 3 + 2 * (D - 1) + 1;
+  rg.slab_s = slab_s;
+  rg.nslab = nslab;
   rg.wave = wave;
   rg.lane = lane;
-  rg.pre.stage = 0;
-  rg.pre.tile = 0;
-  rg.vmc = 0;
-  // the first stage with tiles (the forward kernel's sequence always starts at stage 0)
-  while (rg.pre.stage < rg.nstage && int_s[2 * RB_NSTAGE + rg.pre.stage] == 0) ++rg.pre.stage;
-  rg.template issue_next<0>(lds);
-  rg.template issue_next<1>(lds);
-  rg.template issue_next<2>(lds);
+#ifdef UPNERF_STAMPS
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < 10; ++i) rg.st_acc[i] = 0;
+  rg.st_prev = st_t0;
+#endif
+  rg.start(lds);
 
   // ---- sign bits of the stages ahead: forward slots [D (g1)], D-1, ..., 0, each a 1 KiB LDS-DMA into buffer (slot & 1) of this
   // wave, requested two uses ahead; counted like every other vector-memory instruction of the loop
@@ -965,16 +1158,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
         (const __attribute__((address_space(1))) void*)((const char*)a.hmask + (((size_t)slot * nt32 + t32) * 64 + lane) * 16),
         (__attribute__((address_space(3))) void*)(msk + (slot & 1) * 1024), 16, 0, 0);
     asm volatile("" ::: "memory");
-    rg.count(1);
+    rg.count_dma(1);
     if (slot & 1) mmark1 = rg.vmc;
     else mmark0 = rg.vmc;
   };
-  auto mask_acquire = [&](int slot, unsigned int (&bits)[4]) {
+  auto mask_acquire = [&](int slot) -> u32x4_t {
     wait_vmcnt(rg.vmc - ((slot & 1) ? mmark1 : mmark0));
     asm volatile("" ::: "memory");
     const u32x4_t w = *(const u32x4_t*)(msk + (slot & 1) * 1024 + lane * 16);
-    bits[0] = w[0], bits[1] = w[1], bits[2] = w[2], bits[3] = w[3];
     if (slot >= 2) mask_request(slot - 2);
+    return w;
   };
   if (use_cand) {
     mask_request(D);
@@ -987,9 +1180,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
   h8 Bh[16];  // operand of the running stage
   h8 Nh[16];  // operand of the next stage
   f32x16 acc;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   float amax_in = 0.0f;
   int e_in = 0;
+  h2 novmax2 = {(_Float16)0, (_Float16)0};
+  // a 256-deep stage: the contraction of one slab with the DMA request at this wave's quarter of the k loop
+  auto mma16 = [&](const char* p) {
+    kpart<16, 16, true>(acc, p, Bh);
+  };
 
   if (heads) {
     // ---- elementwise head stages, in operand order.  d g2 = relu'(g2) (w_csig dpre_c + w_cj g_G_c[ray]) (candidate_sigma /
@@ -997,102 +1194,124 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
     h8 Gh[8];
     float amax_g2 = 0.0f, amax_r1 = 0.0f;
     int e_g2 = 0;
+    // value of element u of quad q of a tile, masked by the tile's sign-bit word
+    auto masked = [](float t, unsigned int tw, int q, int u) {
+      const int bit = 16 * (u & 1) + 2 * q + (u >> 1);
+      return __uint_as_float(__float_as_uint(t) & (unsigned int)(((int)(tw << (31 - bit))) >> 31));
+    };
+    auto tile_word = [](const u32x4_t& words, int jt) { return words[jt >> 1] >> (8 * (jt & 1)); };
     if (use_cand) {
-      float vals[4][4][4];  // [tile][quad][u]
-      float vmax = 0.0f;
       const float* gG = rows_s + rs * C::ROWF + 256;
+      float vmax = 0.0f;
+      // two passes over the 128 features (maximum first: the exponent of the operand), nothing kept in between
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+          amax_g2 = wave_max_rr(vmax);
+          track_lds(mx_s, D + 2, amax_g2, lane);
+          e_g2 = scale_exp(amax_g2);
+        }
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < 4; ++jt) {
+          const unsigned int tw = tile_word(bits_g2, jt);
+          h8 blk[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int col = 32 * jt + 8 * q + 4 * hh;
-          const f32x4 wv = *(const f32x4*)&vec_s[RB_V_WCSIG + col], gg = *(const f32x4*)&gG[col];
+          for (int q = 0; q < 4; ++q) {
+            const int col = 32 * jt + 8 * q + 4 * hh;
+            const f32x4 wv = *(const f32x4*)&vec_s[RB_V_WCSIG + col], gg = *(const f32x4*)&gG[col];
+            float v[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float t = fmaf(wv[u], dpc, cwj * gg[u]);
-            const float v = __uint_as_float(__float_as_uint(t) & mask_word(bits_g2, jt, q, u));
-            vals[jt][q][u] = v;
-            vmax = fmaxf(vmax, fabsf(v));
+            for (int u = 0; u < 4; ++u) {
+              v[u] = masked(fmaf(wv[u], dpc, cwj * gg[u]), tw, q, u);
+              vmax = fmaxf(vmax, fabsf(v[u]));
+            }
+            if (pass == 1) {
+              stg_put(stg, li, hh, q, f32x4{v[0], v[1], v[2], v[3]});
+              h4 hi, lo;
+              split_quad<1>(ldexpf(v[0], e_g2), ldexpf(v[1], e_g2), ldexpf(v[2], e_g2), ldexpf(v[3], e_g2), hi, lo);
+              if (q & 1) blk[q >> 1] = __builtin_shufflevector(blk[q >> 1], __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3), 0, 1, 2, 3, 12, 13, 14, 15);
+              else blk[q >> 1] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3);
+            }
+          }
+          if (pass == 1) {
+            Gh[2 * jt] = blk[0];
+            Gh[2 * jt + 1] = blk[1];
+            stg_flush(stg, lane, a.gz_g2 + (size_t)m0 * W2, W2, 32 * jt);
+            rg.count(4);
           }
         }
-      amax_g2 = wave_max_rr(vmax);
-      track_lds(mx_s, D + 2, amax_g2, lane);
-      e_g2 = scale_exp(amax_g2);
-      float* __restrict__ dst = a.gz_g2 + (size_t)m0 * W2;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          stg_put(stg, li, hh, q, f32x4{vals[jt][q][0], vals[jt][q][1], vals[jt][q][2], vals[jt][q][3]});
-          h4 hi, lo;
-          split_quad<1>(ldexpf(vals[jt][q][0], e_g2), ldexpf(vals[jt][q][1], e_g2), ldexpf(vals[jt][q][2], e_g2), ldexpf(vals[jt][q][3], e_g2), hi, lo);
-          const int blk = 2 * jt + (q >> 1);
-          if (q & 1) Gh[blk] = __builtin_shufflevector(Gh[blk], __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3), 0, 1, 2, 3, 12, 13, 14, 15);
-          else Gh[blk] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3);
-        }
-        stg_flush(stg, lane, dst, W2, 32 * jt);
-        rg.count(4);
       }
     }
-    float r1v[4][4][4];
+    int erg = 0;
     if (use_rgb) {
       float vmax = 0.0f;
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+          amax_r1 = wave_max_rr(vmax);
+          track_lds(mx_s, D + 3, amax_r1, lane);
+          // exponent of the joint operand [gz_r1 | gz_g1] of the d e stage
+          erg = scale_exp(fmaxf(use_cand ? wnt[D + hs + 3] * amax_g2 : 0.0f, amax_r1));
+        }
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < 4; ++jt) {
+          const unsigned int tw = tile_word(bits_r1, jt);
+          h8 blk[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int col = 32 * jt + 8 * q + 4 * hh;
-          const f32x4 w0 = *(const f32x4*)&vec_s[RB_V_WR2 + col], w1 = *(const f32x4*)&vec_s[RB_V_WR2 + W2 + col],
-                      w2 = *(const f32x4*)&vec_s[RB_V_WR2 + 2 * W2 + col];
+          for (int q = 0; q < 4; ++q) {
+            const int col = 32 * jt + 8 * q + 4 * hh;
+            const f32x4 w0 = *(const f32x4*)&vec_s[RB_V_WR2 + col], w1 = *(const f32x4*)&vec_s[RB_V_WR2 + W2 + col],
+                        w2 = *(const f32x4*)&vec_s[RB_V_WR2 + 2 * W2 + col];
+            float v[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float t = w0[u] * dprgb[0] + w1[u] * dprgb[1] + w2[u] * dprgb[2];
-            const float v = __uint_as_float(__float_as_uint(t) & mask_word(bits_r1, jt, q, u));
-            r1v[jt][q][u] = v;
-            vmax = fmaxf(vmax, fabsf(v));
+            for (int u = 0; u < 4; ++u) {
+              v[u] = masked(w0[u] * dprgb[0] + w1[u] * dprgb[1] + w2[u] * dprgb[2], tw, q, u);
+              vmax = fmaxf(vmax, fabsf(v[u]));
+            }
+            if (pass == 1) {
+              stg_put(stg, li, hh, q, f32x4{v[0], v[1], v[2], v[3]});
+              h4 hi, lo;
+              split_quad<1>(ldexpf(v[0], erg), ldexpf(v[1], erg), ldexpf(v[2], erg), ldexpf(v[3], erg), hi, lo);
+              if (q & 1) blk[q >> 1] = __builtin_shufflevector(blk[q >> 1], __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3), 0, 1, 2, 3, 12, 13, 14, 15);
+              else blk[q >> 1] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3);
+            }
+          }
+          if (pass == 1) {
+            Bh[2 * jt] = blk[0];
+            Bh[2 * jt + 1] = blk[1];
+            stg_flush(stg, lane, a.gz_r1 + (size_t)m0 * gld, gld, 32 * jt);
+            rg.count(4);
           }
         }
-      amax_r1 = wave_max_rr(vmax);
-      track_lds(mx_s, D + 3, amax_r1, lane);
-    }
-    // exponent of the joint operand [gz_r1 | gz_g1] of the d e stage
-    const float bound_g1 = use_cand ? wnt[D + hs + 3] * amax_g2 : 0.0f;
-    const int erg = scale_exp(fmaxf(bound_g1, amax_r1));
-    if (use_rgb) {
-      float* __restrict__ dst = a.gz_r1 + (size_t)m0 * gld;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          stg_put(stg, li, hh, q, f32x4{r1v[jt][q][0], r1v[jt][q][1], r1v[jt][q][2], r1v[jt][q][3]});
-          h4 hi, lo;
-          split_quad<1>(ldexpf(r1v[jt][q][0], erg), ldexpf(r1v[jt][q][1], erg), ldexpf(r1v[jt][q][2], erg), ldexpf(r1v[jt][q][3], erg), hi, lo);
-          const int blk = 2 * jt + (q >> 1);
-          if (q & 1) Bh[blk] = __builtin_shufflevector(Bh[blk], __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3), 0, 1, 2, 3, 12, 13, 14, 15);
-          else Bh[blk] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3);
-        }
-        stg_flush(stg, lane, dst, gld, 32 * jt);
-        rg.count(4);
       }
     } else {
+      erg = scale_exp(use_cand ? wnt[D + hs + 3] * amax_g2 : 0.0f);
 #pragma unroll
       for (int s = 0; s < 8; ++s) Bh[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
     }
     float amax_g1 = 0.0f;
     if (use_cand) {
       // ---- gz_g1 = relu'(g1) (gz_g2 . W_c2)   (candidate_encoding.2, nerf.py:98)
-      unsigned int bits[4];
-      mask_acquire(D, bits);
+      const u32x4_t words = mask_acquire(D);
       const float un = pow2r(-(e_g2 + wexp[10]));
+      const float pe = pow2r(erg);
+      TileOut to;
+      to.frag = nullptr;
+      to.rows = a.gz_g1 + (size_t)m0 * gld;
+      to.ld = gld;
       float vmax = 0.0f;
-      float* __restrict__ dst = a.gz_g1 + (size_t)m0 * gld;
-      run_stage<NW, 4, 8>(rg, lds, lane, lag, acc, Gh, [&](auto JP) {
-        constexpr int jp = decltype(JP)::value;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) quad_epilogue_b<EB_MASK | EB_CONV>(acc, jp, q, un, zero4, bits, vmax, stg, erg, Bh, 8, li, hh);
-        stg_flush(stg, lane, dst, gld, 32 * jp);
-        rg.count(4);
-      });
+      run_tiles<NW, 4>(
+          rg, lds, lag,
+          [&](const char* p) {
+            kpart<8, 8, true>(acc, p, Gh);
+          },
+          [&](auto JP) {
+            constexpr int jp = decltype(JP)::value;
+            u32x4_t blk[2];
+            unsigned int tw;
+            tile_epilogue<false, 0, 1, false, false>(acc, jp, un, pe, nullptr, 0.0f, mask_tile<jp>(words), tw, vmax, novmax2, stg, blk, li, hh);
+            tile_out<NW, 8, jp>(rg, to, blk, Bh, stg, t32, lane);
+          });
       amax_g1 = wave_max_rr(vmax);
       track_lds(mx_s, D + 1, amax_g1, lane);
     } else {
@@ -1106,19 +1325,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
       const float wfmax = wave_max_rr(fabsf(wf));
       const float bound = wnt[D + hs + 1] * amax_r1 + wnt[D + hs + 2] * amax_g1 + wfmax * gEmax;
       const int eo = scale_exp(bound);
+      const float pe = pow2r(eo);
       const float* gE = rows_s + rs * C::ROWF;
-      unsigned int nobits[4] = {0u, 0u, 0u, 0u};
+      TileOut to;
+      to.frag = nullptr;
+      to.rows = a.gz_e + (size_t)m0 * W;
+      to.ld = W;
       float vmax = 0.0f;
-      float* __restrict__ dst = a.gz_e + (size_t)m0 * W;
-      run_stage<NW, 8, 16>(rg, lds, lane, lag, acc, Bh, [&](auto JP) {
+      run_tiles<NW, 8>(rg, lds, lag, mma16, [&](auto JP) {
         constexpr int jp = decltype(JP)::value;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 g = *(const f32x4*)&gE[32 * jp + 8 * q + 4 * hh];
-          quad_epilogue_b<EB_CONV>(acc, jp, q, un, g * wf, nobits, vmax, stg, eo, Nh, 0, li, hh);
-        }
-        stg_flush(stg, lane, dst, W, 32 * jp);
-        rg.count(4);
+        u32x4_t blk[2];
+        unsigned int tw;
+        tile_epilogue<false, 2, 0, false, false>(acc, jp, un, pe, gE, wf, 0u, tw, vmax, novmax2, stg, blk, li, hh);
+        tile_out<NW, 0, jp>(rg, to, blk, Nh, stg, t32, lane);
       });
       amax_in = wave_max_rr(vmax);
       track_lds(mx_s, D, amax_in, lane);
@@ -1130,40 +1349,41 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
     // no head consumed e (density-only evaluation): d e = 0, written because the weight gradient of the final layer reads it
 #pragma unroll
     for (int s = 0; s < 16; ++s) Bh[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-    float* __restrict__ dst = a.gz_e + (size_t)m0 * W;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q) stg_put(stg, li, hh, q, zero4);
-#pragma unroll
+#pragma unroll 1
     for (int jt = 0; jt < 8; ++jt) {
-      stg_flush(stg, lane, dst, W, 32 * jt);
+      stg_flush(stg, lane, a.gz_e + (size_t)m0 * W, W, 32 * jt);
       rg.count(4);
     }
   }
   // ---- d h_{D-1} = relu'(h_{D-1}) (gz_e . W_e + w_sig dpre_s)
   {
-    unsigned int bits[4];
-    mask_acquire(D - 1, bits);
+    const u32x4_t words = mask_acquire(D - 1);
     const float un = pow2r(-(e_in + wexp[8]));
     float wsmax = 0.0f;
     for (int c = lane; c < W; c += 64) wsmax = fmaxf(wsmax, fabsf(vec_s[RB_V_WSIG + c]));
     wsmax = wave_max_rr(wsmax);
     const float bound = wnt[D + hs] * amax_in + wsmax * wave_max_rr(fabsf(dps));
     const int eo = scale_exp(bound);
-    float vmax = 0.0f;
-    uint16_t* __restrict__ gzl = a.gz16 + (size_t)(D - 1) * nt32 * 16 * 512;
-    run_stage<NW, 8, 16>(rg, lds, lane, lag, acc, Bh, [&](auto JP) {
+    const float pe = pow2r(eo);
+    TileOut to;
+    to.frag = a.gz16 + (size_t)(D - 1) * nt32 * 16 * 512;
+    to.rows = nullptr;
+    to.ld = 0;
+    float novmax = 0.0f;
+    h2 vmax2 = {(_Float16)0, (_Float16)0};
+    const float dps_pe = dps * pe;  // the rank-1 term in units of 2^-eo
+    run_tiles<NW, 8>(rg, lds, lag, mma16, [&](auto JP) {
       constexpr int jp = decltype(JP)::value;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 ws = *(const f32x4*)&vec_s[RB_V_WSIG + 32 * jp + 8 * q + 4 * hh];
-        quad_epilogue_b<EB_MASK | EB_CONV>(acc, jp, q, un, ws * dps, bits, vmax, nullptr, eo, Nh, 0, li, hh);
-      }
-      frag_store(gzl, t32, 2 * jp, lane, Nh[2 * jp]);
-      frag_store(gzl, t32, 2 * jp + 1, lane, Nh[2 * jp + 1]);
-      rg.count(2);
+      u32x4_t blk[2];
+      unsigned int tw;
+      tile_epilogue<true, 2, 1, false, false>(acc, jp, un, pe, vec_s + RB_V_WSIG, dps_pe, mask_tile<jp>(words), tw, novmax, vmax2, nullptr, blk, li, hh);
+      tile_out<NW, 0, jp>(rg, to, blk, Nh, stg, t32, lane);
     });
     if (lane == 0) a.gzexp[(size_t)(D - 1) * nt32 + t32] = eo;
-    amax_in = wave_max_rr(vmax);
+    amax_in = wave_max_rr(pk_hmax(vmax2) * pow2r(-eo));
     track_lds(mx_s, D - 1, amax_in, lane);
     e_in = eo;
 #pragma unroll
@@ -1173,40 +1393,42 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
   f32x16 accx[2];
   acc_clear(accx[0]);
   acc_clear(accx[1]);
+  // d x0 (+)= gz . W[:, :64]: a stage of two tiles of 32 encoding features, issued twice so that the ring slots stay aligned
+  auto dx0_stage = [&](float unx) {
+    static_for<0, 4>([&](auto J) {
+      constexpr int j = decltype(J)::value, slot = j & 3;
+      rg.begin(lds, slot);
+      if constexpr (j < 2) {
+        acc_clear(acc);
+        kpart<16>(acc, lds + slot * RR_SLOT + lane * 16, Bh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[j][r] = fmaf(acc[r], unx, accx[j][r]);
+      }
+    });
+  };
 #pragma unroll 1
   for (int l = D - 1; l >= 1; --l) {
     const int wel = wexp[l];
-    if (need_dxyz && L.skip > 0 && l == L.skip) {
-      // d x0 += gz_skip . W_skip[:, :64]: two tiles of 32 encoding features (the stage is issued twice: slots stay aligned)
-      const float unx = pow2r(-(e_in + wel));
-      static_for<0, 4>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        rg.template begin<(j & 3)>(lds);
-        if constexpr (j < 2) {
-          const char* p = lds + (j & 3) * RR_SLOT + lane * 16;
-          acc_clear(acc);
-          kpart<16, false>(acc, p, Bh, [](int) {});
-#pragma unroll
-          for (int r = 0; r < 16; ++r) accx[j][r] = acc[r] * unx;
-        }
-      });
-    }
-    unsigned int bits[4];
-    mask_acquire(l - 1, bits);
+    if (need_dxyz && L.skip > 0 && l == L.skip) dx0_stage(pow2r(-(e_in + wel)));
+    const u32x4_t words = mask_acquire(l - 1);
     const float un = pow2r(-(e_in + wel));
     const int eo = scale_exp(wnt[l + ((hs && l >= L.skip) ? 1 : 0)] * amax_in);
-    float vmax = 0.0f;
-    uint16_t* __restrict__ gzl = a.gz16 + (size_t)(l - 1) * nt32 * 16 * 512;
-    run_stage<NW, 8, 16>(rg, lds, lane, lag, acc, Bh, [&](auto JP) {
+    const float pe = pow2r(eo);
+    TileOut to;
+    to.frag = a.gz16 + (size_t)(l - 1) * nt32 * 16 * 512;
+    to.rows = nullptr;
+    to.ld = 0;
+    float novmax = 0.0f;
+    h2 vmax2 = {(_Float16)0, (_Float16)0};
+    run_tiles<NW, 8>(rg, lds, lag, mma16, [&](auto JP) {
       constexpr int jp = decltype(JP)::value;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) quad_epilogue_b<EB_MASK | EB_CONV>(acc, jp, q, un, zero4, bits, vmax, nullptr, eo, Nh, 0, li, hh);
-      frag_store(gzl, t32, 2 * jp, lane, Nh[2 * jp]);
-      frag_store(gzl, t32, 2 * jp + 1, lane, Nh[2 * jp + 1]);
-      rg.count(2);
+      u32x4_t blk[2];
+      unsigned int tw;
+      tile_epilogue<true, 0, 1, false, false>(acc, jp, un, pe, nullptr, 0.0f, mask_tile<jp>(words), tw, novmax, vmax2, nullptr, blk, li, hh);
+      tile_out<NW, 0, jp>(rg, to, blk, Nh, stg, t32, lane);
     });
     if (lane == 0) a.gzexp[(size_t)(l - 1) * nt32 + t32] = eo;
-    amax_in = wave_max_rr(vmax);
+    amax_in = wave_max_rr(pk_hmax(vmax2) * pow2r(-eo));
     track_lds(mx_s, l - 1, amax_in, lane);
     e_in = eo;
 #pragma unroll
@@ -1214,18 +1436,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
   }
   if (need_dxyz) {
     // ---- d x0 += gz_0 . W_0, then d xyz through the encoding
-    const float unx = pow2r(-(e_in + wexp[0]));
-    static_for<0, 4>([&](auto J) {
-      constexpr int j = decltype(J)::value;
-      rg.template begin<(j & 3)>(lds);
-      if constexpr (j < 2) {
-        const char* p = lds + (j & 3) * RR_SLOT + lane * 16;
-        acc_clear(acc);
-        kpart<16, false>(acc, p, Bh, [](int) {});
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accx[j][r] = fmaf(acc[r], unx, accx[j][r]);
-      }
-    });
+    dx0_stage(pow2r(-(e_in + wexp[0])));
     __syncthreads();  // every wave is done with the ring: it becomes the exchange scratch of d x0 (64 floats per row)
     float* Gs = (float*)lds + (32 * wave + li) * UPNERF_X0;
 #pragma unroll
@@ -1252,6 +1463,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
       }
     }
   }
+#ifdef UPNERF_STAMPS
+  if (lane == 0 && (blockIdx.x & 15) == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&upnerf_stamp_acc_rr[8 + i], rg.st_acc[i]);
+    atomicAdd(&upnerf_stamp_acc_rr[12], __builtin_amdgcn_s_memtime() - st_t0);
+    atomicAdd(&upnerf_stamp_acc_rr[13], 1ull);
+  }
+#endif
   // running maxima -> global table, once per workgroup
   __syncthreads();
   if (a.gmax && tid < 14) {
@@ -1264,6 +1482,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
 
 // Entry points behind upnerf_field_fwd_f16x3 / upnerf_field_bwd_f16x3 (csrc/field16.hip validates the arguments): planes = 1 and
 // tile_rows = 256.  Needs a->P16 / PT16 written by upnerf_frag16 with perm = 1 and a->wnorm from the same call.
+#ifdef UPNERF_STAMPS
+extern "C" int upnerf_stamps_read_rr(unsigned long long* out16, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(upnerf_stamp_acc_rr), 24 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[24] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(upnerf_stamp_acc_rr), z, sizeof(z)));
+  }
+  return 0;
+}
+#endif
+
 int upnerf_rr16_bwd_launch(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream) {
   const long long M = (long long)a->R * a->S;
   const int grid = (int)((M + 255) / 256);

@@ -55,10 +55,6 @@ def _field16_ok(pk, S: int) -> bool:
 #   (Also measured and dropped: lossless hi + lo fp16 PAIRS -- the same bytes as fp32 -- gave the field kernels and the
 #   weight-gradient kernel nothing: 2.69 / 2.65 / 0.25 ms against 2.69 / 2.66 / 0.22.  It is the bytes, not the store pattern.)
 WGRAD_STORE = __import__("os").environ.get("UPNERF_WGRAD_STORE", "f32")
-# Samples per workgroup of the f16x3 / f16 field kernels (include/upnerf_hip.h: tile_rows): 0 / 64 = four-wave workgroups of 64
-# samples (default), 128 = the eight-wave software-pipelined kernels (rays of >= 64 samples; falls back to 64 below that).
-# Forward and backward pass always get the same value.
-FIELD_TILE = int(__import__("os").environ.get("UPNERF_FIELD_TILE", "0"))
 # Per-tile partial sums of the vector heads and per-ray sums from the backward field kernel (upnerf_field_bwd_args.tile_part);
 # 0 = the separate upnerf_vec_wgrad / upnerf_ray_sum launches (always used with 128-sample tiles and the fp32-MFMA kernels).
 TILE_PARTIALS = int(__import__("os").environ.get("UPNERF_TILE_PARTIALS", "1"))
@@ -186,10 +182,8 @@ class _FieldPass(torch.autograd.Function):
         g1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and train) else None
         g2 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and (train or joint)) else None
         r1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_rgb and train) else None
-        # 128-sample tiles (S >= 64): scratch for the encoding as operand fragments, read back at the skip layer
-        tile = RR_TILE if rr else (128 if (FIELD_TILE == 128 and S >= 64) else 64)
-        x0f = (torch.empty(((M + 127) // 128) * 32768, device=dev, dtype=torch.uint8)
-               if (use16 and pk.skip > 0 and tile == 128) else None)
+        tile = RR_TILE if rr else 64  # samples per workgroup (include/upnerf_hip.h: tile_rows); the backward pass gets the same
+        x0f = None
         fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
                           rays_d=ptr(rays_d), z=ptr(z), c_rows=ptr(c_rows), aux=ptr(aux),
                           wk_xyz=(C.c_float * 10)(*cfg.wk_xyz), P=ptr(PF), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
