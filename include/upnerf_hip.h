@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UPNERF_ABI_VERSION 6
+#define UPNERF_ABI_VERSION 7
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
@@ -276,7 +276,9 @@ typedef struct {
                                     forward pass's x0f may be reused: its content is dead by now) */
   float* tile_part;              /* NULL, or [ceil(M/64)][UPNERF_TILE_PART_STRIDE] (f16x3 variant, tile_rows 0 / 64 only): per-tile
                                     partial sums of what upnerf_vec_wgrad (dpre_sig_c x g2, dpre_rgb x r1) and upnerf_ray_sum
-                                    (gz_g1, gz_r1) would re-read M x W/2 tensors for; finished by upnerf_tile_part_finish */
+                                    (gz_g1, gz_r1) would re-read M x W/2 tensors for; finished by upnerf_tile_part_finish.
+                                    tile_rows = 256: NULL, or [ceil(M/256) * 8][UPNERF_RR_PART_STRIDE]: the per-ray sums only, per
+                                    32 samples, finished by upnerf_ray_part_finish */
   int32_t gz_rg_ld;              /* f16x3 variant: row stride (floats) of gz_r1 and gz_g1; 0 = W/2 (two dense tensors).  With
                                     gz_g1 = gz_r1 + W/2 and a stride of W the two form ONE [M][W] tensor [gz_r1 | gz_g1], whose
                                     weight gradient against e is one launch (upnerf_wgrad_f16x3_chain2); its running maximum is
@@ -294,6 +296,12 @@ typedef struct {
  * order (bitwise reproducible).  scratch: 128 * 520 floats. */
 int upnerf_tile_part_finish(int R, int S, const float* tile_part, float* rs_g1, float* rs_r1, float* d_wcsig, float* d_bcsig,
                             float* d_wr2, float* d_br2, float* scratch, void* stream);
+
+/* tile_rows = 256: one row of tile_part per 32 samples: sums of gz_r1 over the rows of the first / second ray of those 32 samples
+ * [2][128], then the same for gz_g1 (S >= 32: at most two rays; the second block is only written when there is a second ray). */
+#define UPNERF_RR_PART_STRIDE 512
+/* rs_g1 / rs_r1 [R][128] from those rows, in a fixed order (either may be NULL). */
+int upnerf_ray_part_finish(int R, int S, const float* tile_part, float* rs_g1, float* rs_r1, void* stream);
 
 int upnerf_field_bwd(const upnerf_layout* L, const upnerf_field_bwd_args* a, void* stream);
 /* f16x3 variant: W = 256 and S >= 32 (at most 3 rays per 64-sample tile); hmask from upnerf_field_fwd_f16x3. */

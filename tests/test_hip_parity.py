@@ -20,7 +20,10 @@ TOL_MAP, TOL_W, TOL_GRAD = 1e-4, 2e-4, 1e-3
 # oracle at the GPU's own depths.  The set is PINNED: a change that makes another case flip fails
 # test_only_the_known_goldens_take_the_flipped_branch instead of quietly moving it to the loose gate.
 KNOWN_FLIPPED = frozenset({"cfg1_small_fine", "cfg2_det_phase1", "cfg2_phase0", "cfg2_phase1", "cfg2_phase2", "cfg2_trained_p045",
-                           "cfg2_trained_p08", "small_nocand"})  # round 3, both field tilings
+                           "cfg2_trained_p08", "small_nocand",  # round 3, both field tilings
+                           # round 4's cases at the reference's 128 + 128 samples: new here, and held to the strict gate at the
+                           # reference's own depths by test_training_step_matches_reference_golden_at_the_reference_depths
+                           "yaml_phase0", "yaml_phase1"})
 _FLIPPED_SEEN = {}
 
 

@@ -20,3 +20,33 @@ def test_lazy_results_behave_like_a_dict():
     r2.lazy("b", lambda: 5)
     r2["b"] = 9                                     # an explicit value replaces the thunk
     assert r2["b"] == 9 and sorted(r2.keys()) == ["a", "b"] and list(r2.values()).count(9) == 1
+
+
+def test_lazy_results_follow_the_whole_dict_protocol():
+    """r3 ADVICE: pop / copy / update / setdefault / == / pickling must see the lazily evaluated entries too."""
+    import pickle
+    from upnerf_amd.nerf_system import _LazyResults
+
+    def make():
+        calls = []
+        r = _LazyResults({"a": 1})
+        r.lazy("b", lambda: calls.append("b") or 2)
+        return r, calls
+
+    r, calls = make()
+    assert len(r) == 2 and "b" in r and calls == []
+    assert r.pop("b") == 2 and calls == ["b"] and "b" not in r
+    r, _ = make()
+    assert r.copy() == {"a": 1, "b": 2} and type(r.copy()) is dict
+    r, _ = make()
+    assert r == {"a": 1, "b": 2}
+    r, _ = make()
+    assert r.setdefault("b", 7) == 2
+    r, _ = make()
+    assert sorted(r.keys()) == ["a", "b"] and sorted(r.values()) == [1, 2] and dict(r.items()) == {"a": 1, "b": 2}
+    r, _ = make()
+    back = pickle.loads(pickle.dumps(r))
+    assert back == {"a": 1, "b": 2} and type(back) is dict
+    r, _ = make()
+    r.update({"b": 5})
+    assert r["b"] == 5

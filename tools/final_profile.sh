@@ -14,6 +14,8 @@ bash tools/pmc_collect.sh "$OUT/pmc" --no-extras > "$OUT/pmc.log" 2>&1
 bash tools/pmc_collect.sh "$OUT/pmc_trevi" --no-extras --config trevi > "$OUT/pmc_trevi.log" 2>&1
 python tools/pmc_current.py "$OUT/pmc.json" --field f16x3 --config brandenburg --progress 0.3 > "$OUT/pmc_current.log" 2>&1
 cp profiles/pmc_current.json "$OUT/pmc_current.json"
+python tools/pmc_current.py "$OUT/pmc_trevi.json" --field f16 --config trevi --progress 0.3 --out pmc_current_trevi.json > "$OUT/pmc_current_trevi.log" 2>&1
+cp profiles/pmc_current_trevi.json "$OUT/pmc_current_trevi.json"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --config trevi > "$OUT/bench_trevi.json" 2> "$OUT/bench_trevi.err"
 python tools/prof_summary.py "$OUT/prof" 27 45 > "$OUT/kernel_summary.txt" 2>&1

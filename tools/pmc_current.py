@@ -13,12 +13,14 @@ ap.add_argument("pmc_json")
 ap.add_argument("--field", default="f16x3")
 ap.add_argument("--config", default="brandenburg")
 ap.add_argument("--progress", type=float, default=0.3)
+ap.add_argument("--out", default="pmc_current.json", help="file name under profiles/ (bench.py reads pmc_current.json for the headline, pmc_current_trevi.json for the trevi object)")
 a = ap.parse_args()
 pmc = json.load(open(a.pmc_json))
 np_ = "1" if a.field == "f16" else "2"
-pick = {"field_fwd": (f"field16_fwd_kernel<{np_}, 64, 4>" if a.field != "f32" else "field_fwd_kernel<256, 64>"),
-        "field_bwd": (f"field16_bwd_kernel<{np_}, 64, 4>" if a.field != "f32" else "field_bwd_kernel<256, 64>"),
-        "wgrad16_256x256": f"wgrad_f16x3_kernel<{np_}, 4, 4>", "wgrad16p_256x256": "wgrad_f16p_kernel<4, 4, 1>",
+rr = a.field == "f16" and "rr16_fwd_kernel<8>" in pmc  # the fp16 mode's register-resident kernels (csrc/field16rr.hip)
+pick = {"field_fwd": "rr16_fwd_kernel<8>" if rr else (f"field16_fwd_kernel<{np_}, 64, 4>" if a.field != "f32" else "field_fwd_kernel<256, 64>"),
+        "field_bwd": "rr16_bwd_kernel<8>" if rr else (f"field16_bwd_kernel<{np_}, 64, 4>" if a.field != "f32" else "field_bwd_kernel<256, 64>"),
+        "wgrad16_256x256": f"wgrad_f16x3_kernel<{np_}, 4, 4>", "wgrad16p_256x256": "wgrad_f16p_kernel<4, 4, 1, 1>" if rr else "wgrad_f16p_kernel<4, 4, 1, 0>",
         "wgrad_256x256": "wgrad_kernel<4, 4>"}
 kern = {}
 for name, key in pick.items():
@@ -35,5 +37,5 @@ if steps:
                      for t in pmc.values() if isinstance(t, dict)) / steps
 out = {"src_sha16": bench.source_sha16(), "hbm_bytes_per_step": step_bytes, "field": a.field, "config": a.config, "progress": a.progress,
        "file": os.path.basename(a.pmc_json), "kernels": kern}
-json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_current.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", a.out), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -126,6 +126,7 @@ class WgradGroup(C.Structure):
 
 MAX_WGRAD_GROUPS = 32
 TILE_PART_STRIDE = 1288  # UPNERF_TILE_PART_STRIDE
+RR_PART_STRIDE = 512  # UPNERF_RR_PART_STRIDE
 
 
 class EmbedGroup(C.Structure):
@@ -176,6 +177,7 @@ _SIGNATURES = {
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
+    "upnerf_ray_part_finish": [_i, _i, _p, _p, _p, _p],
     "upnerf_tile_part_finish": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "upnerf_ray_geom_bwd": [_i, _i, _p, _p, _p, _p, _p],
     "upnerf_pack": [_p, C.POINTER(PackDesc), _i, _i, _p],
@@ -211,7 +213,7 @@ def _load():
 
 
 lib = _load()
-ABI_VERSION = 6
+ABI_VERSION = 7
 if lib.upnerf_abi_version() != ABI_VERSION:
     raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
 

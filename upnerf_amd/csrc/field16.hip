@@ -1062,7 +1062,7 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   if (a->tile_rows == 256) {  // register-resident kernels (csrc/field16rr.hip)
     if (a->planes != 1) return UPNERF_EUNSUP;
-    if (!a->wnorm || !a->gz16 || a->tile_part) return UPNERF_EINVAL;
+    if (!a->wnorm || !a->gz16) return UPNERF_EINVAL;
     return upnerf_rr16_bwd_launch(L, a, stream);
   }
   if (a->wnorm) return UPNERF_EUNSUP;

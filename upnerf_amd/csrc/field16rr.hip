@@ -343,9 +343,14 @@ __device__ __forceinline__ h8 row_op(const float* row, int s, int hh, int e) {
 __device__ __forceinline__ void stg_put(char* stg, int li, int hh, int q, const f32x4& v) {
   *(f32x4*)(stg + li * 128 + (((2 * q + hh) ^ (li & 7)) << 4)) = v;
 }
-// rows [0, 32) of the tile -> dst[(row0 + r) * ld + col0 + 0..31]; four store instructions of 8 rows x 128 B
-__device__ __forceinline__ void stg_flush(const char* stg, int lane, float* __restrict__ dst, size_t ld, int col0) {
+// rows [0, 32) of the tile -> dst[(row0 + r) * ld + col0 + 0..31]; four store instructions of 8 rows x 128 B.
+// part != nullptr: the tile's column sums over rows [0, rb) and [rb, 32) (the wave's first and second ray; rb >= 32: one ray)
+// also go to part[col0 + ..] and part[128 + col0 + ..] -- this wave's share of upnerf_ray_sum, in a fixed order.  Those two
+// stores are NOT counted by the caller (an under-count only makes a later wait stricter).
+__device__ __forceinline__ void stg_flush(const char* stg, int lane, float* __restrict__ dst, size_t ld, int col0,
+                                          float* __restrict__ part = nullptr, int rb = 32) {
   const int c = lane & 7;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 8 * i + (lane >> 3);
@@ -355,6 +360,25 @@ __device__ __forceinline__ void stg_flush(const char* stg, int lane, float* __re
 #else
     asm volatile("" ::"v"(v));
 #endif
+    if (part) {
+      const float k = row < rb ? 1.0f : 0.0f;
+      s0 += v * k;
+      s1 += v * (1.0f - k);
+    }
+  }
+  if (part) {
+#pragma unroll
+    for (int sh = 8; sh < 64; sh <<= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s0[u] += __shfl_xor(s0[u], sh);
+        s1[u] += __shfl_xor(s1[u], sh);
+      }
+    }
+    if (lane < 8) {
+      *(f32x4*)(part + col0 + 4 * c) = s0;
+      if (rb < 32) *(f32x4*)(part + 128 + col0 + 4 * c) = s1;
+    }
   }
 }
 
@@ -487,6 +511,8 @@ struct TileOut {
   uint16_t* frag;   // fragment-ordered fp16 tensor of this stage, or nullptr
   float* rows;      // row-major fp32 tensor (this wave's first row), or nullptr
   int ld;           // its row stride
+  float* part = nullptr;  // per-ray column sums of the rows (stg_flush), or nullptr
+  int rb = 32;            // first row of the wave's second ray
 };
 template <int NW, int BLK0, int JP, int NB>
 __device__ __forceinline__ void tile_out(Ring<NW>& rg, const TileOut& o, const u32x4_t (&blk)[2], h8 (&nx)[NB], char* stg, size_t t32, int lane) {
@@ -498,7 +524,7 @@ __device__ __forceinline__ void tile_out(Ring<NW>& rg, const TileOut& o, const u
     rg.count(2);
   }
   if (o.rows) {
-    stg_flush(stg, lane, o.rows, o.ld, 32 * JP);
+    stg_flush(stg, lane, o.rows, o.ld, 32 * JP, o.part, o.rb);
     rg.count(4);
   }
 }
@@ -1040,6 +1066,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
   const int hs = L.skip > 0 ? 1 : 0;                 // the skip layer has two transposed descriptors (row norms: descriptor order)
   const int gld = a.gz_rg_ld > 0 ? a.gz_rg_ld : W2;  // row stride of gz_r1 / gz_g1
   const bool lag = wave >= NW / 2;
+  // per-ray sums of gz_r1 / gz_g1, this wave's part (a.tile_part: [M/32][UPNERF_RR_PART_STRIDE] = [gz_r1, gz_g1][ray slot 2][128])
+  float* __restrict__ rpart = a.tile_part ? a.tile_part + t32 * UPNERF_RR_PART_STRIDE : nullptr;
+  const int rb = __builtin_amdgcn_readfirstlane((m0 / S + 1) * S - m0);  // first row of this wave's second ray (>= 32: none)
 
   // ---- stage tables.  Order of consumption: [t_wc2] [t_head] t_we, then for l = D-1 .. 1: [t_skipx at l == skip] t_w[l], then
   // [t_w[0]].  Stage ids: 0 wc2, 1 head, 2 we, 3 + 2 i (skipx) / 4 + 2 i (trunk) for l = D-1-i, 3 + 2 (D-1) = layer 0.
@@ -1279,7 +1308,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
           if (pass == 1) {
             Bh[2 * jt] = blk[0];
             Bh[2 * jt + 1] = blk[1];
-            stg_flush(stg, lane, a.gz_r1 + (size_t)m0 * gld, gld, 32 * jt);
+            stg_flush(stg, lane, a.gz_r1 + (size_t)m0 * gld, gld, 32 * jt, rpart, rb);
             rg.count(4);
           }
         }
@@ -1299,6 +1328,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
       to.frag = nullptr;
       to.rows = a.gz_g1 + (size_t)m0 * gld;
       to.ld = gld;
+      to.part = rpart ? rpart + 2 * W2 : nullptr;
+      to.rb = rb;
       float vmax = 0.0f;
       run_tiles<NW, 4>(
           rg, lds, lag,

@@ -600,6 +600,25 @@ extern "C" int upnerf_ray_aux(int R, const float* rays_d, const float* a_rows, c
   return (int)hipGetLastError();
 }
 
+// the register-resident backward kernel's per-32-sample partial sums (include/upnerf_hip.h, UPNERF_RR_PART_STRIDE) -> per-ray sums
+__global__ void ray_part_finish_kernel(int S, const float* __restrict__ part, float* __restrict__ rs_g1, float* __restrict__ rs_r1) {
+  const int r = blockIdx.x, t = threadIdx.x >> 7, col = threadIdx.x & 127;
+  float* __restrict__ out = t ? rs_g1 : rs_r1;
+  if (!out) return;
+  const int w0 = (int)(((long long)r * S) >> 5), w1 = (int)((((long long)(r + 1) * S) - 1) >> 5);
+  float acc = 0.0f;
+  for (int w = w0; w <= w1; ++w) {
+    const int slot = r - (int)(((long long)w << 5) / S);  // 0: the 32 samples start in this ray, 1: the ray starts inside them
+    acc += part[(size_t)w * UPNERF_RR_PART_STRIDE + (2 * t + slot) * 128 + col];
+  }
+  out[(size_t)r * 128 + col] = acc;
+}
+extern "C" int upnerf_ray_part_finish(int R, int S, const float* tile_part, float* rs_g1, float* rs_r1, void* stream) {
+  if (R <= 0 || S < 32 || !tile_part) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(ray_part_finish_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, S, tile_part, rs_g1, rs_r1);
+  return (int)hipGetLastError();
+}
+
 extern "C" int upnerf_ray_sum(int R, int S, const float* X, int C, float* out, void* stream) {
   if (R <= 0 || S <= 0 || C <= 0 || C > 256 || !X || !out) return UPNERF_EINVAL;
   const int threads = ((C + 63) / 64) * 64;

@@ -99,6 +99,49 @@ class _LazyResults(dict):
         self._force()
         return super().__iter__()
 
+    # the rest of the dict protocol sees every entry too (r3 ADVICE: pop / copy / update / setdefault / == / pickling bypassed
+    # the thunks): all pending entries are evaluated first
+    def pop(self, key, *default):
+        self._force(key)
+        return super().pop(key, *default)
+
+    def setdefault(self, key, default=None):
+        self._force(key)
+        return super().setdefault(key, default)
+
+    def copy(self):
+        self._force()
+        return dict(self)
+
+    def update(self, *a, **k):
+        for key, value in dict(*a, **k).items():
+            self[key] = value  # (an explicit value replaces a pending thunk)
+
+    def keys(self):
+        self._force()
+        return super().keys()
+
+    def values(self):
+        self._force()
+        return super().values()
+
+    def items(self):
+        self._force()
+        return super().items()
+
+    def __len__(self):
+        return super().__len__() + len([k for k in self._thunks if not super().__contains__(k)])
+
+    def __eq__(self, other):
+        self._force()
+        return dict(self) == other
+
+    __hash__ = None
+
+    def __reduce__(self):  # pickles (and torch.saves) as the plain dict it stands for
+        self._force()
+        return (dict, (dict(self),))
+
     def __len__(self):
         return super().__len__() + len(self._thunks)
 

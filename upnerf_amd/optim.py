@@ -67,9 +67,11 @@ class FlatAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step_device(self):
-        """The device half of step(): gather the gradients into the flat buffer and launch the update(s).  No host state
-        changes, so it can be captured in a HIP graph: under a capture (step_scalars.current()) the launches read the
-        step size and bias correction from device memory, refreshed before every replay."""
+        """The device half of step(): launch the update(s).  When every live gradient is a contiguous fp32 CUDA tensor the
+        kernels read the gradients where autograd left them (`self.in_place` = True: `flat_g` is NOT written and holds stale
+        values -- read `p.grad`); otherwise the gradients are first gathered into `flat_g`.  No host state changes, so it can
+        be captured in a HIP graph: under a capture (step_scalars.current()) the launches read the step size and bias
+        correction from device memory, refreshed before every replay."""
         from . import step_scalars
         from ._lib import check, lib, ptr, stream
         group = self.param_groups[0]
@@ -80,7 +82,9 @@ class FlatAdam(torch.optim.Optimizer):
         from ._lib import MAX_ADAM_DESC, AdamDesc
         dyn = step_scalars.current()
         grads = {i: self._spans[i][0].grad for i in live}
-        in_place = all(g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda for g in grads.values())
+        in_place = all(g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda and g.numel() == self._spans[i][2]
+                       for i, g in grads.items())
+        self.in_place = in_place  # (whether flat_g is current after this call)
         if not in_place:  # (strided or foreign gradients: gather them into the flat buffer first)
             torch._foreach_copy_([self.flat_g[self._spans[i][1]:self._spans[i][1] + self._spans[i][2]].view_as(self._spans[i][0])
                                   for i in live], [grads[i] for i in live])

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib, step_scalars
-from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, TILE_PART_STRIDE, X0, check, lib,
+from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, RR_PART_STRIDE, TILE_PART_STRIDE, X0, check, lib,
                    ptr, stream)
 from .ops import (TIMER, WgradChain, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16p_into,
                   wgrad_f16x3_into, wgrad_into, workspace)
@@ -267,8 +267,8 @@ class _FieldPass(torch.autograd.Function):
         # [gz_r1 | gz_g1] as ONE [M][W] tensor when both heads are on and the chained f16x3 weight gradients run: the two first
         # layers of the heads are both fed by e, so their weight gradients are one launch that reads e once (chain.wgrad2)
         joined = bool(use16 and cfg.use_cand and cfg.use_rgb and JOIN_HEADS and WGRAD_CHAIN and W == 256
-                      and ctx.tile_rows == 64 and TILE_PARTIALS)  # (upnerf_ray_sum, the fallback, wants dense tensors)
-        gz_rg = _empty(M, W, device=dev) if joined else None
+                      and (ctx.tile_rows == 64 or rr) and TILE_PARTIALS)  # (upnerf_ray_sum, the fallback, wants dense tensors)
+        gz_rg = _empty(Mp, W, device=dev)[:M] if joined else None
         gz_g1 = (gz_rg[:, W2:] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_cand else None
         gz_g2 = _empty(Mp, W2, device=dev)[:M] if cfg.use_cand else None
         gz_r1 = (gz_rg[:, :W2] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_rgb else None
@@ -282,6 +282,10 @@ class _FieldPass(torch.autograd.Function):
         # that read M x 128 tensors again
         tile_part = (_empty((M + 63) // 64, TILE_PART_STRIDE, device=dev)
                      if (use16 and ctx.tile_rows == 64 and TILE_PARTIALS and (cfg.use_cand or cfg.use_rgb)) else None)
+        # register-resident kernels: the per-ray sums only, per 32 samples (the 128-wide vector heads stay separate launches:
+        # that kernel works from the sign bits of g2 / r1 and never holds their values)
+        ray_part = (_empty(Mp // 32, RR_PART_STRIDE, device=dev)
+                    if (rr and TILE_PARTIALS and (cfg.use_cand or cfg.use_rgb)) else None)
         w_feat = (sv["w_sj"] if joint else sv["w_s"]) if gE is not None else None
         fb = FieldBwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), need_dxyz=int(need_dxyz),
                           PT=ptr(PT), P=ptr(P), d_sigma_s=ptr(d_sigma_s), d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb),
@@ -292,7 +296,7 @@ class _FieldPass(torch.autograd.Function):
                           gz_g1=(gz_rg.data_ptr() + 4 * W2) if joined else ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_rg) if joined else ptr(gz_r1), gz_rg_ld=W if joined else 0, dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, tile_rows=ctx.tile_rows, xs=ptr(sv.get("x0f")), gz16=ptr(gz16),
-                          gzexp=ptr(gzexp), tile_part=ptr(tile_part), wnorm=ptr(sv.get("wnorm")))
+                          gzexp=ptr(gzexp), tile_part=ptr(ray_part if rr else tile_part), wnorm=ptr(sv.get("wnorm")))
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
         check(TIMER.run("field_bwd", lambda: bwd_fn(C.byref(L), C.byref(fb), st), units=M), "upnerf_field_bwd")
 
@@ -363,8 +367,10 @@ class _FieldPass(torch.autograd.Function):
                 at(L.wcsig) if (want_w and cfg.use_cand) else None, at(L.bcsig) if (want_w and cfg.use_cand) else None,
                 at(L.wr2) if (want_w and cfg.use_rgb) else None, at(L.br2) if (want_w and cfg.use_rgb) else None,
                 ptr(ws), st), "upnerf_tile_part_finish")
+        if ray_part is not None:
+            check(lib.upnerf_ray_part_finish(R, S, ptr(ray_part), ptr(rs_c), ptr(rs_r), st), "upnerf_ray_part_finish")
         if cfg.use_cand:
-            if tile_part is None:
+            if tile_part is None and ray_part is None:
                 check(lib.upnerf_ray_sum(R, S, ptr(gz_g1), W2, ptr(rs_c), st), "upnerf_ray_sum")
             if dP is not None:
                 if joined:  # rows [0, W2) -> wr1 / br1 (colour head), rows [W2, W) -> wc1 / bc1 (candidate head)
@@ -379,7 +385,7 @@ class _FieldPass(torch.autograd.Function):
             if ctx.needs_input_grad[3]:
                 d_c_rows = linear_kn_view(rs_c, P, L.wc1 + W, W + CK, CK)  # rs . wc1[:, W:]
         if cfg.use_rgb:
-            if tile_part is None:
+            if tile_part is None and ray_part is None:
                 check(lib.upnerf_ray_sum(R, S, ptr(gz_r1), W2, ptr(rs_r), st), "upnerf_ray_sum")
             if dP is not None:
                 if not joined:
