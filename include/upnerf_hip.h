@@ -270,7 +270,8 @@ typedef struct {
   const int32_t* wexp;           /* [16] */
   int32_t planes;                /* as in upnerf_field_fwd_args: 0 / 2 = f16x3, 1 = f16 */
   int32_t tile_rows;             /* as in upnerf_field_fwd_args; must equal the forward pass's */
-  uint16_t* gz16;                /* [D][M][W] fp16 bits of gz_h, tile-scaled like h16 (then gz_h may be NULL) */
+  uint16_t* gz16;                /* [D][M][W] fp16 bits of gz_h, tile-scaled like h16 (then gz_h may be NULL).  tile_rows = 256
+                                    with gz_e == NULL: [D + 1] layers, the last one d e in the same form (and gzexp [D + 1] rows) */
   int32_t* gzexp;                /* [D][ceil(M/64)] */
   void* xs;                      /* 128-sample tiles with a skip layer and need_dxyz: scratch of ceil(M/128) * 32768 bytes (the
                                     forward pass's x0f may be reused: its content is dead by now) */
@@ -405,11 +406,21 @@ int upnerf_wgrad_finish(upnerf_wgrad_pending* pending, void* stream);
 int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
                       const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, float* slabs, int nsplit,
                       const int* expo_a, const int* expo_b, void* stream);
+/* chained like upnerf_wgrad_f16x3_chain, on the same pending record (a run may mix the two kinds of launches) */
+int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
+                            const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, float* slabs, int nsplit,
+                            const int* expo_a, const int* expo_b, upnerf_wgrad_pending* pending, void* stream);
 
 /* dw[c][k] = sum_m v[m*ldv + c] * X[m][k], c < nvec <= 3; dbv[c] = sum_m v[m*ldv + c]   (N=1/3 heads);
  * K in {32, 64, 128, 256}; scratch: nsplit * 4 * (K+1) floats */
 int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const float* X, int ldx, int K,
                      float* dw /*[nvec][K]*/, float* dbv /*[nvec]*/, float* scratch, int nsplit, void* stream);
+
+/* upnerf_vec_wgrad for one vector (nvec = 1, ldv = 1) against a 256-wide fp16 tensor in the operand-fragment order of the
+ * register-resident field kernels (upnerf_field_fwd_args.tile_rows = 256: h16 / hexp of one layer, padded to whole 32-sample
+ * tiles); scratch: nsplit * 4 * 257 floats.  Fixed summation order. */
+int upnerf_vec_wgrad_frag16(int M, const float* v, const uint16_t* X16, const int32_t* xexp, float* dw, float* dbv,
+                            float* scratch, int nsplit, void* stream);
 
 /* out[r][c] = sum_{i<S} X[(r*S+i)][c]  (per-ray sums of a per-sample tensor; embedding-row gradients) */
 int upnerf_ray_sum(int R, int S, const float* X, int C, float* out, void* stream);

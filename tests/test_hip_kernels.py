@@ -425,7 +425,7 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     hs = sv["h"] if sv.get("h16") is None else rd.dequant16(sv["h16"], sv["hexp"], frag=getattr(node, "rr", False))[:, :M]
     for l in range(pk.D):
         ok &= cmp(f"h{l}", hs[l], f["h"][l], TOL_ACT)
-    if sv.get("h16") is not None:
+    if sv.get("h16") is not None and sv.get("h") is not None:  # (the register-resident kernels keep no fp32 copy)
         ok &= cmp("h_last_fp32", sv["h"][0], f["h"][pk.D - 1], TOL_ACT)
     ok &= cmp("sigma_s", sv["sigma_s"], f["sigma_s"], TOL_ACT)
     ok &= cmp("e", sv["e"], f["e"], TOL_ACT)

@@ -1047,7 +1047,7 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   int rc = check_layout16(L);
   if (rc) return rc;
   if (!a || a->R <= 0 || a->S <= 0 || !a->P || !a->PT16 || !a->wexp || !a->d_sigma_s || !a->sigma_s || (!a->gz_h && !a->gz16) ||
-      !a->gz_e || !a->dpre_sig_s || !a->hmask)
+      (!a->gz_e && a->tile_rows != 256) || !a->dpre_sig_s || !a->hmask)
     return UPNERF_EINVAL;
   if (a->S < 32) return UPNERF_EUNSUP;  // at most 3 rays per 64-sample tile
   if (a->use_cand && (!a->d_sigma_c || !a->sigma_c || !a->g2 || !a->gz_g1 || !a->gz_g2 || !a->dpre_sig_c))

@@ -1358,19 +1358,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
       const int eo = scale_exp(bound);
       const float pe = pow2r(eo);
       const float* gE = rows_s + rs * C::ROWF;
+      // a.gz_e == NULL: d e leaves as operand fragments, layer D of gz16 / gzexp (the final layer's weight gradient then reads
+      // 512 bytes per sample instead of 1024, and this stage stores two 1 KiB pieces per tile instead of four)
+      const bool efrag = a.gz_e == nullptr;
       TileOut to;
-      to.frag = nullptr;
-      to.rows = a.gz_e + (size_t)m0 * W;
+      to.frag = efrag ? a.gz16 + (size_t)D * nt32 * 16 * 512 : nullptr;
+      to.rows = efrag ? nullptr : a.gz_e + (size_t)m0 * W;
       to.ld = W;
       float vmax = 0.0f;
+      h2 vmax2 = {(_Float16)0, (_Float16)0};
+      const float wf_pe = wf * pe;
       run_tiles<NW, 8>(rg, lds, lag, mma16, [&](auto JP) {
         constexpr int jp = decltype(JP)::value;
         u32x4_t blk[2];
         unsigned int tw;
-        tile_epilogue<false, 2, 0, false, false>(acc, jp, un, pe, gE, wf, 0u, tw, vmax, novmax2, stg, blk, li, hh);
+        if (efrag) tile_epilogue<true, 2, 0, false, false>(acc, jp, un, pe, gE, wf_pe, 0u, tw, vmax, vmax2, nullptr, blk, li, hh);
+        else tile_epilogue<false, 2, 0, false, false>(acc, jp, un, pe, gE, wf, 0u, tw, vmax, novmax2, stg, blk, li, hh);
         tile_out<NW, 0, jp>(rg, to, blk, Nh, stg, t32, lane);
       });
-      amax_in = wave_max_rr(vmax);
+      if (efrag && lane == 0) a.gzexp[(size_t)D * nt32 + t32] = eo;
+      amax_in = wave_max_rr(fmaxf(vmax, pk_hmax(vmax2) * pow2r(-eo)));
       track_lds(mx_s, D, amax_in, lane);
       e_in = eo;
 #pragma unroll
@@ -1380,13 +1387,22 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
     // no head consumed e (density-only evaluation): d e = 0, written because the weight gradient of the final layer reads it
 #pragma unroll
     for (int s = 0; s < 16; ++s) Bh[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.gz_e) {
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) stg_put(stg, li, hh, q, zero4);
+      for (int q = 0; q < 4; ++q) stg_put(stg, li, hh, q, zero4);
 #pragma unroll 1
-    for (int jt = 0; jt < 8; ++jt) {
-      stg_flush(stg, lane, a.gz_e + (size_t)m0 * W, W, 32 * jt);
-      rg.count(4);
+      for (int jt = 0; jt < 8; ++jt) {
+        stg_flush(stg, lane, a.gz_e + (size_t)m0 * W, W, 32 * jt);
+        rg.count(4);
+      }
+    } else {
+#pragma unroll 1
+      for (int b = 0; b < 16; ++b) {
+        frag_store(a.gz16 + (size_t)D * nt32 * 16 * 512, t32, b, lane, Bh[0]);
+        rg.count(1);
+      }
+      if (lane == 0) a.gzexp[(size_t)D * nt32 + t32] = 0;
     }
   }
   // ---- d h_{D-1} = relu'(h_{D-1}) (gz_e . W_e + w_sig dpre_s)

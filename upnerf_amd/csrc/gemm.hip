@@ -289,6 +289,62 @@ __global__ void vec_wgrad_reduce_kernel(int nvec, int K, int nsplit, const float
   else if (dbv) dbv[c] = s;
 }
 
+// upnerf_vec_wgrad for ONE vector against a 256-wide fp16 tensor in the operand-fragment order of the register-resident field
+// kernels (include/upnerf_hip.h, tile_rows = 256): [32-row tile][k-block s 16][lane 64][8], feature 16 s + 8 (j / 4) + 4 (lane / 32)
+// + j % 4, row 32 tile + lane % 32, values scaled by 2^xexp[tile].  A thread keeps one (s, lane) piece position and walks the
+// tiles of its workgroup's slice (a wave reads 1 KiB contiguous per tile); the 32 rows meet in a shuffle tree at the end.
+__global__ __launch_bounds__(1024) void vec_wgrad_frag16_kernel(int M, const float* __restrict__ v, const uint16_t* __restrict__ X16,
+                                                               const int* __restrict__ xexp, float* __restrict__ part,
+                                                               int tiles_per_split) {
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  const int tid = threadIdx.x, lane = tid & 63, s = tid >> 6, li = lane & 31, hh = lane >> 5;
+  const int ntile = (M + 31) >> 5;
+  const int t0 = blockIdx.x * tiles_per_split;
+  const int t1 = t0 + tiles_per_split < ntile ? t0 + tiles_per_split : ntile;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float vsum = 0.0f;
+  const h8v* __restrict__ src = (const h8v*)X16 + (size_t)s * 64 + lane;
+  int t = t0;
+  for (; t + 4 <= t1; t += 4) {
+    h8v x[4];
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = __builtin_nontemporal_load(src + (size_t)(t + u) * 1024);
+      const int m = (t + u) * 32 + li;
+      w[u] = m < M ? v[m] : 0.0f;
+      vsum += w[u];
+      w[u] = ldexpf(w[u], -xexp[t + u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(w[u], (float)x[u][j], acc[j]);
+    }
+  }
+  for (; t < t1; ++t) {
+    const h8v x = __builtin_nontemporal_load(src + (size_t)t * 1024);
+    const int m = t * 32 + li;
+    float w = m < M ? v[m] : 0.0f;
+    vsum += w;
+    w = ldexpf(w, -xexp[t]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, (float)x[j], acc[j]);
+  }
+#pragma unroll
+  for (int sh = 1; sh < 32; sh <<= 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], sh);
+    vsum += __shfl_xor(vsum, sh);
+  }
+  if (li == 0) {
+    float* __restrict__ dst = part + (size_t)blockIdx.x * 4 * 257;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)] = acc[j];
+    if (s == 0 && hh == 0) dst[256] = vsum;
+  }
+}
+
 // ---- generic linear: C = act(A B^T + bias) for the per-ray layers (M = rays: a few thousand rows).
 // 64 x 64 output tile per workgroup (one 32 x 32 MFMA tile per wave), A and B staged in LDS in K-chunks of 64 with
 // coalesced 16-byte loads: 16 x (N/64) x ... = several hundred workgroups even at M = 4096, four or five per CU, so
@@ -732,7 +788,8 @@ extern "C" int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, c
 
 extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, const int* aexp, int N, const void* B, int ldb,
                                          const int* bexp, int b_is_f16, int K, const int* expo_a, const int* expo_b, float* slabs,
-                                         float* bslabs, int nsplit, int rows, int TN, int TK, void* stream);
+                                         float* bslabs, int nsplit, int rows, int TN, int TK, const upnerf_wgrad_pending* prev,
+                                         void* stream);
 
 // upnerf_wgrad with fp16-stored, tile-scaled operands (the f16 field mode): same slabs + fixed-order reduction.
 extern "C" int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
@@ -749,9 +806,47 @@ extern "C" int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int3
   const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
   float* bslabs = slabs + (size_t)nsplit * gy * gz * TN * TK;
   int rc = upnerf_wgrad_f16p_partial(M, A16, lda, aexp, N, B, ldb, bexp, b_is_f16, K, expo_a, expo_b, slabs, bslabs, nsplit, rows,
-                                     TN, TK, stream);
+                                     TN, TK, nullptr, stream);
   if (rc) return rc;
   launch_reduce(st, reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db));
+  return (int)hipGetLastError();
+}
+
+// Chained upnerf_wgrad_f16p: same pending record as upnerf_wgrad_f16x3_chain (one run may mix both kinds of launches).
+extern "C" int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
+                                       const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, float* slabs,
+                                       int nsplit, const int* expo_a, const int* expo_b, upnerf_wgrad_pending* pending, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A16 || !aexp || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b || !pending)
+    return UPNERF_EINVAL;
+  if ((b_is_f16 & 1) && !bexp) return UPNERF_EINVAL;
+  if ((N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || (ldo & 3)) return UPNERF_EINVAL;
+  if (pending->nsplit > 0 && pending->slabs == slabs) return UPNERF_EINVAL;  // the pending slabs would be overwritten
+  int TN, TK;
+  wgrad_shape(N, K, &TN, &TK);
+  const int rows = (((M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
+  float* bslabs = slabs + (size_t)nsplit * gy * gz * TN * TK;
+  if (pending->nsplit > 0 && pending->rblocks > nsplit * gy * gz) {  // grid too small to carry the previous reduction
+    int rc = upnerf_wgrad_finish(pending, stream);
+    if (rc) return rc;
+  }
+  int rc = upnerf_wgrad_f16p_partial(M, A16, lda, aexp, N, B, ldb, bexp, b_is_f16, K, expo_a, expo_b, slabs, bslabs, nsplit, rows,
+                                     TN, TK, pending->nsplit > 0 ? pending : nullptr, stream);
+  if (rc) return rc;
+  *pending = reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db);
+  return 0;
+}
+
+extern "C" int upnerf_vec_wgrad_frag16(int M, const float* v, const uint16_t* X16, const int32_t* xexp, float* dw, float* dbv,
+                                       float* scratch, int nsplit, void* stream) {
+  if (M <= 0 || !v || !X16 || !xexp || !dw || !scratch || nsplit <= 0) return UPNERF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntile = (M + 31) / 32;
+  const int per = (ntile + nsplit - 1) / nsplit;
+  hipLaunchKernelGGL(vec_wgrad_frag16_kernel, dim3(nsplit), dim3(1024), 0, st, M, v, X16, xexp, scratch, per);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(vec_wgrad_reduce_kernel, dim3(2), dim3(256), 0, st, 1, 256, nsplit, scratch, dw, dbv);
   return (int)hipGetLastError();
 }
 

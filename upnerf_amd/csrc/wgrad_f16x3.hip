@@ -250,7 +250,8 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
                                                                  const int* __restrict__ aexp, const void* __restrict__ Bv, int ldb,
                                                                  const int* __restrict__ bexp, const int* __restrict__ expo_a,
                                                                  const int* __restrict__ expo_b, float* __restrict__ slabs,
-                                                                 float* __restrict__ bslabs, int rows_per_split) {
+                                                                 float* __restrict__ bslabs, int rows_per_split,
+                                                                 upnerf_wgrad_pending prev) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   constexpr int FX_CHUNK = (MTW * NTW == 16) ? FX_CHUNK_BIG : 32;
   constexpr int PN = (TN + 127) / 128, PK = (TK + 127) / 128;
@@ -272,6 +273,14 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   const int nblk = blockIdx.y * TN, kblk = blockIdx.z * TK;
   const int mbeg = split * rows_per_split;
   const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  // Prologue: the first prev.rblocks workgroups sum the slabs the PREVIOUS weight-gradient launch left (upnerf_wgrad_f16p_chain)
+  if (prev.nsplit > 0) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < prev.rblocks) {
+      wgrad_reduce_body(wg, tid, prev, (f32x4(*)[64])lds);
+      __syncthreads();
+    }
+  }
   const int ea = expo_a[0], eb = expo_b[0];
   const float* __restrict__ Bf = (const float*)Bv;
   const uint16_t* __restrict__ Bh = (const uint16_t*)Bv;
@@ -453,11 +462,14 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
 
 template <int MTW, int NTW, int PKB, int FRAG>
 int launch_p(int M, int N, int K, const uint16_t* A, int lda, const int* aexp, const void* B, int ldb, const int* bexp,
-             const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st) {
+             const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st,
+             const upnerf_wgrad_pending* prevp) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   dim3 grid(nsplit, (N + TN - 1) / TN, (K + TK - 1) / TK);
+  upnerf_wgrad_pending prev = {};
+  if (prevp) prev = *prevp;
   hipLaunchKernelGGL((wgrad_f16p_kernel<MTW, NTW, PKB, FRAG>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, aexp, B, ldb, bexp, expo_a,
-                     expo_b, slabs, bslabs, rows);
+                     expo_b, slabs, bslabs, rows, prev);
   return (int)hipGetLastError();
 }
 
@@ -502,16 +514,17 @@ extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N,
 // 256 x 64 (fp32 B: the encoding).  Returns UPNERF_EUNSUP for any other block shape.
 extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, const int* aexp, int N, const void* B, int ldb,
                                          const int* bexp, int b_is_f16, int K, const int* expo_a, const int* expo_b, float* slabs,
-                                         float* bslabs, int nsplit, int rows, int TN, int TK, void* stream) {
+                                         float* bslabs, int nsplit, int rows, int TN, int TK, const upnerf_wgrad_pending* prev,
+                                         void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool frag = (b_is_f16 & 2) != 0;  // bit 1: fp16 operands in the fragment order of the register-resident field kernels
   b_is_f16 &= 1;
   if (frag && (N != 256 || (b_is_f16 && K != 256))) return UPNERF_EUNSUP;
   if (TN == 256 && TK == 256 && b_is_f16)
-    return frag ? launch_p<4, 4, 1, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st)
-                : launch_p<4, 4, 1, 0>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+    return frag ? launch_p<4, 4, 1, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev)
+                : launch_p<4, 4, 1, 0>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev);
   if (TN == 256 && TK == 64 && !b_is_f16)
-    return frag ? launch_p<4, 1, 0, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st)
-                : launch_p<4, 1, 0, 0>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st);
+    return frag ? launch_p<4, 1, 0, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev)
+                : launch_p<4, 1, 0, 0>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev);
   return UPNERF_EUNSUP;
 }

@@ -244,6 +244,15 @@ class WgradChain:
             C.byref(self.pending), stream()), units=M)
         check(rc, "upnerf_wgrad_f16x3_chain2")
 
+    def wgrad_p(self, M, A16, lda, aexp, N, B, ldb, bexp, K, dW_ptr, ldo, db_ptr, expo_a, expo_b, frag=False):
+        """wgrad_f16p_into (fp16-stored operands of the f16 field mode) as a link of the run."""
+        ns = nsplit_for(M)
+        ws = self._slabs(ns)
+        rc = TIMER.run(f"wgrad16p_{N}x{K}", lambda: lib.upnerf_wgrad_f16p_chain(
+            M, ptr(A16), lda, ptr(aexp), N, ptr(B), ldb, ptr(bexp), int(bexp is not None) | (2 if frag else 0), K, dW_ptr, ldo, db_ptr,
+            ptr(ws), ns, expo_a, expo_b, C.byref(self.pending), stream()), units=M)
+        check(rc, "upnerf_wgrad_f16p_chain")
+
     def finish(self):
         check(lib.upnerf_wgrad_finish(C.byref(self.pending), stream()), "upnerf_wgrad_finish")
 
@@ -268,6 +277,13 @@ def vec_wgrad_into(M: int, v: torch.Tensor, ldv: int, nvec: int, X: torch.Tensor
     ws = workspace("vec_wgrad", ns * 4 * (K + 1), device)
     check(lib.upnerf_vec_wgrad(M, ptr(v), ldv, nvec, ptr(X), ldx, K, dw_ptr, dbv_ptr, ptr(ws), ns, stream()),
           "upnerf_vec_wgrad")
+
+
+def vec_wgrad_frag16_into(M: int, v: torch.Tensor, X16: torch.Tensor, xexp: torch.Tensor, dw_ptr: int, dbv_ptr: Optional[int], device):
+    """vec_wgrad_into for one vector against a 256-wide layer of the register-resident kernels' fp16 operand fragments."""
+    ns = nsplit_for(M)
+    ws = workspace("vec_wgrad", ns * 4 * 257, device)
+    check(lib.upnerf_vec_wgrad_frag16(M, ptr(v), ptr(X16), ptr(xexp), dw_ptr, dbv_ptr, ptr(ws), ns, stream()), "upnerf_vec_wgrad_frag16")
 
 
 def linear_raw(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int, w_is_kn: bool = False) -> torch.Tensor:

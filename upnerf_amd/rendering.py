@@ -20,7 +20,7 @@ import torch
 from . import _lib, step_scalars
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, RR_PART_STRIDE, TILE_PART_STRIDE, X0, check, lib,
                    ptr, stream)
-from .ops import (TIMER, WgradChain, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_into, wgrad_f16p_into,
+from .ops import (TIMER, WgradChain, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_frag16_into, vec_wgrad_into, wgrad_f16p_into,
                   wgrad_f16x3_into, wgrad_into, workspace)
 
 __all__ = ["render_rays", "sample_pdf", "band_weights"]
@@ -171,7 +171,8 @@ class _FieldPass(torch.autograd.Function):
         ntile = Mp // 32 if rr else (M + 63) // 64  # exponent tables: one entry per 64 rows whatever the kernel's tile (rr: per 32)
         h16 = torch.empty(D, Mp, W, device=dev, dtype=torch.float16) if store16 else None  # (rr: fragment order, see dequant16)
         hexp = torch.empty(D, ntile, device=dev, dtype=torch.int32) if store16 else None
-        h = (_empty(1, Mp, W, device=dev)[:, :M] if store16 else _empty(D, M, W, device=dev)) if train else None
+        # (rr: no fp32 copy of the last layer either -- the density head's and the final layer's weight gradients read its fragments)
+        h = (None if rr else _empty(1, M, W, device=dev) if store16 else _empty(D, M, W, device=dev)) if train else None
         e = _empty(Mp, W, device=dev)[:M] if (train or want_feat) else None
         hmask = (torch.empty((D + 3) * Mp * 4 if rr else (D + 1) * ((M + 127) // 128) * 512 * HMASK_SCALE, device=dev,
                              dtype=torch.int64) if train else None)  # 64 bits per lane and tile, either tiling (rr: 128 per lane)
@@ -260,10 +261,10 @@ class _FieldPass(torch.autograd.Function):
         PT = None if use16 else pk.frag_t_hip(P)
         store16 = sv.get("h16") is not None
         rr, Mp = ctx.rr, ctx.Mp  # register-resident fp16 kernels: per-sample tensors padded to whole 256-sample tiles
-        gz_e = _empty(Mp, W, device=dev)[:M]
+        gz_e = None if rr else _empty(M, W, device=dev)  # (rr: layer D of gz16, as fragments)
         gz_h = None if store16 else _empty(D, M, W, device=dev)
-        gz16 = torch.empty(D, Mp, W, device=dev, dtype=torch.float16) if store16 else None  # (rr: fragment order)
-        gzexp = torch.empty(D, sv["hexp"].shape[1], device=dev, dtype=torch.int32) if store16 else None
+        gz16 = torch.empty(D + int(rr), Mp, W, device=dev, dtype=torch.float16) if store16 else None  # (rr: fragment order)
+        gzexp = torch.empty(D + int(rr), sv["hexp"].shape[1], device=dev, dtype=torch.int32) if store16 else None
         # [gz_r1 | gz_g1] as ONE [M][W] tensor when both heads are on and the chained f16x3 weight gradients run: the two first
         # layers of the heads are both fed by e, so their weight gradients are one launch that reads e once (chain.wgrad2)
         joined = bool(use16 and cfg.use_cand and cfg.use_rgb and JOIN_HEADS and WGRAD_CHAIN and W == 256
@@ -302,7 +303,8 @@ class _FieldPass(torch.autograd.Function):
 
         if _DEBUG_SINK is not None:
             _DEBUG_SINK.update(d_sigma_s=d_sigma_s, d_sigma_c=d_sigma_c, d_rgb=d_rgb,
-                               gz_h=gz_h if gz_h is not None else dequant16(gz16, gzexp, frag=rr)[:, :M], gz_e=gz_e, gz_g1=gz_g1,
+                               gz_h=gz_h if gz_h is not None else dequant16(gz16[:D], gzexp[:D], frag=rr)[:, :M],
+                               gz_e=gz_e if gz_e is not None else dequant16(gz16[D:], gzexp[D:], frag=True)[0, :M], gz_g1=gz_g1,
                                gz_g2=gz_g2, gz_r1=gz_r1, dpre_s=dpre_s, dpre_c=dpre_c, dpre_rgb=dpre_rgb, dxyz=dxyz)
         # ---- weight gradients, written straight into a buffer with P's layout
         dP = torch.zeros(L.total, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
@@ -334,8 +336,12 @@ class _FieldPass(torch.autograd.Function):
                 h16, hexp = sv["h16"], sv["hexp"]
 
                 def wgp(l, B, ldb, bexp, K, off, ldo, boff, ib):
-                    wgrad_f16p_into(M, gz16[l], W, gzexp[l], W, B, ldb, bexp, K, at(off), ldo, None if boff is None else at(boff),
-                                    dev, EA(l), EB(ib), frag=rr)
+                    if chain is not None:
+                        chain.wgrad_p(M, gz16[l], W, gzexp[l], W, B, ldb, bexp, K, at(off), ldo, None if boff is None else at(boff),
+                                      EA(l), EB(ib), frag=rr)
+                    else:
+                        wgrad_f16p_into(M, gz16[l], W, gzexp[l], W, B, ldb, bexp, K, at(off), ldo, None if boff is None else at(boff),
+                                        dev, EA(l), EB(ib), frag=rr)
 
                 for l in range(D):
                     if l == 0:
@@ -354,9 +360,15 @@ class _FieldPass(torch.autograd.Function):
                     wg(gz, W, W, h[l - 1], W, W, L.w[l] + X0, X0 + W, None, l, l - 1)
                 else:
                     wg(gz, W, W, h[l - 1], W, W, L.w[l], W, L.b[l], l, l - 1)
-            h_last = h[0] if store16 else h[D - 1]
-            wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
-            vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
+            if rr:  # both operands of the final layer's gradient, and the density head's, as fragments
+                chain.wgrad_p(M, gz16[D], W, gzexp[D], W, h16[D - 1], W, hexp[D - 1], W, at(L.we), W, at(L.be), EA(D), EB(D - 1), frag=True) \
+                    if chain is not None else \
+                    wgrad_f16p_into(M, gz16[D], W, gzexp[D], W, h16[D - 1], W, hexp[D - 1], W, at(L.we), W, at(L.be), dev, EA(D), EB(D - 1), frag=True)
+                vec_wgrad_frag16_into(M, dpre_s, h16[D - 1], hexp[D - 1], at(L.wsig), at(L.bsig), dev)
+            else:
+                h_last = h[0] if store16 else h[D - 1]
+                wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
+                vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
         rs_c = _empty(R, W2, device=dev) if cfg.use_cand else None
         rs_r = _empty(R, W2, device=dev) if cfg.use_rgb else None
         if tile_part is not None:
