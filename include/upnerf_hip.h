@@ -175,6 +175,9 @@ typedef struct {
   void* x0f;                     /* upnerf_field_fwd_f16x3 with 128-sample tiles and a skip layer: scratch of ceil(M/128) * 32768
                                     bytes.  The workgroup parks the encoding of its tile there as fp16 operand fragments and
                                     reads them back at the skip layer (the planes hold h_{skip-1} by then) */
+  uint16_t* e16;                 /* tile_rows = 256 only, or NULL: e as fp16 operand fragments [ceil(M/256) * 8][16][64][8] like one
+                                    layer of h16 (then `e` may be NULL); upnerf_composite_fwd / _bwd and upnerf_wgrad_f16p read it */
+  int32_t* eexp;                 /* [ceil(M/256) * 8] */
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -210,6 +213,10 @@ typedef struct {
   float* c_depth;                /* [R] sum_i w_all z */
   float* s_depth;                /* [R] sum_i w_s z */
   float* rgb_map;                /* [R][3] sum_i w_s rgb_i */
+  /* W = 256: e as the fp16 operand fragments of the register-resident field kernels instead of fp32 rows (then `e` is
+   * ignored): upnerf_field_fwd_args.e16 / eexp */
+  const uint16_t* e16;
+  const int32_t* eexp;
 } upnerf_composite_fwd_args;
 
 int upnerf_composite_fwd(const upnerf_composite_fwd_args* a, void* stream);
@@ -234,6 +241,8 @@ typedef struct {
   float* d_sigma_s;              /* [M] */
   float* d_sigma_c;              /* [M] modes 0,1 */
   float* d_rgb;                  /* [M][3] has_rgb */
+  const uint16_t* e16;           /* as in upnerf_composite_fwd_args */
+  const int32_t* eexp;
 } upnerf_composite_bwd_args;
 
 int upnerf_composite_bwd(const upnerf_composite_bwd_args* a, void* stream);
@@ -286,6 +295,9 @@ typedef struct {
                                     tracked in gmax slot D+4 */
   int32_t reserved_;
   const float* wnorm;            /* as in upnerf_field_fwd_args (tile_rows = 256: required; else NULL) */
+  uint16_t* gz_rg16;             /* tile_rows = 256 with both heads, or NULL: [gz_r1 | gz_g1] as ONE 256-wide tensor of fp16 operand
+                                    fragments (then gz_r1 / gz_g1 may be NULL: with tile_part their per-ray sums still leave) */
+  int32_t* gzrgexp;              /* [ceil(M/256) * 8] */
 } upnerf_field_bwd_args;
 
 /* Layout of one row of tile_part (floats): d w_csig [W/2] | d w_r2 [3][W/2] | sum dpre_sig_c, sum dpre_rgb[0..2] | 4 pad |
@@ -408,8 +420,9 @@ int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int32_t* aexp, 
                       const int* expo_a, const int* expo_b, void* stream);
 /* chained like upnerf_wgrad_f16x3_chain, on the same pending record (a run may mix the two kinds of launches) */
 int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
-                            const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, float* slabs, int nsplit,
-                            const int* expo_a, const int* expo_b, upnerf_wgrad_pending* pending, void* stream);
+                            const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, int n2, float* dW2, int ldo2,
+                            float* db2, float* slabs, int nsplit, const int* expo_a, const int* expo_b,
+                            upnerf_wgrad_pending* pending, void* stream);  /* n2 > 0: rows [n2, N) -> dW2 / db2 (as chain2) */
 
 /* dw[c][k] = sum_m v[m*ldv + c] * X[m][k], c < nvec <= 3; dbv[c] = sum_m v[m*ldv + c]   (N=1/3 heads);
  * K in {32, 64, 128, 256}; scratch: nsplit * 4 * (K+1) floats */

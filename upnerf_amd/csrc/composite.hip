@@ -87,6 +87,17 @@ __device__ __forceinline__ Alphas alphas_at(const float* __restrict__ z, const f
   return A;
 }
 
+// e [M][256] as the fp16 operand fragments of the register-resident field kernels (include/upnerf_hip.h, tile_rows = 256):
+// [32-sample tile][k-block s 16][lane 64][8], feature 16 s + 8 (u / 4) + 4 (lane / 32) + u % 4, sample 32 tile + lane % 32, scaled
+// by 2^eexp[tile].  Lane position p = lane % 32 of a wave takes the piece (s = p / 2, half = p % 2) of sample m: 16 bytes,
+// features e16_col(p) + {0..3} and e16_col(p) + 8 + {0..3}; the two halves of a wave take two consecutive samples.
+typedef _Float16 h8c __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ h8c e16_piece(const uint16_t* __restrict__ e16, size_t m, int lane) {
+  const int p = lane & 31;
+  return *(const h8c*)(e16 + ((((m >> 5) * 16 + (p >> 1)) * 64 + (p & 1) * 32 + (m & 31)) << 3));
+}
+__device__ __forceinline__ int e16_col(int lane) { return 16 * ((lane & 31) >> 1) + 4 * (lane & 1); }
+
 template <int W>
 __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composite_fwd_args a) {
   constexpr int W2 = W / 2;
@@ -101,6 +112,7 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
   float carryT = 1.0f, carryTs = 1.0f;
   float acc_cd = 0.f, acc_sd = 0.f, acc_tw = 0.f, acc_sf = 0.f, acc_rgb[3] = {0.f, 0.f, 0.f};
   f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accG = {0.f, 0.f, 0.f, 0.f};
+  float accE8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (e16: this lane's piece position, see e16_piece)
   const bool laneE = lane < W / 4, laneG = lane < W2 / 4;
   for (int c0 = 0; c0 < S; c0 += 64) {
     const int i = c0 + lane;
@@ -137,10 +149,23 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
       const float wf = feat_from_ws ? w_s : w_sj;
       acc_sf += wf;
       const int nv = (S - c0) < 64 ? (S - c0) : 64;
+      if (W == 256 && a.e16) {
+        // e as the fp16 operand fragments of the register-resident field kernels (see E16Piece): two samples per step
+        const float wfs = valid ? wf * ldexpf(1.0f, -a.eexp[(base + i) >> 5]) : 0.0f;
+        for (int j = 0; j < nv; j += 2) {
+          const int jj = j + (lane >> 5);
+          const float wj = __shfl(wfs, jj & 63);
+          if (jj < nv) {
+            const h8c x = e16_piece(a.e16, base + c0 + jj, lane);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) accE8[u] = fmaf(wj, (float)x[u], accE8[u]);
+          }
+        }
+      }
       for (int j = 0; j < nv; ++j) {
         const float wj = __shfl(wf, j);
         const size_t m = base + c0 + j;
-        if (laneE) {
+        if (laneE && !(W == 256 && a.e16)) {
           const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
           accE.x += wj * ev.x; accE.y += wj * ev.y; accE.z += wj * ev.z; accE.w += wj * ev.w;
         }
@@ -165,6 +190,15 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
     if (a.has_rgb) { a.rgb_map[r * 3] = rg[0]; a.rgb_map[r * 3 + 1] = rg[1]; a.rgb_map[r * 3 + 2] = rg[2]; }
   }
   if (want_feat) {
+    if (W == 256 && a.e16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) accE8[u] += __shfl_xor(accE8[u], 32);
+      if (lane < 32) {
+        float* __restrict__ dst = a.E_s + (size_t)r * W + e16_col(lane);
+        *(f32x4*)dst = f32x4{accE8[0], accE8[1], accE8[2], accE8[3]};
+        *(f32x4*)(dst + 8) = f32x4{accE8[4], accE8[5], accE8[6], accE8[7]};
+      }
+    } else
     if (laneE) *(f32x4*)&a.E_s[(size_t)r * W + 4 * lane] = accE;
     if (joint && laneG) *(f32x4*)&a.G_c[(size_t)r * W2 + 4 * lane] = accG;
   }
@@ -207,6 +241,12 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   f32x4 gE = {0.f, 0.f, 0.f, 0.f}, gG = {0.f, 0.f, 0.f, 0.f};
+  const bool efrag = W == 256 && a.e16 != nullptr;
+  f32x4 gE8a = {0.f, 0.f, 0.f, 0.f}, gE8b = {0.f, 0.f, 0.f, 0.f};  // (e16: g_E_s at this lane's piece position, see e16_piece)
+  if (want_feat && a.g_E_s && efrag) {
+    gE8a = *(const f32x4*)&a.g_E_s[(size_t)r * W + e16_col(lane)];
+    gE8b = *(const f32x4*)&a.g_E_s[(size_t)r * W + e16_col(lane) + 8];
+  }
   if (want_feat && a.g_E_s && laneE) gE = *(const f32x4*)&a.g_E_s[(size_t)r * W + 4 * lane];
   if (joint && a.g_G_c && laneG) gG = *(const f32x4*)&a.g_G_c[(size_t)r * W2 + 4 * lane];
   const float g_sf = (want_feat && a.g_sum_sfeat) ? a.g_sum_sfeat[r] : 0.f;
@@ -225,10 +265,27 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
     float dotE = 0.f, dotG = 0.f;
     if (need_dots) {
       const int nv = (S - c0) < 64 ? (S - c0) : 64;
+      if (efrag) {
+        for (int j = 0; j < nv; j += 2) {  // two samples per step, one per half of the wave
+          const int jj = j + (lane >> 5);
+          float pe = 0.f;
+          if (jj < nv) {
+            const h8c x = e16_piece(a.e16, base + c0 + jj, lane);
+            pe = gE8a.x * (float)x[0] + gE8a.y * (float)x[1] + gE8a.z * (float)x[2] + gE8a.w * (float)x[3] +
+                 gE8b.x * (float)x[4] + gE8b.y * (float)x[5] + gE8b.z * (float)x[6] + gE8b.w * (float)x[7];
+          }
+#pragma unroll
+          for (int d = 16; d >= 1; d >>= 1) pe += __shfl_xor(pe, d);
+          const float p0 = __shfl(pe, 0), p1 = __shfl(pe, 32);
+          if (lane == j) dotE = p0;
+          if (lane == j + 1) dotE = p1;
+        }
+        if (valid) dotE *= ldexpf(1.0f, -a.eexp[(base + i) >> 5]);
+      }
       for (int j = 0; j < nv; ++j) {
         const size_t m = base + c0 + j;
         float pe = 0.f, pg = 0.f;
-        if (laneE) {
+        if (laneE && !efrag) {
           const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
           pe = gE.x * ev.x + gE.y * ev.y + gE.z * ev.z + gE.w * ev.w;
         }
@@ -236,9 +293,12 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
           const f32x4 gv = NT_LOAD((const f32x4*)&a.g2[m * W2 + 4 * lane]);
           pg = gG.x * gv.x + gG.y * gv.y + gG.z * gv.z + gG.w * gv.w;
         }
-        pe = wave_sum(pe);
+        if (!efrag) pe = wave_sum(pe);
         if (joint) pg = wave_sum(pg);
-        if (lane == j) { dotE = pe; dotG = pg; }
+        if (lane == j) {
+          if (!efrag) dotE = pe;
+          dotG = pg;
+        }
       }
     }
     Alphas A;
@@ -305,7 +365,7 @@ extern "C" int upnerf_composite_fwd(const upnerf_composite_fwd_args* a, void* st
   if (!a->z || !a->sigma_s || !a->w_s || !a->s_depth) return UPNERF_EINVAL;
   if (joint && (!a->sigma_c || !a->w_all || !a->w_sj || !a->w_cj || !a->c_depth || !a->t_weight || !a->g2 || !a->G_c))
     return UPNERF_EINVAL;
-  if (want_feat && (!a->e || !a->E_s || !a->sum_sfeat)) return UPNERF_EINVAL;
+  if (want_feat && ((!a->e && !a->e16) || (a->e16 && (!a->eexp || a->W != 256)) || !a->E_s || !a->sum_sfeat)) return UPNERF_EINVAL;
   if (a->has_rgb && (!a->rgb || !a->rgb_map)) return UPNERF_EINVAL;
   const dim3 grid((a->R + 3) / 4), block(NTHREADS);
   if (a->W == 256)
@@ -322,7 +382,7 @@ extern "C" int upnerf_composite_bwd(const upnerf_composite_bwd_args* a, void* st
   const bool joint = a->mode <= 1, want_feat = a->mode != 2;
   if (!a->z || !a->sigma_s || !a->d_sigma_s) return UPNERF_EINVAL;
   if (joint && (!a->sigma_c || !a->d_sigma_c)) return UPNERF_EINVAL;
-  if (want_feat && a->g_E_s && !a->e) return UPNERF_EINVAL;
+  if (want_feat && a->g_E_s && ((!a->e && !a->e16) || (a->e16 && (!a->eexp || a->W != 256)))) return UPNERF_EINVAL;
   if (joint && a->g_G_c && !a->g2) return UPNERF_EINVAL;
   if (a->has_rgb && (!a->rgb || !a->d_rgb)) return UPNERF_EINVAL;
   const dim3 grid((a->R + 3) / 4), block(NTHREADS);

@@ -356,7 +356,7 @@ __device__ __forceinline__ void stg_flush(const char* stg, int lane, float* __re
     const int row = 8 * i + (lane >> 3);
     const f32x4 v = *(const f32x4*)(stg + row * 128 + ((c ^ (row & 7)) << 4));
 #ifndef RR_EXP_NOSTORE
-    NT_STORE((f32x4*)(dst + (size_t)row * ld + col0 + 4 * c), v);
+    if (dst) NT_STORE((f32x4*)(dst + (size_t)row * ld + col0 + 4 * c), v);  // (dst == nullptr: the sums only; the caller counts no stores)
 #else
     asm volatile("" ::"v"(v));
 #endif
@@ -523,9 +523,9 @@ __device__ __forceinline__ void tile_out(Ring<NW>& rg, const TileOut& o, const u
     frag_store(o.frag, t32, 2 * JP + 1, lane, nx[BLK0 + 2 * JP + 1]);
     rg.count(2);
   }
-  if (o.rows) {
+  if (o.rows || o.part) {
     stg_flush(stg, lane, o.rows, o.ld, 32 * JP, o.part, o.rb);
-    rg.count(4);
+    if (o.rows) rg.count(4);
   }
 }
 // sign-bit words of a stage: tiles 2 w, 2 w + 1 -> word w
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
       e_E = scale_exp(bound);
       const float pe = pow2r(e_E);
       TileOut to;
-      to.frag = nullptr;
+      to.frag = a.e16;  // (nullptr, or e as operand fragments: compositing and the heads' weight gradients read those instead)
       to.rows = a.e ? a.e + (size_t)m0 * W : nullptr;
       to.ld = W;
       char* stg_e = a.e ? stg : nullptr;
@@ -870,6 +870,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
             tile_epilogue<false, 1, 0, false, false>(acc, jp, un, pe, vec_s + RR_V_BE, 1.0f, 0u, tw, vmax, novmax2, stg_e, blk, li, hh);
             tile_out<NW, 0, jp>(rg, to, blk, Nh, stg, t32, lane);
           });
+      if (a.e16 && lane == 0) a.eexp[t32] = e_E;  // (one lane: not counted)
       amax_e = wave_max_rr(vmax);
       track_lds(mx_s, D, amax_e, lane);
 #pragma unroll
@@ -1308,8 +1309,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
           if (pass == 1) {
             Bh[2 * jt] = blk[0];
             Bh[2 * jt + 1] = blk[1];
-            stg_flush(stg, lane, a.gz_r1 + (size_t)m0 * gld, gld, 32 * jt, rpart, rb);
-            rg.count(4);
+            stg_flush(stg, lane, a.gz_r1 ? a.gz_r1 + (size_t)m0 * gld : nullptr, gld, 32 * jt, rpart, rb);
+            if (a.gz_r1) rg.count(4);
           }
         }
       }
@@ -1326,7 +1327,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
       const float pe = pow2r(erg);
       TileOut to;
       to.frag = nullptr;
-      to.rows = a.gz_g1 + (size_t)m0 * gld;
+      to.rows = a.gz_g1 ? a.gz_g1 + (size_t)m0 * gld : nullptr;
       to.ld = gld;
       to.part = rpart ? rpart + 2 * W2 : nullptr;
       to.rb = rb;
@@ -1350,6 +1351,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
       for (int s = 8; s < 16; ++s) Bh[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
     }
     if (use_cand && use_rgb) track_lds(mx_s, D + 4, fmaxf(amax_g1, amax_r1), lane);  // of [gz_r1 | gz_g1] as one tensor (gz_rg_ld)
+    if (a.gz_rg16) {
+      // [gz_r1 | gz_g1] as it stands in the operand registers: the fp16 fragments of the d e stage, one exponent per wave
+#pragma unroll
+      for (int b = 0; b < 16; ++b) frag_store(a.gz_rg16, t32, b, lane, Bh[b]);
+      rg.count(16);
+      if (lane == 0) a.gzrgexp[t32] = erg;
+    }
     // ---- d e = [gz_r1 | gz_g1] . [W_fold | W_c1e] + w_feat g_E_s[ray]   (e has no activation)
     {
       const float un = pow2r(-(erg + wexp[12]));

@@ -814,8 +814,10 @@ extern "C" int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int3
 
 // Chained upnerf_wgrad_f16p: same pending record as upnerf_wgrad_f16x3_chain (one run may mix both kinds of launches).
 extern "C" int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
-                                       const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, float* slabs,
-                                       int nsplit, const int* expo_a, const int* expo_b, upnerf_wgrad_pending* pending, void* stream) {
+                                       const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, int n2, float* dW2,
+                                       int ldo2, float* db2, float* slabs, int nsplit, const int* expo_a, const int* expo_b,
+                                       upnerf_wgrad_pending* pending, void* stream) {
+  if (n2 < 0 || n2 >= N || (n2 > 0 && (!dW2 || (ldo2 & 3)))) return UPNERF_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0 || !A16 || !aexp || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b || !pending)
     return UPNERF_EINVAL;
   if ((b_is_f16 & 1) && !bexp) return UPNERF_EINVAL;
@@ -833,7 +835,12 @@ extern "C" int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, cons
   int rc = upnerf_wgrad_f16p_partial(M, A16, lda, aexp, N, B, ldb, bexp, b_is_f16, K, expo_a, expo_b, slabs, bslabs, nsplit, rows,
                                      TN, TK, pending->nsplit > 0 ? pending : nullptr, stream);
   if (rc) return rc;
-  *pending = reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db);
+  upnerf_wgrad_pending P = reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db);
+  P.n2 = n2;
+  P.dW2 = dW2;
+  P.db2 = db2;
+  P.ldo2 = ldo2;
+  *pending = P;
   return 0;
 }
 

@@ -173,7 +173,12 @@ class _FieldPass(torch.autograd.Function):
         hexp = torch.empty(D, ntile, device=dev, dtype=torch.int32) if store16 else None
         # (rr: no fp32 copy of the last layer either -- the density head's and the final layer's weight gradients read its fragments)
         h = (None if rr else _empty(1, M, W, device=dev) if store16 else _empty(D, M, W, device=dev)) if train else None
-        e = _empty(Mp, W, device=dev)[:M] if (train or want_feat) else None
+        # rr: e leaves as fp16 operand fragments only (compositing and the joined heads' weight gradient read those) unless a
+        # single head is on in training, whose separate weight gradient wants fp32 rows
+        e_frag = bool(rr and (train or want_feat) and (not train or _join_ok(cfg, W, use16, rr, tile_ok=True)))
+        e = _empty(Mp, W, device=dev)[:M] if ((train or want_feat) and not e_frag) else None
+        e16 = torch.empty(Mp, W, device=dev, dtype=torch.float16) if e_frag else None
+        eexp = torch.empty(Mp // 32, device=dev, dtype=torch.int32) if e_frag else None
         hmask = (torch.empty((D + 3) * Mp * 4 if rr else (D + 1) * ((M + 127) // 128) * 512 * HMASK_SCALE, device=dev,
                              dtype=torch.int64) if train else None)  # 64 bits per lane and tile, either tiling (rr: 128 per lane)
         # running max|.| of the stored tensors (scales of the f16x3 weight gradients): slots [0, 16) filled by this pass, [16, 32)
@@ -191,7 +196,7 @@ class _FieldPass(torch.autograd.Function):
                           rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1),
                           P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None,
                           planes=_planes(), tile_rows=tile, wnorm=ptr(wnorm), h16=ptr(h16), hexp=ptr(hexp),
-                          h_last_only=int(store16), x0f=ptr(x0f))
+                          h_last_only=int(store16), x0f=ptr(x0f), e16=ptr(e16), eexp=ptr(eexp))
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
@@ -210,7 +215,7 @@ class _FieldPass(torch.autograd.Function):
                               rgb=ptr(rgb), has_rgb=int(cfg.use_rgb), e=ptr(e), g2=ptr(g2), w_all=ptr(w_all),
                               w_sj=ptr(w_sj), w_cj=ptr(w_cj), w_s=ptr(w_s), E_s=ptr(E_s), G_c=ptr(G_c),
                               sum_sfeat=ptr(sum_sfeat), t_weight=ptr(t_weight), c_depth=ptr(c_depth),
-                              s_depth=ptr(s_depth), rgb_map=ptr(rgb_map))
+                              s_depth=ptr(s_depth), rgb_map=ptr(rgb_map), e16=ptr(e16), eexp=ptr(eexp))
         check(TIMER.run("composite_fwd", lambda: lib.upnerf_composite_fwd(C.byref(ca), st), units=M),
               "upnerf_composite_fwd")
 
@@ -218,7 +223,7 @@ class _FieldPass(torch.autograd.Function):
         ctx.rr, ctx.Mp = rr, Mp
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, mx32=mx32, e=e, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, mx32=mx32, e=e, e16=e16, eexp=eexp, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
                          w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s, wnorm=wnorm)
         z0 = torch.zeros(0, device=dev)
@@ -251,7 +256,7 @@ class _FieldPass(torch.autograd.Function):
                               w_cj=ptr(sv["w_cj"]), w_s=ptr(sv["w_s"]), g_E_s=ptr(gE), g_G_c=ptr(gG),
                               g_sum_sfeat=ptr(gsf), g_t_weight=ptr(gtw), g_c_depth=ptr(gcd), g_s_depth=ptr(gsd),
                               g_rgb_map=ptr(grm), g_w_all=ptr(gwall), g_w_s=ptr(gws), d_sigma_s=ptr(d_sigma_s),
-                              d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb))
+                              d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb), e16=ptr(sv.get("e16")), eexp=ptr(sv.get("eexp")))
         check(TIMER.run("composite_bwd", lambda: lib.upnerf_composite_bwd(C.byref(cb), st), units=M),
               "upnerf_composite_bwd")
 
@@ -267,12 +272,14 @@ class _FieldPass(torch.autograd.Function):
         gzexp = torch.empty(D + int(rr), sv["hexp"].shape[1], device=dev, dtype=torch.int32) if store16 else None
         # [gz_r1 | gz_g1] as ONE [M][W] tensor when both heads are on and the chained f16x3 weight gradients run: the two first
         # layers of the heads are both fed by e, so their weight gradients are one launch that reads e once (chain.wgrad2)
-        joined = bool(use16 and cfg.use_cand and cfg.use_rgb and JOIN_HEADS and WGRAD_CHAIN and W == 256
-                      and (ctx.tile_rows == 64 or rr) and TILE_PARTIALS)  # (upnerf_ray_sum, the fallback, wants dense tensors)
-        gz_rg = _empty(Mp, W, device=dev)[:M] if joined else None
-        gz_g1 = (gz_rg[:, W2:] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_cand else None
+        joined = _join_ok(cfg, W, use16, rr, tile_ok=ctx.tile_rows == 64)  # (upnerf_ray_sum, the fallback, wants dense tensors)
+        rg16 = joined and rr and sv.get("e16") is not None  # rr: [gz_r1 | gz_g1] as fp16 fragments only, against e's fragments
+        gz_rg = _empty(Mp, W, device=dev)[:M] if (joined and not rg16) else None
+        gz_rg16 = torch.empty(Mp, W, device=dev, dtype=torch.float16) if rg16 else None
+        gzrgexp = torch.empty(Mp // 32, device=dev, dtype=torch.int32) if rg16 else None
+        gz_g1 = (None if rg16 else gz_rg[:, W2:] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_cand else None
         gz_g2 = _empty(Mp, W2, device=dev)[:M] if cfg.use_cand else None
-        gz_r1 = (gz_rg[:, :W2] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_rgb else None
+        gz_r1 = (None if rg16 else gz_rg[:, :W2] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_rgb else None
         dpre_s = _empty(M, device=dev)
         dpre_c = _empty(M, device=dev) if cfg.use_cand else None
         dpre_rgb = _empty(M, 4, device=dev) if cfg.use_rgb else None
@@ -294,8 +301,9 @@ class _FieldPass(torch.autograd.Function):
                           w_feat_s=ptr(w_feat), w_cj=ptr(sv["w_cj"]) if gG is not None else None, g_E_s=ptr(gE),
                           g_G_c=ptr(gG), x0=ptr(sv["x0"]), h=ptr(sv["h"]), g1=ptr(sv["g1"]), g2=ptr(sv["g2"]),
                           r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e),
-                          gz_g1=(gz_rg.data_ptr() + 4 * W2) if joined else ptr(gz_g1), gz_g2=ptr(gz_g2),
-                          gz_r1=ptr(gz_rg) if joined else ptr(gz_r1), gz_rg_ld=W if joined else 0, dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
+                          gz_g1=(gz_rg.data_ptr() + 4 * W2) if gz_rg is not None else ptr(gz_g1), gz_g2=ptr(gz_g2),
+                          gz_r1=ptr(gz_rg) if gz_rg is not None else ptr(gz_r1), gz_rg_ld=W if gz_rg is not None else 0,
+                          gz_rg16=ptr(gz_rg16), gzrgexp=ptr(gzrgexp), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, tile_rows=ctx.tile_rows, xs=ptr(sv.get("x0f")), gz16=ptr(gz16),
                           gzexp=ptr(gzexp), tile_part=ptr(ray_part if rr else tile_part), wnorm=ptr(sv.get("wnorm")))
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
@@ -304,8 +312,10 @@ class _FieldPass(torch.autograd.Function):
         if _DEBUG_SINK is not None:
             _DEBUG_SINK.update(d_sigma_s=d_sigma_s, d_sigma_c=d_sigma_c, d_rgb=d_rgb,
                                gz_h=gz_h if gz_h is not None else dequant16(gz16[:D], gzexp[:D], frag=rr)[:, :M],
-                               gz_e=gz_e if gz_e is not None else dequant16(gz16[D:], gzexp[D:], frag=True)[0, :M], gz_g1=gz_g1,
-                               gz_g2=gz_g2, gz_r1=gz_r1, dpre_s=dpre_s, dpre_c=dpre_c, dpre_rgb=dpre_rgb, dxyz=dxyz)
+                               gz_e=gz_e if gz_e is not None else dequant16(gz16[D:], gzexp[D:], frag=True)[0, :M],
+                               gz_g1=dequant16(gz_rg16[None], gzrgexp[None], frag=True)[0, :M, W2:] if rg16 else gz_g1,
+                               gz_r1=dequant16(gz_rg16[None], gzrgexp[None], frag=True)[0, :M, :W2] if rg16 else gz_r1,
+                               gz_g2=gz_g2, dpre_s=dpre_s, dpre_c=dpre_c, dpre_rgb=dpre_rgb, dxyz=dxyz)
         # ---- weight gradients, written straight into a buffer with P's layout
         dP = torch.zeros(L.total, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
         d_c_rows = d_a_rows = None
@@ -385,7 +395,10 @@ class _FieldPass(torch.autograd.Function):
             if tile_part is None and ray_part is None:
                 check(lib.upnerf_ray_sum(R, S, ptr(gz_g1), W2, ptr(rs_c), st), "upnerf_ray_sum")
             if dP is not None:
-                if joined:  # rows [0, W2) -> wr1 / br1 (colour head), rows [W2, W) -> wc1 / bc1 (candidate head)
+                if rg16:
+                    chain.wgrad_p(M, gz_rg16, W, gzrgexp, W, sv["e16"], W, sv["eexp"], W, at(L.wr1), W + AUXK, at(L.br1), EA(D + 4), EB(D),
+                                  frag=True, n2=W2, dW2_ptr=at(L.wc1), ldo2=W + CK, db2_ptr=at(L.bc1))
+                elif joined:  # rows [0, W2) -> wr1 / br1 (colour head), rows [W2, W) -> wc1 / bc1 (candidate head)
                     chain.wgrad2(M, gz_rg, W, W, sv["e"], W, W, at(L.wr1), W + AUXK, at(L.br1), W2, at(L.wc1), W + CK, at(L.bc1),
                                  EA(D + 4), EB(D), planes=ctx.planes)
                 else:
@@ -417,6 +430,13 @@ class _FieldPass(torch.autograd.Function):
         return d_o, d_d, None, d_c_rows, d_a_rows, dP, None
 
 
+def _join_ok(cfg, W: int, use16: bool, rr: bool, tile_ok: bool) -> bool:
+    """[gz_r1 | gz_g1] as one tensor with one weight-gradient launch against e (both heads on, chained f16 weight gradients,
+    per-tile partial sums: the 64-sample tiling or the register-resident kernels)."""
+    return bool(use16 and cfg.use_cand and cfg.use_rgb and JOIN_HEADS and WGRAD_CHAIN and W == 256 and (tile_ok or rr)
+                and TILE_PARTIALS)
+
+
 def dequant16(t16: torch.Tensor, texp: torch.Tensor, frag: bool = False) -> torch.Tensor:
     """fp32 view of an fp16-stored, tile-scaled tensor [D][M][W] with exponents [D][ceil(M/64)] (tests, debugging).
     frag: the register-resident kernels' layout (include/upnerf_hip.h, tile_rows = 256) -- [D][M/32][k-block 16][lane 64][8]
@@ -429,6 +449,14 @@ def dequant16(t16: torch.Tensor, texp: torch.Tensor, frag: bool = False) -> torc
         return rows.float() * scale[:, :, None]
     scale = torch.ldexp(torch.ones((), device=t16.device), -texp.float()).repeat_interleave(64, dim=1)[:, :M]
     return t16.float() * scale[:, :, None]
+
+
+def quant16_frag(rows: torch.Tensor, texp: torch.Tensor) -> torch.Tensor:
+    """Inverse of dequant16(frag=True) for one layer (tests): rows [M][W] fp32 (M a multiple of 32), texp [M/32] -> fp16
+    fragments [M][W] holding rows * 2^texp[tile]."""
+    M, W = rows.shape
+    x = (rows * torch.ldexp(torch.ones((), device=rows.device), texp.float()).repeat_interleave(32)[:, None]).to(torch.float16)
+    return x.view(M // 32, 32, W // 16, 2, 2, 4).permute(0, 2, 4, 1, 3, 5).reshape(M, W).contiguous()  # [tile][s][hh][li][j>>2][j&3]
 
 
 def sample_pdf(z_coarse: torch.Tensor, weights: torch.Tensor, n: int, det: bool, out: torch.Tensor, col0: int,
