@@ -89,18 +89,21 @@ __device__ __forceinline__ Alphas alphas_at(const float* __restrict__ z, const f
 
 // e [M][256] as the fp16 operand fragments of the register-resident field kernels (include/upnerf_hip.h, tile_rows = 256):
 // [32-sample tile][k-block s 16][lane 64][8], feature 16 s + 8 (u / 4) + 4 (lane / 32) + u % 4, sample 32 tile + lane % 32, scaled
-// by 2^eexp[tile].  Lane position p = lane % 32 of a wave takes the piece (s = p / 2, half = p % 2) of sample m: 16 bytes,
-// features e16_col(p) + {0..3} and e16_col(p) + 8 + {0..3}; the two halves of a wave take two consecutive samples.
+// by 2^eexp[tile].  A wave walks the tiles its ray touches: sixteen coalesced 1 KiB loads per tile, lane = (sample, feature half)
+// as stored, so a sample's share of E_s accumulates in 128 per-lane registers (ONE cross-lane reduction per ray) and a sample's
+// dot product with g_E_s closes inside two lanes -- no per-sample shuffles at all, half the bytes of the fp32 rows.
 typedef _Float16 h8c __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ h8c e16_piece(const uint16_t* __restrict__ e16, size_t m, int lane) {
-  const int p = lane & 31;
-  return *(const h8c*)(e16 + ((((m >> 5) * 16 + (p >> 1)) * 64 + (p & 1) * 32 + (m & 31)) << 3));
+#define E16_MAXS 1024  // = 64 * MAX_CHUNKS
+__device__ __forceinline__ void e16_half(const uint16_t* __restrict__ e16, int t, int s0, int lane, h8c (&x)[8]) {
+  const h8c* __restrict__ p = (const h8c*)e16 + (size_t)t * 1024 + s0 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) x[s] = __builtin_nontemporal_load(p + s * 64);
 }
-__device__ __forceinline__ int e16_col(int lane) { return 16 * ((lane & 31) >> 1) + 4 * (lane & 1); }
 
-template <int W>
+template <int W, bool EFRAG>
 __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composite_fwd_args a) {
   constexpr int W2 = W / 2;
+  __shared__ float wf_lds[EFRAG ? 4 : 1][EFRAG ? E16_MAXS : 1];  // (e16: the feature weights of the ray, scaled per tile)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
   if (r >= a.R) return;
@@ -112,7 +115,6 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
   float carryT = 1.0f, carryTs = 1.0f;
   float acc_cd = 0.f, acc_sd = 0.f, acc_tw = 0.f, acc_sf = 0.f, acc_rgb[3] = {0.f, 0.f, 0.f};
   f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accG = {0.f, 0.f, 0.f, 0.f};
-  float accE8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (e16: this lane's piece position, see e16_piece)
   const bool laneE = lane < W / 4, laneG = lane < W2 / 4;
   for (int c0 = 0; c0 < S; c0 += 64) {
     const int i = c0 + lane;
@@ -149,25 +151,17 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
       const float wf = feat_from_ws ? w_s : w_sj;
       acc_sf += wf;
       const int nv = (S - c0) < 64 ? (S - c0) : 64;
-      if (W == 256 && a.e16) {
-        // e as the fp16 operand fragments of the register-resident field kernels (see E16Piece): two samples per step
-        const float wfs = valid ? wf * ldexpf(1.0f, -a.eexp[(base + i) >> 5]) : 0.0f;
-        for (int j = 0; j < nv; j += 2) {
-          const int jj = j + (lane >> 5);
-          const float wj = __shfl(wfs, jj & 63);
-          if (jj < nv) {
-            const h8c x = e16_piece(a.e16, base + c0 + jj, lane);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) accE8[u] = fmaf(wj, (float)x[u], accE8[u]);
-          }
-        }
+      if constexpr (EFRAG) {
+        if (valid) wf_lds[wave][i] = wf * ldexpf(1.0f, -a.eexp[(base + i) >> 5]);
       }
       for (int j = 0; j < nv; ++j) {
         const float wj = __shfl(wf, j);
         const size_t m = base + c0 + j;
-        if (laneE && !(W == 256 && a.e16)) {
-          const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
-          accE.x += wj * ev.x; accE.y += wj * ev.y; accE.z += wj * ev.z; accE.w += wj * ev.w;
+        if constexpr (!EFRAG) {
+          if (laneE) {
+            const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
+            accE.x += wj * ev.x; accE.y += wj * ev.y; accE.z += wj * ev.z; accE.w += wj * ev.w;
+          }
         }
         if (joint) {
           const float cj = __shfl(w_cj, j);
@@ -189,26 +183,61 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
     if (want_feat) a.sum_sfeat[r] = sf;
     if (a.has_rgb) { a.rgb_map[r * 3] = rg[0]; a.rgb_map[r * 3 + 1] = rg[1]; a.rgb_map[r * 3 + 2] = rg[2]; }
   }
-  if (want_feat) {
-    if (W == 256 && a.e16) {
+  if constexpr (EFRAG) {
+    if (want_feat) {
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      const int t0 = (int)(base >> 5), t1 = (int)((base + S - 1) >> 5);
+      // two passes over the tiles, eight k-blocks each (every piece is still read once): 64 accumulators at a time
+#pragma unroll 1
+      for (int hf = 0; hf < 2; ++hf) {
+        float acc[8][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) accE8[u] += __shfl_xor(accE8[u], 32);
-      if (lane < 32) {
-        float* __restrict__ dst = a.E_s + (size_t)r * W + e16_col(lane);
-        *(f32x4*)dst = f32x4{accE8[0], accE8[1], accE8[2], accE8[3]};
-        *(f32x4*)(dst + 8) = f32x4{accE8[4], accE8[5], accE8[6], accE8[7]};
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc[s][u] = 0.0f;
+        for (int t = t0; t <= t1; ++t) {
+          const long long idx = (long long)t * 32 + (lane & 31) - (long long)base;
+          const float w = (idx >= 0 && idx < S) ? wf_lds[wave][idx] : 0.0f;
+          h8c x[8];
+          e16_half(a.e16, t, 8 * hf, lane, x);
+#pragma unroll
+          for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[s][u] = fmaf(w, (float)x[s][u], acc[s][u]);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            float v = acc[s][u];
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d);
+            acc[s][u] = v;
+          }
+        if ((lane & 31) == 0) {
+          float* __restrict__ dst = a.E_s + (size_t)r * W + 128 * hf + 4 * (lane >> 5);
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            *(f32x4*)(dst + 16 * s) = f32x4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]};
+            *(f32x4*)(dst + 16 * s + 8) = f32x4{acc[s][4], acc[s][5], acc[s][6], acc[s][7]};
+          }
+        }
       }
-    } else
-    if (laneE) *(f32x4*)&a.E_s[(size_t)r * W + 4 * lane] = accE;
+    }
+  }
+  if (want_feat) {
+    if (!EFRAG && laneE) *(f32x4*)&a.E_s[(size_t)r * W + 4 * lane] = accE;
     if (joint && laneG) *(f32x4*)&a.G_c[(size_t)r * W2 + 4 * lane] = accG;
   }
 }
 
 #define MAX_CHUNKS 16
-template <int W>
+template <int W, bool EFRAG>
 __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composite_bwd_args a) {
   constexpr int W2 = W / 2;
   __shared__ double carry_s[4][2][MAX_CHUNKS];
+  __shared__ float dot_lds[EFRAG ? 4 : 1][EFRAG ? E16_MAXS : 1];  // (e16: <g_E_s, e_i> of every sample of the ray)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
   if (r >= a.R) return;
@@ -241,13 +270,7 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   f32x4 gE = {0.f, 0.f, 0.f, 0.f}, gG = {0.f, 0.f, 0.f, 0.f};
-  const bool efrag = W == 256 && a.e16 != nullptr;
-  f32x4 gE8a = {0.f, 0.f, 0.f, 0.f}, gE8b = {0.f, 0.f, 0.f, 0.f};  // (e16: g_E_s at this lane's piece position, see e16_piece)
-  if (want_feat && a.g_E_s && efrag) {
-    gE8a = *(const f32x4*)&a.g_E_s[(size_t)r * W + e16_col(lane)];
-    gE8b = *(const f32x4*)&a.g_E_s[(size_t)r * W + e16_col(lane) + 8];
-  }
-  if (want_feat && a.g_E_s && laneE) gE = *(const f32x4*)&a.g_E_s[(size_t)r * W + 4 * lane];
+  if (!EFRAG && want_feat && a.g_E_s && laneE) gE = *(const f32x4*)&a.g_E_s[(size_t)r * W + 4 * lane];
   if (joint && a.g_G_c && laneG) gG = *(const f32x4*)&a.g_G_c[(size_t)r * W2 + 4 * lane];
   const float g_sf = (want_feat && a.g_sum_sfeat) ? a.g_sum_sfeat[r] : 0.f;
   const float g_tw = (joint && a.g_t_weight) ? a.g_t_weight[r] : 0.f;
@@ -256,6 +279,42 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
   float g_rm[3] = {0.f, 0.f, 0.f};
   if (a.has_rgb && a.g_rgb_map) { g_rm[0] = a.g_rgb_map[r * 3]; g_rm[1] = a.g_rgb_map[r * 3 + 1]; g_rm[2] = a.g_rgb_map[r * 3 + 2]; }
   const bool need_dots = want_feat && (a.g_E_s || (joint && a.g_G_c));
+  if constexpr (EFRAG) {
+    if (want_feat && a.g_E_s) {
+      const int t0 = (int)(base >> 5), t1 = (int)((base + S - 1) >> 5);
+      const float* __restrict__ gsrc = a.g_E_s + (size_t)r * W + 4 * (lane >> 5);
+      // two passes over the tiles, eight k-blocks each (every piece is still read once); the second adds to the first's sums
+#pragma unroll 1
+      for (int hf = 0; hf < 2; ++hf) {
+        // this lane's 64 entries of g_E_s[r] for these k-blocks, in the order its fragment pieces hold the features
+        f32x4 ga[8], gb[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          ga[s] = *(const f32x4*)(gsrc + 128 * hf + 16 * s);
+          gb[s] = *(const f32x4*)(gsrc + 128 * hf + 16 * s + 8);
+        }
+        for (int t = t0; t <= t1; ++t) {
+          h8c x[8];
+          e16_half(a.e16, t, 8 * hf, lane, x);
+          float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            p0 += ga[s].x * (float)x[s][0] + ga[s].y * (float)x[s][1] + ga[s].z * (float)x[s][2] + ga[s].w * (float)x[s][3];
+            p1 += gb[s].x * (float)x[s][4] + gb[s].y * (float)x[s][5] + gb[s].z * (float)x[s][6] + gb[s].w * (float)x[s][7];
+          }
+          float pe = p0 + p1;
+          pe += __shfl_xor(pe, 32);
+          const long long idx = (long long)t * 32 + (lane & 31) - (long long)base;
+          if (lane < 32 && idx >= 0 && idx < S) {
+            pe *= ldexpf(1.0f, -a.eexp[t]);
+            dot_lds[wave][idx] = hf ? dot_lds[wave][idx] + pe : pe;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+    }
+  }
 
   double sufX = 0.0, sufY = 0.0;  // suffix sums over later chunks
   for (int c = nchunk - 1; c >= 0; --c) {
@@ -265,40 +324,25 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
     float dotE = 0.f, dotG = 0.f;
     if (need_dots) {
       const int nv = (S - c0) < 64 ? (S - c0) : 64;
-      if (efrag) {
-        for (int j = 0; j < nv; j += 2) {  // two samples per step, one per half of the wave
-          const int jj = j + (lane >> 5);
-          float pe = 0.f;
-          if (jj < nv) {
-            const h8c x = e16_piece(a.e16, base + c0 + jj, lane);
-            pe = gE8a.x * (float)x[0] + gE8a.y * (float)x[1] + gE8a.z * (float)x[2] + gE8a.w * (float)x[3] +
-                 gE8b.x * (float)x[4] + gE8b.y * (float)x[5] + gE8b.z * (float)x[6] + gE8b.w * (float)x[7];
-          }
-#pragma unroll
-          for (int d = 16; d >= 1; d >>= 1) pe += __shfl_xor(pe, d);
-          const float p0 = __shfl(pe, 0), p1 = __shfl(pe, 32);
-          if (lane == j) dotE = p0;
-          if (lane == j + 1) dotE = p1;
-        }
-        if (valid) dotE *= ldexpf(1.0f, -a.eexp[(base + i) >> 5]);
-      }
       for (int j = 0; j < nv; ++j) {
         const size_t m = base + c0 + j;
         float pe = 0.f, pg = 0.f;
-        if (laneE && !efrag) {
-          const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
-          pe = gE.x * ev.x + gE.y * ev.y + gE.z * ev.z + gE.w * ev.w;
+        if constexpr (!EFRAG) {
+          if (laneE) {
+            const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
+            pe = gE.x * ev.x + gE.y * ev.y + gE.z * ev.z + gE.w * ev.w;
+          }
         }
         if (joint && laneG) {
           const f32x4 gv = NT_LOAD((const f32x4*)&a.g2[m * W2 + 4 * lane]);
           pg = gG.x * gv.x + gG.y * gv.y + gG.z * gv.z + gG.w * gv.w;
         }
-        if (!efrag) pe = wave_sum(pe);
+        if constexpr (!EFRAG) pe = wave_sum(pe);
         if (joint) pg = wave_sum(pg);
-        if (lane == j) {
-          if (!efrag) dotE = pe;
-          dotG = pg;
-        }
+        if (lane == j) { dotE = pe; dotG = pg; }
+      }
+      if constexpr (EFRAG) {
+        if (valid && a.g_E_s) dotE = dot_lds[wave][i];
       }
     }
     Alphas A;
@@ -368,10 +412,12 @@ extern "C" int upnerf_composite_fwd(const upnerf_composite_fwd_args* a, void* st
   if (want_feat && ((!a->e && !a->e16) || (a->e16 && (!a->eexp || a->W != 256)) || !a->E_s || !a->sum_sfeat)) return UPNERF_EINVAL;
   if (a->has_rgb && (!a->rgb || !a->rgb_map)) return UPNERF_EINVAL;
   const dim3 grid((a->R + 3) / 4), block(NTHREADS);
-  if (a->W == 256)
-    hipLaunchKernelGGL(composite_fwd_kernel<256>, grid, block, 0, (hipStream_t)stream, *a);
+  if (a->W == 256 && a->e16 && want_feat)
+    hipLaunchKernelGGL((composite_fwd_kernel<256, true>), grid, block, 0, (hipStream_t)stream, *a);
+  else if (a->W == 256)
+    hipLaunchKernelGGL((composite_fwd_kernel<256, false>), grid, block, 0, (hipStream_t)stream, *a);
   else
-    hipLaunchKernelGGL(composite_fwd_kernel<64>, grid, block, 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL((composite_fwd_kernel<64, false>), grid, block, 0, (hipStream_t)stream, *a);
   return (int)hipGetLastError();
 }
 
@@ -386,9 +432,11 @@ extern "C" int upnerf_composite_bwd(const upnerf_composite_bwd_args* a, void* st
   if (joint && a->g_G_c && !a->g2) return UPNERF_EINVAL;
   if (a->has_rgb && (!a->rgb || !a->d_rgb)) return UPNERF_EINVAL;
   const dim3 grid((a->R + 3) / 4), block(NTHREADS);
-  if (a->W == 256)
-    hipLaunchKernelGGL(composite_bwd_kernel<256>, grid, block, 0, (hipStream_t)stream, *a);
+  if (a->W == 256 && a->e16 && want_feat && a->g_E_s)
+    hipLaunchKernelGGL((composite_bwd_kernel<256, true>), grid, block, 0, (hipStream_t)stream, *a);
+  else if (a->W == 256)
+    hipLaunchKernelGGL((composite_bwd_kernel<256, false>), grid, block, 0, (hipStream_t)stream, *a);
   else
-    hipLaunchKernelGGL(composite_bwd_kernel<64>, grid, block, 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL((composite_bwd_kernel<64, false>), grid, block, 0, (hipStream_t)stream, *a);
   return (int)hipGetLastError();
 }
