@@ -178,6 +178,10 @@ typedef struct {
   uint16_t* e16;                 /* tile_rows = 256 only, or NULL: e as fp16 operand fragments [ceil(M/256) * 8][16][64][8] like one
                                     layer of h16 (then `e` may be NULL); upnerf_composite_fwd / _bwd and upnerf_wgrad_f16p read it */
   int32_t* eexp;                 /* [ceil(M/256) * 8] */
+  uint16_t* g2_16;               /* the same for g2 (128 wide: [..][8][64][8]; then `g2` may be NULL) and for r1: compositing / */
+  int32_t* g2exp;                /* upnerf_vec_wgrad_frag16 read them; the backward kernel works from the sign bits in hmask */
+  uint16_t* r1_16;
+  int32_t* r1exp;
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -217,6 +221,8 @@ typedef struct {
    * ignored): upnerf_field_fwd_args.e16 / eexp */
   const uint16_t* e16;
   const int32_t* eexp;
+  const uint16_t* g2_16;         /* with e16 (modes 0, 1): g2 the same way, 128 wide = 8 k-blocks per 32 samples (then `g2` is ignored) */
+  const int32_t* g2exp;
 } upnerf_composite_fwd_args;
 
 int upnerf_composite_fwd(const upnerf_composite_fwd_args* a, void* stream);
@@ -243,6 +249,8 @@ typedef struct {
   float* d_rgb;                  /* [M][3] has_rgb */
   const uint16_t* e16;           /* as in upnerf_composite_fwd_args */
   const int32_t* eexp;
+  const uint16_t* g2_16;
+  const int32_t* g2exp;
 } upnerf_composite_bwd_args;
 
 int upnerf_composite_bwd(const upnerf_composite_bwd_args* a, void* stream);
@@ -429,11 +437,11 @@ int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, const int32_t* 
 int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const float* X, int ldx, int K,
                      float* dw /*[nvec][K]*/, float* dbv /*[nvec]*/, float* scratch, int nsplit, void* stream);
 
-/* upnerf_vec_wgrad for one vector (nvec = 1, ldv = 1) against a 256-wide fp16 tensor in the operand-fragment order of the
- * register-resident field kernels (upnerf_field_fwd_args.tile_rows = 256: h16 / hexp of one layer, padded to whole 32-sample
- * tiles); scratch: nsplit * 4 * 257 floats.  Fixed summation order. */
-int upnerf_vec_wgrad_frag16(int M, const float* v, const uint16_t* X16, const int32_t* xexp, float* dw, float* dbv,
-                            float* scratch, int nsplit, void* stream);
+/* upnerf_vec_wgrad (same v / ldv / nvec / dw / dbv) against a 256- or 128-wide fp16 tensor in the operand-fragment order of the
+ * register-resident field kernels (upnerf_field_fwd_args.tile_rows = 256: h16 / hexp of one layer, g2_16, r1_16; padded to whole
+ * 32-sample tiles); scratch: nsplit * 4 * (K + 1) floats.  Fixed summation order. */
+int upnerf_vec_wgrad_frag16(int M, const float* v, int ldv, int nvec, const uint16_t* X16, const int32_t* xexp, int K, float* dw,
+                            float* dbv, float* scratch, int nsplit, void* stream);  /* nvec <= 3, K = 256 or 128 */
 
 /* out[r][c] = sum_{i<S} X[(r*S+i)][c]  (per-ray sums of a per-sample tensor; embedding-row gradients) */
 int upnerf_ray_sum(int R, int S, const float* X, int C, float* out, void* stream);

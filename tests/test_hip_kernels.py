@@ -430,13 +430,15 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     ok &= cmp("sigma_s", sv["sigma_s"], f["sigma_s"], TOL_ACT)
     e_got = sv["e"] if sv.get("e") is not None else rd.dequant16(sv["e16"][None], sv["eexp"][None], frag=True)[0, :M]  # (rr: fragments only)
     ok &= cmp("e", e_got, f["e"], TOL_ACT)
+    def stored(k):  # (rr: g2 / r1 may be held as fp16 fragments only)
+        return sv[k] if sv.get(k) is not None else rd.dequant16(sv[k + "_16"][None], sv[k + "exp"][None], frag=True)[0, :M]
     if s["use_cand"]:
         for k in ("g1", "g2", "sigma_c"):
-            ok &= cmp(k, sv[k], f[k], TOL_ACT)
+            ok &= cmp(k, stored(k), f[k], TOL_ACT)
     if s["use_rgb"]:
         ok &= cmp("aux", sv["aux"], aux_ref, 2e-6)
         for k in ("r1", "rgb"):
-            ok &= cmp(k, sv[k], f[k], TOL_ACT)
+            ok &= cmp(k, stored(k), f[k], TOL_ACT)
     for i, n in enumerate(names):
         if n in out_ref:
             ok &= cmp("out_" + n, outs[i], out_ref[n], TOL_ACT)
@@ -494,8 +496,11 @@ def test_compositing_reads_e_as_fp16_fragments(hip, R, S, mode):
     texp = torch.randint(-3, 4, (Mp // 32,), generator=torch.Generator().manual_seed(5)).to(torch.int32).to(dev)
     e16 = rd.quant16_frag(gen((Mp, W), 1).to(dev), texp)
     e = rd.dequant16(e16[None], texp[None], frag=True)[0, :M].contiguous()
+    gexp = torch.randint(-2, 3, (Mp // 32,), generator=torch.Generator().manual_seed(15)).to(torch.int32).to(dev)
+    g2_16 = rd.quant16_frag(gen((Mp, W2), 7).to(dev), gexp)
     z = torch.sort(gen((R, S), 2, 0.1, 4.0), dim=-1).values.to(dev)
-    sig_s, sig_c, rgb, g2 = gen((M,), 3, 0.0, 3.0).to(dev), gen((M,), 4, 0.0, 3.0).to(dev), gen((M, 3), 6, 0.0, 1.0).to(dev), gen((M, W2), 7).to(dev)
+    sig_s, sig_c, rgb = gen((M,), 3, 0.0, 3.0).to(dev), gen((M,), 4, 0.0, 3.0).to(dev), gen((M, 3), 6, 0.0, 1.0).to(dev)
+    g2 = rd.dequant16(g2_16[None], gexp[None], frag=True)[0, :M].contiguous()
     joint = mode <= 1
     p = lambda t: None if t is None else t.data_ptr()
 
@@ -503,25 +508,29 @@ def test_compositing_reads_e_as_fp16_fragments(hip, R, S, mode):
         o = {k: torch.zeros(*shp, device=dev) for k, shp in dict(w_all=(M,), w_sj=(M,), w_cj=(M,), w_s=(M,), E_s=(R, W), G_c=(R, W2), sum_sfeat=(R,),
                                                                 t_weight=(R,), c_depth=(R,), s_depth=(R,), rgb_map=(R, 3)).items()}
         fa = CompositeFwdArgs(R=R, S=S, W=W, mode=mode, z=p(z), sigma_s=p(sig_s), sigma_c=p(sig_c), rgb=p(rgb), has_rgb=1,
-                              e=None if frag else p(e), g2=p(g2), e16=p(e16) if frag else None, eexp=p(texp) if frag else None,
-                              **{k: p(v) for k, v in o.items()})
+                              e=None if frag else p(e), g2=p(g2) if frag < 2 else None, e16=p(e16) if frag else None,
+                              eexp=p(texp) if frag else None, g2_16=p(g2_16) if frag == 2 else None,
+                              g2exp=p(gexp) if frag == 2 else None, **{k: p(v) for k, v in o.items()})
         assert lib.lib.upnerf_composite_fwd(C.byref(fa), None) == 0
         gE, gG = gen((R, W), 8).to(dev), gen((R, W2), 9).to(dev)
         gr = {k: gen(shp, 10 + i).to(dev) for i, (k, shp) in enumerate(dict(g_sum_sfeat=(R,), g_t_weight=(R,), g_c_depth=(R,), g_s_depth=(R,),
                                                                             g_rgb_map=(R, 3), g_w_all=(M,), g_w_s=(M,)).items())}
         d = dict(d_sigma_s=torch.zeros(M, device=dev), d_sigma_c=torch.zeros(M, device=dev), d_rgb=torch.zeros(M, 3, device=dev))
         ba = CompositeBwdArgs(R=R, S=S, W=W, mode=mode, has_rgb=1, z=p(z), sigma_s=p(sig_s), sigma_c=p(sig_c), rgb=p(rgb),
-                              e=None if frag else p(e), g2=p(g2), w_all=p(o["w_all"]), w_sj=p(o["w_sj"]), w_cj=p(o["w_cj"]), w_s=p(o["w_s"]),
+                              e=None if frag else p(e), g2=p(g2) if frag < 2 else None, w_all=p(o["w_all"]), w_sj=p(o["w_sj"]), w_cj=p(o["w_cj"]), w_s=p(o["w_s"]),
                               g_E_s=p(gE), g_G_c=p(gG) if joint else None, e16=p(e16) if frag else None, eexp=p(texp) if frag else None,
+                              g2_16=p(g2_16) if frag == 2 else None, g2exp=p(gexp) if frag == 2 else None,
                               **{k: p(v) for k, v in gr.items()}, **{k: p(v) for k, v in d.items()})
         assert lib.lib.upnerf_composite_bwd(C.byref(ba), None) == 0
         torch.cuda.synchronize()
         return {**o, **d}
 
-    a, b = run(False), run(True)
-    for k in a:
-        assert rel_err(cpu(b[k]), cpu(a[k])) < 5e-6, k
-    assert float(a["E_s"].abs().max()) > 0
+    a = run(0)
+    for frag in (1, 2):  # e as fragments; e and g2 as fragments
+        b = run(frag)
+        for k in a:
+            assert rel_err(cpu(b[k]), cpu(a[k])) < 5e-6, (frag, k)
+    assert float(a["E_s"].abs().max()) > 0 and (not joint or float(a["G_c"].abs().max()) > 0)
 
 
 @pytest.mark.parametrize("R,S,mode,use_cand,use_rgb", [(7, 40, 1, True, True), (5, 33, 0, True, False),

@@ -38,8 +38,9 @@ for tag, fm, rr in (("f32", "f32", 0), ("tile", "f16", 0), ("rr", "f16", 1)):
     sv = node.saved
     M = R * S
     got = {k: sv[k].float().cpu() for k in ("x0", "e", "g1", "g2", "r1", "sigma_s", "sigma_c", "rgb") if sv.get(k) is not None}
-    if sv.get("e") is None and sv.get("e16") is not None:
-        got["e"] = rd.dequant16(sv["e16"][None], sv["eexp"][None], frag=True)[0, :M].cpu()
+    for k, k16, kexp in (("e", "e16", "eexp"), ("g2", "g2_16", "g2exp"), ("r1", "r1_16", "r1exp")):
+        if sv.get(k) is None and sv.get(k16) is not None:
+            got[k] = rd.dequant16(sv[k16][None], sv[kexp][None], frag=True)[0, :M].cpu()
     if sv.get("h16") is not None:
         got["h"] = rd.dequant16(sv["h16"], sv["hexp"], frag=bool(rr))[:, :M].cpu()
         got["h_last"] = sv["h"][0].cpu() if sv.get("h") is not None else got["h"][-1]

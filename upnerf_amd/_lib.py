@@ -36,7 +36,8 @@ class FieldFwdArgs(C.Structure):
                 ("sigma_s", _fp), ("sigma_c", _fp), ("rgb", _fp),
                 ("x0", _fp), ("h", _fp), ("hmask", _fp), ("amax", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp),
                 ("P16", _fp), ("wexp", _fp), ("wk_xyz_dev", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("wnorm", _fp),
-                ("h16", _fp), ("hexp", _fp), ("h_last_only", C.c_int32), ("x0f", _fp), ("e16", _fp), ("eexp", _fp)]
+                ("h16", _fp), ("hexp", _fp), ("h_last_only", C.c_int32), ("x0f", _fp), ("e16", _fp), ("eexp", _fp),
+                ("g2_16", _fp), ("g2exp", _fp), ("r1_16", _fp), ("r1exp", _fp)]
 
 
 class CompositeFwdArgs(C.Structure):
@@ -45,7 +46,7 @@ class CompositeFwdArgs(C.Structure):
                 ("e", _fp), ("g2", _fp),
                 ("w_all", _fp), ("w_sj", _fp), ("w_cj", _fp), ("w_s", _fp),
                 ("E_s", _fp), ("G_c", _fp), ("sum_sfeat", _fp), ("t_weight", _fp), ("c_depth", _fp),
-                ("s_depth", _fp), ("rgb_map", _fp), ("e16", _fp), ("eexp", _fp)]
+                ("s_depth", _fp), ("rgb_map", _fp), ("e16", _fp), ("eexp", _fp), ("g2_16", _fp), ("g2exp", _fp)]
 
 
 class CompositeBwdArgs(C.Structure):
@@ -54,7 +55,7 @@ class CompositeBwdArgs(C.Structure):
                 ("w_all", _fp), ("w_sj", _fp), ("w_cj", _fp), ("w_s", _fp),
                 ("g_E_s", _fp), ("g_G_c", _fp), ("g_sum_sfeat", _fp), ("g_t_weight", _fp), ("g_c_depth", _fp),
                 ("g_s_depth", _fp), ("g_rgb_map", _fp), ("g_w_all", _fp), ("g_w_s", _fp),
-                ("d_sigma_s", _fp), ("d_sigma_c", _fp), ("d_rgb", _fp), ("e16", _fp), ("eexp", _fp)]
+                ("d_sigma_s", _fp), ("d_sigma_c", _fp), ("d_rgb", _fp), ("e16", _fp), ("eexp", _fp), ("g2_16", _fp), ("g2exp", _fp)]
 
 
 class FieldBwdArgs(C.Structure):
@@ -179,7 +180,7 @@ _SIGNATURES = {
     "upnerf_wgrad_grouped_scratch": [C.POINTER(WgradGroup), _i, _i],
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
-    "upnerf_vec_wgrad_frag16": [_i, _p, _p, _p, _p, _p, _p, _i, _p],
+    "upnerf_vec_wgrad_frag16": [_i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_part_finish": [_i, _i, _p, _p, _p, _p],
     "upnerf_tile_part_finish": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],

@@ -94,16 +94,85 @@ __device__ __forceinline__ Alphas alphas_at(const float* __restrict__ z, const f
 // dot product with g_E_s closes inside two lanes -- no per-sample shuffles at all, half the bytes of the fp32 rows.
 typedef _Float16 h8c __attribute__((ext_vector_type(8)));
 #define E16_MAXS 1024  // = 64 * MAX_CHUNKS
-__device__ __forceinline__ void e16_half(const uint16_t* __restrict__ e16, int t, int s0, int lane, h8c (&x)[8]) {
-  const h8c* __restrict__ p = (const h8c*)e16 + (size_t)t * 1024 + s0 * 64 + lane;
+// eight k-blocks (s0 .. s0 + 7) of tile t of a fragment-ordered tensor with `bpt` k-blocks per tile (16: 256 wide, 8: 128 wide)
+__device__ __forceinline__ void frag_half(const uint16_t* __restrict__ x16, int bpt, int t, int s0, int lane, h8c (&x)[8]) {
+  const h8c* __restrict__ p = (const h8c*)x16 + ((size_t)t * bpt + s0) * 64 + lane;
 #pragma unroll
   for (int s = 0; s < 8; ++s) x[s] = __builtin_nontemporal_load(p + s * 64);
+}
+// out[16 s0 + 0 .. 127] = sum over the ray's samples of wl[sample] * x[sample][16 s0 + ..]  (wl: LDS, already scaled by 2^-exp[tile])
+__device__ __forceinline__ void frag_weighted_sum(const uint16_t* __restrict__ x16, int bpt, int s0, const float* wl, size_t base, int S,
+                                                  int lane, float* __restrict__ out) {
+  const int t0 = (int)(base >> 5), t1 = (int)((base + S - 1) >> 5);
+  float acc[8][8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[s][u] = 0.0f;
+  for (int t = t0; t <= t1; ++t) {
+    const long long idx = (long long)t * 32 + (lane & 31) - (long long)base;
+    const float w = (idx >= 0 && idx < S) ? wl[idx] : 0.0f;
+    h8c x[8];
+    frag_half(x16, bpt, t, s0, lane, x);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[s][u] = fmaf(w, (float)x[s][u], acc[s][u]);
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float v = acc[s][u];
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d);
+      acc[s][u] = v;
+    }
+  if ((lane & 31) == 0) {
+    float* __restrict__ dst = out + 4 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      *(f32x4*)(dst + 16 * s) = f32x4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]};
+      *(f32x4*)(dst + 16 * s + 8) = f32x4{acc[s][4], acc[s][5], acc[s][6], acc[s][7]};
+    }
+  }
+}
+// dl[sample] (=, or += when `add`) <g[16 s0 + 0 .. 127], x[sample][16 s0 + ..]> * 2^-xexp[tile], for every sample of the ray
+__device__ __forceinline__ void frag_dots(const uint16_t* __restrict__ x16, const int* __restrict__ xexp, int bpt, int s0,
+                                          const float* __restrict__ g, size_t base, int S, int lane, float* dl, bool add) {
+  const int t0 = (int)(base >> 5), t1 = (int)((base + S - 1) >> 5);
+  // this lane's 64 entries of g for these k-blocks, in the order its fragment pieces hold the features
+  f32x4 ga[8], gb[8];
+  const float* __restrict__ gsrc = g + 4 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    ga[s] = *(const f32x4*)(gsrc + 16 * s);
+    gb[s] = *(const f32x4*)(gsrc + 16 * s + 8);
+  }
+  for (int t = t0; t <= t1; ++t) {
+    h8c x[8];
+    frag_half(x16, bpt, t, s0, lane, x);
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      p0 += ga[s].x * (float)x[s][0] + ga[s].y * (float)x[s][1] + ga[s].z * (float)x[s][2] + ga[s].w * (float)x[s][3];
+      p1 += gb[s].x * (float)x[s][4] + gb[s].y * (float)x[s][5] + gb[s].z * (float)x[s][6] + gb[s].w * (float)x[s][7];
+    }
+    float pe = p0 + p1;
+    pe += __shfl_xor(pe, 32);
+    const long long idx = (long long)t * 32 + (lane & 31) - (long long)base;
+    if (lane < 32 && idx >= 0 && idx < S) {
+      pe *= ldexpf(1.0f, -xexp[t]);
+      dl[idx] = add ? dl[idx] + pe : pe;
+    }
+  }
 }
 
 template <int W, bool EFRAG>
 __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composite_fwd_args a) {
   constexpr int W2 = W / 2;
   __shared__ float wf_lds[EFRAG ? 4 : 1][EFRAG ? E16_MAXS : 1];  // (e16: the feature weights of the ray, scaled per tile)
+  __shared__ float wc_lds[EFRAG ? 4 : 1][EFRAG ? E16_MAXS : 1];  // (g2_16: the candidate weights, likewise)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
   if (r >= a.R) return;
@@ -153,21 +222,34 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
       const int nv = (S - c0) < 64 ? (S - c0) : 64;
       if constexpr (EFRAG) {
         if (valid) wf_lds[wave][i] = wf * ldexpf(1.0f, -a.eexp[(base + i) >> 5]);
+        if (valid && joint && a.g2_16) wc_lds[wave][i] = w_cj * ldexpf(1.0f, -a.g2exp[(base + i) >> 5]);
       }
-      for (int j = 0; j < nv; ++j) {
-        const float wj = __shfl(wf, j);
-        const size_t m = base + c0 + j;
-        if constexpr (!EFRAG) {
-          if (laneE) {
-            const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
-            accE.x += wj * ev.x; accE.y += wj * ev.y; accE.z += wj * ev.z; accE.w += wj * ev.w;
+      const bool g_rows = joint && !(EFRAG && a.g2_16);  // g2 as fp32 rows: the per-sample loop below
+      // four samples' rows are requested before the first is used (the compiler keeps ONE load in flight otherwise, and a wave
+      // per ray then waits out a full memory latency per sample); same summation order as a plain loop
+      constexpr int B = EFRAG ? 4 : 1;
+      if (!EFRAG || g_rows)
+      for (int j0 = 0; j0 < nv; j0 += B) {
+        f32x4 ev[B], gv[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+          const size_t m = base + c0 + (j0 + u < nv ? j0 + u : nv - 1);
+          if constexpr (!EFRAG) {
+            if (laneE) ev[u] = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
           }
+          if (g_rows && laneG) gv[u] = NT_LOAD((const f32x4*)&a.g2[m * W2 + 4 * lane]);
         }
-        if (joint) {
-          const float cj = __shfl(w_cj, j);
-          if (laneG) {
-            const f32x4 gv = NT_LOAD((const f32x4*)&a.g2[m * W2 + 4 * lane]);
-            accG.x += cj * gv.x; accG.y += cj * gv.y; accG.z += cj * gv.z; accG.w += cj * gv.w;
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+          if (j0 + u < nv) {
+            const float wj = __shfl(wf, j0 + u);
+            if constexpr (!EFRAG) {
+              if (laneE) { accE.x += wj * ev[u].x; accE.y += wj * ev[u].y; accE.z += wj * ev[u].z; accE.w += wj * ev[u].w; }
+            }
+            if (g_rows) {
+              const float cj = __shfl(w_cj, j0 + u);
+              if (laneG) { accG.x += cj * gv[u].x; accG.y += cj * gv[u].y; accG.z += cj * gv[u].z; accG.w += cj * gv[u].w; }
+            }
           }
         }
       }
@@ -187,48 +269,15 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
     if (want_feat) {
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();
-      const int t0 = (int)(base >> 5), t1 = (int)((base + S - 1) >> 5);
-      // two passes over the tiles, eight k-blocks each (every piece is still read once): 64 accumulators at a time
+      // passes over the ray's tiles, eight k-blocks each (every piece is read once): 64 accumulators at a time
 #pragma unroll 1
-      for (int hf = 0; hf < 2; ++hf) {
-        float acc[8][8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc[s][u] = 0.0f;
-        for (int t = t0; t <= t1; ++t) {
-          const long long idx = (long long)t * 32 + (lane & 31) - (long long)base;
-          const float w = (idx >= 0 && idx < S) ? wf_lds[wave][idx] : 0.0f;
-          h8c x[8];
-          e16_half(a.e16, t, 8 * hf, lane, x);
-#pragma unroll
-          for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[s][u] = fmaf(w, (float)x[s][u], acc[s][u]);
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            float v = acc[s][u];
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d);
-            acc[s][u] = v;
-          }
-        if ((lane & 31) == 0) {
-          float* __restrict__ dst = a.E_s + (size_t)r * W + 128 * hf + 4 * (lane >> 5);
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            *(f32x4*)(dst + 16 * s) = f32x4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]};
-            *(f32x4*)(dst + 16 * s + 8) = f32x4{acc[s][4], acc[s][5], acc[s][6], acc[s][7]};
-          }
-        }
-      }
+      for (int hf = 0; hf < 2; ++hf) frag_weighted_sum(a.e16, 16, 8 * hf, wf_lds[wave], base, S, lane, a.E_s + (size_t)r * W + 128 * hf);
+      if (joint && a.g2_16) frag_weighted_sum(a.g2_16, 8, 0, wc_lds[wave], base, S, lane, a.G_c + (size_t)r * W2);
     }
   }
   if (want_feat) {
     if (!EFRAG && laneE) *(f32x4*)&a.E_s[(size_t)r * W + 4 * lane] = accE;
-    if (joint && laneG) *(f32x4*)&a.G_c[(size_t)r * W2 + 4 * lane] = accG;
+    if (joint && laneG && !(EFRAG && a.g2_16)) *(f32x4*)&a.G_c[(size_t)r * W2 + 4 * lane] = accG;
   }
 }
 
@@ -238,6 +287,7 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
   constexpr int W2 = W / 2;
   __shared__ double carry_s[4][2][MAX_CHUNKS];
   __shared__ float dot_lds[EFRAG ? 4 : 1][EFRAG ? E16_MAXS : 1];  // (e16: <g_E_s, e_i> of every sample of the ray)
+  __shared__ float dotg_lds[EFRAG ? 4 : 1][EFRAG ? E16_MAXS : 1];  // (g2_16: <g_G_c, g2_i>)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
   if (r >= a.R) return;
@@ -279,38 +329,15 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
   float g_rm[3] = {0.f, 0.f, 0.f};
   if (a.has_rgb && a.g_rgb_map) { g_rm[0] = a.g_rgb_map[r * 3]; g_rm[1] = a.g_rgb_map[r * 3 + 1]; g_rm[2] = a.g_rgb_map[r * 3 + 2]; }
   const bool need_dots = want_feat && (a.g_E_s || (joint && a.g_G_c));
+  const bool g_frag = EFRAG && joint && a.g_G_c && a.g2_16;
   if constexpr (EFRAG) {
-    if (want_feat && a.g_E_s) {
-      const int t0 = (int)(base >> 5), t1 = (int)((base + S - 1) >> 5);
-      const float* __restrict__ gsrc = a.g_E_s + (size_t)r * W + 4 * (lane >> 5);
-      // two passes over the tiles, eight k-blocks each (every piece is still read once); the second adds to the first's sums
+    if (want_feat) {
+      if (a.g_E_s) {
 #pragma unroll 1
-      for (int hf = 0; hf < 2; ++hf) {
-        // this lane's 64 entries of g_E_s[r] for these k-blocks, in the order its fragment pieces hold the features
-        f32x4 ga[8], gb[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          ga[s] = *(const f32x4*)(gsrc + 128 * hf + 16 * s);
-          gb[s] = *(const f32x4*)(gsrc + 128 * hf + 16 * s + 8);
-        }
-        for (int t = t0; t <= t1; ++t) {
-          h8c x[8];
-          e16_half(a.e16, t, 8 * hf, lane, x);
-          float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            p0 += ga[s].x * (float)x[s][0] + ga[s].y * (float)x[s][1] + ga[s].z * (float)x[s][2] + ga[s].w * (float)x[s][3];
-            p1 += gb[s].x * (float)x[s][4] + gb[s].y * (float)x[s][5] + gb[s].z * (float)x[s][6] + gb[s].w * (float)x[s][7];
-          }
-          float pe = p0 + p1;
-          pe += __shfl_xor(pe, 32);
-          const long long idx = (long long)t * 32 + (lane & 31) - (long long)base;
-          if (lane < 32 && idx >= 0 && idx < S) {
-            pe *= ldexpf(1.0f, -a.eexp[t]);
-            dot_lds[wave][idx] = hf ? dot_lds[wave][idx] + pe : pe;
-          }
-        }
+        for (int hf = 0; hf < 2; ++hf)
+          frag_dots(a.e16, a.eexp, 16, 8 * hf, a.g_E_s + (size_t)r * W + 128 * hf, base, S, lane, dot_lds[wave], hf != 0);
       }
+      if (g_frag) frag_dots(a.g2_16, a.g2exp, 8, 0, a.g_G_c + (size_t)r * W2, base, S, lane, dotg_lds[wave], false);
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();
     }
@@ -324,24 +351,37 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
     float dotE = 0.f, dotG = 0.f;
     if (need_dots) {
       const int nv = (S - c0) < 64 ? (S - c0) : 64;
-      for (int j = 0; j < nv; ++j) {
-        const size_t m = base + c0 + j;
-        float pe = 0.f, pg = 0.f;
-        if constexpr (!EFRAG) {
-          if (laneE) {
-            const f32x4 ev = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
-            pe = gE.x * ev.x + gE.y * ev.y + gE.z * ev.z + gE.w * ev.w;
+      constexpr int B = EFRAG ? 4 : 1;  // (rows of four samples in flight, see the forward kernel)
+      const bool g_rows = joint && a.g_G_c && !g_frag;
+      if (!EFRAG || g_rows)
+      for (int j0 = 0; j0 < nv; j0 += B) {
+        f32x4 ev[B], gv[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+          const size_t m = base + c0 + (j0 + u < nv ? j0 + u : nv - 1);
+          if constexpr (!EFRAG) {
+            if (laneE) ev[u] = NT_LOAD((const f32x4*)&a.e[m * W + 4 * lane]);
+          }
+          if (g_rows && laneG) gv[u] = NT_LOAD((const f32x4*)&a.g2[m * W2 + 4 * lane]);
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+          if (j0 + u < nv) {
+            float pe = 0.f, pg = 0.f;
+            if constexpr (!EFRAG) {
+              if (laneE) pe = gE.x * ev[u].x + gE.y * ev[u].y + gE.z * ev[u].z + gE.w * ev[u].w;
+              pe = wave_sum(pe);
+            }
+            if (g_rows) {
+              if (laneG) pg = gG.x * gv[u].x + gG.y * gv[u].y + gG.z * gv[u].z + gG.w * gv[u].w;
+              pg = wave_sum(pg);
+            }
+            if (lane == j0 + u) { dotE = pe; dotG = pg; }
           }
         }
-        if (joint && laneG) {
-          const f32x4 gv = NT_LOAD((const f32x4*)&a.g2[m * W2 + 4 * lane]);
-          pg = gG.x * gv.x + gG.y * gv.y + gG.z * gv.z + gG.w * gv.w;
-        }
-        if constexpr (!EFRAG) pe = wave_sum(pe);
-        if (joint) pg = wave_sum(pg);
-        if (lane == j) { dotE = pe; dotG = pg; }
       }
       if constexpr (EFRAG) {
+        if (valid && g_frag) dotG = dotg_lds[wave][i];
         if (valid && a.g_E_s) dotE = dot_lds[wave][i];
       }
     }
@@ -407,9 +447,10 @@ extern "C" int upnerf_composite_fwd(const upnerf_composite_fwd_args* a, void* st
   if (rc) return rc;
   const bool joint = a->mode <= 1, want_feat = a->mode != 2;
   if (!a->z || !a->sigma_s || !a->w_s || !a->s_depth) return UPNERF_EINVAL;
-  if (joint && (!a->sigma_c || !a->w_all || !a->w_sj || !a->w_cj || !a->c_depth || !a->t_weight || !a->g2 || !a->G_c))
+  if (joint && (!a->sigma_c || !a->w_all || !a->w_sj || !a->w_cj || !a->c_depth || !a->t_weight || (!a->g2 && !a->g2_16) || !a->G_c))
     return UPNERF_EINVAL;
   if (want_feat && ((!a->e && !a->e16) || (a->e16 && (!a->eexp || a->W != 256)) || !a->E_s || !a->sum_sfeat)) return UPNERF_EINVAL;
+  if (a->g2_16 && (!a->e16 || !a->g2exp)) return UPNERF_EINVAL;  // (the fragment walk lives in the e16 kernels)
   if (a->has_rgb && (!a->rgb || !a->rgb_map)) return UPNERF_EINVAL;
   const dim3 grid((a->R + 3) / 4), block(NTHREADS);
   if (a->W == 256 && a->e16 && want_feat)
@@ -429,10 +470,11 @@ extern "C" int upnerf_composite_bwd(const upnerf_composite_bwd_args* a, void* st
   if (!a->z || !a->sigma_s || !a->d_sigma_s) return UPNERF_EINVAL;
   if (joint && (!a->sigma_c || !a->d_sigma_c)) return UPNERF_EINVAL;
   if (want_feat && a->g_E_s && ((!a->e && !a->e16) || (a->e16 && (!a->eexp || a->W != 256)))) return UPNERF_EINVAL;
-  if (joint && a->g_G_c && !a->g2) return UPNERF_EINVAL;
+  if (a->g2_16 && (!a->e16 || !a->g2exp)) return UPNERF_EINVAL;
+  if (joint && a->g_G_c && !a->g2 && !a->g2_16) return UPNERF_EINVAL;
   if (a->has_rgb && (!a->rgb || !a->d_rgb)) return UPNERF_EINVAL;
   const dim3 grid((a->R + 3) / 4), block(NTHREADS);
-  if (a->W == 256 && a->e16 && want_feat && a->g_E_s)
+  if (a->W == 256 && a->e16 && want_feat)
     hipLaunchKernelGGL((composite_bwd_kernel<256, true>), grid, block, 0, (hipStream_t)stream, *a);
   else if (a->W == 256)
     hipLaunchKernelGGL((composite_bwd_kernel<256, false>), grid, block, 0, (hipStream_t)stream, *a);

@@ -494,11 +494,12 @@ __device__ __forceinline__ void operand_dots(const h8 (&op)[N], int e, const flo
 }
 
 // one operand fragment (k-block blk of this wave's 32-row tile) -> the fragment-ordered fp16 tensor: 1 KiB per instruction
-__device__ __forceinline__ void frag_store(uint16_t* __restrict__ base, size_t tile32, int blk, int lane, const h8& v) {
+// (fb: k-blocks per 32-row tile of the tensor -- 16 for a 256-wide one, 8 for a 128-wide one)
+__device__ __forceinline__ void frag_store(uint16_t* __restrict__ base, size_t tile32, int blk, int lane, const h8& v, int fb = 16) {
 #ifdef RR_EXP_NOSTORE  // timing experiment (wrong results): no activation / gradient stores at all
   return;
 #endif
-  NT_STORE((f32x4*)((char*)base + (tile32 * 16 + blk) * 1024 + lane * 16), __builtin_bit_cast(f32x4, v));
+  NT_STORE((f32x4*)((char*)base + (tile32 * fb + blk) * 1024 + lane * 16), __builtin_bit_cast(f32x4, v));
 }
 
 __device__ __forceinline__ void track_lds(unsigned int* mx_s, int slot, float wave_mx, int lane) {
@@ -511,6 +512,7 @@ struct TileOut {
   uint16_t* frag;   // fragment-ordered fp16 tensor of this stage, or nullptr
   float* rows;      // row-major fp32 tensor (this wave's first row), or nullptr
   int ld;           // its row stride
+  int fb = 16;            // k-blocks per tile of `frag` (8: a 128-wide tensor)
   float* part = nullptr;  // per-ray column sums of the rows (stg_flush), or nullptr
   int rb = 32;            // first row of the wave's second ray
 };
@@ -519,8 +521,8 @@ __device__ __forceinline__ void tile_out(Ring<NW>& rg, const TileOut& o, const u
   nx[BLK0 + 2 * JP] = __builtin_bit_cast(h8, blk[0]);
   nx[BLK0 + 2 * JP + 1] = __builtin_bit_cast(h8, blk[1]);
   if (o.frag) {
-    frag_store(o.frag, t32, 2 * JP, lane, nx[BLK0 + 2 * JP]);
-    frag_store(o.frag, t32, 2 * JP + 1, lane, nx[BLK0 + 2 * JP + 1]);
+    frag_store(o.frag, t32, 2 * JP, lane, nx[BLK0 + 2 * JP], o.fb);
+    frag_store(o.frag, t32, 2 * JP + 1, lane, nx[BLK0 + 2 * JP + 1], o.fb);
     rg.count(2);
   }
   if (o.rows || o.part) {
@@ -885,10 +887,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
       const int e_R = scale_exp(wnorm[D + 3] * fmaxf(amax_e, sidemax) + vec_s[RR_V_BMAX + 9]);  // r1 as an operand: feeds the colour dots
       const float pe = pow2r(e_R);
       TileOut to;
-      to.frag = nullptr;
-      to.rows = train ? a.r1 + (size_t)m0 * W2 : nullptr;
+      to.frag = train ? a.r1_16 : nullptr;  // (nullptr, or r1 as operand fragments for the colour output layer's weight gradient)
+      to.fb = 8;
+      to.rows = (train && a.r1) ? a.r1 + (size_t)m0 * W2 : nullptr;
       to.ld = W2;
-      char* stg_r = train ? stg : nullptr;
+      char* stg_r = to.rows ? stg : nullptr;
       u32x4_t words = {0u, 0u, 0u, 0u};
       float vmax = 0.0f;
       run_tiles<NW, 4>(
@@ -911,6 +914,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
 #endif
         rg.count(1);
       }
+      if (train && a.r1_16 && lane == 0) a.r1exp[t32] = e_R;
       track_lds(mx_s, D + 3, wave_max_rr(vmax), lane);
       operand_dots<8, 3>(Nh, e_R, vec_s + RR_V_WR2, W2, hh, dot3);
 #pragma unroll
@@ -962,9 +966,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
         const int e_G2 = scale_exp(wnorm[D + 2] * amax_g1 + vec_s[RR_V_BMAX + 11]);  // g2 as an operand: feeds the candidate density dot
         const float pe = pow2r(e_G2);
         TileOut to;
-        to.frag = nullptr;
-        to.rows = a.g2 + (size_t)m0 * W2;  // compositing reads g2 in inference too
+        to.frag = a.g2_16;  // (nullptr, or g2 as operand fragments: compositing and the candidate density's weight gradient read those)
+        to.fb = 8;
+        to.rows = a.g2 ? a.g2 + (size_t)m0 * W2 : nullptr;  // compositing reads g2 in inference too
         to.ld = W2;
+        char* stg_g2 = a.g2 ? stg : nullptr;
         u32x4_t words = {0u, 0u, 0u, 0u};
         float vmax = 0.0f;
         // (operand: g1 in Nh[0..8); result: g2 into Bh[0..8) -- E is no longer needed)
@@ -977,7 +983,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
               constexpr int jp = decltype(JP)::value;
               u32x4_t blk[2];
               unsigned int tw;
-              tile_epilogue<false, 1, 0, true, true>(acc, jp, un, pe, vec_s + RR_V_BC2, 1.0f, 0u, tw, vmax, novmax2, stg, blk, li, hh);
+              tile_epilogue<false, 1, 0, true, true>(acc, jp, un, pe, vec_s + RR_V_BC2, 1.0f, 0u, tw, vmax, novmax2, stg_g2, blk, li, hh);
               mask_add<jp>(words, tw);
               tile_out<NW, 0, jp>(rg, to, blk, Bh, stg, t32, lane);
             });
@@ -987,6 +993,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
 #endif
           rg.count(1);
         }
+        if (a.g2_16 && lane == 0) a.g2exp[t32] = e_G2;
         operand_dots<8, 1>(Bh, e_G2, vec_s + RR_V_WCSIG, W2, hh, dot3);
         if (hh == 0 && valid) a.sigma_c[m] = softplus_f(dot3[0] + bcsig);
       }

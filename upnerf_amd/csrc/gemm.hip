@@ -289,59 +289,83 @@ __global__ void vec_wgrad_reduce_kernel(int nvec, int K, int nsplit, const float
   else if (dbv) dbv[c] = s;
 }
 
-// upnerf_vec_wgrad for ONE vector against a 256-wide fp16 tensor in the operand-fragment order of the register-resident field
-// kernels (include/upnerf_hip.h, tile_rows = 256): [32-row tile][k-block s 16][lane 64][8], feature 16 s + 8 (j / 4) + 4 (lane / 32)
-// + j % 4, row 32 tile + lane % 32, values scaled by 2^xexp[tile].  A thread keeps one (s, lane) piece position and walks the
-// tiles of its workgroup's slice (a wave reads 1 KiB contiguous per tile); the 32 rows meet in a shuffle tree at the end.
-__global__ __launch_bounds__(1024) void vec_wgrad_frag16_kernel(int M, const float* __restrict__ v, const uint16_t* __restrict__ X16,
-                                                               const int* __restrict__ xexp, float* __restrict__ part,
-                                                               int tiles_per_split) {
+// upnerf_vec_wgrad against a fp16 tensor in the operand-fragment order of the register-resident field kernels
+// (include/upnerf_hip.h, tile_rows = 256): [32-row tile][k-block s KB][lane 64][8], feature 16 s + 8 (j / 4) + 4 (lane / 32)
+// + j % 4, row 32 tile + lane % 32, values scaled by 2^xexp[tile]; KB = 16 (256 wide) or 8 (128 wide).  A thread keeps one
+// (s, lane) piece position and walks the tiles of its workgroup's slice (a wave reads 1 KiB contiguous per tile); the 32 rows
+// meet in a shuffle tree at the end.  NV vectors share every piece read.
+template <int KB, int NV>
+__global__ __launch_bounds__(64 * KB) void vec_wgrad_frag16_kernel(int M, const float* __restrict__ v, int ldv,
+                                                                 const uint16_t* __restrict__ X16, const int* __restrict__ xexp,
+                                                                 float* __restrict__ part, int tiles_per_split) {
   typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  constexpr int K = 16 * KB;
   const int tid = threadIdx.x, lane = tid & 63, s = tid >> 6, li = lane & 31, hh = lane >> 5;
   const int ntile = (M + 31) >> 5;
   const int t0 = blockIdx.x * tiles_per_split;
   const int t1 = t0 + tiles_per_split < ntile ? t0 + tiles_per_split : ntile;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float vsum = 0.0f;
+  float acc[NV][8], vsum[NV];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    vsum[c] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[c][j] = 0.0f;
+  }
   const h8v* __restrict__ src = (const h8v*)X16 + (size_t)s * 64 + lane;
+  constexpr int U = NV == 1 ? 4 : 2;  // tiles in flight
   int t = t0;
-  for (; t + 4 <= t1; t += 4) {
-    h8v x[4];
-    float w[4];
+  for (; t + U <= t1; t += U) {
+    h8v x[U];
+    float w[U][NV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      x[u] = __builtin_nontemporal_load(src + (size_t)(t + u) * 1024);
+    for (int u = 0; u < U; ++u) {
+      x[u] = __builtin_nontemporal_load(src + (size_t)(t + u) * (64 * KB));
       const int m = (t + u) * 32 + li;
-      w[u] = m < M ? v[m] : 0.0f;
-      vsum += w[u];
-      w[u] = ldexpf(w[u], -xexp[t + u]);
+      const int e = -xexp[t + u];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const float wv = m < M ? v[(size_t)m * ldv + c] : 0.0f;
+        vsum[c] += wv;
+        w[u][c] = ldexpf(wv, e);
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(w[u], (float)x[u][j], acc[j]);
-    }
+      for (int c = 0; c < NV; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[c][j] = fmaf(w[u][c], (float)x[u][j], acc[c][j]);
   }
   for (; t < t1; ++t) {
-    const h8v x = __builtin_nontemporal_load(src + (size_t)t * 1024);
+    const h8v x = __builtin_nontemporal_load(src + (size_t)t * (64 * KB));
     const int m = t * 32 + li;
-    float w = m < M ? v[m] : 0.0f;
-    vsum += w;
-    w = ldexpf(w, -xexp[t]);
+    const int e = -xexp[t];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, (float)x[j], acc[j]);
+    for (int c = 0; c < NV; ++c) {
+      const float wv = m < M ? v[(size_t)m * ldv + c] : 0.0f;
+      vsum[c] += wv;
+      const float w = ldexpf(wv, e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[c][j] = fmaf(w, (float)x[j], acc[c][j]);
+    }
   }
 #pragma unroll
   for (int sh = 1; sh < 32; sh <<= 1) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], sh);
-    vsum += __shfl_xor(vsum, sh);
+    for (int c = 0; c < NV; ++c) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[c][j] += __shfl_xor(acc[c][j], sh);
+      vsum[c] += __shfl_xor(vsum[c], sh);
+    }
   }
   if (li == 0) {
-    float* __restrict__ dst = part + (size_t)blockIdx.x * 4 * 257;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dst[16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)] = acc[j];
-    if (s == 0 && hh == 0) dst[256] = vsum;
+    for (int c = 0; c < NV; ++c) {
+      float* __restrict__ dst = part + ((size_t)blockIdx.x * 4 + c) * (K + 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)] = acc[c][j];
+      if (s == 0 && hh == 0) dst[K] = vsum[c];
+    }
   }
 }
 
@@ -844,16 +868,23 @@ extern "C" int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, cons
   return 0;
 }
 
-extern "C" int upnerf_vec_wgrad_frag16(int M, const float* v, const uint16_t* X16, const int32_t* xexp, float* dw, float* dbv,
-                                       float* scratch, int nsplit, void* stream) {
-  if (M <= 0 || !v || !X16 || !xexp || !dw || !scratch || nsplit <= 0) return UPNERF_EINVAL;
+extern "C" int upnerf_vec_wgrad_frag16(int M, const float* v, int ldv, int nvec, const uint16_t* X16, const int32_t* xexp, int K,
+                                       float* dw, float* dbv, float* scratch, int nsplit, void* stream) {
+  if (M <= 0 || !v || !X16 || !xexp || !dw || !scratch || nsplit <= 0 || ldv < nvec) return UPNERF_EINVAL;
+  if ((K != 256 && K != 128) || (nvec != 1 && nvec != 3)) return UPNERF_EUNSUP;
   hipStream_t st = (hipStream_t)stream;
   const int ntile = (M + 31) / 32;
   const int per = (ntile + nsplit - 1) / nsplit;
-  hipLaunchKernelGGL(vec_wgrad_frag16_kernel, dim3(nsplit), dim3(1024), 0, st, M, v, X16, xexp, scratch, per);
+#define VWF(KB, NV) hipLaunchKernelGGL((vec_wgrad_frag16_kernel<KB, NV>), dim3(nsplit), dim3(64 * KB), 0, st, M, v, ldv, X16, xexp, scratch, per)
+  if (K == 256 && nvec == 1) VWF(16, 1);
+  else if (K == 256) VWF(16, 3);
+  else if (nvec == 1) VWF(8, 1);
+  else VWF(8, 3);
+#undef VWF
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(vec_wgrad_reduce_kernel, dim3(2), dim3(256), 0, st, 1, 256, nsplit, scratch, dw, dbv);
+  const int total = nvec * (K + 1);
+  hipLaunchKernelGGL(vec_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, nvec, K, nsplit, scratch, dw, dbv);
   return (int)hipGetLastError();
 }
 

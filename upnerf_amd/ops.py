@@ -281,11 +281,13 @@ def vec_wgrad_into(M: int, v: torch.Tensor, ldv: int, nvec: int, X: torch.Tensor
           "upnerf_vec_wgrad")
 
 
-def vec_wgrad_frag16_into(M: int, v: torch.Tensor, X16: torch.Tensor, xexp: torch.Tensor, dw_ptr: int, dbv_ptr: Optional[int], device):
-    """vec_wgrad_into for one vector against a 256-wide layer of the register-resident kernels' fp16 operand fragments."""
+def vec_wgrad_frag16_into(M: int, v: torch.Tensor, ldv: int, nvec: int, X16: torch.Tensor, xexp: torch.Tensor, K: int, dw_ptr: int,
+                          dbv_ptr: Optional[int], device):
+    """vec_wgrad_into against a 256- or 128-wide tensor of the register-resident kernels' fp16 operand fragments."""
     ns = nsplit_for(M)
     ws = workspace("vec_wgrad", ns * 4 * 257, device)
-    check(lib.upnerf_vec_wgrad_frag16(M, ptr(v), ptr(X16), ptr(xexp), dw_ptr, dbv_ptr, ptr(ws), ns, stream()), "upnerf_vec_wgrad_frag16")
+    check(lib.upnerf_vec_wgrad_frag16(M, ptr(v), ldv, nvec, ptr(X16), ptr(xexp), K, dw_ptr, dbv_ptr, ptr(ws), ns, stream()),
+          "upnerf_vec_wgrad_frag16")
 
 
 def linear_raw(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int, w_is_kn: bool = False) -> torch.Tensor:

@@ -186,8 +186,14 @@ class _FieldPass(torch.autograd.Function):
         mx32 = torch.zeros(32, device=dev) if train else None
         amax = mx32[:16] if train else None
         g1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and train) else None
-        g2 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and (train or joint)) else None
-        r1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_rgb and train) else None
+        # rr with e as fragments: g2 and r1 leave the same way (compositing / the 128-wide output layers' weight gradients read
+        # them; the backward kernel works from the sign bits)
+        g2 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and (train or joint) and not e_frag) else None
+        r1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_rgb and train and not e_frag) else None
+        g2_16 = torch.empty(Mp, W2, device=dev, dtype=torch.float16) if (cfg.use_cand and (train or joint) and e_frag) else None
+        g2exp = torch.empty(Mp // 32, device=dev, dtype=torch.int32) if g2_16 is not None else None
+        r1_16 = torch.empty(Mp, W2, device=dev, dtype=torch.float16) if (cfg.use_rgb and train and e_frag) else None
+        r1exp = torch.empty(Mp // 32, device=dev, dtype=torch.int32) if r1_16 is not None else None
         tile = RR_TILE if rr else 64  # samples per workgroup (include/upnerf_hip.h: tile_rows); the backward pass gets the same
         x0f = None
         fa = FieldFwdArgs(R=R, S=S, use_cand=int(cfg.use_cand), use_rgb=int(cfg.use_rgb), rays_o=ptr(rays_o),
@@ -196,7 +202,8 @@ class _FieldPass(torch.autograd.Function):
                           rgb=ptr(rgb), x0=ptr(x0), h=ptr(h), hmask=ptr(hmask), amax=ptr(amax), e=ptr(e), g1=ptr(g1), g2=ptr(g2), r1=ptr(r1),
                           P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None,
                           planes=_planes(), tile_rows=tile, wnorm=ptr(wnorm), h16=ptr(h16), hexp=ptr(hexp),
-                          h_last_only=int(store16), x0f=ptr(x0f), e16=ptr(e16), eexp=ptr(eexp))
+                          h_last_only=int(store16), x0f=ptr(x0f), e16=ptr(e16), eexp=ptr(eexp),
+                          g2_16=ptr(g2_16), g2exp=ptr(g2exp), r1_16=ptr(r1_16), r1exp=ptr(r1exp))
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
@@ -215,7 +222,7 @@ class _FieldPass(torch.autograd.Function):
                               rgb=ptr(rgb), has_rgb=int(cfg.use_rgb), e=ptr(e), g2=ptr(g2), w_all=ptr(w_all),
                               w_sj=ptr(w_sj), w_cj=ptr(w_cj), w_s=ptr(w_s), E_s=ptr(E_s), G_c=ptr(G_c),
                               sum_sfeat=ptr(sum_sfeat), t_weight=ptr(t_weight), c_depth=ptr(c_depth),
-                              s_depth=ptr(s_depth), rgb_map=ptr(rgb_map), e16=ptr(e16), eexp=ptr(eexp))
+                              s_depth=ptr(s_depth), rgb_map=ptr(rgb_map), e16=ptr(e16), eexp=ptr(eexp), g2_16=ptr(g2_16), g2exp=ptr(g2exp))
         check(TIMER.run("composite_fwd", lambda: lib.upnerf_composite_fwd(C.byref(ca), st), units=M),
               "upnerf_composite_fwd")
 
@@ -223,7 +230,7 @@ class _FieldPass(torch.autograd.Function):
         ctx.rr, ctx.Mp = rr, Mp
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, mx32=mx32, e=e, e16=e16, eexp=eexp, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, mx32=mx32, e=e, e16=e16, eexp=eexp, g2_16=g2_16, g2exp=g2exp, r1_16=r1_16, r1exp=r1exp, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
                          w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s, wnorm=wnorm)
         z0 = torch.zeros(0, device=dev)
@@ -256,7 +263,8 @@ class _FieldPass(torch.autograd.Function):
                               w_cj=ptr(sv["w_cj"]), w_s=ptr(sv["w_s"]), g_E_s=ptr(gE), g_G_c=ptr(gG),
                               g_sum_sfeat=ptr(gsf), g_t_weight=ptr(gtw), g_c_depth=ptr(gcd), g_s_depth=ptr(gsd),
                               g_rgb_map=ptr(grm), g_w_all=ptr(gwall), g_w_s=ptr(gws), d_sigma_s=ptr(d_sigma_s),
-                              d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb), e16=ptr(sv.get("e16")), eexp=ptr(sv.get("eexp")))
+                              d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb), e16=ptr(sv.get("e16")), eexp=ptr(sv.get("eexp")),
+                              g2_16=ptr(sv.get("g2_16")), g2exp=ptr(sv.get("g2exp")))
         check(TIMER.run("composite_bwd", lambda: lib.upnerf_composite_bwd(C.byref(cb), st), units=M),
               "upnerf_composite_bwd")
 
@@ -374,7 +382,7 @@ class _FieldPass(torch.autograd.Function):
                 chain.wgrad_p(M, gz16[D], W, gzexp[D], W, h16[D - 1], W, hexp[D - 1], W, at(L.we), W, at(L.be), EA(D), EB(D - 1), frag=True) \
                     if chain is not None else \
                     wgrad_f16p_into(M, gz16[D], W, gzexp[D], W, h16[D - 1], W, hexp[D - 1], W, at(L.we), W, at(L.be), dev, EA(D), EB(D - 1), frag=True)
-                vec_wgrad_frag16_into(M, dpre_s, h16[D - 1], hexp[D - 1], at(L.wsig), at(L.bsig), dev)
+                vec_wgrad_frag16_into(M, dpre_s, 1, 1, h16[D - 1], hexp[D - 1], W, at(L.wsig), at(L.bsig), dev)
             else:
                 h_last = h[0] if store16 else h[D - 1]
                 wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
@@ -405,7 +413,9 @@ class _FieldPass(torch.autograd.Function):
                     wg(gz_g1, W2, W2, sv["e"], W, W, L.wc1, W + CK, L.bc1, D + 1, D)
                 wgrad_into(R, rs_c, W2, W2, sv["c_rows"], CK, CK, at(L.wc1 + W), W + CK, None, dev)
                 wg(gz_g2, W2, W2, sv["g1"], W2, W2, L.wc2, W2, L.bc2, D + 2, D + 1)
-                if tile_part is None:
+                if sv.get("g2_16") is not None:
+                    vec_wgrad_frag16_into(M, dpre_c, 1, 1, sv["g2_16"], sv["g2exp"], W2, at(L.wcsig), at(L.bcsig), dev)
+                elif tile_part is None:
                     vec_wgrad_into(M, dpre_c, 1, 1, sv["g2"], W2, W2, at(L.wcsig), at(L.bcsig), dev)
             if ctx.needs_input_grad[3]:
                 d_c_rows = linear_kn_view(rs_c, P, L.wc1 + W, W + CK, CK)  # rs . wc1[:, W:]
@@ -416,7 +426,9 @@ class _FieldPass(torch.autograd.Function):
                 if not joined:
                     wg(gz_r1, W2, W2, sv["e"], W, W, L.wr1, W + AUXK, L.br1, D + 3, D)
                 wgrad_into(R, rs_r, W2, W2, sv["aux"], AUXK, AUXK, at(L.wr1 + W), W + AUXK, None, dev)
-                if tile_part is None:
+                if sv.get("r1_16") is not None:
+                    vec_wgrad_frag16_into(M, dpre_rgb, 4, 3, sv["r1_16"], sv["r1exp"], W2, at(L.wr2), at(L.br2), dev)
+                elif tile_part is None:
                     vec_wgrad_into(M, dpre_rgb, 4, 3, sv["r1"], W2, W2, at(L.wr2), at(L.br2), dev)
             if ctx.has_a and ctx.needs_input_grad[4]:
                 d_a_rows = linear_kn_view(rs_r, P, L.wr1 + W + 27, W + AUXK, 48)  # rs . wr1[:, W+27 : W+75]
