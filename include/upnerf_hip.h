@@ -182,6 +182,8 @@ typedef struct {
   int32_t* g2exp;                /* upnerf_vec_wgrad_frag16 read them; the backward kernel works from the sign bits in hmask */
   uint16_t* r1_16;
   int32_t* r1exp;
+  uint16_t* g1_16;               /* and for g1 (candidate_encoding.2's weight gradient reads it: upnerf_wgrad_f16p, 128-wide fragments) */
+  int32_t* g1exp;
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -306,6 +308,8 @@ typedef struct {
   uint16_t* gz_rg16;             /* tile_rows = 256 with both heads, or NULL: [gz_r1 | gz_g1] as ONE 256-wide tensor of fp16 operand
                                     fragments (then gz_r1 / gz_g1 may be NULL: with tile_part their per-ray sums still leave) */
   int32_t* gzrgexp;              /* [ceil(M/256) * 8] */
+  uint16_t* gz_g2_16;            /* tile_rows = 256, or NULL: gz_g2 as 128-wide fp16 operand fragments (then gz_g2 may be NULL) */
+  int32_t* gzg2exp;
 } upnerf_field_bwd_args;
 
 /* Layout of one row of tile_part (floats): d w_csig [W/2] | d w_r2 [3][W/2] | sum dpre_sig_c, sum dpre_rgb[0..2] | 4 pad |

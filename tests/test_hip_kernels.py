@@ -484,6 +484,111 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     assert ok, "BWD over tolerance: " + repr(errs)
 
 
+@pytest.mark.parametrize("M,K,nvec", [(1000, 256, 1), (1000, 128, 3), (77, 128, 1), (4099, 256, 3)])
+def test_vec_wgrad_frag16_matches_fp64(hip, M, K, nvec):
+    """upnerf_vec_wgrad_frag16 (dw[c][k] = sum_m v[m][c] X[m][k], dbv[c] = sum_m v[m][c]) on a fragment-ordered fp16 tensor
+    against fp64 on the values the fragments decode to; M not a multiple of the 32-sample tile."""
+    lib, rd, ops = hip["lib"], hip["rendering"], hip["ops"]
+    dev = "cuda"
+    Mp = (M + 31) // 32 * 32
+    texp = torch.randint(-3, 4, (Mp // 32,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(dev)
+    X16 = rd.quant16_frag(gen((Mp, K), 2).to(dev), texp)
+    X = rd.dequant16(X16[None], texp[None], frag=True)[0, :M].double()
+    ldv = 4 if nvec == 3 else 1
+    v = gen((M, ldv), 3).to(dev)
+    dw, dbv = torch.full((nvec, K), 7.0, device=dev), torch.full((nvec,), 7.0, device=dev)
+    ns = ops.nsplit_for(M)
+    ws = torch.empty(ns * 4 * (K + 1), device=dev)
+    assert lib.lib.upnerf_vec_wgrad_frag16(M, v.data_ptr(), ldv, nvec, X16.data_ptr(), texp.data_ptr(), K, dw.data_ptr(), dbv.data_ptr(),
+                                           ws.data_ptr(), ns, None) == 0
+    torch.cuda.synchronize()
+    ref = v[:, :nvec].double().t() @ X
+    assert rel_err(cpu(dw), cpu(ref)) < 1e-5
+    assert rel_err(cpu(dbv), cpu(v[:, :nvec].double().sum(0))) < 1e-5
+
+
+@pytest.mark.parametrize("R,S", [(7, 40), (5, 33), (3, 128), (4, 257)])
+def test_ray_part_finish_sums_the_per_32_sample_partials(hip, R, S):
+    """upnerf_ray_part_finish: per-ray sums from the register-resident backward kernel's partials (one row per 32 samples: the
+    sums over the rows of its first / second ray, for gz_r1 and gz_g1), rays that straddle and rays that span several rows."""
+    lib = hip["lib"]
+    dev = "cuda"
+    M = R * S
+    Mp = (M + 255) // 256 * 256
+    x = [torch.zeros(Mp, 128, device=dev), torch.zeros(Mp, 128, device=dev)]
+    for t in range(2):
+        x[t][:M] = gen((M, 128), 10 + t).to(dev)
+    part = torch.full((Mp // 32, 512), float("nan"), device=dev)  # unwritten second-ray blocks must never be read
+    m = torch.arange(Mp, device=dev)
+    first = (m // 32 * 32) // S  # ray of the first sample of each 32-sample row group
+    slot = m // S - first
+    for t in range(2):
+        for sl in range(2):
+            sums = (x[t] * (slot == sl)[:, None]).view(Mp // 32, 32, 128).sum(1)
+            has = ((slot == sl).view(Mp // 32, 32).any(1)) | (sl == 0)
+            part[has, (2 * t + sl) * 128:(2 * t + sl + 1) * 128] = sums[has]
+    rs_g1, rs_r1 = torch.empty(R, 128, device=dev), torch.empty(R, 128, device=dev)
+    assert lib.lib.upnerf_ray_part_finish(R, S, part.data_ptr(), rs_g1.data_ptr(), rs_r1.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert rel_err(cpu(rs_r1), cpu(x[0][:M].view(R, S, 128).sum(1))) < 1e-5
+    assert rel_err(cpu(rs_g1), cpu(x[1][:M].view(R, S, 128).sum(1))) < 1e-5
+
+
+def test_wgrad_f16p_on_128_wide_fragments(hip):
+    """upnerf_wgrad_f16p with 128-wide fragment operands on both sides (candidate_encoding.2: gz_g2 x g1) against fp64."""
+    lib, rd, ops = hip["lib"], hip["rendering"], hip["ops"]
+    dev, M = "cuda", 2999
+    Mp = (M + 255) // 256 * 256
+    ea = torch.randint(-2, 3, (Mp // 32,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(dev)
+    eb = torch.randint(-2, 3, (Mp // 32,), generator=torch.Generator().manual_seed(2)).to(torch.int32).to(dev)
+    A16, B16 = rd.quant16_frag(gen((Mp, 128), 3).to(dev), ea), rd.quant16_frag(gen((Mp, 128), 4).to(dev), eb)
+    A = rd.dequant16(A16[None], ea[None], frag=True)[0, :M].double()
+    B = rd.dequant16(B16[None], eb[None], frag=True)[0, :M].double()
+    expo = torch.tensor([3, 3], device=dev, dtype=torch.int32)
+    dW, db = torch.full((128, 128), 7.0, device=dev), torch.full((128,), 7.0, device=dev)
+    ns = ops.nsplit_for(M)
+    ws = torch.empty(ns * (256 * 256 + 256), device=dev)
+    rc = lib.lib.upnerf_wgrad_f16p(M, A16.data_ptr(), 128, ea.data_ptr(), 128, B16.data_ptr(), 128, eb.data_ptr(), 3, 128, dW.data_ptr(), 128,
+                                   db.data_ptr(), ws.data_ptr(), ns, expo.data_ptr(), expo.data_ptr() + 4, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_err(cpu(dW), cpu(A.t() @ B)) < 1e-5 and rel_err(cpu(db), cpu(A.sum(0))) < 1e-5
+
+
+@pytest.mark.parametrize("M,n2", [(3000, 0), (3000, 128), (100, 128)])
+def test_wgrad_f16p_chain_on_fragments_with_a_split_result(hip, M, n2):
+    """upnerf_wgrad_f16p_chain with both operands as fp16 fragments (b_is_f16 = 3) and the result split by rows between two
+    destinations, finished by upnerf_wgrad_finish, against fp64 on the decoded values."""
+    lib, rd, ops = hip["lib"], hip["rendering"], hip["ops"]
+    from upnerf_amd._lib import WgradPending
+    dev = "cuda"
+    Mp = (M + 255) // 256 * 256
+    ea = torch.randint(-2, 3, (Mp // 32,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(dev)
+    eb = torch.randint(-2, 3, (Mp // 32,), generator=torch.Generator().manual_seed(2)).to(torch.int32).to(dev)
+    A16, B16 = rd.quant16_frag(gen((Mp, 256), 3).to(dev), ea), rd.quant16_frag(gen((Mp, 256), 4).to(dev), eb)
+    A = rd.dequant16(A16[None], ea[None], frag=True)[0, :M].double()
+    B = rd.dequant16(B16[None], eb[None], frag=True)[0, :M].double()
+    expo = torch.tensor([3, 3], device=dev, dtype=torch.int32)  # tensor-wide exponents: |x| < 1 -> |x * 2^3| < 8
+    n1 = n2 if n2 else 256
+    dW, db = torch.full((n1, 256), 7.0, device=dev), torch.full((n1,), 7.0, device=dev)
+    dW2, db2 = torch.full((256 - n1 if n2 else 1, 300), 7.0, device=dev), torch.full((256,), 7.0, device=dev)
+    ns = ops.nsplit_for(M)
+    ws = torch.empty(ns * (256 * 256 + 256), device=dev)
+    pend = WgradPending()
+    rc = lib.lib.upnerf_wgrad_f16p_chain(M, A16.data_ptr(), 256, ea.data_ptr(), 256, B16.data_ptr(), 256, eb.data_ptr(), 3, 256,
+                                         dW.data_ptr(), 256, db.data_ptr(), n2, dW2.data_ptr() if n2 else None, 300,
+                                         db2.data_ptr() if n2 else None, ws.data_ptr(), ns, expo.data_ptr(), expo.data_ptr() + 4,
+                                         C.byref(pend), None)
+    assert rc == 0
+    assert lib.lib.upnerf_wgrad_finish(C.byref(pend), None) == 0
+    torch.cuda.synchronize()
+    ref, refb = A.t() @ B, A.sum(0)
+    assert rel_err(cpu(dW), cpu(ref[:n1])) < 1e-5 and rel_err(cpu(db), cpu(refb[:n1])) < 1e-5
+    if n2:
+        assert rel_err(cpu(dW2[:, :256]), cpu(ref[n1:])) < 1e-5 and rel_err(cpu(db2[:256 - n1]), cpu(refb[n1:])) < 1e-5
+        assert float((dW2[:, 256:] - 7.0).abs().max()) == 0.0  # nothing written past the 256 columns of a row
+
+
 @pytest.mark.parametrize("R,S,mode", [(5, 70, 1), (3, 33, 3), (2, 129, 0)])
 def test_compositing_reads_e_as_fp16_fragments(hip, R, S, mode):
     """upnerf_composite_fwd / _bwd with e given as the register-resident field kernels' fp16 operand fragments (e16 / eexp)

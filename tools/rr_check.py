@@ -38,7 +38,7 @@ for tag, fm, rr in (("f32", "f32", 0), ("tile", "f16", 0), ("rr", "f16", 1)):
     sv = node.saved
     M = R * S
     got = {k: sv[k].float().cpu() for k in ("x0", "e", "g1", "g2", "r1", "sigma_s", "sigma_c", "rgb") if sv.get(k) is not None}
-    for k, k16, kexp in (("e", "e16", "eexp"), ("g2", "g2_16", "g2exp"), ("r1", "r1_16", "r1exp")):
+    for k, k16, kexp in (("e", "e16", "eexp"), ("g2", "g2_16", "g2exp"), ("r1", "r1_16", "r1exp"), ("g1", "g1_16", "g1exp")):
         if sv.get(k) is None and sv.get(k16) is not None:
             got[k] = rd.dequant16(sv[k16][None], sv[kexp][None], frag=True)[0, :M].cpu()
     if sv.get("h16") is not None:

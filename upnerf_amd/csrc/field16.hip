@@ -1026,13 +1026,13 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
     if (a->planes != 1) return UPNERF_EUNSUP;
     if (a->S < 32) return UPNERF_EUNSUP;  // at most 9 rays per 256-sample tile
     if (!a->wnorm) return UPNERF_EINVAL;
-    if ((a->e16 && !a->eexp) || (a->g2_16 && !a->g2exp) || (a->r1_16 && !a->r1exp)) return UPNERF_EINVAL;
+    if ((a->e16 && !a->eexp) || (a->g2_16 && !a->g2exp) || (a->r1_16 && !a->r1exp) || (a->g1_16 && !a->g1exp)) return UPNERF_EINVAL;
     if (a->h16 && !a->hmask) return UPNERF_EINVAL;
     if (a->use_cand && !a->g2 && !a->g2_16) return UPNERF_EINVAL;
-    if (a->h16 && ((a->use_cand && !a->g1) || (a->use_rgb && !a->r1 && !a->r1_16))) return UPNERF_EINVAL;
+    if (a->h16 && ((a->use_cand && !a->g1 && !a->g1_16) || (a->use_rgb && !a->r1 && !a->r1_16))) return UPNERF_EINVAL;
     return upnerf_rr16_fwd_launch(L, a, stream);
   }
-  if (a->wnorm || a->e16 || a->g2_16 || a->r1_16) return UPNERF_EUNSUP;  // only the register-resident kernels read the row norms / write e as fragments
+  if (a->wnorm || a->e16 || a->g2_16 || a->r1_16 || a->g1_16) return UPNERF_EUNSUP;  // only the register-resident kernels read the row norms / write e as fragments
   const int tile = tile_rows16(a->tile_rows, a->S);
   if (tile < 0) return UPNERF_EINVAL;
   const int grid = (int)((M + tile - 1) / tile);
@@ -1053,7 +1053,7 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->S < 32) return UPNERF_EUNSUP;  // at most 3 rays per 64-sample tile
   const bool rg16 = a->tile_rows == 256 && a->gz_rg16 && a->gzrgexp && a->use_cand && a->use_rgb;  // fp16 fragments instead of gz_r1 / gz_g1
   if (a->gz_rg16 && !rg16) return UPNERF_EINVAL;
-  if (a->use_cand && (!a->d_sigma_c || !a->sigma_c || (!a->g2 && a->tile_rows != 256) || (!a->gz_g1 && !rg16) || !a->gz_g2 || !a->dpre_sig_c))
+  if (a->use_cand && (!a->d_sigma_c || !a->sigma_c || (!a->g2 && a->tile_rows != 256) || (!a->gz_g1 && !rg16) || (!a->gz_g2 && !(a->tile_rows == 256 && a->gz_g2_16 && a->gzg2exp)) || !a->dpre_sig_c))
     return UPNERF_EINVAL;
   if (a->use_cand && a->g_G_c && !a->w_cj) return UPNERF_EINVAL;
   if (a->use_rgb && (!a->d_rgb || !a->rgb || (!a->r1 && a->tile_rows != 256) || (!a->gz_r1 && !rg16) || !a->dpre_rgb)) return UPNERF_EINVAL;

@@ -932,10 +932,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
         e_G = scale_exp(wnorm[D + 1] * fmaxf(amax_e, sidemax) + vec_s[RR_V_BMAX + 10]);
         const float pe = pow2r(e_G);
         TileOut to;
-        to.frag = nullptr;
-        to.rows = train ? a.g1 + (size_t)m0 * W2 : nullptr;
+        to.frag = train ? a.g1_16 : nullptr;  // (nullptr, or g1 as operand fragments for candidate_encoding.2's weight gradient)
+        to.fb = 8;
+        to.rows = (train && a.g1) ? a.g1 + (size_t)m0 * W2 : nullptr;
         to.ld = W2;
-        char* stg_g = train ? stg : nullptr;
+        char* stg_g = to.rows ? stg : nullptr;
         u32x4_t words = {0u, 0u, 0u, 0u};
         float vmax = 0.0f;
         run_tiles<NW, 4>(
@@ -958,6 +959,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
 #endif
           rg.count(1);
         }
+        if (train && a.g1_16 && lane == 0) a.g1exp[t32] = e_G;
         amax_g1 = wave_max_rr(vmax);
         track_lds(mx_s, D + 1, amax_g1, lane);
       }
@@ -1247,6 +1249,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
           amax_g2 = wave_max_rr(vmax);
           track_lds(mx_s, D + 2, amax_g2, lane);
           e_g2 = scale_exp(amax_g2);
+          if (a.gz_g2_16 && lane == 0) a.gzg2exp[t32] = e_g2;
         }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
@@ -1263,7 +1266,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
               vmax = fmaxf(vmax, fabsf(v[u]));
             }
             if (pass == 1) {
-              stg_put(stg, li, hh, q, f32x4{v[0], v[1], v[2], v[3]});
+              if (a.gz_g2) stg_put(stg, li, hh, q, f32x4{v[0], v[1], v[2], v[3]});
               h4 hi, lo;
               split_quad<1>(ldexpf(v[0], e_g2), ldexpf(v[1], e_g2), ldexpf(v[2], e_g2), ldexpf(v[3], e_g2), hi, lo);
               if (q & 1) blk[q >> 1] = __builtin_shufflevector(blk[q >> 1], __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3), 0, 1, 2, 3, 12, 13, 14, 15);
@@ -1273,8 +1276,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
           if (pass == 1) {
             Gh[2 * jt] = blk[0];
             Gh[2 * jt + 1] = blk[1];
-            stg_flush(stg, lane, a.gz_g2 + (size_t)m0 * W2, W2, 32 * jt);
-            rg.count(4);
+            if (a.gz_g2) {
+              stg_flush(stg, lane, a.gz_g2 + (size_t)m0 * W2, W2, 32 * jt);
+              rg.count(4);
+            }
+            if (a.gz_g2_16) {  // the operand fragments themselves (candidate_encoding.2's weight gradient reads them)
+              frag_store(a.gz_g2_16, t32, 2 * jt, lane, blk[0], 8);
+              frag_store(a.gz_g2_16, t32, 2 * jt + 1, lane, blk[1], 8);
+              rg.count(2);
+            }
           }
         }
       }

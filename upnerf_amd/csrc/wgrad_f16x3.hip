@@ -263,7 +263,10 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   constexpr int WK = (TK >= 128) ? 4 : 2, WN = 8 / WK;
   constexpr int MT = (TN / WN >= 32) ? TN / WN / 32 : 1, NT = TK / WK / 32;
   static_assert(TN / WN >= 32, "packed variant is built for 256-row blocks");
-  static_assert(!FRAG || (TN == 256 && (!PKB || TK == 256) && FX_CHUNK % 16 == 0), "fragment-ordered operands are 256 wide");
+  static_assert(!FRAG || ((TN == 256 || TN == 128) && (!PKB || TK == TN) && FX_CHUNK % 16 == 0), "fragment-ordered operands are 256 or 128 wide");
+  // fragment-ordered operands: a row has TN / 8 (TK / 8) 16-byte pieces, the 512 threads cover RPA (RPB) rows per pass
+  constexpr int RPA = FX_THREADS / (TN / 8), RPB = PKB ? FX_THREADS / (TK / 8) : 1;
+  static_assert(!FRAG || (FX_CHUNK % RPA == 0 && (!PKB || FX_CHUNK % RPB == 0)), "whole passes per chunk");
   __shared__ __attribute__((aligned(16))) char lds[2 * (SZA + SZB)];  // [buffer][A | B], one plane each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
@@ -297,9 +300,9 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
 #pragma unroll
     for (int q = 0; q < A8; ++q) {
       if constexpr (FRAG) {
-        const int m = mc + (tid & 15) + 16 * q, s2 = tid >> 4;  // row of the chunk; (k-block, lane half) of this thread
+        const int m = mc + (tid % RPA) + RPA * q, s2 = tid / RPA;  // row of the chunk; (k-block, lane half) of this thread
         const bool ok = m < mend;
-        ra[q] = ok ? NT_LOAD((const h8*)((const char*)A + (((size_t)(m >> 5) * 16 + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16)) : zero8;
+        ra[q] = ok ? NT_LOAD((const h8*)((const char*)A + (((size_t)(m >> 5) * (TN / 16) + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16)) : zero8;
         xa[q] = ok ? aexp[m >> 5] : 0;
       } else {
         const int idx = tid + q * FX_THREADS, row = idx / (TN / 8), c8 = idx - row * (TN / 8);
@@ -313,9 +316,9 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
 #pragma unroll
       for (int q = 0; q < B8; ++q) {
         if constexpr (FRAG) {
-          const int m = mc + (tid & 15) + 16 * q, s2 = tid >> 4;
+          const int m = mc + (tid % RPB) + RPB * q, s2 = tid / RPB;
           const bool ok = m < mend;
-          rbp[q] = ok ? NT_LOAD((const h8*)((const char*)Bh + (((size_t)(m >> 5) * 16 + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16)) : zero8;
+          rbp[q] = ok ? NT_LOAD((const h8*)((const char*)Bh + (((size_t)(m >> 5) * (TK / 16) + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16)) : zero8;
           xb[q] = ok ? bexp[m >> 5] : 0;
         } else {
           const int idx = tid + q * FX_THREADS, row = idx / (TK / 8), c8 = idx - row * (TK / 8);
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * f;
       if constexpr (FRAG) {
-        const int r = (tid & 15) + 16 * q, s2 = tid >> 4, col = 16 * (s2 >> 1) + 4 * (s2 & 1);
+        const int r = (tid % RPA) + RPA * q, s2 = tid / RPA, col = 16 * (s2 >> 1) + 4 * (s2 & 1);
         *(h4*)(base + himg<FX_CHUNK>(r, col)) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
         *(h4*)(base + himg<FX_CHUNK>(r, col + 8)) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
       } else {
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] * f;
         if constexpr (FRAG) {
-          const int r = (tid & 15) + 16 * q, s2 = tid >> 4, col = 16 * (s2 >> 1) + 4 * (s2 & 1);
+          const int r = (tid % RPB) + RPB * q, s2 = tid / RPB, col = 16 * (s2 >> 1) + 4 * (s2 & 1);
           *(h4*)(base + SZA + himg<FX_CHUNK>(r, col)) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
           *(h4*)(base + SZA + himg<FX_CHUNK>(r, col + 8)) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
         } else {
@@ -446,10 +449,10 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
     constexpr int Q = TN / 8, G = FX_THREADS / Q;
     if (tid < TN) {
       float sacc = 0.0f;
-      if constexpr (FRAG) {  // column tid = 16 s + 8 (j / 4) + 4 hh + j % 4 is held, as element j, by the 16 threads with tid / 16 = 2 s + hh
+      if constexpr (FRAG) {  // column tid = 16 s + 8 (j / 4) + 4 hh + j % 4 is held, as element j, by the RPA threads with tid / RPA = 2 s + hh
         const int s2 = 2 * (tid >> 4) + ((tid >> 2) & 1), j = 4 * ((tid >> 3) & 1) + (tid & 3);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) sacc += red[(s2 * 16 + t) * 8 + j];
+        for (int t = 0; t < RPA; ++t) sacc += red[(s2 * RPA + t) * 8 + j];
       } else {
         const int grp = tid >> 3, j = tid & 7;
 #pragma unroll
@@ -519,7 +522,9 @@ extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, co
   hipStream_t st = (hipStream_t)stream;
   const bool frag = (b_is_f16 & 2) != 0;  // bit 1: fp16 operands in the fragment order of the register-resident field kernels
   b_is_f16 &= 1;
-  if (frag && (N != 256 || (b_is_f16 && K != 256))) return UPNERF_EUNSUP;
+  if (frag && ((N != 256 && N != 128) || (b_is_f16 && K != N) || (!b_is_f16 && N != 256))) return UPNERF_EUNSUP;
+  if (TN == 128 && TK == 128 && b_is_f16 && frag)  // 128-wide fragments on both sides (candidate_encoding.2: gz_g2 x g1)
+    return launch_p<2, 2, 1, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev);
   if (TN == 256 && TK == 256 && b_is_f16)
     return frag ? launch_p<4, 4, 1, 1>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev)
                 : launch_p<4, 4, 1, 0>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev);

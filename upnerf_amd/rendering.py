@@ -185,7 +185,9 @@ class _FieldPass(torch.autograd.Function):
         # by the backward kernel -- one zero fill and, later, one exponent launch for both
         mx32 = torch.zeros(32, device=dev) if train else None
         amax = mx32[:16] if train else None
-        g1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and train) else None
+        g1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and train and not e_frag) else None
+        g1_16 = torch.empty(Mp, W2, device=dev, dtype=torch.float16) if (cfg.use_cand and train and e_frag) else None
+        g1exp = torch.empty(Mp // 32, device=dev, dtype=torch.int32) if g1_16 is not None else None
         # rr with e as fragments: g2 and r1 leave the same way (compositing / the 128-wide output layers' weight gradients read
         # them; the backward kernel works from the sign bits)
         g2 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and (train or joint) and not e_frag) else None
@@ -203,7 +205,7 @@ class _FieldPass(torch.autograd.Function):
                           P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None,
                           planes=_planes(), tile_rows=tile, wnorm=ptr(wnorm), h16=ptr(h16), hexp=ptr(hexp),
                           h_last_only=int(store16), x0f=ptr(x0f), e16=ptr(e16), eexp=ptr(eexp),
-                          g2_16=ptr(g2_16), g2exp=ptr(g2exp), r1_16=ptr(r1_16), r1exp=ptr(r1exp))
+                          g2_16=ptr(g2_16), g2exp=ptr(g2exp), r1_16=ptr(r1_16), r1exp=ptr(r1exp), g1_16=ptr(g1_16), g1exp=ptr(g1exp))
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
@@ -230,7 +232,7 @@ class _FieldPass(torch.autograd.Function):
         ctx.rr, ctx.Mp = rr, Mp
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, mx32=mx32, e=e, e16=e16, eexp=eexp, g2_16=g2_16, g2exp=g2exp, r1_16=r1_16, r1exp=r1exp, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, mx32=mx32, e=e, e16=e16, eexp=eexp, g2_16=g2_16, g2exp=g2exp, r1_16=r1_16, r1exp=r1exp, g1_16=g1_16, g1exp=g1exp, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
                          w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s, wnorm=wnorm)
         z0 = torch.zeros(0, device=dev)
@@ -286,7 +288,10 @@ class _FieldPass(torch.autograd.Function):
         gz_rg16 = torch.empty(Mp, W, device=dev, dtype=torch.float16) if rg16 else None
         gzrgexp = torch.empty(Mp // 32, device=dev, dtype=torch.int32) if rg16 else None
         gz_g1 = (None if rg16 else gz_rg[:, W2:] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_cand else None
-        gz_g2 = _empty(Mp, W2, device=dev)[:M] if cfg.use_cand else None
+        g2f = cfg.use_cand and sv.get("g1_16") is not None  # rr: gz_g2 as fragments against g1's (candidate_encoding.2)
+        gz_g2 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and not g2f) else None
+        gz_g2_16 = torch.empty(Mp, W2, device=dev, dtype=torch.float16) if g2f else None
+        gzg2exp = torch.empty(Mp // 32, device=dev, dtype=torch.int32) if g2f else None
         gz_r1 = (None if rg16 else gz_rg[:, :W2] if joined else _empty(Mp, W2, device=dev)[:M]) if cfg.use_rgb else None
         dpre_s = _empty(M, device=dev)
         dpre_c = _empty(M, device=dev) if cfg.use_cand else None
@@ -311,7 +316,7 @@ class _FieldPass(torch.autograd.Function):
                           r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e),
                           gz_g1=(gz_rg.data_ptr() + 4 * W2) if gz_rg is not None else ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_rg) if gz_rg is not None else ptr(gz_r1), gz_rg_ld=W if gz_rg is not None else 0,
-                          gz_rg16=ptr(gz_rg16), gzrgexp=ptr(gzrgexp), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
+                          gz_rg16=ptr(gz_rg16), gzrgexp=ptr(gzrgexp), gz_g2_16=ptr(gz_g2_16), gzg2exp=ptr(gzg2exp), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, tile_rows=ctx.tile_rows, xs=ptr(sv.get("x0f")), gz16=ptr(gz16),
                           gzexp=ptr(gzexp), tile_part=ptr(ray_part if rr else tile_part), wnorm=ptr(sv.get("wnorm")))
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
@@ -323,7 +328,8 @@ class _FieldPass(torch.autograd.Function):
                                gz_e=gz_e if gz_e is not None else dequant16(gz16[D:], gzexp[D:], frag=True)[0, :M],
                                gz_g1=dequant16(gz_rg16[None], gzrgexp[None], frag=True)[0, :M, W2:] if rg16 else gz_g1,
                                gz_r1=dequant16(gz_rg16[None], gzrgexp[None], frag=True)[0, :M, :W2] if rg16 else gz_r1,
-                               gz_g2=gz_g2, dpre_s=dpre_s, dpre_c=dpre_c, dpre_rgb=dpre_rgb, dxyz=dxyz)
+                               gz_g2=gz_g2 if gz_g2 is not None else (dequant16(gz_g2_16[None], gzg2exp[None], frag=True)[0, :M] if g2f else None),
+                               dpre_s=dpre_s, dpre_c=dpre_c, dpre_rgb=dpre_rgb, dxyz=dxyz)
         # ---- weight gradients, written straight into a buffer with P's layout
         dP = torch.zeros(L.total, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
         d_c_rows = d_a_rows = None
@@ -412,7 +418,11 @@ class _FieldPass(torch.autograd.Function):
                 else:
                     wg(gz_g1, W2, W2, sv["e"], W, W, L.wc1, W + CK, L.bc1, D + 1, D)
                 wgrad_into(R, rs_c, W2, W2, sv["c_rows"], CK, CK, at(L.wc1 + W), W + CK, None, dev)
-                wg(gz_g2, W2, W2, sv["g1"], W2, W2, L.wc2, W2, L.bc2, D + 2, D + 1)
+                if g2f:
+                    chain.wgrad_p(M, gz_g2_16, W2, gzg2exp, W2, sv["g1_16"], W2, sv["g1exp"], W2, at(L.wc2), W2, at(L.bc2), EA(D + 2),
+                                  EB(D + 1), frag=True)
+                else:
+                    wg(gz_g2, W2, W2, sv["g1"], W2, W2, L.wc2, W2, L.bc2, D + 2, D + 1)
                 if sv.get("g2_16") is not None:
                     vec_wgrad_frag16_into(M, dpre_c, 1, 1, sv["g2_16"], sv["g2exp"], W2, at(L.wcsig), at(L.bcsig), dev)
                 elif tile_part is None:
