@@ -484,6 +484,31 @@ def test_field_pass_stage_by_stage(hip, name, typ, field_mode):
     assert ok, "BWD over tolerance: " + repr(errs)
 
 
+def test_frag16_row_norms_bound_every_matrix(hip):
+    """upnerf_frag16(..., wnorm): wnorm[j] (forward set) / wnorm[32 + j] (transposed set) = max over the rows of descriptor j of
+    the row's 1-norm -- what the register-resident kernels bound |W x|_inf with before a layer's outputs exist."""
+    from upnerf_amd import synth
+    from upnerf_amd.nerf import NeRF
+    kw = dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    model = NeRF("coarse", c2f=None, **kw)
+    model.load_state_dict(synth.nerf_state("coarse", seed=3, trunk_gain=1.6, **kw))
+    model = model.cuda()
+    pk = model.packer
+    P = model.packed().detach()
+    _, _, _, wnorm = pk.frag16_hip(P, perm=True)
+    torch.cuda.synchronize()
+    fd, nf, bd, nb = pk._descs16()
+    Pc = P.cpu().double()
+    for base, descs, n in ((0, fd, nf), (32, bd, nb)):
+        for j in range(n):
+            q = descs[j]
+            idx = q.src_off + (torch.arange(q.rows)[:, None] * (1 if q.transpose else q.src_ld) +
+                               torch.arange(q.cols)[None, :] * (q.src_ld if q.transpose else 1))
+            ref = Pc[idx].abs().sum(1).max()
+            got = float(wnorm[base + j])
+            assert abs(got - float(ref)) <= 1e-5 * float(ref) + 1e-12, (base, j, got, float(ref))
+
+
 @pytest.mark.parametrize("M,K,nvec", [(1000, 256, 1), (1000, 128, 3), (77, 128, 1), (4099, 256, 3)])
 def test_vec_wgrad_frag16_matches_fp64(hip, M, K, nvec):
     """upnerf_vec_wgrad_frag16 (dw[c][k] = sum_m v[m][c] X[m][k], dbv[c] = sum_m v[m][c]) on a fragment-ordered fp16 tensor
