@@ -18,7 +18,9 @@ python tools/pmc_current.py "$OUT/pmc_trevi.json" --field f16 --config trevi --p
 cp profiles/pmc_current_trevi.json "$OUT/pmc_current_trevi.json"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --config trevi > "$OUT/bench_trevi.json" 2> "$OUT/bench_trevi.err"
-python tools/prof_summary.py "$OUT/prof" 27 45 > "$OUT/kernel_summary.txt" 2>&1
-python tools/prof_summary.py "$OUT/prof_trevi" 27 45 > "$OUT/kernel_summary_trevi.txt" 2>&1
+python tools/prof_summary.py "$OUT/prof" 67 45 > "$OUT/kernel_summary.txt" 2>&1
+python tools/prof_summary.py "$OUT/prof_trevi" 67 45 > "$OUT/kernel_summary_trevi.txt" 2>&1
+python tools/step_sequence.py "$OUT/prof" > "$OUT/step_sequence.txt" 2>&1
+python tools/step_sequence.py "$OUT/prof_trevi" > "$OUT/step_sequence_trevi.txt" 2>&1
 rm -f "$OUT/prof/"*kernel_trace.csv "$OUT/prof_trevi/"*kernel_trace.csv
 ls "$OUT"
