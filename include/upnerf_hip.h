@@ -497,6 +497,9 @@ int upnerf_embed_bwd_grouped(int R, int N, const int64_t* idx, const upnerf_embe
  * form, no transposed copy needed.  N arbitrary (ldb/ldc are row strides). */
 int upnerf_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                   const float* bias, float* C, int ldc, int act, void* stream);
+/* Matrix-vector products in a fixed summation order (the bias fold of the colour layer, both directions):
+ * trans = 0: y[m] = add[m] + sum_k A[m][k] x[k], m < M;  trans = 1: y[k] = add[k] + sum_m A[m][k] x[m], k < K.  add may be NULL. */
+int upnerf_matvec(int M, int K, const float* A, int lda, const float* x, const float* add, float* y, int trans, void* stream);
 
 /* ---- a15 + a17: depth-prior affine (models/nerf_system.py:169-177) fused with UPNeRFLoss (losses.py:21-64) --------
  * Per-ray inputs only ([R], [R,3], [R,F]); any absent tensor is NULL.  `terms` receives the 8 loss terms in the order

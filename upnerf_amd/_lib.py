@@ -180,6 +180,7 @@ _SIGNATURES = {
     "upnerf_wgrad_grouped_scratch": [C.POINTER(WgradGroup), _i, _i],
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
+    "upnerf_matvec": [_i, _i, _p, _i, _p, _p, _p, _i, _p],
     "upnerf_vec_wgrad_frag16": [_i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_part_finish": [_i, _i, _p, _p, _p, _p],

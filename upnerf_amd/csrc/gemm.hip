@@ -904,6 +904,35 @@ extern "C" int upnerf_vec_wgrad_frag16(int M, const float* v, int ldv, int nvec,
   return (int)hipGetLastError();
 }
 
+// ---- small matrix-vector products of the folded colour layer (packing): y[m] = add[m] + sum_k A[m][k] x[k] (trans = 0, one wave
+// per row, lane-strided partial sums + a shuffle tree: fixed order) or y[k] = sum_m A[m][k] x[m] (trans = 1, one thread per
+// column walking the rows in order).  128 x 384: one 5 us launch where a 64 x 64-tile GEMM launch plus two copies stood.
+__global__ __launch_bounds__(256) void matvec_kernel(int M, int K, const float* __restrict__ A, int lda, const float* __restrict__ x,
+                                                     const float* __restrict__ add, float* __restrict__ y, int trans) {
+  if (trans) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.0f;
+    for (int m = 0; m < M; ++m) s += A[(size_t)m * lda + k] * x[m];
+    y[k] = s + (add ? add[k] : 0.0f);
+    return;
+  }
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  float s = 0.0f;
+  for (int k = lane; k < K; k += 64) s += A[(size_t)m * lda + k] * x[k];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if (lane == 0) y[m] = s + (add ? add[m] : 0.0f);
+}
+extern "C" int upnerf_matvec(int M, int K, const float* A, int lda, const float* x, const float* add, float* y, int trans,
+                             void* stream) {
+  if (M <= 0 || K <= 0 || !A || !x || !y || lda < K) return UPNERF_EINVAL;
+  const int blocks = trans ? (K + 255) / 256 : (M + 3) / 4;
+  hipLaunchKernelGGL(matvec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, K, A, lda, x, add, y, trans);
+  return (int)hipGetLastError();
+}
+
 extern "C" int upnerf_wgrad_grouped_scratch(const upnerf_wgrad_group* groups, int ngroups, int nsplit) {
   if (!groups || ngroups <= 0 || ngroups > UPNERF_MAX_WGRAD_GROUPS || nsplit <= 0) return UPNERF_EINVAL;
   long long tiles = 0;

@@ -41,14 +41,11 @@ class _PackFn(torch.autograd.Function):
         # folded colour layer: W_r1[:, :F] . W_feat -> wr1[:, :W];  W_r1[:, :F] . b_feat + b_r1 -> br1
         check(lib.upnerf_linear(W2, W, Fd, wrF, Fd, ptr(p["feat_share_layer.weight"]), W, None, base + 4 * L.wr1, W + AUXK, 2,
                                 st), "upnerf_linear")
-        # (a 128 x 384 matrix-vector product; r3 ADVICE: rocBLAS gemv made the summation order -- and with it the bitwise
-        # replay == eager contract -- depend on the rocBLAS version, and created its handle inside a capture: upnerf_linear with
-        # the bias vector as a one-row "weight", fixed order, 13 us)
-        check(lib.upnerf_linear(W2, 8, Fd, wrF, Fd, ptr(packer._bias_rows(p["feat_share_layer.bias"])), Fd, None,
-                                ptr(packer._bias_out(dev)), 8, 0, st), "upnerf_linear")
-        buf[L.br1:L.br1 + W2].copy_(packer._bias_out(dev)[:, 0])
-        acc = (PackDesc * 1)(PackDesc(ptr(p["rgb_share_layer.0.bias"]), 1, W2, W2, L.br1, W2, 1))
-        check(lib.upnerf_pack(ptr(buf), acc, 1, 0, st), "upnerf_pack")
+        # W_r1[:, :F] . b_feat + b_r1 -> br1: one small matrix-vector launch straight into P (r3 ADVICE: rocBLAS gemv made the
+        # summation order -- and with it the bitwise replay == eager contract -- depend on the rocBLAS version, and created its
+        # handle inside a capture)
+        check(lib.upnerf_matvec(W2, Fd, wrF, Fd, ptr(p["feat_share_layer.bias"]), ptr(p["rgb_share_layer.0.bias"]), base + 4 * L.br1, 0,
+                                st), "upnerf_matvec")
         ctx.packer, ctx.names, ctx.buf = packer, names, buf
         ctx.save_for_backward(p["feat_share_layer.weight"], p["feat_share_layer.bias"])
         ctx.shapes = [tuple(t.shape) for t in tensors]
@@ -89,7 +86,7 @@ class _PackFn(torch.autograd.Function):
             wgrad_blocks_into(W2, wrF, Fd, Fd, dP, W + AUXK, W, g_fw.data_ptr(), W, None, dev, b_off=L.wr1)
         else:
             wgrad_into(W2, wrF, Fd, Fd, dP, W + AUXK, W, g_fw.data_ptr(), W, None, dev, b_off=L.wr1)
-        grads["feat_share_layer.bias"].copy_(torch.mv(wrF.t(), gbr1))
+        check(lib.upnerf_matvec(W2, Fd, ptr(wrF), Fd, ptr(gbr1), None, ptr(grads["feat_share_layer.bias"]), 1, st), "upnerf_matvec")
         grads["rgb_share_layer.0.bias"].copy_(gbr1)
         return (None, None) + tuple(grads[n] for n in names)
 
@@ -250,20 +247,6 @@ class NerfPacker:
     def pack_names(self):
         names = [f"xyz_encoding_{l + 1}.0.{k}" for l in range(self.D) for k in ("weight", "bias")] + self.PACK_NAMES_BASE
         return names + (self.PACK_NAMES_CAND if self.has_cand else [])
-
-    def _bias_rows(self, b: torch.Tensor) -> torch.Tensor:
-        """b as the first of 8 rows (the linear kernel wants N % 8 == 0): y[:, 0] = x . b."""
-        buf = getattr(self, "_brow", None)
-        if buf is None or buf.device != b.device:
-            buf = self._brow = torch.zeros(8, b.numel(), device=b.device, dtype=torch.float32)
-        buf[0].copy_(b)
-        return buf
-
-    def _bias_out(self, dev) -> torch.Tensor:
-        buf = getattr(self, "_bout", None)
-        if buf is None or buf.device != dev:
-            buf = self._bout = torch.empty(self.W2, 8, device=dev, dtype=torch.float32)
-        return buf
 
     def pack_hip(self, p: Dict[str, torch.Tensor]) -> torch.Tensor:
         """pack() with HIP kernels and a hand-written backward: 4 launches instead of ~45 (and ~10 instead of ~50 in the
