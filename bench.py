@@ -200,6 +200,11 @@ class Bench:
         TIMER.reset()
         TIMER.enabled, TIMER.only = timer_only is not None, timer_only or None
         calls0 = _lib.CALLS[0]
+        # no cyclic garbage collection inside the timed region: a generation-2 pass over the module / ctypes objects of a freshly
+        # built system costs tens of ms of host time and lands wherever the allocation counters put it (seen inside a 4-step
+        # region: 134 k instead of 240 k rays/s); collected here instead, re-enabled after the last repeat
+        gc.collect()
+        gc.disable()
         self.barrier()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -231,6 +236,7 @@ class Bench:
                 vals.append(self.world * self.rays * steps / d2)
             out["value_spread"] = {"min": min(vals), "max": max(vals), "repeats": repeats, "steps_each": steps,
                                    "note": "the first of these measurements is `value`"}
+        gc.enable()
         if graph:
             out["graph_stats"] = dict(step.stats)
         summ = TIMER.summary() if timer_only is not None else None
