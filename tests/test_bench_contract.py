@@ -99,8 +99,12 @@ def test_world_size_mismatch_is_an_error():
 def test_two_ranks_spawned_on_one_device_run_the_real_step():
     """The spawn path with the real workload: two ranks share cuda:0 through gloo (diagnostic switches of parallel.py),
     graph replay with the all-reduce between the two graphs of a step."""
-    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--no-kernel-timing"],
-               env={"UPNERF_DIST_BACKEND": "gloo", "UPNERF_SHARE_DEVICE": "1"}, timeout=900)
+    args, env = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--no-kernel-timing"], \
+        {"UPNERF_DIST_BACKEND": "gloo", "UPNERF_SHARE_DEVICE": "1"}
+    try:  # (the run takes ~5 s; a rendezvous that never completes was seen once in a round of runs: one retry on a fresh port)
+        out = _run(args, env=env, timeout=240)
+    except subprocess.TimeoutExpired:
+        out = _run(args, env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout
