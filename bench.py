@@ -25,6 +25,7 @@ Extra objects on the line:
   phases        the three schedule phases BASELINE configs[1] asks for (progress 0.05 / 0.3 / 0.8), same K and W each
   strict_f32    the same step with every contraction on the fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of the f16x3 split
   wgrad_f16     the same step with fp16-stored operands for the trunk weight gradients (an option; see its note)
+  wgrad_f24     the same step with 24-bit stored operands (fp16 + residual byte) for the trunk weight gradients (an option)
   trevi         BASELINE.json configs[3] (8192 rays, 1689 images, fp16 field mode): value, ms_per_step, dtype, its own roofline
   tto           BASELINE.json configs[4]: pose stage and appearance stage at 1024 rays per step (graph replay), and the no-grad
                 render rate of a full held-out image (4096-ray chunks, density-only coarse pass)
@@ -367,6 +368,9 @@ def main():
                     help="strong scaling (SURVEY.md 8d config 3): the configuration's rays per step are split over the ranks "
                          "(4096 rays total = 512 per rank at --gpus 8) instead of every rank rendering a full batch")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--wgrad-store", choices=["f32", "f16", "f24"], default="f32",
+                    help="diagnostic: storage of the trunk weight-gradient operands in the MAIN leg (f32 = the strict default; the "
+                         "other two are the options the default line reports as wgrad_f16 / wgrad_f24); named in config.wgrad_store")
     ap.add_argument("--no-extras", action="store_true", help="skip the `phases` and `strict_f32` legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs34", action="store_true", help="skip the `trevi` (configs[3]) and `tto` (configs[4]) objects")
@@ -420,7 +424,7 @@ def main():
     B = Bench(args, rank, world, dev)
     graph = not args.no_graph
 
-    main_leg, _ = B.leg(args.progress, field, graph, repeats=3)
+    main_leg, _ = B.leg(args.progress, field, graph, repeats=3, wgrad_store=args.wgrad_store)
     extras = {}
     if not args.no_extras:
         phases = {}
@@ -436,6 +440,15 @@ def main():
                                            "and data-gradient chain are unchanged (bitwise the outputs of `value`); a weight "
                                            "gradient carries ~3e-4 of unbiased rounding noise (golden gradient gates 1e-3 stay "
                                            "green, tests/test_hip_parity.py).  An option (rendering.WGRAD_STORE), not `value`."}
+        if field == "f16x3":
+            w24, _ = B.leg(args.progress, field, graph, wgrad_store="f24")
+            extras["wgrad_f24"] = {"value": w24["value"], "ms_per_step": w24["ms_per_step"],
+                                   "note": "same step with the operands of the trunk WEIGHT gradients stored as fp16 + a residual "
+                                           "byte (hi + lo to 2^-20 of the tile's maximum: 3 bytes per element instead of 4), three "
+                                           "MFMAs per product as in `value`.  Forward pass and data-gradient chain unchanged "
+                                           "(bitwise); trunk weight gradients within 2e-5 of the fp32-stored ones "
+                                           "(test_24bit_stored_weight_gradient_operands_option).  An option "
+                                           "(rendering.WGRAD_STORE = \"f24\"), not `value`."}
         if field != "f32":
             f32, _ = B.leg(args.progress, "f32", graph)
             extras["strict_f32"] = {"value": f32["value"], "ms_per_step": f32["ms_per_step"], "dtype": "f32",
@@ -449,7 +462,7 @@ def main():
     if not args.no_kernel_timing:
         only = {"field_fwd", "field_bwd"} if args.kernel_timing == "field" else set()
         _, summ = B.leg(args.progress, field, False, timer_only=only if only else set(),
-                        steps=min(args.steps, 10), warmup=2)
+                        steps=min(args.steps, 10), warmup=2, wgrad_store=args.wgrad_store)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -465,7 +478,7 @@ def main():
         "vs_baseline": None, "dtype": DTYPE[field], "data": "synthetic",
         "config": {"workload": cfg["workload"], "rays_per_gpu": rays, "n_images": B.n_images, "N_samples": NC,
                    "N_importance": NF, "progress": args.progress, "sched_mult": sched, "parallelism": f"dp{world}",
-                   "field": field,
+                   "field": field, **({"wgrad_store": args.wgrad_store} if args.wgrad_store != "f32" else {}),
                    "launch": "HIP graph replay (one graph per shape signature, per-step scalars in device memory)"
                              if graph else "eager launches"},
         "world_size_observed": observed, "backend": backend,

@@ -184,6 +184,9 @@ typedef struct {
   int32_t* r1exp;
   uint16_t* g1_16;               /* and for g1 (candidate_encoding.2's weight gradient reads it: upnerf_wgrad_f16p, 128-wide fragments) */
   int32_t* g1exp;
+  uint8_t* h_lo8;                /* f16x3 mode with h16, or NULL: [D][M][W] bytes, the rounding residual of every h16 element in 1/32 of
+                                    its tile's scaled unit (byte = round(32 lo) + 128): h16 + h_lo8 = the trunk activation to 2^-20
+                                    of its tile's maximum in 3 bytes ("24-bit" weight-gradient operands, upnerf_wgrad_f24p_chain) */
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -310,6 +313,7 @@ typedef struct {
   int32_t* gzrgexp;              /* [ceil(M/256) * 8] */
   uint16_t* gz_g2_16;            /* tile_rows = 256, or NULL: gz_g2 as 128-wide fp16 operand fragments (then gz_g2 may be NULL) */
   int32_t* gzg2exp;
+  uint8_t* gz_lo8;               /* f16x3 mode with gz16, or NULL: [D][M][W] residual bytes of gz16 (as upnerf_field_fwd_args.h_lo8) */
 } upnerf_field_bwd_args;
 
 /* Layout of one row of tile_part (floats): d w_csig [W/2] | d w_r2 [3][W/2] | sum dpre_sig_c, sum dpre_rgb[0..2] | 4 pad |
@@ -435,6 +439,14 @@ int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, const int32_t* 
                             const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, int n2, float* dW2, int ldo2,
                             float* db2, float* slabs, int nsplit, const int* expo_a, const int* expo_b,
                             upnerf_wgrad_pending* pending, void* stream);  /* n2 > 0: rows [n2, N) -> dW2 / db2 (as chain2) */
+
+/* "24-bit" operands (f16x3 mode): A16 / Alo8 [M][lda] and, with b_is_f16 = 1, B16 / Blo8 [M][ldb] hold hi + lo8 as the f16x3 field
+ * kernels write them (h16 + h_lo8, gz16 + gz_lo8; exponents per 64 rows); with b_is_f16 = 0 B is fp32 rows, split into hi + lo
+ * on load.  Three MFMAs per block as upnerf_wgrad_f16x3: the operands are exact to 2^-20 of their tile's maximum.  256 x 256
+ * and 256 x 64 blocks; chained on the same pending record as the other two kinds. */
+int upnerf_wgrad_f24p_chain(int M, const uint16_t* A16, const uint8_t* Alo8, int lda, const int32_t* aexp, int N, const void* B,
+                            const uint8_t* Blo8, int ldb, const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db,
+                            float* slabs, int nsplit, const int* expo_a, const int* expo_b, upnerf_wgrad_pending* pending, void* stream);
 
 /* dw[c][k] = sum_m v[m*ldv + c] * X[m][k], c < nvec <= 3; dbv[c] = sum_m v[m*ldv + c]   (N=1/3 heads);
  * K in {32, 64, 128, 256}; scratch: nsplit * 4 * (K+1) floats */

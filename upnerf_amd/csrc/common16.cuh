@@ -26,6 +26,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 // (fp16 half HALF of `pair`) * s + c in one instruction
 template <int HALF>

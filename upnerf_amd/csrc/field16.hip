@@ -205,11 +205,38 @@ __device__ __forceinline__ void tile_copy16(const char* Ph, int e, int e2, uint1
 #if F16_WAVES == 8  // (128-register build; in the default build the hoisted, partly spilled offsets measured FASTER than recomputing them)
   asm volatile("" : "+v"(tid));
 #endif
+  if (dexp == nullptr) asm volatile("" : "+v"(tid));
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
     const int idx = tid + it * THREADS, row = idx / GPR, g = idx % GPR;
     const f32x4 v = *(const f32x4*)(Ph + poff<W>(row, 8 * g));
     if (m0 + row < M) ACT_STORE((f32x4*)((char*)dst + ((size_t)(m0 + row) * W + 8 * g) * 2), v);
+  }
+}
+// The lo plane of the tile -> row-major byte tensor: the rounding residual of every element in 1/32 of the tile's scaled unit,
+// byte = round(32 lo) + 128 (|lo| <= half an ulp of a value below 2^14: |32 lo| <= 128, clamped to 127).  With the hi plane
+// (tile_copy16) that is the "24-bit" storage of the weight-gradient operands (upnerf_wgrad_f24p): hi + lo to 2^-20 of the
+// tile's maximum in 3 bytes.  The fp16 magic-number add rounds to nearest and leaves the byte in the low mantissa bits.
+template <int W, int TILE, int THREADS>
+__device__ __forceinline__ void tile_copy8(const char* Pl, uint8_t* __restrict__ dst, int m0, int M, int tid) {
+  constexpr int GPR = W >> 4, ITER = TILE * GPR / THREADS;  // 16 elements = 16 output bytes per thread and step
+  const h8 k32 = {32, 32, 32, 32, 32, 32, 32, 32}, lim = {127, 127, 127, 127, 127, 127, 127, 127}, magic = {1408, 1408, 1408, 1408, 1408, 1408, 1408, 1408};
+  // (offsets re-derived per call: hoisted out of the layer loop they spill, and every scratch reload is a vmcnt(0) wait behind
+  // the stores in flight)
+  asm volatile("" : "+v"(tid));
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * THREADS, row = idx / GPR, g = idx % GPR;
+    u32x4_t out;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      h8 v = *(const h8*)(Pl + poff<W>(row, 16 * g + 8 * hf)) * k32;
+      v = __builtin_elementwise_min(__builtin_elementwise_max(v, -lim), lim) + magic;  // 1024 + 256 + 128 + q: low byte = q + 128
+      const u32x4_t w = __builtin_bit_cast(u32x4_t, v);
+      out[2 * hf] = __builtin_amdgcn_perm(w[1], w[0], 0x06040200u);
+      out[2 * hf + 1] = __builtin_amdgcn_perm(w[3], w[2], 0x06040200u);
+    }
+    if (m0 + row < M) ACT_STORE((u32x4_t*)(dst + (size_t)(m0 + row) * W + 16 * g), out);
   }
 }
 template <int W, int TILE, int THREADS>
@@ -426,6 +453,9 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     // fp16 storage: the (hi) plane IS the stored tile -- the next write to it is a barrier away.  (f16x3 mode: an option;
     // the weight-gradient operand then is the activation rounded to fp16, the forward chain keeps hi + lo.)
     if (a.h16) tile_copy16<W, TILE, THREADS>(Ph, ecur, a.h16 + (size_t)l * M * W, a.hexp + (size_t)l * ((M + 63) >> 6), m0, M, tid);
+    if constexpr (NP == 2) {
+      if (a.h16 && a.h_lo8) tile_copy8<W, TILE, THREADS>(Pl, a.h_lo8 + (size_t)l * M * W, m0, M, tid);
+    }
     STAMP(6);
   }
 
@@ -892,6 +922,9 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
     if (a.gz16) tile_copy16<W, TILE, THREADS>(Ph, ecur, a.gz16 + (size_t)(D - 1) * M * W, a.gzexp + (size_t)(D - 1) * ((M + 63) >> 6), m0, M, tid);
+    if constexpr (NP == 2) {
+      if (a.gz16 && a.gz_lo8) tile_copy8<W, TILE, THREADS>(Pl, a.gz_lo8 + (size_t)(D - 1) * M * W, m0, M, tid);
+    }
   }
   STAMP(2);  // d h_{D-1}
   // ---- trunk, last layer to first
@@ -929,6 +962,9 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     acc_to_planes<NP, W>(acc, Ph, Pl, row0, n0, 0, ecur, lane);
     __syncthreads();
     if (a.gz16) tile_copy16<W, TILE, THREADS>(Ph, ecur, a.gz16 + (size_t)(l - 1) * M * W, a.gzexp + (size_t)(l - 1) * ((M + 63) >> 6), m0, M, tid);
+    if constexpr (NP == 2) {
+      if (a.gz16 && a.gz_lo8) tile_copy8<W, TILE, THREADS>(Pl, a.gz_lo8 + (size_t)(l - 1) * M * W, m0, M, tid);
+    }
   }
   }
   STAMP(3);  // D-1 trunk layers

@@ -829,7 +829,7 @@ extern "C" int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, c
 extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, const int* aexp, int N, const void* B, int ldb,
                                          const int* bexp, int b_is_f16, int K, const int* expo_a, const int* expo_b, float* slabs,
                                          float* bslabs, int nsplit, int rows, int TN, int TK, const upnerf_wgrad_pending* prev,
-                                         void* stream);
+                                         const uint8_t* Alo, const uint8_t* Blo, void* stream);
 
 // upnerf_wgrad with fp16-stored, tile-scaled operands (the f16 field mode): same slabs + fixed-order reduction.
 extern "C" int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
@@ -846,17 +846,17 @@ extern "C" int upnerf_wgrad_f16p(int M, const uint16_t* A16, int lda, const int3
   const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
   float* bslabs = slabs + (size_t)nsplit * gy * gz * TN * TK;
   int rc = upnerf_wgrad_f16p_partial(M, A16, lda, aexp, N, B, ldb, bexp, b_is_f16, K, expo_a, expo_b, slabs, bslabs, nsplit, rows,
-                                     TN, TK, nullptr, stream);
+                                     TN, TK, nullptr, nullptr, nullptr, stream);
   if (rc) return rc;
   launch_reduce(st, reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db));
   return (int)hipGetLastError();
 }
 
 // Chained upnerf_wgrad_f16p: same pending record as upnerf_wgrad_f16x3_chain (one run may mix both kinds of launches).
-extern "C" int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
-                                       const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, int n2, float* dW2,
-                                       int ldo2, float* db2, float* slabs, int nsplit, const int* expo_a, const int* expo_b,
-                                       upnerf_wgrad_pending* pending, void* stream) {
+static int wgrad_f16p_chain_impl(int M, const uint16_t* A16, const uint8_t* Alo, int lda, const int32_t* aexp, int N, const void* B,
+                                 const uint8_t* Blo, int ldb, const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db,
+                                 int n2, float* dW2, int ldo2, float* db2, float* slabs, int nsplit, const int* expo_a,
+                                 const int* expo_b, upnerf_wgrad_pending* pending, void* stream) {
   if (n2 < 0 || n2 >= N || (n2 > 0 && (!dW2 || (ldo2 & 3)))) return UPNERF_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0 || !A16 || !aexp || !B || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b || !pending)
     return UPNERF_EINVAL;
@@ -873,7 +873,7 @@ extern "C" int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, cons
     if (rc) return rc;
   }
   int rc = upnerf_wgrad_f16p_partial(M, A16, lda, aexp, N, B, ldb, bexp, b_is_f16, K, expo_a, expo_b, slabs, bslabs, nsplit, rows,
-                                     TN, TK, pending->nsplit > 0 ? pending : nullptr, stream);
+                                     TN, TK, pending->nsplit > 0 ? pending : nullptr, Alo, Blo, stream);
   if (rc) return rc;
   upnerf_wgrad_pending P = reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db);
   P.n2 = n2;
@@ -902,6 +902,24 @@ extern "C" int upnerf_vec_wgrad_frag16(int M, const float* v, int ldv, int nvec,
   const int total = nvec * (K + 1);
   hipLaunchKernelGGL(vec_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, nvec, K, nsplit, scratch, dw, dbv);
   return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, const int32_t* aexp, int N, const void* B, int ldb,
+                                       const int32_t* bexp, int b_is_f16, int K, float* dW, int ldo, float* db, int n2, float* dW2,
+                                       int ldo2, float* db2, float* slabs, int nsplit, const int* expo_a, const int* expo_b,
+                                       upnerf_wgrad_pending* pending, void* stream) {
+  return wgrad_f16p_chain_impl(M, A16, nullptr, lda, aexp, N, B, nullptr, ldb, bexp, b_is_f16, K, dW, ldo, db, n2, dW2, ldo2, db2, slabs,
+                               nsplit, expo_a, expo_b, pending, stream);
+}
+// The same with "24-bit" operands: A16 / Alo8 (and B16 / Blo8 when b_is_f16 = 1; a fp32 B is split in the kernel) hold hi + lo8 as
+// written by the f16x3 field kernels (upnerf_field_fwd_args.h_lo8, upnerf_field_bwd_args.gz_lo8); three MFMAs per block.
+extern "C" int upnerf_wgrad_f24p_chain(int M, const uint16_t* A16, const uint8_t* Alo8, int lda, const int32_t* aexp, int N,
+                                       const void* B, const uint8_t* Blo8, int ldb, const int32_t* bexp, int b_is_f16, int K, float* dW,
+                                       int ldo, float* db, float* slabs, int nsplit, const int* expo_a, const int* expo_b,
+                                       upnerf_wgrad_pending* pending, void* stream) {
+  if (!Alo8 || (b_is_f16 & 2)) return UPNERF_EINVAL;
+  return wgrad_f16p_chain_impl(M, A16, Alo8, lda, aexp, N, B, Blo8, ldb, bexp, b_is_f16, K, dW, ldo, db, 0, nullptr, 0, nullptr, slabs, nsplit,
+                               expo_a, expo_b, pending, stream);
 }
 
 // ---- small matrix-vector products of the folded colour layer (packing): y[m] = add[m] + sum_k A[m][k] x[k] (trans = 0, one wave

@@ -20,6 +20,7 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef short s4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 // Rows per staged chunk: two 16-deep MFMA steps, or one for the 256x256 block, whose 128 accumulator registers per wave
 // leave room for two register sets only at half the chunk size (same bytes in flight, but continuously).
@@ -245,13 +246,18 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
 // [k-block 16][lane 64][8], feature 16 s + 8 (j / 4) + 4 (lane / 32) + j % 4, one exponent per 32 rows.  A thread moves the 16 bytes
 // of one lane: sixteen consecutive threads read sixteen consecutive rows of one (k-block, lane half) = 256 contiguous bytes, and
 // the two 8-byte halves of the piece land at their natural columns of the same LDS image.  256-wide operands only.
-template <int MTW, int NTW, int PKB, int FRAG>
+// NP = 2 ("24-bit" storage, upnerf_wgrad_f24p): beside every fp16 tensor a byte tensor of the same shape holds the rounding
+// residual the field kernels' lo plane held, quantised to 1/32 of the tile's scaled unit (byte = round(32 lo) + 128): the
+// operand is hi + lo again to 2^-20 of its tile's maximum, three MFMAs per block as in the f16x3 kernel; a fp32 B operand is
+// split into hi + lo here.  3 bytes per stored element instead of 4.  Row-major operands only (no FRAG).
+template <int MTW, int NTW, int PKB, int FRAG, int NP>
 __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N, int K, const uint16_t* __restrict__ A, int lda,
                                                                  const int* __restrict__ aexp, const void* __restrict__ Bv, int ldb,
                                                                  const int* __restrict__ bexp, const int* __restrict__ expo_a,
                                                                  const int* __restrict__ expo_b, float* __restrict__ slabs,
                                                                  float* __restrict__ bslabs, int rows_per_split,
-                                                                 upnerf_wgrad_pending prev) {
+                                                                 upnerf_wgrad_pending prev, const uint8_t* __restrict__ Alo,
+                                                                 const uint8_t* __restrict__ Blo) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   constexpr int FX_CHUNK = (MTW * NTW == 16) ? FX_CHUNK_BIG : 32;
   constexpr int PN = (TN + 127) / 128, PK = (TK + 127) / 128;
@@ -267,7 +273,10 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   // fragment-ordered operands: a row has TN / 8 (TK / 8) 16-byte pieces, the 512 threads cover RPA (RPB) rows per pass
   constexpr int RPA = FX_THREADS / (TN / 8), RPB = PKB ? FX_THREADS / (TK / 8) : 1;
   static_assert(!FRAG || (FX_CHUNK % RPA == 0 && (!PKB || FX_CHUNK % RPB == 0)), "whole passes per chunk");
-  __shared__ __attribute__((aligned(16))) char lds[2 * (SZA + SZB)];  // [buffer][A | B], one plane each
+  static_assert(NP == 1 || !FRAG, "hi + lo8 operands are row-major");
+  constexpr int BUF = NP * (SZA + SZB);                                 // [buffer][A hi | A lo | B hi | B lo] (NP = 1: no lo planes)
+  constexpr int OB = NP * SZA;                                          // B planes start here
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int wn = wave / WK, wk = wave % WK;
@@ -295,8 +304,11 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   h8 ra0[A8], ra1[A8], rbp0[B8 ? B8 : 1], rbp1[B8 ? B8 : 1];
   f32x4 rbf0[B4 ? B4 : 1], rbf1[B4 ? B4 : 1];
   int xa0[A8], xa1[A8], xb0[B8 ? B8 : 1], xb1[B8 ? B8 : 1];  // tile exponents of the rows just loaded
+  u32x2_t la0[A8], la1[A8], lb0[B8 ? B8 : 1], lb1[B8 ? B8 : 1];  // NP = 2: the residual bytes of the same pieces
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto gload = [&](h8 (&ra)[A8], int (&xa)[A8], h8 (&rbp)[B8 ? B8 : 1], int (&xb)[B8 ? B8 : 1], f32x4 (&rbf)[B4 ? B4 : 1], int mc) {
+  const u32x2_t mid8 = {0x80808080u, 0x80808080u};  // (byte 128 = residual 0)
+  auto gload = [&](h8 (&ra)[A8], int (&xa)[A8], h8 (&rbp)[B8 ? B8 : 1], int (&xb)[B8 ? B8 : 1], f32x4 (&rbf)[B4 ? B4 : 1],
+                   u32x2_t (&la)[A8], u32x2_t (&lb)[B8 ? B8 : 1], int mc) {
 #pragma unroll
     for (int q = 0; q < A8; ++q) {
       if constexpr (FRAG) {
@@ -309,6 +321,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
         const int m = mc + row;
         const bool ok = m < mend && nblk + 8 * c8 < N;
         ra[q] = ok ? NT_LOAD((const h8*)&A[(size_t)m * lda + nblk + 8 * c8]) : zero8;
+        if constexpr (NP == 2) la[q] = ok ? NT_LOAD((const u32x2_t*)&Alo[(size_t)m * lda + nblk + 8 * c8]) : mid8;
         xa[q] = ok ? aexp[m >> 6] : 0;
       }
     }
@@ -325,6 +338,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
           const int m = mc + row;
           const bool ok = m < mend && kblk + 8 * c8 < K;
           rbp[q] = ok ? NT_LOAD((const h8*)&Bh[(size_t)m * ldb + kblk + 8 * c8]) : zero8;
+          if constexpr (NP == 2) lb[q] = ok ? NT_LOAD((const u32x2_t*)&Blo[(size_t)m * ldb + kblk + 8 * c8]) : mid8;
           xb[q] = ok ? bexp[m >> 6] : 0;
         }
       }
@@ -341,9 +355,21 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
     e = e > 15 ? 15 : (e < -24 ? -24 : e);
     return (_Float16)ldexpf(1.0f, e);
   };
+  // eight residual bytes -> fp16 residuals in units of 2^-e of the tensor: (byte - 128) / 32 * f, f = 2^(e_tensor - e_tile)
+  auto lo8 = [](u32x2_t w, _Float16 f) {
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    us8 u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] = (unsigned short)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+    h8 v = __builtin_convertvector(u, h8);
+    const _Float16 s = f * (_Float16)0.03125f, o = f * (_Float16)-4.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * s + o;
+    return v;
+  };
   auto lstore = [&](const h8 (&ra)[A8], const int (&xa)[A8], const h8 (&rbp)[B8 ? B8 : 1], const int (&xb)[B8 ? B8 : 1],
-                    const f32x4 (&rbf)[B4 ? B4 : 1], int buf) {
-    char* base = lds + buf * (SZA + SZB);
+                    const f32x4 (&rbf)[B4 ? B4 : 1], const u32x2_t (&la)[A8], const u32x2_t (&lb)[B8 ? B8 : 1], int buf) {
+    char* base = lds + buf * BUF;
 #pragma unroll
     for (int q = 0; q < A8; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TN / 8), c8 = idx - row * (TN / 8);
@@ -354,6 +380,12 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
       h8 v = ra[q];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * f;
+      if constexpr (NP == 2) {
+        const h8 vl = lo8(la[q], (_Float16)1.0f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += (float)vl[j] * inv;
+        *(h8*)(base + SZA + himg<FX_CHUNK>(row, 8 * c8)) = lo8(la[q], f);
+      }
       if constexpr (FRAG) {
         const int r = (tid % RPA) + RPA * q, s2 = tid / RPA, col = 16 * (s2 >> 1) + 4 * (s2 & 1);
         *(h4*)(base + himg<FX_CHUNK>(r, col)) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
@@ -372,10 +404,11 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
         for (int j = 0; j < 8; ++j) v[j] = v[j] * f;
         if constexpr (FRAG) {
           const int r = (tid % RPB) + RPB * q, s2 = tid / RPB, col = 16 * (s2 >> 1) + 4 * (s2 & 1);
-          *(h4*)(base + SZA + himg<FX_CHUNK>(r, col)) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
-          *(h4*)(base + SZA + himg<FX_CHUNK>(r, col + 8)) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+          *(h4*)(base + OB + himg<FX_CHUNK>(r, col)) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+          *(h4*)(base + OB + himg<FX_CHUNK>(r, col + 8)) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
         } else {
-          *(h8*)(base + SZA + himg<FX_CHUNK>(row, 8 * c8)) = v;
+          *(h8*)(base + OB + himg<FX_CHUNK>(row, 8 * c8)) = v;
+          if constexpr (NP == 2) *(h8*)(base + OB + SZB + himg<FX_CHUNK>(row, 8 * c8)) = lo8(lb[q], f);
         }
       }
     } else {
@@ -385,46 +418,67 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
         const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
         typedef float f2 __attribute__((ext_vector_type(2)));
         typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
-        const hh2 h0 = __builtin_convertvector(f2{rbf[q][0], rbf[q][1]} * sb, hh2), h1 = __builtin_convertvector(f2{rbf[q][2], rbf[q][3]} * sb, hh2);
-        *(h4*)(base + SZA + himg<FX_CHUNK>(row, 4 * c4)) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+        const f2 x0 = f2{rbf[q][0], rbf[q][1]} * sb, x1 = f2{rbf[q][2], rbf[q][3]} * sb;
+        const hh2 h0 = __builtin_convertvector(x0, hh2), h1 = __builtin_convertvector(x1, hh2);
+        *(h4*)(base + OB + himg<FX_CHUNK>(row, 4 * c4)) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+        if constexpr (NP == 2) {  // a fp32 operand (the encoding): split here, as the f16x3 kernel does
+          const hh2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f2), hh2);
+          const hh2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f2), hh2);
+          *(h4*)(base + OB + SZB + himg<FX_CHUNK>(row, 4 * c4)) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+        }
       }
     }
   };
   const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
   const int trow = 8 * (g >> 1) + tq, tcol = 16 * (g & 1) + 4 * tp;
   auto contract = [&](int buf) {
-    const char* base = lds + buf * (SZA + SZB);
+    const char* base = lds + buf * BUF;
 #pragma unroll
     for (int kk = 0; kk < FX_CHUNK / 16; ++kk) {
-      h8 ah[MT];
+      h8 ah[MT], al[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int o0 = himg<FX_CHUNK>(16 * kk + trow, n0 + 32 * mt + tcol), o1 = himg<FX_CHUNK>(16 * kk + trow + 4, n0 + 32 * mt + tcol);
         const h4 x0 = tr_read(base, o0), x1 = tr_read(base, o1);
         ah[mt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (NP == 2) {
+          const h4 y0 = tr_read(base + SZA, o0), y1 = tr_read(base + SZA, o1);
+          al[mt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int o0 = himg<FX_CHUNK>(16 * kk + trow, k0 + 32 * nt + tcol), o1 = himg<FX_CHUNK>(16 * kk + trow + 4, k0 + 32 * nt + tcol);
-        const h4 x0 = tr_read(base + SZA, o0), x1 = tr_read(base + SZA, o1);
+        const h4 x0 = tr_read(base + OB, o0), x1 = tr_read(base + OB, o1);
         const h8 bh = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+        h8 bl;
+        if constexpr (NP == 2) {
+          const h4 y0 = tr_read(base + OB + SZB, o0), y1 = tr_read(base + OB + SZB, o1);
+          bl = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+          if constexpr (NP == 2) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+          }
+        }
       }
     }
   };
   // two register sets: the loads of chunk c+2 are in flight while chunk c is contracted (rows beyond mend load as zeros)
-  gload(ra0, xa0, rbp0, xb0, rbf0, mbeg);
-  gload(ra1, xa1, rbp1, xb1, rbf1, mbeg + FX_CHUNK);
+  gload(ra0, xa0, rbp0, xb0, rbf0, la0, lb0, mbeg);
+  gload(ra1, xa1, rbp1, xb1, rbf1, la1, lb1, mbeg + FX_CHUNK);
 #pragma unroll 1
   for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
-    lstore(ra0, xa0, rbp0, xb0, rbf0, 0);
+    lstore(ra0, xa0, rbp0, xb0, rbf0, la0, lb0, 0);
     __syncthreads();
-    gload(ra0, xa0, rbp0, xb0, rbf0, mc + 2 * FX_CHUNK);
+    gload(ra0, xa0, rbp0, xb0, rbf0, la0, lb0, mc + 2 * FX_CHUNK);
     contract(0);
-    lstore(ra1, xa1, rbp1, xb1, rbf1, 1);
+    lstore(ra1, xa1, rbp1, xb1, rbf1, la1, lb1, 1);
     __syncthreads();
-    gload(ra1, xa1, rbp1, xb1, rbf1, mc + 3 * FX_CHUNK);
+    gload(ra1, xa1, rbp1, xb1, rbf1, la1, lb1, mc + 3 * FX_CHUNK);
     contract(1);
   }
   const float unscale = ldexpf(1.0f, -(ea + eb));
@@ -463,16 +517,16 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   }
 }
 
-template <int MTW, int NTW, int PKB, int FRAG>
+template <int MTW, int NTW, int PKB, int FRAG, int NP = 1>
 int launch_p(int M, int N, int K, const uint16_t* A, int lda, const int* aexp, const void* B, int ldb, const int* bexp,
              const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st,
-             const upnerf_wgrad_pending* prevp) {
+             const upnerf_wgrad_pending* prevp, const uint8_t* Alo = nullptr, const uint8_t* Blo = nullptr) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   dim3 grid(nsplit, (N + TN - 1) / TN, (K + TK - 1) / TK);
   upnerf_wgrad_pending prev = {};
   if (prevp) prev = *prevp;
-  hipLaunchKernelGGL((wgrad_f16p_kernel<MTW, NTW, PKB, FRAG>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, aexp, B, ldb, bexp, expo_a,
-                     expo_b, slabs, bslabs, rows, prev);
+  hipLaunchKernelGGL((wgrad_f16p_kernel<MTW, NTW, PKB, FRAG, NP>), grid, dim3(FX_THREADS), 0, st, M, N, K, A, lda, aexp, B, ldb, bexp,
+                     expo_a, expo_b, slabs, bslabs, rows, prev, Alo, Blo);
   return (int)hipGetLastError();
 }
 
@@ -518,8 +572,16 @@ extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N,
 extern "C" int upnerf_wgrad_f16p_partial(int M, const uint16_t* A16, int lda, const int* aexp, int N, const void* B, int ldb,
                                          const int* bexp, int b_is_f16, int K, const int* expo_a, const int* expo_b, float* slabs,
                                          float* bslabs, int nsplit, int rows, int TN, int TK, const upnerf_wgrad_pending* prev,
-                                         void* stream) {
+                                         const uint8_t* Alo, const uint8_t* Blo, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (Alo) {  // hi + lo8 operands ("24-bit" storage): row-major only; a fp16 B needs its residual bytes too
+    if ((b_is_f16 & 2) || ((b_is_f16 & 1) && !Blo)) return UPNERF_EINVAL;
+    if (TN == 256 && TK == 256 && (b_is_f16 & 1))
+      return launch_p<4, 4, 1, 0, 2>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev, Alo, Blo);
+    if (TN == 256 && TK == 64 && !(b_is_f16 & 1))
+      return launch_p<4, 1, 0, 0, 2>(M, N, K, A16, lda, aexp, B, ldb, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev, Alo, nullptr);
+    return UPNERF_EUNSUP;
+  }
   const bool frag = (b_is_f16 & 2) != 0;  // bit 1: fp16 operands in the fragment order of the register-resident field kernels
   b_is_f16 &= 1;
   if (frag && ((N != 256 && N != 128) || (b_is_f16 && K != N) || (!b_is_f16 && N != 256))) return UPNERF_EUNSUP;

@@ -255,6 +255,15 @@ class WgradChain:
             n2, dW2_ptr, ldo2, db2_ptr, ptr(ws), ns, expo_a, expo_b, C.byref(self.pending), stream()), units=M)
         check(rc, "upnerf_wgrad_f16p_chain")
 
+    def wgrad_p24(self, M, A16, Alo8, lda, aexp, N, B, Blo8, ldb, bexp, K, dW_ptr, ldo, db_ptr, expo_a, expo_b):
+        """The "24-bit" operands of the f16x3 mode (hi fp16 + residual byte, upnerf_wgrad_f24p_chain) as a link of the run."""
+        ns = nsplit_for(M)
+        ws = self._slabs(ns)
+        rc = TIMER.run(f"wgrad24p_{N}x{K}", lambda: lib.upnerf_wgrad_f24p_chain(
+            M, ptr(A16), ptr(Alo8), lda, ptr(aexp), N, ptr(B), ptr(Blo8), ldb, ptr(bexp), int(bexp is not None), K, dW_ptr, ldo, db_ptr,
+            ptr(ws), ns, expo_a, expo_b, C.byref(self.pending), stream()), units=M)
+        check(rc, "upnerf_wgrad_f24p_chain")
+
     def finish(self):
         check(lib.upnerf_wgrad_finish(C.byref(self.pending), stream()), "upnerf_wgrad_finish")
 

@@ -167,10 +167,14 @@ class _FieldPass(torch.autograd.Function):
         # f16 mode: trunk activations are STORED as fp16 (the kernel's LDS plane per 64-sample tile + the tile's exponent):
         # half the bytes written here and read back by the weight-gradient kernels; fp32 only for the last layer (its
         # consumers are the density-head and final-layer weight gradients)
-        store16 = train and use16 and (FIELD_MODE == "f16" or WGRAD_STORE == "f16")
+        store16 = train and use16 and (FIELD_MODE == "f16" or WGRAD_STORE in ("f16", "f24"))
+        # "f24" (f16x3 mode only): beside h16 a byte tensor with the residual of every element -- hi + lo to 2^-20 of the tile's
+        # maximum in 3 bytes instead of 4 (an option like "f16", reported beside `value`)
+        store24 = store16 and FIELD_MODE != "f16" and WGRAD_STORE == "f24" and not rr
         ntile = Mp // 32 if rr else (M + 63) // 64  # exponent tables: one entry per 64 rows whatever the kernel's tile (rr: per 32)
         h16 = torch.empty(D, Mp, W, device=dev, dtype=torch.float16) if store16 else None  # (rr: fragment order, see dequant16)
         hexp = torch.empty(D, ntile, device=dev, dtype=torch.int32) if store16 else None
+        h_lo8 = torch.empty(D, M, W, device=dev, dtype=torch.uint8) if store24 else None
         # (rr: no fp32 copy of the last layer either -- the density head's and the final layer's weight gradients read its fragments)
         h = (None if rr else _empty(1, M, W, device=dev) if store16 else _empty(D, M, W, device=dev)) if train else None
         # rr: e leaves as fp16 operand fragments only (compositing and the joined heads' weight gradient read those) unless a
@@ -205,7 +209,7 @@ class _FieldPass(torch.autograd.Function):
                           P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None,
                           planes=_planes(), tile_rows=tile, wnorm=ptr(wnorm), h16=ptr(h16), hexp=ptr(hexp),
                           h_last_only=int(store16), x0f=ptr(x0f), e16=ptr(e16), eexp=ptr(eexp),
-                          g2_16=ptr(g2_16), g2exp=ptr(g2exp), r1_16=ptr(r1_16), r1exp=ptr(r1exp), g1_16=ptr(g1_16), g1exp=ptr(g1exp))
+                          g2_16=ptr(g2_16), g2exp=ptr(g2exp), r1_16=ptr(r1_16), r1exp=ptr(r1exp), g1_16=ptr(g1_16), g1exp=ptr(g1exp), h_lo8=ptr(h_lo8))
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
@@ -232,7 +236,7 @@ class _FieldPass(torch.autograd.Function):
         ctx.rr, ctx.Mp = rr, Mp
         ctx.has_a = a_rows is not None
         ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, z=z, c_rows=c_rows, aux=aux, P=P, sigma_s=sigma_s,
-                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, hmask=hmask, amax=amax, mx32=mx32, e=e, e16=e16, eexp=eexp, g2_16=g2_16, g2exp=g2exp, r1_16=r1_16, r1exp=r1exp, g1_16=g1_16, g1exp=g1exp, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
+                         sigma_c=sigma_c, rgb=rgb, x0=x0, h=h, h16=h16, hexp=hexp, h_lo8=h_lo8, hmask=hmask, amax=amax, mx32=mx32, e=e, e16=e16, eexp=eexp, g2_16=g2_16, g2exp=g2exp, r1_16=r1_16, r1exp=r1exp, g1_16=g1_16, g1exp=g1exp, g1=g1, g2=g2, r1=r1, PT16=PT16, wexp=wexp, x0f=x0f,
                          w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s, wnorm=wnorm)
         z0 = torch.zeros(0, device=dev)
@@ -280,6 +284,8 @@ class _FieldPass(torch.autograd.Function):
         gz_h = None if store16 else _empty(D, M, W, device=dev)
         gz16 = torch.empty(D + int(rr), Mp, W, device=dev, dtype=torch.float16) if store16 else None  # (rr: fragment order)
         gzexp = torch.empty(D + int(rr), sv["hexp"].shape[1], device=dev, dtype=torch.int32) if store16 else None
+        store24 = sv.get("h_lo8") is not None
+        gz_lo8 = torch.empty(D, M, W, device=dev, dtype=torch.uint8) if store24 else None
         # [gz_r1 | gz_g1] as ONE [M][W] tensor when both heads are on and the chained f16x3 weight gradients run: the two first
         # layers of the heads are both fed by e, so their weight gradients are one launch that reads e once (chain.wgrad2)
         joined = _join_ok(cfg, W, use16, rr, tile_ok=ctx.tile_rows == 64)  # (upnerf_ray_sum, the fallback, wants dense tensors)
@@ -316,7 +322,7 @@ class _FieldPass(torch.autograd.Function):
                           r1=ptr(sv["r1"]), hmask=ptr(sv["hmask"]), gmax=ptr(gmax), gz_h=ptr(gz_h), gz_e=ptr(gz_e),
                           gz_g1=(gz_rg.data_ptr() + 4 * W2) if gz_rg is not None else ptr(gz_g1), gz_g2=ptr(gz_g2),
                           gz_r1=ptr(gz_rg) if gz_rg is not None else ptr(gz_r1), gz_rg_ld=W if gz_rg is not None else 0,
-                          gz_rg16=ptr(gz_rg16), gzrgexp=ptr(gzrgexp), gz_g2_16=ptr(gz_g2_16), gzg2exp=ptr(gzg2exp), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
+                          gz_rg16=ptr(gz_rg16), gzrgexp=ptr(gzrgexp), gz_g2_16=ptr(gz_g2_16), gzg2exp=ptr(gzg2exp), gz_lo8=ptr(gz_lo8), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, tile_rows=ctx.tile_rows, xs=ptr(sv.get("x0f")), gz16=ptr(gz16),
                           gzexp=ptr(gzexp), tile_part=ptr(ray_part if rr else tile_part), wnorm=ptr(sv.get("wnorm")))
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
@@ -360,7 +366,11 @@ class _FieldPass(torch.autograd.Function):
                 h16, hexp = sv["h16"], sv["hexp"]
 
                 def wgp(l, B, ldb, bexp, K, off, ldo, boff, ib):
-                    if chain is not None:
+                    if store24:  # hi + lo8 operands, three MFMAs per block (B: the previous layer's pair, or the fp32 encoding)
+                        blo = sv["h_lo8"][l - 1] if bexp is not None else None
+                        chain.wgrad_p24(M, gz16[l], gz_lo8[l], W, gzexp[l], W, B, blo, ldb, bexp, K, at(off), ldo,
+                                        None if boff is None else at(boff), EA(l), EB(ib))
+                    elif chain is not None:
                         chain.wgrad_p(M, gz16[l], W, gzexp[l], W, B, ldb, bexp, K, at(off), ldo, None if boff is None else at(boff),
                                       EA(l), EB(ib), frag=rr)
                     else:
