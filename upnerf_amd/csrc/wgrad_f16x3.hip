@@ -186,14 +186,28 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     gload(ra1, rb1, mbeg + FX_CHUNK);
 #pragma unroll 1
     for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
+      // (WG_EXP_*: timing experiments with wrong results -- what is left of the launch without the loads / the staging (which is
+      // also the only consumer of the loads: nothing waits for them any more) / the MFMAs; tools/bench_wgrad.py)
+#ifndef WG_EXP_NOSTAGE
       lstore(ra0, rb0, 0);
+#endif
       __syncthreads();
+#ifndef WG_EXP_NOLOAD
       gload(ra0, rb0, mc + 2 * FX_CHUNK);
+#endif
+#ifndef WG_EXP_NOMMA
       contract(0);
+#endif
+#ifndef WG_EXP_NOSTAGE
       lstore(ra1, rb1, 1);
+#endif
       __syncthreads();
+#ifndef WG_EXP_NOLOAD
       gload(ra1, rb1, mc + 3 * FX_CHUNK);
+#endif
+#ifndef WG_EXP_NOMMA
       contract(1);
+#endif
     }
   } else {
     int buf = 0;
