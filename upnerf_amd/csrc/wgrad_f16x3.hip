@@ -315,10 +315,18 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   acc_zero(acc);
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this thread's 8 columns of A, summed over its rows (natural units)
 
-  h8 ra0[A8], ra1[A8], rbp0[B8 ? B8 : 1], rbp1[B8 ? B8 : 1];
-  f32x4 rbf0[B4 ? B4 : 1], rbf1[B4 ? B4 : 1];
-  int xa0[A8], xa1[A8], xb0[B8 ? B8 : 1], xb1[B8 ? B8 : 1];  // tile exponents of the rows just loaded
-  u32x2_t la0[A8], la1[A8], lb0[B8 ? B8 : 1], lb1[B8 ? B8 : 1];  // NP = 2: the residual bytes of the same pieces
+  // NS register sets: the loads of chunk c + NS are requested when chunk c has been staged.  Two sets (one loop iteration, ~2 us)
+  // left the kernel waiting for HBM latency (with nothing waiting for the loads it runs at 7.3 TB/s); the fp16
+  // operands are small enough for four (10 registers per set at the 256 x 256 block).
+#ifndef WG_P_SETS
+#define WG_P_SETS 4
+#endif
+  constexpr int NS = NP == 1 ? WG_P_SETS : 2;
+  static_assert(NS % 2 == 0, "the LDS image is double buffered: set u goes to buffer u & 1");
+  h8 ra[NS][A8], rbp[NS][B8 ? B8 : 1];
+  f32x4 rbf[NS][B4 ? B4 : 1];
+  int xa[NS][A8], xb[NS][B8 ? B8 : 1];  // tile exponents of the rows just loaded
+  u32x2_t la[NS][A8], lb[NS][B8 ? B8 : 1];  // NP = 2: the residual bytes of the same pieces
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const u32x2_t mid8 = {0x80808080u, 0x80808080u};  // (byte 128 = residual 0)
   auto gload = [&](h8 (&ra)[A8], int (&xa)[A8], h8 (&rbp)[B8 ? B8 : 1], int (&xb)[B8 ? B8 : 1], f32x4 (&rbf)[B4 ? B4 : 1],
@@ -482,18 +490,17 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
     }
   };
   // two register sets: the loads of chunk c+2 are in flight while chunk c is contracted (rows beyond mend load as zeros)
-  gload(ra0, xa0, rbp0, xb0, rbf0, la0, lb0, mbeg);
-  gload(ra1, xa1, rbp1, xb1, rbf1, la1, lb1, mbeg + FX_CHUNK);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], mbeg + u * FX_CHUNK);
 #pragma unroll 1
-  for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
-    lstore(ra0, xa0, rbp0, xb0, rbf0, la0, lb0, 0);
-    __syncthreads();
-    gload(ra0, xa0, rbp0, xb0, rbf0, la0, lb0, mc + 2 * FX_CHUNK);
-    contract(0);
-    lstore(ra1, xa1, rbp1, xb1, rbf1, la1, lb1, 1);
-    __syncthreads();
-    gload(ra1, xa1, rbp1, xb1, rbf1, la1, lb1, mc + 3 * FX_CHUNK);
-    contract(1);
+  for (int mc = mbeg; mc < mend; mc += NS * FX_CHUNK) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {  // (chunks past mend load and contract zeros)
+      lstore(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], u & 1);
+      __syncthreads();
+      gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], mc + (NS + u) * FX_CHUNK);
+      contract(u & 1);
+    }
   }
   const float unscale = ldexpf(1.0f, -(ea + eb));
   const size_t blk = ((size_t)split * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
