@@ -149,9 +149,9 @@ typedef struct {
                                     product); 1 = f16 (fp16 weights and activations, one MFMA per product, fp32 accumulate:
                                     BASELINE.json configs[3]); the lo halves of P16 are then never read */
   int32_t tile_rows;             /* upnerf_field_fwd_f16x3 only: samples per workgroup.  0 or 64: four waves, two workgroups per CU.
-                                    128 (needs S >= 64): eight waves, software-pipelined trunk, each weight fragment enters the
-                                    CU once per 128 samples; needs x0f when the field has a skip layer.  The backward pass of the
-                                    same evaluation must be given the same value (the hmask layout follows the tile).
+                                    (128, round 3's software-pipelined trunk, left the library in round 4: UPNERF_EINVAL.)  The
+                                    backward pass of the same evaluation must be given the same value (the hmask layout follows
+                                    the tile).
                                     256 (planes = 1 only, S >= 32): the REGISTER-RESIDENT kernels of csrc/field16rr.hip -- eight waves
                                     of 32 samples whose activations stay in registers, every weight slab staged once per workgroup
                                     in an LDS ring by LDS-DMA.  Contract of that variant: P16 / PT16 from upnerf_frag16 with
@@ -172,9 +172,7 @@ typedef struct {
   int32_t* hexp;                 /* [D][ceil(M/64)] */
   int32_t h_last_only;           /* with h16: `h` (if non-NULL) receives layer D-1 only, as [M][W] fp32 (density-head and
                                     final-layer weight gradients read it) */
-  void* x0f;                     /* upnerf_field_fwd_f16x3 with 128-sample tiles and a skip layer: scratch of ceil(M/128) * 32768
-                                    bytes.  The workgroup parks the encoding of its tile there as fp16 operand fragments and
-                                    reads them back at the skip layer (the planes hold h_{skip-1} by then) */
+  void* x0f;                     /* reserved (was the 128-sample tiling's encoding scratch): ignored */
   uint16_t* e16;                 /* tile_rows = 256 only, or NULL: e as fp16 operand fragments [ceil(M/256) * 8][16][64][8] like one
                                     layer of h16 (then `e` may be NULL); upnerf_composite_fwd / _bwd and upnerf_wgrad_f16p read it */
   int32_t* eexp;                 /* [ceil(M/256) * 8] */
@@ -295,8 +293,7 @@ typedef struct {
   uint16_t* gz16;                /* [D][M][W] fp16 bits of gz_h, tile-scaled like h16 (then gz_h may be NULL).  tile_rows = 256
                                     with gz_e == NULL: [D + 1] layers, the last one d e in the same form (and gzexp [D + 1] rows) */
   int32_t* gzexp;                /* [D][ceil(M/64)] */
-  void* xs;                      /* 128-sample tiles with a skip layer and need_dxyz: scratch of ceil(M/128) * 32768 bytes (the
-                                    forward pass's x0f may be reused: its content is dead by now) */
+  void* xs;                      /* reserved (was the 128-sample tiling's scratch): ignored */
   float* tile_part;              /* NULL, or [ceil(M/64)][UPNERF_TILE_PART_STRIDE] (f16x3 variant, tile_rows 0 / 64 only): per-tile
                                     partial sums of what upnerf_vec_wgrad (dpre_sig_c x g2, dpre_rgb x r1) and upnerf_ray_sum
                                     (gz_g1, gz_r1) would re-read M x W/2 tensors for; finished by upnerf_tile_part_finish.

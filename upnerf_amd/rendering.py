@@ -56,7 +56,7 @@ def _field16_ok(pk, S: int) -> bool:
 #   weight-gradient kernel nothing: 2.69 / 2.65 / 0.25 ms against 2.69 / 2.66 / 0.22.  It is the bytes, not the store pattern.)
 WGRAD_STORE = __import__("os").environ.get("UPNERF_WGRAD_STORE", "f32")
 # Per-tile partial sums of the vector heads and per-ray sums from the backward field kernel (upnerf_field_bwd_args.tile_part);
-# 0 = the separate upnerf_vec_wgrad / upnerf_ray_sum launches (always used with 128-sample tiles and the fp32-MFMA kernels).
+# 0 = the separate upnerf_vec_wgrad / upnerf_ray_sum launches (always used with the fp32-MFMA kernels).
 TILE_PARTIALS = int(__import__("os").environ.get("UPNERF_TILE_PARTIALS", "1"))
 # Slab reductions of the f16x3 weight gradients inside the next weight-gradient launch (upnerf_wgrad_f16x3_chain).
 WGRAD_CHAIN = int(__import__("os").environ.get("UPNERF_WGRAD_CHAIN", "1"))
