@@ -614,6 +614,88 @@ def test_wgrad_f16p_chain_on_fragments_with_a_split_result(hip, M, n2):
         assert float((dW2[:, 256:] - 7.0).abs().max()) == 0.0  # nothing written past the 256 columns of a row
 
 
+@pytest.mark.parametrize("R,S,mode,use_cand,use_rgb,raygrad", [(300, 64, 3, False, False, False), (41, 70, 3, False, True, True),
+                                                                 (37, 70, 1, True, True, False), (1, 40, 1, True, True, True),
+                                                                 (2, 32, 0, True, False, False)])
+def test_rr_kernels_match_the_tile_kernels_on_the_rarer_paths(hip, R, S, mode, use_cand, use_rgb, raygrad):
+    """f16 mode: register-resident kernels against the 64-sample tile kernels of the same arithmetic on paths the goldens do not
+    take -- a field without candidate encoding (mode 3: the feature map's rank-1 term is then ALL of d e; round 4 found it
+    dropped), no gradient into the rays (the d x0 stages leave the slab sequence), a single ray, S = 32."""
+    from upnerf_amd import synth
+    from upnerf_amd.nerf import NeRF
+    rd = hip["rendering"]
+    kw = dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    model = NeRF("coarse", c2f=None, **kw)
+    model.load_state_dict(synth.nerf_state("coarse", seed=3, **kw))
+    model = model.cuda()
+    pk = model.packer
+    g = lambda shape, seed: torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+    o = (g((R, 3), 70) * 0.3).cuda()
+    d = torch.nn.functional.normalize(g((R, 3), 71), dim=-1).cuda()
+    z = (torch.sort(g((R, S), 72).abs() * 3 + 0.1, dim=-1).values).cuda()
+    c_rows, a_rows = g((R, 16), 73).cuda(), g((R, 48), 74).cuda()
+    old = rd.FIELD_MODE, rd.FIELD_RR
+    res = {}
+    try:
+        for tag, rr in (("tile", 0), ("rr", 1)):
+            rd.FIELD_MODE, rd.FIELD_RR = "f16", rr
+            cfg = rd._PassCfg(pk, mode, use_cand, use_rgb, [1.0] * 10, [1.0] * 4)
+            leaves = [t.clone().requires_grad_(rg) for t, rg in zip((o, d, c_rows, a_rows, model.packed().detach()),
+                                                                     (raygrad, raygrad, True, True, True))]
+            outs = rd._FieldPass.apply(leaves[0], leaves[1], z, leaves[2], leaves[3], leaves[4], cfg)
+            sum((t * g(tuple(t.shape), 80 + i).cuda()).sum() for i, t in enumerate(outs) if t.numel() and t.requires_grad).backward()
+            torch.cuda.synchronize()
+            res[tag] = ([cpu(t) for t in outs], [cpu(t.grad) if t.grad is not None else None for t in leaves])
+    finally:
+        rd.FIELD_MODE, rd.FIELD_RR = old
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+    for i, (a, b) in enumerate(zip(res["rr"][0], res["tile"][0])):
+        if a.numel():
+            assert l2(a, b) < 2e-3, ("out", i, l2(a, b))
+    for i, (a, b) in enumerate(zip(res["rr"][1], res["tile"][1])):
+        assert (a is None) == (b is None), i
+        if a is not None and float(b.abs().max()) > 0:
+            assert l2(a, b) < 2e-2, ("grad", i, l2(a, b))
+    assert float(res["rr"][1][4].abs().max()) > 0
+
+
+@pytest.mark.parametrize("R,S,mode,use_cand,use_rgb", [(37, 70, 1, True, True), (11, 33, 0, True, False), (9, 128, 2, False, True),
+                                                         (5, 64, 3, False, False)])
+def test_rr_inference_pass_matches_the_training_forward(hip, R, S, mode, use_cand, use_rgb):
+    """f16 mode, register-resident kernels: the no-grad pass (e / g2 leave as fp16 fragments, nothing else is stored) gives the
+    outputs of the training forward (which may keep fp32 rows of e for a single head) to the mode's rounding -- including the
+    density-only mode 3, whose feature map needs the final layer although no head consumes e (round 4: it was skipped)."""
+    from upnerf_amd import synth
+    from upnerf_amd.nerf import NeRF
+    rd = hip["rendering"]
+    kw = dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    model = NeRF("coarse", c2f=None, **kw)
+    model.load_state_dict(synth.nerf_state("coarse", seed=3, **kw))
+    model = model.cuda()
+    pk = model.packer
+    g = lambda shape, seed: torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+    o = (g((R, 3), 70) * 0.3).cuda()
+    d = torch.nn.functional.normalize(g((R, 3), 71), dim=-1).cuda()
+    z = (torch.sort(g((R, S), 72).abs() * 3 + 0.1, dim=-1).values).cuda()
+    c_rows, a_rows = g((R, 16), 73).cuda(), g((R, 48), 74).cuda()
+    old = rd.FIELD_MODE, rd.FIELD_RR
+    res = []
+    try:
+        rd.FIELD_MODE, rd.FIELD_RR = "f16", 1
+        for grad in (True, False):
+            with torch.set_grad_enabled(grad):
+                cfg = rd._PassCfg(pk, mode, use_cand, use_rgb, [1.0] * 10, [1.0] * 4)
+                leaves = [t.clone().requires_grad_(grad) for t in (o, d, c_rows, a_rows, model.packed().detach())]
+                outs = rd._FieldPass.apply(leaves[0], leaves[1], z, leaves[2], leaves[3], leaves[4], cfg)
+                torch.cuda.synchronize()
+                res.append([cpu(t) for t in outs])
+    finally:
+        rd.FIELD_MODE, rd.FIELD_RR = old
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        if a.numel():
+            assert rel_err(a, b) < 1e-3, (i, rel_err(a, b))
+
+
 @pytest.mark.parametrize("R,S,mode", [(5, 70, 1), (3, 33, 3), (2, 129, 0)])
 def test_compositing_reads_e_as_fp16_fragments(hip, R, S, mode):
     """upnerf_composite_fwd / _bwd with e given as the register-resident field kernels' fp16 operand fragments (e16 / eexp)

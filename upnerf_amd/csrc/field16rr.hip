@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
   const float* wnorm = (const float*)(int_s + 80);
   const bool use_rgb = a.use_rgb != 0, use_cand = a.use_cand != 0;
   const bool train = a.h16 != nullptr;
-  const int last_stage = (!a.e && !use_rgb && !use_cand) ? D - 1 : ((!use_rgb && !use_cand) ? D : D + 3);
+  const int last_stage = (!a.e && !a.e16 && !use_rgb && !use_cand) ? D - 1 : ((!use_rgb && !use_cand) ? D : D + 3);
 
   // ---- stage tables, vectors, per-ray rows (ordinary loads: all of them BEFORE the first DMA is in flight)
   if (tid < RR_MAXSTAGE) {
@@ -1409,26 +1409,47 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
       for (int s = 0; s < 16; ++s) Bh[s] = Nh[s];
     }
   } else {
-    // no head consumed e (density-only evaluation): d e = 0, written because the weight gradient of the final layer reads it
+    // no head consumed e: d e is the rank-1 feature term alone, w_feat g_E_s[ray] (a field without candidate encoding before the
+    // colour head switches on: rendering.py:134-150) -- zero in a density-only evaluation; written either way because the weight
+    // gradient of the final layer reads it.  Elementwise: the exponent comes from the bound max|w_feat| max|g_E_s|.
+    const float wfmax = wave_max_rr(fabsf(wf));
+    const int eo = scale_exp(wfmax * gEmax);
+    const float* gE = rows_s + rs * C::ROWF;
+    float vmax = 0.0f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) Bh[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (a.gz_e) {
-      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int jt = 0; jt < 8; ++jt) {
+      h8 blk[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) stg_put(stg, li, hh, q, zero4);
-#pragma unroll 1
-      for (int jt = 0; jt < 8; ++jt) {
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * jt + 8 * q + 4 * hh;
+        const f32x4 gg = *(const f32x4*)&gE[col];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[u] = wf * gg[u];
+          vmax = fmaxf(vmax, fabsf(v[u]));
+        }
+        if (a.gz_e) stg_put(stg, li, hh, q, f32x4{v[0], v[1], v[2], v[3]});
+        h4 hi, lo;
+        split_quad<1>(ldexpf(v[0], eo), ldexpf(v[1], eo), ldexpf(v[2], eo), ldexpf(v[3], eo), hi, lo);
+        if (q & 1) blk[q >> 1] = __builtin_shufflevector(blk[q >> 1], __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3), 0, 1, 2, 3, 12, 13, 14, 15);
+        else blk[q >> 1] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 0, 1, 2, 3);
+      }
+      Bh[2 * jt] = blk[0];
+      Bh[2 * jt + 1] = blk[1];
+      if (a.gz_e) {
         stg_flush(stg, lane, a.gz_e + (size_t)m0 * W, W, 32 * jt);
         rg.count(4);
+      } else {
+        frag_store(a.gz16 + (size_t)D * nt32 * 16 * 512, t32, 2 * jt, lane, blk[0]);
+        frag_store(a.gz16 + (size_t)D * nt32 * 16 * 512, t32, 2 * jt + 1, lane, blk[1]);
+        rg.count(2);
       }
-    } else {
-#pragma unroll 1
-      for (int b = 0; b < 16; ++b) {
-        frag_store(a.gz16 + (size_t)D * nt32 * 16 * 512, t32, b, lane, Bh[0]);
-        rg.count(1);
-      }
-      if (lane == 0) a.gzexp[(size_t)D * nt32 + t32] = 0;
     }
+    if (!a.gz_e && lane == 0) a.gzexp[(size_t)D * nt32 + t32] = eo;
+    amax_in = wave_max_rr(vmax);
+    track_lds(mx_s, D, amax_in, lane);
+    e_in = eo;
   }
   // ---- d h_{D-1} = relu'(h_{D-1}) (gz_e . W_e + w_sig dpre_s)
   {
