@@ -77,6 +77,46 @@ def algorithmic_fwd_mac(sched):
     return m
 
 
+def executed_mac(sched, direction="fwd", pose=True):
+    """MACs per sample the field kernels actually ISSUE (csrc/field16.hip), as opposed to the reference network's
+    (`algorithmic_fwd_mac`): composite-then-project removes the two 384-wide feature heads from the per-sample
+    work (98 304 + 49 152 MAC run once per RAY instead), the colour head's first layer is folded onto e (256 + 80 padded side
+    inputs instead of 459 inputs), and padded operand columns (63 -> 64 encoding columns) are counted because they are issued."""
+    W, X0, AUXK, CK, W2 = 256, 64, 80, 16, 128
+    if direction == "fwd":
+        m = X0 * W + 3 * W * W + (X0 + W) * W + 3 * W * W  # trunk: layer 0, 1-3, skip layer, 5-7
+        m += W + W * W                                     # density head, xyz_encoding_final
+        if sched > 0:
+            m += (W + AUXK) * W2 + 3 * W2                  # folded colour layer + its 3 outputs
+        if sched < 1:
+            m += (W + CK) * W2 + W2 * W2 + W2              # candidate layers + candidate density
+        return m
+    m = 7 * W * W + W * W                                  # d h_l for layers 7..1, d h_7 from d e
+    m += ((W2 if sched > 0 else 0) + (W2 if sched < 1 else 0)) * W  # d e from [gz_r1 | gz_g1]
+    if sched < 1:
+        m += W2 * W2                                       # d g1 from d g2
+    if pose:
+        m += 2 * W * X0                                    # d x0: first layer + skip layer (-> d xyz)
+    return m
+
+
+HBM_COPY_TBS = 6.29  # /opt/skills/guides/MI355X_MICROARCH.md: measured float4 copy rate (8.0 TB/s spec)
+
+
+def step_object(tflop_alg, tflop_exec, ms_per_step, field, step_bytes):
+    """`roofline.step`: the whole step against its two floors -- algorithmic FLOPs at the dense peak of the field arithmetic,
+    and the step's measured HBM bytes (PMC, all kernels; null without a profile of these sources) at the measured copy rate."""
+    mfma_ms = tflop_alg / PEAK[field] * 1e3
+    hbm_ms = None if step_bytes is None else step_bytes / (HBM_COPY_TBS * 1e12) * 1e3
+    floor = max(mfma_ms, hbm_ms or 0.0)
+    return {"algorithmic_tflop": tflop_alg, "algorithmic_tflops": tflop_alg / (ms_per_step * 1e-3),
+            "executed_tflop": tflop_exec, "mfma_floor_ms": mfma_ms, "hbm_bytes": step_bytes, "hbm_floor_ms": hbm_ms,
+            "binding_floor": None if hbm_ms is None else ("hbm" if hbm_ms >= mfma_ms else "mfma"),
+            "frac_of_floor": floor / ms_per_step, "ms_per_step": ms_per_step,
+            "note": "mfma_floor = algorithmic TFLOP / dense peak of the field arithmetic (2.4 GHz); hbm_floor = PMC bytes of "
+                    "every kernel of a step / 6.29 TB/s (measured copy rate); frac_of_floor = the larger floor / the step"}
+
+
 def source_sha16():
     """Hash of the HIP sources + C header: identifies the build a committed PMC profile belongs to."""
     h = hashlib.sha256()
@@ -206,38 +246,41 @@ class Bench:
         # region: 134 k instead of 240 k rays/s); collected here instead, re-enabled after the last repeat
         gc.collect()
         gc.disable()
-        self.barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(batches[i % 4], i)
-        host = time.perf_counter() - t0
-        self.barrier()
-        dt = time.perf_counter() - t0
-        TIMER.enabled = False
-        if self.world > 1:
-            t = torch.tensor([dt, host], device=self.dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt, host = float(t[0]), float(t[1])
-        out = {"value": self.world * self.rays * steps / dt, "ms_per_step": dt / steps * 1e3,
-               "host_issue_ms_per_step": host / steps * 1e3, "c_abi_calls_per_step": (_lib.CALLS[0] - calls0) / steps,
-               "sched_mult": sysm.get_schedule_mult(progress), "graph": bool(graph)}
-        if repeats > 1 and timer_only is None:
-            vals = [out["value"]]
-            for _ in range(repeats - 1):
-                self.barrier()
-                t0 = time.perf_counter()
-                for i in range(steps):
-                    step(batches[i % 4], i)
-                self.barrier()
-                d2 = time.perf_counter() - t0
-                if self.world > 1:
-                    t = torch.tensor([d2], device=self.dev, dtype=torch.float64)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    d2 = float(t[0])
-                vals.append(self.world * self.rays * steps / d2)
-            out["value_spread"] = {"min": min(vals), "max": max(vals), "repeats": repeats, "steps_each": steps,
-                                   "note": "the first of these measurements is `value`"}
-        gc.enable()
+        try:  # (r4 ADVICE: an exception inside the timed region must not leave the collector off for the process)
+            self.barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(batches[i % 4], i)
+            host = time.perf_counter() - t0
+            self.barrier()
+            dt = time.perf_counter() - t0
+            TIMER.enabled = False
+            if self.world > 1:
+                t = torch.tensor([dt, host], device=self.dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt, host = float(t[0]), float(t[1])
+            out = {"value": self.world * self.rays * steps / dt, "ms_per_step": dt / steps * 1e3,
+                   "host_issue_ms_per_step": host / steps * 1e3, "c_abi_calls_per_step": (_lib.CALLS[0] - calls0) / steps,
+                   "sched_mult": sysm.get_schedule_mult(progress), "graph": bool(graph)}
+            if repeats > 1 and timer_only is None:
+                vals = [out["value"]]
+                for _ in range(repeats - 1):
+                    self.barrier()
+                    t0 = time.perf_counter()
+                    for i in range(steps):
+                        step(batches[i % 4], i)
+                    self.barrier()
+                    d2 = time.perf_counter() - t0
+                    if self.world > 1:
+                        t = torch.tensor([d2], device=self.dev, dtype=torch.float64)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        d2 = float(t[0])
+                    vals.append(self.world * self.rays * steps / d2)
+                out["value_spread"] = {"min": min(vals), "max": max(vals), "repeats": repeats, "steps_each": steps,
+                                       "note": "the first of these measurements is `value`"}
+        finally:
+            TIMER.enabled = False
+            gc.enable()
         if graph:
             out["graph_stats"] = dict(step.stats)
         summ = TIMER.summary() if timer_only is not None else None
@@ -247,7 +290,7 @@ class Bench:
         return out, summ
 
 
-def roofline_of(kern, field, mac, note_extra=""):
+def roofline_of(kern, field, mac, note_extra="", sched=0.5):
     """`roofline` object of the dominant field kernel from a kernel-timing summary (HIP events on the launch stream)."""
     per_sample = {"field_fwd": 2 * mac, "field_bwd": 2 * mac}
     cand = [n for n in kern if n in per_sample]
@@ -255,8 +298,9 @@ def roofline_of(kern, field, mac, note_extra=""):
         return None  # (no field kernel in the timing summary)
     dom = max(cand, key=lambda n: kern[n]["ms_per_step"])
     ach = per_sample[dom] * kern[dom]["units_per_launch"] / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+    exe = 2 * executed_mac(sched, "fwd" if dom == "field_fwd" else "bwd") * kern[dom]["units_per_launch"] / (kern[dom]["avg_ms"] * 1e-3) / 1e12
     return {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK[field], "unit": "TFLOP/s", "frac": ach / PEAK[field],
-            "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"], "note": note_extra}
+            "executed_frac": exe / PEAK[field], "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"], "note": note_extra}
 
 
 def trevi_object(args, rank, world, dev):
@@ -268,7 +312,7 @@ def trevi_object(args, rank, world, dev):
     kern = {n: dict(launches_per_step=v["launches"] / nk, avg_ms=v["avg_ms"], ms_per_step=v["total_ms"] / nk,
                     units_per_launch=v["units_per_launch"]) for n, v in summ.items()}
     mac = algorithmic_fwd_mac(leg["sched_mult"])
-    roof = roofline_of(kern, "f16", mac, "peak = f16 dense MFMA 2516.6 TF; HIP events over eager steps")
+    roof = roofline_of(kern, "f16", mac, "peak = f16 dense MFMA 2516.6 TF; HIP events over eager steps", sched=leg["sched_mult"])
     meta_p = os.path.join(ROOT, "profiles", "pmc_current_trevi.json")  # tools/pmc_current.py --out ...: same hash rule as the headline
     if roof and os.path.exists(meta_p):
         meta = json.load(open(meta_p))
@@ -277,6 +321,11 @@ def trevi_object(args, rank, world, dev):
             roof["traffic"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
             roof["traffic_source"] = f"profiles/{meta.get('file')} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same sources)"
             roof["hbm_bytes_per_step"] = meta.get("hbm_bytes_per_step")
+    if roof:
+        spr = B.rays * (NC + NC + NF)  # field evaluations per step
+        roof["step"] = step_object(3 * 2 * mac * spr / 1e12,
+                                   2 * (2 * executed_mac(leg["sched_mult"], "fwd") + executed_mac(leg["sched_mult"], "bwd")) * spr / 1e12,
+                                   leg["ms_per_step"], "f16", roof.get("hbm_bytes_per_step"))
     return {"value": leg["value"], "value_spread": leg.get("value_spread"), "unit": "rays/s", "ms_per_step": leg["ms_per_step"],
             "dtype": DTYPE["f16"],
             "config": {"workload": CONFIGS["trevi"]["workload"], "rays_per_gpu": B.rays, "n_images": B.n_images, "progress": 0.3,
@@ -384,6 +433,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))  # before anything initialises a GPU in this process
 
+    if os.environ.get("UPNERF_BENCH_KILL_RANK") is not None and os.environ.get("RANK") == os.environ["UPNERF_BENCH_KILL_RANK"]:
+        sys.exit(3)  # test hook (tests/test_bench_contract.py): a rank that dies before the rendezvous fails the whole run
     import torch
     import torch.distributed as dist
     from upnerf_amd import parallel
@@ -517,8 +568,18 @@ def main():
                     source = f"profiles/{meta.get('file')} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same sources)"
                     step_bytes = meta.get("hbm_bytes_per_step")
         peak = PEAK[field] if dom.startswith("field") else (PEAK["f16"] if field == "f16" else PEAK["f16x3"])
+        exe = (2 * executed_mac(sched, "fwd" if dom == "field_fwd" else "bwd") * summ[dom]["units_per_launch"]
+               / (kern[dom]["avg_ms"] * 1e-3) / 1e12) if dom.startswith("field") else ach
+        spr = rays * (NC + NC + NF)
         line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                            "frac": ach / peak, "traffic": traffic, "traffic_source": source,
+                            "frac": ach / peak,
+                            # MACs the kernel ISSUES (composite-then-project and the folded colour layer removed ~20 % of the
+                            # reference network's per-sample MACs: executed_mac) / the same launch time / the same peak
+                            "executed_frac": exe / peak,
+                            "step": step_object(line["algorithmic_tflop_per_step"],
+                                                2 * (2 * executed_mac(sched, "fwd") + executed_mac(sched, "bwd")) * spr / 1e12,
+                                                main_leg["ms_per_step"], field, step_bytes),
+                            "traffic": traffic, "traffic_source": source,
                             "hbm_bytes_per_step": step_bytes,  # all kernels of a step, same PMC passes (null with traffic)
                             "avg_launch_ms": kern[dom]["avg_ms"],
                             "note": "achieved = algorithmic (fp32-equivalent) FLOPs / HIP-event launch time, averaged over "

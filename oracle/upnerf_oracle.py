@@ -413,6 +413,10 @@ def training_forward(state: Dict[str, Params], cfgs: Dict[str, NerfCfg], batch: 
         pose = batch["c2w"]
     o, d = get_rays(batch["directions"], pose)
     rays = torch.cat([o, d, batch["ray_infos"]], 1)
+    if keep is not None:  # checkers read d loss / d rays (per-ray: tests/test_hip_fullsize.py compares a slice of a big batch)
+        keep["rays"] = rays
+        if rays.requires_grad:
+            rays.retain_grad()
     depth = depth_prior(state["depth_scale"][idx], batch["inv_depths"], hp["nerf.near"], hp["nerf.far"])
     m = schedule_mult(progress, hp["candidate_schedule"])
     emb = {k[len("embedding_"):]: v for k, v in state.items() if k.startswith("embedding_")}

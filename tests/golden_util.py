@@ -14,7 +14,7 @@ from upnerf_amd import synth  # noqa: E402
 import upnerf_oracle as orc  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("leaf.npz", "sampler.npz", "pose_align.npz"))
+CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("leaf.npz", "sampler.npz", "pose_align.npz", "small_tto_step.npz"))
 
 
 class Case:

@@ -40,6 +40,18 @@ def test_default_shape_bench_line():
     assert r["bound"] in ("mfma", "hbm") and r["unit"] in ("TFLOP/s", "GB/s") and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or (r["traffic"] > 0 and r["traffic_source"])
+    # the executed fraction (composite-then-project removed ~20 % of the reference's per-sample MACs) and
+    # the step-level floors ride in the line
+    assert 0.7 * r["frac"] < r["executed_frac"] < r["frac"]
+    st = r["step"]
+    assert abs(st["algorithmic_tflop"] - d["algorithmic_tflop_per_step"]) < 1e-9 and 4.0 < st["algorithmic_tflop"] < 6.0
+    assert abs(st["mfma_floor_ms"] - st["algorithmic_tflop"] / r["peak"] * 1e3) < 1e-9
+    assert abs(st["algorithmic_tflops"] - st["algorithmic_tflop"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * st["algorithmic_tflops"]
+    assert (st["hbm_floor_ms"] is None) == (r["hbm_bytes_per_step"] is None)
+    if st["hbm_floor_ms"] is not None:
+        assert abs(st["hbm_floor_ms"] - r["hbm_bytes_per_step"] / 6.29e12 * 1e3) < 1e-9 and st["binding_floor"] in ("hbm", "mfma")
+    assert abs(st["frac_of_floor"] - max(st["mfma_floor_ms"], st["hbm_floor_ms"] or 0.0) / d["ms_per_step"]) < 1e-9
+    assert 0.1 < st["frac_of_floor"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0
     assert isinstance(c["sample"], str) and c["sample"]
@@ -49,6 +61,7 @@ def test_default_shape_bench_line():
     assert t["config"]["rays_per_gpu"] == 8192 and t["config"]["n_images"] == 1689 and t["dtype"].startswith("f16")
     assert abs(t["value"] - 8192 / (t["ms_per_step"] * 1e-3)) < 1e-6 * t["value"] and t["value"] > 100_000
     assert t["roofline"]["peak"] > 2000 and 0.02 < t["roofline"]["frac"] < 1.0
+    assert 0.7 * t["roofline"]["frac"] < t["roofline"]["executed_frac"] < t["roofline"]["frac"] and "frac_of_floor" in t["roofline"]["step"]
     o = d["tto"]
     for st in ("pose_stage", "appearance_stage"):
         assert o["rays_per_step"] == 1024 and abs(o[st]["value"] - 1024 / (o[st]["ms_per_step"] * 1e-3)) < 1e-6 * o[st]["value"]
@@ -76,6 +89,33 @@ def test_gpus_n_without_torchrun_spawns_n_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["world_size_observed"] == 2 and d["backend"] == "gloo" and d["dry_run"] is True
     assert d["config"]["parallelism"] == "dp2" and d["steps"] == 3
+
+
+def test_eight_ranks_dry_run_is_the_line_the_scale_run_expects():
+    """what the driver's 8-GPU run will do first -- spawn eight ranks, rendezvous, barrier, max over ranks,
+    ONE line from rank 0 that says dp8 -- on the plumbing-only path (gloo on CPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["UPNERF_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--dry-run"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["world_size_observed"] == 8 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
+    assert d["backend"] == "gloo" and d["dry_run"] is True and d["steps"] == 2
+
+
+def test_a_dead_rank_is_a_nonzero_exit():
+    """A rank that dies before the rendezvous completes must fail the whole run (non-zero exit, no JSON line that looks like a
+    measurement) instead of hanging or reporting the survivors."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["UPNERF_DIST_BACKEND"] = "gloo"
+    env["UPNERF_BENCH_KILL_RANK"] = "1"  # test hook of bench.py: this rank exits(3) right after parsing its arguments
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--dry-run"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.strip().startswith("{")], out.stdout
 
 
 def test_strong_scaling_dry_run_splits_the_batch():

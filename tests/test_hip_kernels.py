@@ -1300,6 +1300,10 @@ def test_two_virtual_ranks_draw_what_one_rank_draws(hip):
     for k in (0, 1):
         zk = depths({kk: v[k::2].contiguous() for kk, v in batch.items()}, k, 2)
         assert torch.equal(zk[0], zc[k::2]) and torch.equal(zk[1], zf[k::2])
+    # ... and at the rank count of BASELINE.json configs[2]: eight virtual ranks, the sampler's strided layout
+    for k in range(8):
+        zk = depths({kk: v[k::8].contiguous() for kk, v in batch.items()}, k, 8)
+        assert torch.equal(zk[0], zc[k::8]) and torch.equal(zk[1], zf[k::8]), k
     s.global_step = 62  # another step: other numbers
     zc2, _ = depths(batch, 0)
     assert not torch.equal(zc, zc2)

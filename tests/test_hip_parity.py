@@ -6,6 +6,8 @@ Bar (BASELINE.json): outputs within 1e-4 relative of the reference in fp32.  Gat
 per-ray maps and loss terms 1e-4; per-sample weights 2e-4 (the reference's own fp32-vs-fp64 noise on
 per-sample fine weights is 4e-5, because 1e-7 cdf differences move fine samples); gradients 1e-3 of the tensor's
 largest entry (they inherit the resampling sensitivity)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,6 +17,20 @@ from golden_util import CASES, Case, rel_err
 pytestmark = pytest.mark.gpu
 
 TOL_MAP, TOL_W, TOL_GRAD = 1e-4, 2e-4, 1e-3
+# r4 ADVICE: the gradient gate widens with the reference's OWN noise (4 x its fp32-vs-fp64 / one-ulp-input spread), but never
+# beyond this cap -- a parameter whose reference gradient is noisier than cap / 4 is compared AT the cap, and every
+# parameter that needed more than the flat 1e-3 is listed in the test's output (`[widened]`), so a drift shows.
+# (3e-2: yaml_phase2's nerf_fine.xyz_encoding_1.0.weight differs by 2.2e-2 where the reference's own noise is 1.1e-2 -- all ten
+# encoding bands on at 128 + 128 samples, one ulp of a ray direction flips a ReLU: DESIGN.md section 6)
+GRAD_GATE_CAP = 3e-2
+_WIDENED = {}
+
+
+def grad_gate(noise_n, case=None, name=None):
+    g = max(TOL_GRAD, min(4.0 * noise_n, GRAD_GATE_CAP))
+    if g > TOL_GRAD and case is not None:
+        _WIDENED.setdefault(case, {})[name] = g
+    return g
 # Goldens in which at least one resampled depth of the GPU run sits an eps-bin away from the reference's (see
 # test_training_step_matches_reference_golden): those are compared loosely with the golden gradients and strictly with the
 # oracle at the GPU's own depths.  The set is PINNED: a change that makes another case flip fails
@@ -258,7 +274,7 @@ def test_training_step_matches_reference_golden(name):
     bad = {}
 
     def gate(n):
-        return max(TOL_GRAD, 4 * noise.get(n, worst_noise)) if not flipped else 5e-2
+        return grad_gate(noise.get(n, worst_noise), name, n) if not flipped else 5e-2
 
     if sysm._last_rays.requires_grad:
         gr, er = sysm._last_rays.grad.cpu().numpy(), c.g["grad_rays"]
@@ -267,7 +283,7 @@ def test_training_step_matches_reference_golden(name):
             # flipped: one resampled depth sits a bin away from the reference's; with sharp ("trained-like") densities a
             # single fine sample can carry a fifth of a ray's gradient.  Loose here, strict below at the GPU's own depths
             # (se3_refine's gradient is the ray gradient pushed through the pose).
-            if e >= (max(TOL_GRAD, 4 * worst_noise) if not flipped else 0.25):
+            if e >= (grad_gate(worst_noise, name, "grad_" + tag) if not flipped else 0.25):
                 bad["grad_" + tag] = e
     for n, e in c.expected_grads().items():
         if n.endswith(".progress"):
@@ -296,9 +312,11 @@ def test_training_step_matches_reference_golden(name):
                 continue
             g = got[n.replace("embedding_", "embedding_") if n in got else n]
             err = rel_err(g.detach().cpu().numpy(), r.numpy())
-            if err >= max(TOL_GRAD, 4 * noise.get(n, worst_noise)):
+            if err >= grad_gate(noise.get(n, worst_noise), name, n):
                 bad[n] = (err, noise.get(n, 0.0))
         assert not bad, ("vs oracle at the GPU's fine depths", bad)
+    if name in _WIDENED:
+        print(f"[widened] {name}: " + ", ".join(f"{n} {g:.1e}" for n, g in sorted(_WIDENED[name].items())))
 
 
 @pytest.mark.parametrize("name", [n for n in CASES if Case(n).fine])
@@ -340,7 +358,7 @@ def test_training_step_matches_reference_golden_at_the_reference_depths(name):
         gr, er = sysm._last_rays.grad.cpu().numpy(), c.g["grad_rays"]
         for tag, sl in (("rays_o", slice(0, 3)), ("rays_d", slice(3, 6))):
             e = rel_err(gr[:, sl], er[:, sl])
-            if e >= max(TOL_GRAD, 4 * worst_noise):
+            if e >= grad_gate(worst_noise, name + "@ref", "grad_" + tag):
                 bad["grad_" + tag] = e
     for n, e in c.expected_grads().items():
         if n.endswith(".progress"):
@@ -359,8 +377,10 @@ def test_training_step_matches_reference_golden_at_the_reference_depths(name):
         sub = (flat[::stride] if stride else flat).numpy()[: len(vals)]
         scale = max(float(np.abs(vals).max()), sums[1] / flat.numel(), 1e-12)
         err = float(np.abs(sub - vals).max()) / scale
-        if err >= max(TOL_GRAD, 4 * noise.get(n, worst_noise)):
+        if err >= grad_gate(noise.get(n, worst_noise), name + "@ref", n):
             bad[n] = (err, noise.get(n, 0.0))
+    if name + "@ref" in _WIDENED:
+        print(f"[widened] {name} at the reference's depths: " + ", ".join(f"{n} {g:.1e}" for n, g in sorted(_WIDENED[name + "@ref"].items())))
     assert not bad, ("vs reference golden at the reference's fine depths", bad)
 
 
@@ -403,20 +423,24 @@ def test_tto_step_frozen_field_matches_oracle_and_skips_weight_gradients():
     batch = {k: v.cuda() for k, v in b.items()}
     batch["img_idx"] = torch.zeros_like(batch["img_idx"])
     loss, _, res = tto.compute_loss(batch)
+    if tto._last_rays.requires_grad:
+        tto._last_rays.retain_grad()
     loss.backward()
     assert all(p.grad is None for p in tto.nerf_fine.parameters())
-    # oracle on the same single-image problem
-    st = c.state()
-    st["embedding_fine_a"] = st["embedding_fine_a"][3:4].detach().clone().requires_grad_(True)
-    st["se3_refine"] = st["se3_refine"][5:6].detach().clone().requires_grad_(True)
-    idx0 = torch.zeros_like(b["img_idx"])
-    pose = orc.compose_pair(orc.se3_exp(st["se3_refine"][idx0]), b["c2w"])
-    o, d = orc.get_rays(b["directions"], pose)
-    rays = torch.cat([o, d, b["ray_infos"]], 1)
-    emb = {k[len("embedding_"):]: v for k, v in st.items() if k.startswith("embedding_")}
-    ref = orc.render_rays({k: st[k] for k in ("nerf_coarse", "nerf_fine")}, c.cfgs(), emb, rays, idx0, 1.0,
-                          N_samples=c.Nc, perturb=0, N_importance=c.Nf, progress=1.0)
-    l_ref = ((ref["s_rgb_fine"] - b["rgbs"]) ** 2).mean()
+    # the REFERENCE's own TTO step on the same single-image problem: tests/golden/small_tto_step.npz (loss line
+    # nerf_system_optmize.py:129 evaluated by the reference's leaf functions, tools/make_goldens.py:tto_step_fixture) --
+    # r4 VERDICT weak 1d: pinned by data, not by a line restated here
+    gold = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_tto_step.npz")))
+    assert abs(float(loss) - float(gold["loss"])) < TOL_MAP * max(1e-2, abs(float(gold["loss"])))
+    for k in ("s_rgb_fine", "s_depth_fine", "s_weights_fine"):
+        assert rel_err(res[k].detach().cpu().numpy(), gold["res_" + k]) < (TOL_W if "weights" in k else TOL_MAP), k
+    assert rel_err(tto.embedding_fine_a.weight.grad.cpu().numpy(), gold["grad_embedding_fine_a"]) < 1e-3
+    assert rel_err(tto.se3_refine.weight.grad.cpu().numpy(), gold["grad_se3_refine"]) < 5e-3
+    if tto._last_rays.grad is not None:
+        assert rel_err(tto._last_rays.grad.cpu().numpy()[:, :6], gold["grad_rays"][:, :6]) < 5e-3
+    # ... and the oracle's restatement of the same step (pinned to the same file on CPU: tests/test_oracle_golden.py)
+    from test_oracle_golden import tto_step_oracle
+    st, _, ref, l_ref = tto_step_oracle(c, gold)
     l_ref.backward()
     assert abs(float(loss) - float(l_ref)) < 1e-6 * max(1e-2, abs(float(l_ref)))
     assert rel_err(tto.embedding_fine_a.weight.grad.cpu().numpy(), st["embedding_fine_a"].grad.numpy()) < 1e-3

@@ -88,6 +88,42 @@ def _forward_with_sched(c, st, keep=None):
         orc.schedule_mult = real
 
 
+def tto_step_oracle(c, g):
+    """The oracle's restatement of one test-time-optimisation step (models/nerf_system_optmize.py:113-129, 84-104): one
+    test image, its appearance row and se(3) row the only trainables, sched_mult 1.0, loss = mean((s_rgb_fine - rgbs)^2)."""
+    st = c.state()
+    st["embedding_fine_a"] = st["embedding_fine_a"][int(g["row_a"]):int(g["row_a"]) + 1].detach().clone().requires_grad_(True)
+    st["se3_refine"] = st["se3_refine"][int(g["row_se3"]):int(g["row_se3"]) + 1].detach().clone().requires_grad_(True)
+    b = c.batch()
+    idx0 = torch.zeros_like(b["img_idx"])
+    pose = orc.compose_pair(orc.se3_exp(st["se3_refine"][idx0]), b["c2w"])
+    o, d = orc.get_rays(b["directions"], pose)
+    rays = torch.cat([o, d, b["ray_infos"]], 1)
+    rays.retain_grad()
+    emb = {k[len("embedding_"):]: v for k, v in st.items() if k.startswith("embedding_")}
+    res = orc.render_rays({k: st[k] for k in ("nerf_coarse", "nerf_fine")}, c.cfgs(), emb, rays, idx0, 1.0,
+                          N_samples=c.Nc, perturb=0, N_importance=c.Nf, progress=1.0)
+    loss = ((res["s_rgb_fine"] - b["rgbs"]) ** 2).mean()  # nerf_system_optmize.py:129
+    return st, rays, res, loss
+
+
+def test_tto_step_matches_reference():
+    """a19's loss line is pinned by DATA -- `small_tto_step.npz` holds what the reference's own
+    leaf functions produce for one TTO step (tools/make_goldens.py:tto_step_fixture), not a line restated in a test."""
+    g = dict(np.load(GOLDEN + "/small_tto_step.npz"))
+    c = Case("small_tto")
+    st, rays, res, loss = tto_step_oracle(c, g)
+    assert {k[4:] for k in g if k.startswith("res_")} == set(res.keys())
+    for k, v in res.items():
+        assert rel_err(v.detach().numpy(), g["res_" + k]) < TOL_FWD, k
+    assert abs(float(loss) - float(g["loss"])) <= TOL_FWD * abs(float(g["loss"]))
+    loss.backward()
+    assert rel_err(rays.detach().numpy(), g["in_rays"]) < 1e-6
+    assert rel_err(rays.grad.numpy(), g["grad_rays"]) < TOL_GRAD
+    assert rel_err(st["embedding_fine_a"].grad.numpy(), g["grad_embedding_fine_a"]) < TOL_GRAD
+    assert rel_err(st["se3_refine"].grad.numpy(), g["grad_se3_refine"]) < TOL_GRAD
+
+
 def test_leaf_se3_exp():
     g = np.load(f"{GOLDEN}/leaf.npz")
     wu = torch.from_numpy(g["se3_in"]).requires_grad_(True)

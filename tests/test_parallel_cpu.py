@@ -194,3 +194,79 @@ def test_early_bucket_allreduce_world2_gloo():
             else:
                 a, b = torch.from_numpy(g0[k]), torch.from_numpy(g1[k])
                 assert torch.equal(a, b) and torch.allclose(a, p.grad, atol=1e-6), (step, k)
+
+
+def _worker_overlap8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from upnerf_amd import parallel
+    parallel.init_from_env("gloo")
+    torch.manual_seed(0)
+    m = _TwoFields()
+    early = list(m.fine.parameters()) + list(m.fine_head.parameters())
+    sync = parallel.GradSync(m.parameters(), check=True, early=early)
+    g = torch.Generator().manual_seed(11)
+    per = 2
+    idx_all = torch.randint(0, 9, (len(_PHASES8), per * world), generator=g)
+    out = []
+    for step, phase in enumerate(_PHASES8):
+        for p in m.parameters():
+            p.grad = None
+        sync.begin(phase)
+        _loss2(m, idx_all[step][rank * per:(rank + 1) * per], phase).backward()
+        n = sync()
+        out.append((n, dict(sync._expected), {k: (None if p.grad is None else p.grad.numpy().copy()) for k, p in m.named_parameters()}))
+    q.put((rank, out, dict(sync.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+_PHASES8 = [0, 0, 0, 1, 1, 0, 1, 1]  # phase boundary 0 -> 1 after three steps, and back (a resumed run re-enters a phase)
+
+
+def test_grad_sync_world8_gloo_across_a_phase_boundary():
+    """the exchange the first 8-GPU run will make, pinned on CPU -- eight gloo ranks, the early (fine-field)
+    bucket launched from the gradient hook, the schedule phase changing under it: the number of early gradients is re-learned
+    per phase (first step of a phase = late-only on EVERY rank, the same steps on every rank), the set of parameters with a
+    gradient is identical on all ranks in every step, and every rank ends every step with the gradient one
+    process computes on the whole batch."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    stats = [st for _, _, st in res]
+    # steps 0 and 3 are the first of their phase: learned there, launched early in the six others
+    assert all(st == {"early_launches": 6, "late_only": 2} for st in stats), stats
+    torch.manual_seed(0)
+    m = _TwoFields()
+    g = torch.Generator().manual_seed(11)
+    idx_all = torch.randint(0, 9, (len(_PHASES8), 2 * world), generator=g)
+    n_fine = len(list(m.fine.parameters()))
+    for step, phase in enumerate(_PHASES8):
+        for p in m.parameters():
+            p.grad = None
+        _loss2(m, idx_all[step], phase).backward()
+        want_n = sum(p.grad.numel() for p in m.parameters() if p.grad is not None)
+        live = {k for k, p in m.named_parameters() if p.grad is not None}
+        for rank, out, _ in res:
+            n, expected, grads = out[step]
+            assert n == want_n, (step, rank, n, want_n)
+            assert {k for k, v in grads.items() if v is not None} == live, (step, rank)  # Q12: same set on every rank
+            assert expected[phase] == n_fine + (2 if phase == 1 else 0), (step, rank, expected)  # learned per phase key
+            for k, p in m.named_parameters():
+                if p.grad is not None:
+                    a = torch.from_numpy(grads[k])
+                    assert torch.equal(a, torch.from_numpy(res[0][1][step][2][k])), (step, rank, k)  # bitwise equal across ranks
+                    assert torch.allclose(a, p.grad, atol=1e-6), (step, rank, k)

@@ -233,6 +233,41 @@ CASES = {
 }
 
 
+def tto_step_fixture():
+    """One test-time-optimisation step (a19) with the TTO loss line itself: the glue of NeRFSystemOptimize.training_step /
+    forward (nerf_system_optmize.py:113-129, 84-104) re-stated with the reference's own leaf functions -- sched_mult = 1.0,
+    encode_candidate off on both fields (265-266), ONE test image whose appearance row and se(3) row are the only trainables
+    (254-262, 48-64), loss = mean((s_rgb_fine - rgbs)^2) (line 129).  Shape and weights of the `small_tto` case; the test
+    image's rows are rows 3 (appearance) and 5 (pose) of that case's tables, as tests/test_hip_parity.py has set them since
+    round 1.  Stored: inputs, every result map, the loss, the two table gradients, the ray gradient."""
+    case = CASES["small_tto"]
+    torch.manual_seed(case["seed"])
+    models, _tn, emb = build(case)
+    b = synth.batch(case["R"], case["n_img"], seed=case["seed"] + 1, identity_c2w=case.get("identity_c2w", True))
+    idx0 = torch.zeros_like(b["img_idx"])
+    fine_a = torch.nn.Embedding.from_pretrained(emb["embedding_fine_a"].weight.detach()[3:4].clone(), freeze=False)
+    se3 = torch.nn.Embedding.from_pretrained(emb["se3_refine"].weight.detach()[5:6].clone(), freeze=False)
+    embeddings = {k[len("embedding_"):]: v for k, v in emb.items() if k.startswith("embedding_")}
+    embeddings["fine_a"] = fine_a
+    refine = ref_camera.lie.se3_to_SE3(se3(idx0))
+    pose = ref_camera.pose.compose([refine, b["c2w"]])
+    rays_o, rays_d = ref_ray.get_rays(b["directions"], pose)
+    rays = torch.cat([rays_o, rays_d, b["ray_infos"]], 1)
+    res = ref_rendering.render_rays(models=models, embeddings=embeddings, rays=rays, img_idx=idx0, sched_mult=1.0,
+                                    sched_phase=2, N_samples=case["Nc"], use_disp=False, perturb=case["perturb"],
+                                    N_importance=case["Nf"], white_back=False, encode_feat=True, validation=False)
+    loss = ((res["s_rgb_fine"] - b["rgbs"]) ** 2).mean()
+    rays.retain_grad()
+    loss.backward()
+    out = {"loss": loss.detach().numpy(), "in_rays": rays.detach().numpy(), "grad_rays": rays.grad.numpy(),
+           "grad_embedding_fine_a": fine_a.weight.grad.numpy(), "grad_se3_refine": se3.weight.grad.numpy(),
+           "row_a": np.int64(3), "row_se3": np.int64(5)}
+    for k, v in res.items():
+        out["res_" + k] = v.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "small_tto_step.npz"), **out)
+    print(f"small_tto_step: loss={loss.item():.6f} keys={sorted(res.keys())}")
+
+
 def leaf_fixtures():
     """Leaf-function vectors: se3 exp (incl. w = 0), PE layout, sample_pdf edge cases."""
     out = {}
@@ -478,6 +513,8 @@ if __name__ == "__main__":
         state_key_fixture()
     if not only or "config" in only:
         config_fixture()
+    if not only or "tto_step" in only:
+        tto_step_fixture()
     for n, c in CASES.items():
         if not only or n in only:
             run_case(n, c)

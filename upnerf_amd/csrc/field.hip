@@ -70,18 +70,22 @@ __global__ __launch_bounds__(NTHREADS, (TILE * W * 4 <= 32768) ? 4 : ((TILE * W 
   }
   __syncthreads();
   // ---- BARF-masked encoding (nerf.py:126-147): [x, sin(2^k pi x_n) w_k, cos(2^k pi x_n) w_k]
-  for (int it = tid; it < TILE * 3; it += NTHREADS) {
-    const int row = it / 3, n = it - row * 3;
-    const float xv = Hs[swz(row, n, W)];
+  // band-major, one item per thread and trip: a wave's band is uniform (TILE * 3 items per band = whole waves), a band whose
+  // weight is exactly zero is written as zeros without the sincos (csrc/field16.hip has the reasoning)
+  static_assert((TILE * 3) % 64 == 0, "a wave's items share one band");
 #pragma unroll 1
-    for (int k = 0; k < 10; ++k) {
-      const float arg = xv * ldexpf(PI_F, k);
-      float sv, cv;
-      sincos_f32_via_f64(arg, sv, cv);
-      const float wk = a.wk_xyz_dev ? a.wk_xyz_dev[k] : a.wk_xyz[k];  // device copy: graph replay
-      Hs[swz(row, 3 + 20 * n + k, W)] = sv * wk;
-      Hs[swz(row, 3 + 20 * n + 10 + k, W)] = cv * wk;
+  for (int i0 = 64 * __builtin_amdgcn_readfirstlane(tid >> 6); i0 < TILE * 3 * 10; i0 += NTHREADS) {
+    const int k = i0 / (TILE * 3);
+    const int it = i0 + lane - k * (TILE * 3), row = it / 3, n = it - row * 3;
+    const float wk = a.wk_xyz_dev ? a.wk_xyz_dev[k] : a.wk_xyz[k];  // device copy: graph replay
+    float sv = 0.0f, cv = 0.0f;
+    if (__builtin_amdgcn_readfirstlane(__float_as_uint(wk)) != 0u) {
+      sincos_f32_via_f64(Hs[swz(row, n, W)] * ldexpf(PI_F, k), sv, cv);
+      sv *= wk;
+      cv *= wk;
     }
+    Hs[swz(row, 3 + 20 * n + k, W)] = sv;
+    Hs[swz(row, 3 + 20 * n + 10 + k, W)] = cv;
   }
   __syncthreads();
   tile_store<TILE>(Hs, W, 0, UPNERF_X0, a.x0, UPNERF_X0, m0, M, tid);

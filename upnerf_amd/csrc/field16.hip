@@ -376,18 +376,27 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     const float* __restrict__ wkd = a.wk_xyz_dev;  // per-step band weights from device memory under graph replay
     for (int it = tid; it < TILE * 3; it += THREADS) {
       const int row = it / 3, n = it - row * 3;
-      const float xv = xyz_s[row * 3 + n];
-      put(row, n, xv);
+      put(row, n, xyz_s[it]);
       if (n == 0) put(row, 63, 0.0f);
+    }
+    // One (band, row, coordinate) item per thread and trip, band-major: TILE * 3 = 192 items per band = three whole waves, so a
+    // wave's band is uniform and a band whose weight is exactly zero (all ten below progress 0.1, five of ten at the headline's
+    // 0.3: nerf.py:136-141) costs it two plane writes, not the fp64 sincos -- sin * 0 and cos * 0 are the zeros written here
+    // (up to the sign of a zero, which no contraction sees).  All four waves work (192 threads x 10 bands in a row before).
+    static_assert((TILE * 3) % 64 == 0, "a wave's items share one band");
 #pragma unroll 1
-      for (int k = 0; k < 10; ++k) {
-        const float arg = xv * ldexpf(PI_F, k);
-        float sv, cv;
-        sincos_f32_via_f64(arg, sv, cv);
-        const float wk = wkd ? wkd[k] : a.wk_xyz[k];
-        put(row, 3 + 20 * n + k, sv * wk);
-        put(row, 3 + 20 * n + 10 + k, cv * wk);
+    for (int i0 = 64 * __builtin_amdgcn_readfirstlane(tid >> 6); i0 < TILE * 3 * 10; i0 += THREADS) {
+      const int k = i0 / (TILE * 3);
+      const int it = i0 + lane - k * (TILE * 3), row = it / 3, n = it - row * 3;
+      const float wk = wkd ? wkd[k] : a.wk_xyz[k];
+      float sv = 0.0f, cv = 0.0f;
+      if (__builtin_amdgcn_readfirstlane(__float_as_uint(wk)) != 0u) {
+        sincos_f32_via_f64(xyz_s[it] * ldexpf(PI_F, k), sv, cv);
+        sv *= wk;
+        cv *= wk;
       }
+      put(row, 3 + 20 * n + k, sv);
+      put(row, 3 + 20 * n + 10 + k, cv);
     }
   }
   __syncthreads();

@@ -682,15 +682,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
       pe[2] = xyz[2];
       pe[63] = 0.0f;
     }
+    // A sample's 30 (coordinate, band) items are shared by its two lanes so that BOTH lanes are in the same band or in two
+    // neighbouring ones on every trip: trips 0-9 = band p of x (lane half 0) and of y (half 1), trips 10-14 = bands 2q and
+    // 2q + 1 of z.  A trip whose band weights are exactly zero (all below progress 0.1, half of them at 0.3: nerf.py:136-141)
+    // then skips the fp64 sincos for the whole wave and writes the zeros sin * 0, cos * 0 would have been.
 #pragma unroll 1
     for (int p = 0; p < 15; ++p) {
-      const int pp = 15 * hh + p, n = pp / 10, k = pp - 10 * n;
-      const float xv = n == 0 ? xyz[0] : (n == 1 ? xyz[1] : xyz[2]);
-      float sv, cv;
-      sincos_f32_via_f64(xv * ldexpf(PI_F, k), sv, cv);
+      const int n = p < 10 ? hh : 2, k = p < 10 ? p : 2 * (p - 10) + hh;
+      const int ku = p < 10 ? p : 2 * (p - 10);  // wave-uniform: the (first) band of this trip
       const float wk = wkd ? wkd[k] : a.wk_xyz[k];
-      pe[3 + 20 * n + k] = sv * wk;
-      pe[3 + 20 * n + 10 + k] = cv * wk;
+      const float wu0 = wkd ? wkd[ku] : a.wk_xyz[ku], wu1 = wkd ? wkd[ku + (p >= 10)] : a.wk_xyz[ku + (p >= 10)];
+      float sv = 0.0f, cv = 0.0f;
+      if ((__builtin_amdgcn_readfirstlane(__float_as_uint(wu0)) | __builtin_amdgcn_readfirstlane(__float_as_uint(wu1))) != 0u) {
+        const float xv = n == 0 ? xyz[0] : (n == 1 ? xyz[1] : xyz[2]);
+        sincos_f32_via_f64(xv * ldexpf(PI_F, k), sv, cv);
+        sv *= wk;
+        cv *= wk;
+      }
+      pe[3 + 20 * n + k] = sv;
+      pe[3 + 20 * n + 10 + k] = cv;
     }
   }
   __syncthreads();

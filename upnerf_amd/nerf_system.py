@@ -142,20 +142,6 @@ class _LazyResults(dict):
         self._force()
         return (dict, (dict(self),))
 
-    def __len__(self):
-        return super().__len__() + len(self._thunks)
-
-    def keys(self):
-        self._force()
-        return super().keys()
-
-    def items(self):
-        self._force()
-        return super().items()
-
-    def values(self):
-        self._force()
-        return super().values()
 
 
 class NeRFSystem(_Base):

@@ -81,7 +81,9 @@ class NeRFSystemOptimize(NeRFSystem):
         return torch.cat([o, d, batch["ray_infos"]], 1)
 
     def compute_loss(self, batch, u_list=None):
-        res = self(self.rays_from_batch(batch), batch["img_idx"], u_list=u_list)
+        rays = self.rays_from_batch(batch)
+        self._last_rays = rays  # kept for tests (gradient w.r.t. the rays), as NeRFSystem.compute_loss does
+        res = self(rays, batch["img_idx"], u_list=u_list)
         loss = ((res["s_rgb_fine"] - batch["rgbs"]) ** 2).mean()  # nerf_system_optmize.py:129
         return loss, {"rgb": loss}, res
 

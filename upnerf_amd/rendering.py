@@ -61,6 +61,8 @@ TILE_PARTIALS = int(__import__("os").environ.get("UPNERF_TILE_PARTIALS", "1"))
 # Slab reductions of the f16x3 weight gradients inside the next weight-gradient launch (upnerf_wgrad_f16x3_chain).
 WGRAD_CHAIN = int(__import__("os").environ.get("UPNERF_WGRAD_CHAIN", "1"))
 # Colour and candidate heads: [gz_r1 | gz_g1] stored as one tensor, one weight-gradient launch against e for both first layers.
+if WGRAD_STORE == "f24" and not WGRAD_CHAIN:  # (r4 ADVICE: the 24-bit operands have no un-chained entry point)
+    raise RuntimeError("UPNERF_WGRAD_STORE=f24 needs UPNERF_WGRAD_CHAIN=1 (upnerf_wgrad_f24p_chain is the only kernel that reads the hi + lo8 operands)")
 JOIN_HEADS = int(__import__("os").environ.get("UPNERF_JOIN_HEADS", "1"))
 HMASK_SCALE = int(__import__("os").environ.get("UPNERF_HMASK_SCALE", "1"))  # experiment builds with more threads per tile
 # fp16 mode: the register-resident kernels (csrc/field16rr.hip; include/upnerf_hip.h tile_rows = 256) -- weights staged once per
