@@ -127,6 +127,18 @@ __device__ __forceinline__ void mma16_step(f32x16 (&acc)[MT][NT], const h8 (&xh)
 // before the MFMAs of block t issue (AHEAD x MFMA time >= L2 latency); the activation fragments (LDS, ~100 cycles) stay
 // one block ahead.  One ring revolution is unrolled, so every ring index is a compile-time register name; sched_barrier
 // fences keep the requests ABOVE the matrix work (hipcc otherwise sinks them to their first use).
+// weight-fragment load.  Experiments (make variant): UPNERF_W_NT = non-temporal (L1-bypassing) loads; UPNERF_EXP_SAMEB = every
+// k-block reads the FIRST block of its n-tile (wrong results: the kernel with its weight stream served from L1)
+#if defined(UPNERF_W_NT)
+#define W_LOAD(p, t) __builtin_nontemporal_load((const h8*)((p) + (size_t)(t) * 2048))
+#define W_LOAD_LO(p, t) __builtin_nontemporal_load((const h8*)((p) + (size_t)(t) * 2048 + 1024))
+#elif defined(UPNERF_EXP_SAMEB)
+#define W_LOAD(p, t) (*(const h8*)((p) + (size_t)((t) & 1) * 2048))
+#define W_LOAD_LO(p, t) (*(const h8*)((p) + (size_t)((t) & 1) * 2048 + 1024))
+#else
+#define W_LOAD(p, t) (*(const h8*)((p) + (size_t)(t) * 2048))
+#define W_LOAD_LO(p, t) (*(const h8*)((p) + (size_t)(t) * 2048 + 1024))
+#endif
 template <int NP, int W, int T, int AHEAD, int MT, int NT>
 __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph, const char* Pl, int row0, int kA0,
                                           const char* __restrict__ Wf, int Kp16, int n0, int kB0, int lane) {
@@ -151,8 +163,8 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
     auto ldw = [&](int t) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        uwh[t % SETS][nt] = *(const h8*)(bpu[nt] + (size_t)t * 2048);
-        if constexpr (NP == 2) uwl[t % SETS][nt] = *(const h8*)(bpu[nt] + (size_t)t * 2048 + 1024);
+        uwh[t % SETS][nt] = W_LOAD(bpu[nt], t);
+        if constexpr (NP == 2) uwl[t % SETS][nt] = W_LOAD_LO(bpu[nt], t);
       }
     };
     auto ldx = [&](int t) {
@@ -187,8 +199,8 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
   auto loadw = [&](h8 (&h)[NT], h8 (&l)[NT], int t) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      h[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048);
-      if constexpr (NP == 2) l[nt] = *(const h8*)(bp[nt] + (size_t)t * 2048 + 1024);
+      h[nt] = W_LOAD(bp[nt], t);
+      if constexpr (NP == 2) l[nt] = W_LOAD_LO(bp[nt], t);
     }
   };
   auto loadx = [&](h8 (&h)[MT], h8 (&l)[MT], int t) {
@@ -228,29 +240,48 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
 // Same with the activation operand converted on the fly from fp32 rows in global memory (short side inputs: encoding for
 // the skip connection, per-ray embedding rows): xrow_ptr[mt] points at this lane's row at column 8*(lane>>5); `e` is the
 // exponent of the LDS planes the same accumulators are fed from.  K % 16 == 0.
-template <int NP, int MT, int NT>
+// K is a compile-time constant (64, 80 or 16): every row piece is requested up front and the weight fragments travel one k-block
+// ahead, all in straight-line code -- the rolled form (one k-block per trip: requests, `s_waitcnt vmcnt(0)`, MFMAs) paid one L2
+// round trip per k-block with the matrix pipe idle, ten of them per tile in the schedule phase with all heads on.
+template <int NP, int K, int MT, int NT>
 __device__ __forceinline__ void mma16_glb(f32x16 (&acc)[MT][NT], const float* const (&xrow_ptr)[MT], int e,
-                                          const char* __restrict__ Wf, int Kp16, int n0, int kB0, int K, int lane) {
-  const int T = K >> 4;
-#pragma unroll 1
-  for (int t = 0; t < T; ++t) {
-    h8 xh[MT], xl[MT], wh[NT], wl[NT];
+                                          const char* __restrict__ Wf, int Kp16, int n0, int kB0, int lane) {
+  constexpr int T = K >> 4;
+  static_assert(K % 16 == 0 && T >= 1 && T <= 5, "short side inputs only");
+  f32x4 xr[T][MT][2];
+  h8 wh[2][NT], wl[2][NT];
+  const char* bp[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bp[nt] = Wf + ((size_t)((n0 >> 5) + nt) * Kp16 + (kB0 >> 4)) * 2048 + lane * 16;
+  auto ldw = [&](int t) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const char* p = Wf + ((size_t)((n0 >> 5) + nt) * Kp16 + (kB0 >> 4) + t) * 2048 + lane * 16;
-      wh[nt] = *(const h8*)p;
-      if constexpr (NP == 2) wl[nt] = *(const h8*)(p + 1024);
+      wh[t & 1][nt] = *(const h8*)(bp[nt] + (size_t)t * 2048);
+      if constexpr (NP == 2) wl[t & 1][nt] = *(const h8*)(bp[nt] + (size_t)t * 2048 + 1024);
     }
+  };
+  ldw(0);
+#pragma unroll
+  for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const f32x4 x0 = *(const f32x4*)(xrow_ptr[mt] + 16 * t), x1 = *(const f32x4*)(xrow_ptr[mt] + 16 * t + 4);
+      xr[t][mt][0] = *(const f32x4*)(xrow_ptr[mt] + 16 * t);
+      xr[t][mt][1] = *(const f32x4*)(xrow_ptr[mt] + 16 * t + 4);
+    }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) ldw(t + 1);
+    h8 xh[MT], xl[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 x0 = xr[t][mt][0], x1 = xr[t][mt][1];
       h4 a, b, c, d;
       split_quad<NP>(ldexpf(x0[0], e), ldexpf(x0[1], e), ldexpf(x0[2], e), ldexpf(x0[3], e), a, c);
       split_quad<NP>(ldexpf(x1[0], e), ldexpf(x1[1], e), ldexpf(x1[2], e), ldexpf(x1[3], e), b, d);
       xh[mt] = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
       if constexpr (NP == 2) xl[mt] = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
     }
-    mma16_step<NP>(acc, xh, xl, wh, wl);
+    mma16_step<NP>(acc, xh, xl, wh[t & 1], wl[t & 1]);
   }
 }
 

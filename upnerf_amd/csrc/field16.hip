@@ -294,6 +294,10 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   // layer makes hipcc copy it to scratch and fetch the entry with a VMEM load + s_waitcnt vmcnt(0) -- a full drain of the
   // previous layer's activation stores at the top of every layer.
   __shared__ int loff_s[2 * UPNERF_MAX_D];
+  // weight exponents (wexp, WEXP_SLOTS ints): an epilogue that read its exponent from global memory opened with an L2 round trip
+  // whose wait -- vmcnt retires in order -- also drained every store the previous stage had just issued (round 5: the layer
+  // loop's `s_waitcnt vmcnt(0)` in front of the first weight request)
+  __shared__ int wexp_s[WEXP_SLOTS];
   // trunk biases [D][W]: the epilogues read them from LDS
   __shared__ __attribute__((aligned(16))) float bias_s[UPNERF_MAX_D * W];
   char* Ph = planes;
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE;
   const float* __restrict__ P = a.P;
   const char* __restrict__ P16 = (const char*)a.P16;
-  const int* __restrict__ wexp = a.wexp;
+  const int* wexp = wexp_s;  // (filled below; the first reader sits behind several barriers)
   const int n0 = TW::n0(wave), row0 = TW::row0(wave);
   const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
   const int D = L.D;
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     }
   }
   if (tid < 16) mx_s[tid] = 0u;
+  if (tid >= 64 && tid < 64 + WEXP_SLOTS) wexp_s[tid - 64] = a.wexp[tid - 64];
 #pragma unroll
   for (int l = 0; l < UPNERF_MAX_D; ++l)
     if (l < D)
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
         m = m < M ? m : M - 1;
         ap[mt] = a.x0 + (size_t)m * UPNERF_X0 + 8 * hh;
       }
-      mma16_glb<NP>(acc, ap, ecur, P16 + 4 * (size_t)wl, (UPNERF_X0 + W) / 16, n0, 0, UPNERF_X0, lane);
+      mma16_glb<NP, UPNERF_X0>(acc, ap, ecur, P16 + 4 * (size_t)wl, (UPNERF_X0 + W) / 16, n0, 0, lane);
       mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, (UPNERF_X0 + W) / 16, n0, UPNERF_X0, lane);
     } else {
       mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, W / 16, n0, 0, lane);
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     const float* ap[TH::MT];
 #pragma unroll
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.aux + (size_t)rayrow[mt] * UPNERF_AUXK + 8 * hh;
-    mma16_glb<NP>(accr, ap, ecur, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, W, UPNERF_AUXK, lane);
+    mma16_glb<NP, UPNERF_AUXK>(accr, ap, ecur, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, W, lane);
     acc_fma_bias<true>(accr, pow2f(-(ecur + wexp[11])), br);
     mr = acc_absmax(accr);
   }
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     const float* ap[TH::MT];
 #pragma unroll
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.c_rows + (size_t)rayrow[mt] * UPNERF_CK + 8 * hh;
-    mma16_glb<NP>(accc, ap, ecur, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, UPNERF_CK, lane);
+    mma16_glb<NP, UPNERF_CK>(accc, ap, ecur, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, W, lane);
     const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), bc);
     if (a.hmask) NT_STORE(&((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * THREADS + tid], bits);
     mc = acc_absmax(accc);
@@ -624,6 +629,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
   __shared__ float dpc_s[TILE], cwj_s[TILE];
   __shared__ __attribute__((aligned(16))) float dprgb_s[TILE][4];
   __shared__ int loff_s[UPNERF_MAX_D];  // t_w[l] (see the forward kernel: no runtime index into the by-value struct)
+  __shared__ int wexp_s[WEXP_SLOTS];    // weight exponents (see the forward kernel: no global load in front of a contraction)
   // per-tile partial sums (a.tile_part, 64-sample tiles only): ray slot of every row; cross-wave reduction scratch
   constexpr int TPW = (TILE == F16_TILE && NW == 4) ? NW : 1;  // (the 8-wave experiment of the 64-sample tile: no partial sums)
   __shared__ int slot_s[TILE];
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
   const int S = a.S, M = a.R * a.S, m0 = blockIdx.x * TILE, D = L.D;
   const float* __restrict__ P = a.P;
   const char* __restrict__ PT16 = (const char*)a.PT16;
-  const int* __restrict__ wexp = a.wexp;
+  const int* wexp = wexp_s;
   const int n0 = TW::n0(wave), row0 = TW::row0(wave);
   const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
   const int xn0 = TX::n0(wave), xrow0 = TX::row0(wave);
@@ -660,6 +666,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     for (int l = 0; l < UPNERF_MAX_D; ++l) loff_s[l] = L.t_w[l];
   }
   if (tid >= 64 && tid < 80) mx_s[tid - 64] = 0u;
+  if (tid >= 128 && tid < 128 + WEXP_SLOTS) wexp_s[tid - 128] = a.wexp[tid - 128];
   // softplus'(x) = 1 - exp(-softplus(x)); per-row feature weight on its ray slot; per-row scalars of the head stages
   if (tid < TILE) {
     const int m = m0 + tid;

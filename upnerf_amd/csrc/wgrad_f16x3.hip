@@ -93,19 +93,27 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
   acc_zero(acc);
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // this thread's 4 columns of A, summed over its rows (fp32, unscaled)
 
+  // Loads are UNCONDITIONAL (rows past the split's end are clamped to its last row, columns past the matrix to column 0) and the
+  // out-of-range pieces are zeroed when the chunk is staged.  With a branch around every load (`in range ? load : 0`) hipcc
+  // cannot count the loads of the two register sets apart and waits vmcnt(0) at the top of the loop -- for the set requested
+  // one contraction earlier too, i.e. for a full HBM round trip per two chunks (cdna_hip_programming.md, 'Three .s-level traps'
+  // (c); round 4's elimination: 0.381 ms with the wait, 0.276 ms of staging + MFMAs without any load).
   f32x4 ra0[A4], rb0[B4], ra1[A4], rb1[B4];
+  const int mlast = mend > mbeg ? mend - 1 : (mbeg < M ? mbeg : M - 1);
   auto gload = [&](f32x4 (&ra)[A4], f32x4 (&rb)[B4], int mc) {
 #pragma unroll
     for (int q = 0; q < A4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
-      const int m = mc + row;
-      ra[q] = (m < mend && nblk + 4 * c4 < N && HALFROW_OK(TN, c4)) ? WG_LOAD((const f32x4*)&A[(size_t)m * lda + nblk + 4 * c4]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int m = mc + row < mlast ? mc + row : mlast;
+      const int col = nblk + 4 * c4 < N ? nblk + 4 * c4 : 0;
+      ra[q] = WG_LOAD((const f32x4*)&A[(size_t)m * lda + col]);
     }
 #pragma unroll
     for (int q = 0; q < B4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
-      const int m = mc + row;
-      rb[q] = (m < mend && kblk + 4 * c4 < K && HALFROW_OK(TK, c4)) ? WG_LOAD((const f32x4*)&B[(size_t)m * ldb + kblk + 4 * c4]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int m = mc + row < mlast ? mc + row : mlast;
+      const int col = kblk + 4 * c4 < K ? kblk + 4 * c4 : 0;
+      rb[q] = WG_LOAD((const f32x4*)&B[(size_t)m * ldb + col]);
     }
   };
   auto split_store = [&](char* hi, char* lo, f32x4 v, float s, int row, int col) {
@@ -122,18 +130,22 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       *(h4*)(lo + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
     }
   };
-  auto lstore = [&](const f32x4 (&ra)[A4], const f32x4 (&rb)[B4], int buf) {
+  // mc: first row of the chunk the set holds (rows >= mend and columns past the matrix are staged as zeros)
+  auto lstore = [&](const f32x4 (&ra)[A4], const f32x4 (&rb)[B4], int buf, int mc) {
     char* base = lds + buf * (2 * SZA + 2 * SZB);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < A4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
-      bsum += ra[q];
-      split_store(base, base + SZA, ra[q], sa, row, 4 * c4);
+      const f32x4 v = (mc + row < mend && nblk + 4 * c4 < N && HALFROW_OK(TN, c4)) ? ra[q] : z4;
+      bsum += v;
+      split_store(base, base + SZA, v, sa, row, 4 * c4);
     }
 #pragma unroll
     for (int q = 0; q < B4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
-      split_store(base + 2 * SZA, base + 2 * SZA + SZB, rb[q], sb, row, 4 * c4);
+      const f32x4 v = (mc + row < mend && kblk + 4 * c4 < K && HALFROW_OK(TK, c4)) ? rb[q] : z4;
+      split_store(base + 2 * SZA, base + 2 * SZA + SZB, v, sb, row, 4 * c4);
     }
   };
   // transposed-read address pieces of this lane (cdna_hip_programming.md T10): group g, row q, column quad p
@@ -181,15 +193,49 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
   // them; the 256x256 block (128 accumulator registers per wave) keeps one set.
   constexpr bool TWO_SETS = MT * NT * 16 <= 64 || FX_CHUNK == 16;
   if constexpr (TWO_SETS) {
-    // rows beyond mend load as zeros, so an odd number of chunks simply contracts one all-zero chunk
+    // rows beyond mend are staged as zeros, so an odd number of chunks simply contracts one all-zero chunk
+    // (WG_EXP_*: timing experiments with wrong results -- what is left of the launch without the loads / the staging (which is
+    // also the only consumer of the loads: nothing waits for them any more) / the MFMAs; tools/bench_wgrad.py)
+    // Straight-line on purpose: any control flow between the loads of one set and the staging of the other (a reordering of the two
+    // jobs of an interval for half of the waves was tried in round 5: no gain, and its branches brought the vmcnt(0) back).
     gload(ra0, rb0, mbeg);
     gload(ra1, rb1, mbeg + FX_CHUNK);
+#ifdef WG_STAGGER
+    // Experiment (make variant EXP=-DWG_STAGGER): between two barriers a wave contracts the staged chunk and stages the next one;
+    // waves 4-7 (the SIMD partners of waves 0-3) do the two jobs in the other order.  The branch sits OUTSIDE the loops: each loop
+    // is straight-line code (see above).
+    auto stage = [&](f32x4 (&ra)[A4], f32x4 (&rb)[B4], int buf, int mnext) {  // the set holds chunk mnext - 2 chunks
+      lstore(ra, rb, buf, mnext - 2 * FX_CHUNK);
+      gload(ra, rb, mnext);
+    };
+    stage(ra0, rb0, 0, mbeg + 2 * FX_CHUNK);  // buffer 0 = chunk 0; set 0 <- chunk 2
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= 4) {
+#pragma unroll 1
+      for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
+        stage(ra1, rb1, 1, mc + 3 * FX_CHUNK);
+        contract(0);
+        __syncthreads();
+        stage(ra0, rb0, 0, mc + 4 * FX_CHUNK);
+        contract(1);
+        __syncthreads();
+      }
+    } else {
+#pragma unroll 1
+      for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
+        contract(0);
+        stage(ra1, rb1, 1, mc + 3 * FX_CHUNK);
+        __syncthreads();
+        contract(1);
+        stage(ra0, rb0, 0, mc + 4 * FX_CHUNK);
+        __syncthreads();
+      }
+    }
+#else
 #pragma unroll 1
     for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
-      // (WG_EXP_*: timing experiments with wrong results -- what is left of the launch without the loads / the staging (which is
-      // also the only consumer of the loads: nothing waits for them any more) / the MFMAs; tools/bench_wgrad.py)
 #ifndef WG_EXP_NOSTAGE
-      lstore(ra0, rb0, 0);
+      lstore(ra0, rb0, 0, mc);
 #endif
       __syncthreads();
 #ifndef WG_EXP_NOLOAD
@@ -199,7 +245,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       contract(0);
 #endif
 #ifndef WG_EXP_NOSTAGE
-      lstore(ra1, rb1, 1);
+      lstore(ra1, rb1, 1, mc + FX_CHUNK);
 #endif
       __syncthreads();
 #ifndef WG_EXP_NOLOAD
@@ -209,12 +255,13 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       contract(1);
 #endif
     }
+#endif
   } else {
     int buf = 0;
     gload(ra0, rb0, mbeg);
 #pragma unroll 1
     for (int mc = mbeg; mc < mend; mc += FX_CHUNK) {
-      lstore(ra0, rb0, buf);
+      lstore(ra0, rb0, buf, mc);
       __syncthreads();
       gload(ra0, rb0, mc + FX_CHUNK);
       contract(buf);
@@ -329,47 +376,48 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   u32x2_t la[NS][A8], lb[NS][B8 ? B8 : 1];  // NP = 2: the residual bytes of the same pieces
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const u32x2_t mid8 = {0x80808080u, 0x80808080u};  // (byte 128 = residual 0)
+  // loads are unconditional (clamped rows / columns; see wgrad_f16x3_kernel), out-of-range pieces are zeroed at staging
+  const int mlast = mend > mbeg ? mend - 1 : (mbeg < M ? mbeg : M - 1);
   auto gload = [&](h8 (&ra)[A8], int (&xa)[A8], h8 (&rbp)[B8 ? B8 : 1], int (&xb)[B8 ? B8 : 1], f32x4 (&rbf)[B4 ? B4 : 1],
                    u32x2_t (&la)[A8], u32x2_t (&lb)[B8 ? B8 : 1], int mc) {
 #pragma unroll
     for (int q = 0; q < A8; ++q) {
       if constexpr (FRAG) {
-        const int m = mc + (tid % RPA) + RPA * q, s2 = tid / RPA;  // row of the chunk; (k-block, lane half) of this thread
-        const bool ok = m < mend;
-        ra[q] = ok ? NT_LOAD((const h8*)((const char*)A + (((size_t)(m >> 5) * (TN / 16) + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16)) : zero8;
-        xa[q] = ok ? aexp[m >> 5] : 0;
+        const int mr = mc + (tid % RPA) + RPA * q, m = mr < mlast ? mr : mlast, s2 = tid / RPA;  // row of the chunk; (k-block, lane half) of this thread
+        ra[q] = NT_LOAD((const h8*)((const char*)A + (((size_t)(m >> 5) * (TN / 16) + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16));
+        xa[q] = aexp[m >> 5];
       } else {
         const int idx = tid + q * FX_THREADS, row = idx / (TN / 8), c8 = idx - row * (TN / 8);
-        const int m = mc + row;
-        const bool ok = m < mend && nblk + 8 * c8 < N;
-        ra[q] = ok ? NT_LOAD((const h8*)&A[(size_t)m * lda + nblk + 8 * c8]) : zero8;
-        if constexpr (NP == 2) la[q] = ok ? NT_LOAD((const u32x2_t*)&Alo[(size_t)m * lda + nblk + 8 * c8]) : mid8;
-        xa[q] = ok ? aexp[m >> 6] : 0;
+        const int m = mc + row < mlast ? mc + row : mlast;
+        const int col = nblk + 8 * c8 < N ? nblk + 8 * c8 : 0;
+        ra[q] = NT_LOAD((const h8*)&A[(size_t)m * lda + col]);
+        if constexpr (NP == 2) la[q] = NT_LOAD((const u32x2_t*)&Alo[(size_t)m * lda + col]);
+        xa[q] = aexp[m >> 6];
       }
     }
     if constexpr (PKB) {
 #pragma unroll
       for (int q = 0; q < B8; ++q) {
         if constexpr (FRAG) {
-          const int m = mc + (tid % RPB) + RPB * q, s2 = tid / RPB;
-          const bool ok = m < mend;
-          rbp[q] = ok ? NT_LOAD((const h8*)((const char*)Bh + (((size_t)(m >> 5) * (TK / 16) + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16)) : zero8;
-          xb[q] = ok ? bexp[m >> 5] : 0;
+          const int mr = mc + (tid % RPB) + RPB * q, m = mr < mlast ? mr : mlast, s2 = tid / RPB;
+          rbp[q] = NT_LOAD((const h8*)((const char*)Bh + (((size_t)(m >> 5) * (TK / 16) + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16));
+          xb[q] = bexp[m >> 5];
         } else {
           const int idx = tid + q * FX_THREADS, row = idx / (TK / 8), c8 = idx - row * (TK / 8);
-          const int m = mc + row;
-          const bool ok = m < mend && kblk + 8 * c8 < K;
-          rbp[q] = ok ? NT_LOAD((const h8*)&Bh[(size_t)m * ldb + kblk + 8 * c8]) : zero8;
-          if constexpr (NP == 2) lb[q] = ok ? NT_LOAD((const u32x2_t*)&Blo[(size_t)m * ldb + kblk + 8 * c8]) : mid8;
-          xb[q] = ok ? bexp[m >> 6] : 0;
+          const int m = mc + row < mlast ? mc + row : mlast;
+          const int col = kblk + 8 * c8 < K ? kblk + 8 * c8 : 0;
+          rbp[q] = NT_LOAD((const h8*)&Bh[(size_t)m * ldb + col]);
+          if constexpr (NP == 2) lb[q] = NT_LOAD((const u32x2_t*)&Blo[(size_t)m * ldb + col]);
+          xb[q] = bexp[m >> 6];
         }
       }
     } else {
 #pragma unroll
       for (int q = 0; q < B4; ++q) {
         const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
-        const int m = mc + row;
-        rbf[q] = (m < mend && kblk + 4 * c4 < K) ? NT_LOAD((const f32x4*)&Bf[(size_t)m * ldb + kblk + 4 * c4]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int m = mc + row < mlast ? mc + row : mlast;
+        const int col = kblk + 4 * c4 < K ? kblk + 4 * c4 : 0;
+        rbf[q] = NT_LOAD((const f32x4*)&Bf[(size_t)m * ldb + col]);
       }
     }
   };
@@ -389,9 +437,33 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
     for (int j = 0; j < 8; ++j) v[j] = v[j] * s + o;
     return v;
   };
-  auto lstore = [&](const h8 (&ra)[A8], const int (&xa)[A8], const h8 (&rbp)[B8 ? B8 : 1], const int (&xb)[B8 ? B8 : 1],
-                    const f32x4 (&rbf)[B4 ? B4 : 1], const u32x2_t (&la)[A8], const u32x2_t (&lb)[B8 ? B8 : 1], int buf) {
+  // mc: first row of the chunk the set holds (rows >= mend and columns past the matrix are staged as zeros)
+  auto lstore = [&](const h8 (&ra_)[A8], const int (&xa)[A8], const h8 (&rbp_)[B8 ? B8 : 1], const int (&xb)[B8 ? B8 : 1],
+                    const f32x4 (&rbf_)[B4 ? B4 : 1], const u32x2_t (&la_)[A8], const u32x2_t (&lb_)[B8 ? B8 : 1], int buf, int mc) {
     char* base = lds + buf * BUF;
+    // the masks (what the conditional loads used to deliver as zeros)
+    h8 ra[A8], rbp[B8 ? B8 : 1];
+    f32x4 rbf[B4 ? B4 : 1];
+    u32x2_t la[A8], lb[B8 ? B8 : 1];
+#pragma unroll
+    for (int q = 0; q < A8; ++q) {
+      const int idx = tid + q * FX_THREADS;
+      const bool ok = FRAG ? (mc + (tid % RPA) + RPA * q < mend) : (mc + idx / (TN / 8) < mend && nblk + 8 * (idx % (TN / 8)) < N);
+      ra[q] = ok ? ra_[q] : zero8;
+      la[q] = ok ? la_[q] : mid8;
+    }
+#pragma unroll
+    for (int q = 0; q < B8; ++q) {
+      const int idx = tid + q * FX_THREADS;
+      const bool ok = FRAG ? (mc + (tid % RPB) + RPB * q < mend) : (mc + idx / (TK / 8) < mend && kblk + 8 * (idx % (TK / 8)) < K);
+      rbp[q] = ok ? rbp_[q] : zero8;
+      lb[q] = ok ? lb_[q] : mid8;
+    }
+#pragma unroll
+    for (int q = 0; q < B4; ++q) {
+      const int idx = tid + q * FX_THREADS;
+      rbf[q] = (mc + idx / (TK / 4) < mend && kblk + 4 * (idx % (TK / 4)) < K) ? rbf_[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int q = 0; q < A8; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TN / 8), c8 = idx - row * (TN / 8);
@@ -490,13 +562,14 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
     }
   };
   // two register sets: the loads of chunk c+2 are in flight while chunk c is contracted (rows beyond mend load as zeros)
+  // NS register sets: the loads of chunk c + NS are in flight while chunk c is contracted (rows beyond mend are staged as zeros)
 #pragma unroll
   for (int u = 0; u < NS; ++u) gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], mbeg + u * FX_CHUNK);
 #pragma unroll 1
   for (int mc = mbeg; mc < mend; mc += NS * FX_CHUNK) {
 #pragma unroll
-    for (int u = 0; u < NS; ++u) {  // (chunks past mend load and contract zeros)
-      lstore(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], u & 1);
+    for (int u = 0; u < NS; ++u) {
+      lstore(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], u & 1, mc + u * FX_CHUNK);
       __syncthreads();
       gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], mc + (NS + u) * FX_CHUNK);
       contract(u & 1);
