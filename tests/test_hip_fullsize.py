@@ -339,7 +339,7 @@ def test_full_size_forward_and_ray_gradients_match_the_oracle_on_a_slice(mode, r
     for dt in (torch.float32, torch.float64):
         st, losses, r, okeep = oracle_at(sl, zf, dt)
         sum(losses.values()).backward()
-        out[dt] = (r, okeep["rays"].grad.detach().clone(), okeep["z_coarse"])
+        out[dt] = (r, okeep["rays"].grad.detach().clone(), okeep["z_coarse"].detach())
     r32, gr32, zc32 = out[torch.float32]
     assert rel_err(keep["z_coarse"].cpu()[idx].numpy(), zc32.numpy()) < 1e-6
     tol_map, tol_w = (TOL_MAP, TOL_W) if mode == "f16x3" else (1e-2, 3e-2)

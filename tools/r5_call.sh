@@ -1,13 +1,9 @@
 # scratch driver for this round's GPU calls (edited per call)
 set -u
-mkdir -p gpurun_out/c4
-(timeout 1200 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py -m gpu -x -q -k "wgrad or chain or slab or tto or stage_by_stage or option" 2>&1 | tail -15) > gpurun_out/c4/pytest.log 2>&1
-bash tools/ab_lib.sh upnerf_amd/libupnerf_hip_base.so upnerf_amd/libupnerf_hip.so "wgrad_256x256 wgrad_256x64 wgrad_128x128 field_fwd field_bwd" 2 > gpurun_out/c4/ab.log 2>&1
-for lib in _base ""; do UPNERF_LIB=$PWD/upnerf_amd/libupnerf_hip$lib.so python bench.py --config trevi --steps 10 --warmup 3 --no-extras --no-cpu-baseline --kernel-timing all 2>/dev/null | tail -1 | python -c "
+mkdir -p gpurun_out/c10
+(timeout 600 python -m pytest tests/test_hip_fullsize.py -m gpu -x -q -k "slice" 2>&1 | grep -v "^$" | tail -40) > gpurun_out/c10/slice.log 2>&1
+(timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15) > gpurun_out/c10/pytest.log 2>&1
+for r in 1 2; do for lib in "" _ap1 _ap3; do UPNERF_LIB=$PWD/upnerf_amd/libupnerf_hip$lib.so python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d.get('kernels',{})
-print('trevi $lib', round(d['value']), 'rays/s', ' '.join(f\"{n}={v['ms_per_step']:.3f}\" for n,v in k.items() if v['ms_per_step']>0.15))" >> gpurun_out/c4/ab.log; done
-for lib in _base ""; do UPNERF_LIB=$PWD/upnerf_amd/libupnerf_hip$lib.so python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('brandenburg graph $lib', round(d['value']), d['ms_per_step'])" >> gpurun_out/c4/ab.log; done
-tail -5 gpurun_out/c4/pytest.log; cat gpurun_out/c4/ab.log
+d=json.loads(sys.stdin.read()); k=d['kernels']; print('brandenburg graph $lib', round(d['value']), round(d['ms_per_step'],3), ' '.join(f\"{n}={v['avg_ms']:.3f}\" for n,v in k.items()))" >> gpurun_out/c10/ab.log; done; done
+cat gpurun_out/c10/slice.log; tail -6 gpurun_out/c10/pytest.log; cat gpurun_out/c10/ab.log

@@ -411,11 +411,15 @@ __device__ __forceinline__ void store_policy(T* p, const T& v) {
 // round-robin to 8 thread groups whose partial sums meet in LDS (`part`, 8 KiB); each group keeps 8 loads in flight.
 #define RED_RG 8
 #define RED_THREADS (64 * RED_RG)
+// PW: physical waves of the calling workgroup (8, or 4: every wave then plays thread groups w and w + 4 one after the other -- the
+// same partial sums, added in the same order: bitwise the 8-wave result).
+template <int PW = RED_RG>
 __device__ __forceinline__ void wgrad_reduce_body(int bid, int tid, const upnerf_wgrad_pending& P, f32x4 (*part)[64]) {
+  static_assert(PW == 8 || PW == 4, "8 thread groups on 8 or 4 waves");
   const int N = P.N, K = P.K, TN = P.TN, TK = P.TK, nsplit = P.nsplit;
   const float* __restrict__ slabs = P.slabs;
   const float* __restrict__ bslabs = P.bslabs;
-  const int lane = tid & 63, rg = tid >> 6;
+  const int lane = tid & 63;
   const int q = bid * 64 + lane;  // index of a group of 4 consecutive k
   const int K4 = K >> 2;
   const int gy = (N + TN - 1) / TN, gz = (K + TK - 1) / TK;
@@ -426,30 +430,34 @@ __device__ __forceinline__ void wgrad_reduce_body(int bid, int tid, const upnerf
   const size_t stride = (size_t)gy * gz * TN * TK;
   // 8 waves x 8 loads of 16 bytes per lane = 64 KiB in flight per workgroup (one workgroup per CU at 256 x 256): at 16 KiB
   // the 67 MB of slabs of a 256 x 256 layer came in at 2.7 TB/s
-  f32x4 s[8];
+#pragma unroll 1
+  for (int rg = tid >> 6; rg < RED_RG; rg += PW) {
+    f32x4 s[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (ok) {
-    int sp = rg;
-    for (; sp + 7 * RED_RG < nsplit; sp += 8 * RED_RG) {
-      f32x4 v[8];
+    for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      int sp = rg;
+      for (; sp + 7 * RED_RG < nsplit; sp += 8 * RED_RG) {
+        f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)&slabs[off + (size_t)(sp + u * RED_RG) * stride];
+        for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)&slabs[off + (size_t)(sp + u * RED_RG) * stride];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s[u] += v[u];
+        for (int u = 0; u < 8; ++u) s[u] += v[u];
+      }
+      for (; sp < nsplit; sp += RED_RG) s[0] += *(const f32x4*)&slabs[off + (size_t)sp * stride];
     }
-    for (; sp < nsplit; sp += RED_RG) s[0] += *(const f32x4*)&slabs[off + (size_t)sp * stride];
+    part[rg][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   }
-  part[rg][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
-  if (rg == 0 && ok) {
+  if ((tid >> 6) == 0 && ok) {
     const f32x4 t = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
                     ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
     if (P.n2 > 0 && n >= P.n2) *(f32x4*)&P.dW2[(size_t)(n - P.n2) * P.ldo2 + k] = t;
     else *(f32x4*)&P.dW[(size_t)n * P.ldo + k] = t;
   }
   if (P.db || (P.n2 > 0 && P.db2)) {
-    const int idx = bid * RED_THREADS + tid;
+#pragma unroll 1
+    for (int idx = bid * RED_THREADS + tid; idx < (bid + 1) * RED_THREADS; idx += 64 * PW)
     if (idx < N) {
       const int bby = idx / TN;
       float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -19,6 +19,7 @@
 // stores, per-row scalars (one LDS read per lane instead of one per register).
 #pragma once
 #include "common.cuh"
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -139,9 +140,16 @@ __device__ __forceinline__ void mma16_step(f32x16 (&acc)[MT][NT], const h8 (&xh)
 #define W_LOAD(p, t) (*(const h8*)((p) + (size_t)(t) * 2048))
 #define W_LOAD_LO(p, t) (*(const h8*)((p) + (size_t)(t) * 2048 + 1024))
 #endif
-template <int NP, int W, int T, int AHEAD, int MT, int NT>
+// `piece(t)` (optional) runs once per k-block, in the request section of block t -- behind the weight requests of block
+// t + AHEAD and the operand reads of block t + 1, in front of the MFMAs of block t: the place of work that rides under the
+// contraction (the previous stage's activation stores, one 1 KiB piece per k-block: field16.hip:PlaneStore).
+struct NoPiece {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <int NP, int W, int T, int AHEAD, int MT, int NT, class PIECE = NoPiece>
 __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph, const char* Pl, int row0, int kA0,
-                                          const char* __restrict__ Wf, int Kp16, int n0, int kB0, int lane) {
+                                          const char* __restrict__ Wf, int Kp16, int n0, int kB0, int lane,
+                                          PIECE&& piece = PIECE()) {
   constexpr int SETS = (AHEAD + 1 > T) ? T : AHEAD + 1;  // ring size; the ring runs SETS - 1 blocks ahead
   constexpr int AH = SETS - 1;
 #ifdef UPNERF_EXP_SETPRIO
@@ -182,12 +190,15 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
     for (int t = 0; t < T; ++t) {
       if (t + AH < T) ldw(t + AH);
       if (t + 1 < T) ldx(t + 1);
+      piece(t);
       __builtin_amdgcn_sched_barrier(0);
       mma16_step<NP>(acc, uxh[t & 1], uxl[t & 1], uwh[t % SETS], uwl[t % SETS]);
       __builtin_amdgcn_sched_barrier(0);
     }
     return;
   }
+  static_assert(F16_FORCE_UNROLLED_K || SETS % 2 != 0 || T % SETS != 0 || std::is_same<typename std::remove_reference<PIECE>::type, NoPiece>::value,
+                "per-k-block pieces: unrolled K loops only");
   const int i = lane & 31, hh = lane >> 5;
   const char* bp[NT];
   int arow[MT];

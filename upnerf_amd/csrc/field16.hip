@@ -46,6 +46,13 @@
 #ifndef F16_AHEAD_X3
 #define F16_AHEAD_X3 2
 #endif
+#ifndef F16_STORE_IN_LOOP
+// Activation stores as one 1 KiB piece per k-block INSIDE the next layer's K loop (PlaneStore).  Built, parity-green,
+// measured slower (round 5, alternating runs on one box: forward launch 2.61 / 2.58 ms against 2.52 / 2.54 behind the loop): the K loop
+// already keeps the CU's vector-memory path at the rate it sustains under this mix, a store per k-block lengthens it by what the
+// burst behind the loop costs and the epilogue still waits for its barriers.  0 = behind the loop (shipped); 1 = the experiment.
+#define F16_STORE_IN_LOOP 0
+#endif
 #ifndef F16_AHEAD_F16
 #define F16_AHEAD_F16 5  // (with non-temporal stores: 19.63 ms per Trevi step against 19.78 at three ahead; round 3)
 #endif
@@ -155,6 +162,48 @@ __device__ __forceinline__ void tile_store16(const char* Ph, const char* Pl, int
                                              int ldg, int m0, int M, int tid) {
   tile_store16<NP, W, TILE, THREADS, NCOLS, BATCH, STREAM>(Ph, Pl, c0, unscale, unscale, dst, ldg, m0, M, tid);
 }
+
+// tile_store16 of a full-width (W-column) tensor cut into its 1 KiB pieces -- piece t = the workgroup's store pass t of
+// tile_store16: rows 4 t .. 4 t + 3 at 256 threads -- for issue INSIDE the K loop of the next contraction, one piece per k-block
+// (common16.cuh:mma16_lds `piece`): that loop reads the same planes, nothing writes them before its closing barrier, and the wave
+// that is held by a store's issue (~260 cycles) leaves the matrix pipe to its SIMD partner instead of idling it
+// together with all eight waves of the CU in a burst of sixteen stores behind the loop.  Whole tiles only (no row guard: no control flow in the K loop --
+// a branch there makes hipcc's vmcnt bookkeeping conservative and drains the weight ring).
+template <int NP, int W, int TILE, int THREADS>
+struct PlaneStore {
+  static constexpr int GPR = W >> 2, ITER = TILE * GPR / THREADS;
+  const char *Ph, *Pl;
+  float* __restrict__ dst;  // row m0 of the tensor
+  float un0, un1;
+  int tid;
+  u32x2_t ch, cl;
+  __device__ __forceinline__ void read(int it, u32x2_t& h, u32x2_t& l) const {
+    const int idx = tid + it * THREADS, row = idx / GPR, g = idx % GPR;
+    const int o = poff<W>(row, 4 * g);
+    h = *(const u32x2_t*)(Ph + o);
+    if constexpr (NP == 2) l = *(const u32x2_t*)(Pl + o);
+  }
+  __device__ __forceinline__ PlaneStore(const char* ph, const char* pl, float* d, float u0, float u1, int t)
+      : Ph(ph), Pl(pl), dst(d), un0(u0), un1(u1), tid(t) {
+    // (opaque per layer: the pieces' row offsets are layer-invariant, hipcc hoisted all sixteen address pairs out of the layer
+    // loop, spilled them and reloaded them inside the K loop -- scratch loads, i.e. vmcnt waits behind the stores)
+    asm volatile("" : "+v"(tid));
+  }
+  __device__ __forceinline__ void operator()(int it) {
+    // (read, convert and store in one go: carrying the next piece's LDS words across the MFMAs cost the forward kernel, which
+    // sits at 256 registers, 47 spilled registers)
+    read(it, ch, cl);
+    const int idx = tid + it * THREADS, row = idx / GPR, g = idx % GPR;
+    const float un = row < TILE / 2 ? un0 : un1;
+    f32x4 v;
+    if constexpr (NP == 2)
+      v = f32x4{mix16<0>(ch[0], un, mix16<0>(cl[0], un, 0.f)), mix16<1>(ch[0], un, mix16<1>(cl[0], un, 0.f)),
+                mix16<0>(ch[1], un, mix16<0>(cl[1], un, 0.f)), mix16<1>(ch[1], un, mix16<1>(cl[1], un, 0.f))};
+    else
+      v = f32x4{mix16<0>(ch[0], un, 0.f), mix16<1>(ch[0], un, 0.f), mix16<0>(ch[1], un, 0.f), mix16<1>(ch[1], un, 0.f)};
+    ACT_STORE((f32x4*)&dst[(size_t)row * W + 4 * g], v);
+  }
+};
 
 // tile_store16 for a half-width tensor that also adds every stored row to the accumulator of the row's ray slot (sums[slot],
 // this thread's four columns; slot_s[row] < NS): the per-tile part of upnerf_ray_sum (see upnerf_field_bwd_args.tile_part).
@@ -298,6 +347,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   // whose wait -- vmcnt retires in order -- also drained every store the previous stage had just issued (round 5: the layer
   // loop's `s_waitcnt vmcnt(0)` in front of the first weight request)
   __shared__ int wexp_s[WEXP_SLOTS];
+  __shared__ float wk_s[10];
   // trunk biases [D][W]: the epilogues read them from LDS
   __shared__ __attribute__((aligned(16))) float bias_s[UPNERF_MAX_D * W];
   char* Ph = planes;
@@ -318,6 +368,11 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   const int hn0 = TH::n0(wave), hrow0 = TH::row0(wave);
   const int D = L.D;
   STAMP_DECL;
+#ifdef UPNERF_EXP_ASYMPRIO
+  // experiment: ONE of the two waves that share a SIMD (odd hardware wave slot) runs at a raised priority for the whole kernel --
+  // does an asymmetric pair settle into complementary phases (one workgroup's K loop beside the other's epilogue)?
+  if (__builtin_amdgcn_s_getreg(6148 /* HW_REG_HW_ID, wave_id[3:0] */) & 1) __builtin_amdgcn_s_setprio(UPNERF_EXP_ASYMPRIO);
+#endif
   if (tid == 0) {
 #pragma unroll
     for (int l = 0; l < UPNERF_MAX_D; ++l) {
@@ -327,6 +382,9 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   }
   if (tid < 16) mx_s[tid] = 0u;
   if (tid >= 64 && tid < 64 + WEXP_SLOTS) wexp_s[tid - 64] = a.wexp[tid - 64];
+  // the ten band weights of this step (device table under graph replay): one request here instead of one L2 round trip per trip
+  // of the encoding loop below (round 5 stamps: the stage took 24.9k cycles per tile with five of ten bands skipped, as with none)
+  if (tid >= 128 && tid < 138) wk_s[tid - 128] = a.wk_xyz_dev ? a.wk_xyz_dev[tid - 128] : a.wk_xyz[tid - 128];
 #pragma unroll
   for (int l = 0; l < UPNERF_MAX_D; ++l)
     if (l < D)
@@ -378,7 +436,6 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
       *(_Float16*)(Ph + o) = h;
       if constexpr (NP == 2) *(_Float16*)(Pl + o) = l;
     };
-    const float* __restrict__ wkd = a.wk_xyz_dev;  // per-step band weights from device memory under graph replay
     for (int it = tid; it < TILE * 3; it += THREADS) {
       const int row = it / 3, n = it - row * 3;
       put(row, n, xyz_s[it]);
@@ -393,7 +450,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     for (int i0 = 64 * __builtin_amdgcn_readfirstlane(tid >> 6); i0 < TILE * 3 * 10; i0 += THREADS) {
       const int k = i0 / (TILE * 3);
       const int it = i0 + lane - k * (TILE * 3), row = it / 3, n = it - row * 3;
-      const float wk = wkd ? wkd[k] : a.wk_xyz[k];
+      const float wk = wk_s[k];
       float sv = 0.0f, cv = 0.0f;
       if (__builtin_amdgcn_readfirstlane(__float_as_uint(wk)) != 0u) {
         sincos_f32_via_f64(xyz_s[it] * ldexpf(PI_F, k), sv, cv);
@@ -414,6 +471,12 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
       tile_store16<NP, W, TILE, THREADS, W>(Ph, Pl, 0, un0, un1, a.h + (a.h_last_only ? 0 : (size_t)lidx * M * W), W, m0, M, tid);
 #endif
   };
+  // fp32 activation stores inside the K loops (PlaneStore): whole tiles of a training pass that stores every layer
+#ifdef UPNERF_EXP_NOSTORE
+  const bool h_in_loop = false;
+#else
+  const bool h_in_loop = F16_STORE_IN_LOOP && a.h && !a.h_last_only && (M % TILE) == 0 && NW == 4;
+#endif
   // ---- trunk (nerf.py:84-87)
   STAMP(7);  // sample positions + encoding + x0 store
   // exponents of the two row halves of the planes (rows [0, TILE/2) and [TILE/2, TILE)): the lockstep stages keep them equal
@@ -437,13 +500,19 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
       }
       mma16_glb<NP, UPNERF_X0>(acc, ap, ecur, P16 + 4 * (size_t)wl, (UPNERF_X0 + W) / 16, n0, 0, lane);
       mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, (UPNERF_X0 + W) / 16, n0, UPNERF_X0, lane);
+    } else if (h_in_loop) {
+      // h_{l-1} leaves from the planes this K loop reads, one 1 KiB piece per k-block (PlaneStore)
+      PlaneStore<NP, W, TILE, THREADS> ps(Ph, Pl, a.h + ((size_t)(l - 1) * M + m0) * W, pow2f(-ehalf[0]), pow2f(-ehalf[1]), tid);
+      static_assert(PlaneStore<NP, W, TILE, THREADS>::ITER == W / 16, "one store piece per k-block");
+      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, W / 16, n0, 0, lane, ps);
     } else {
       mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, W / 16, n0, 0, lane);
     }
     STAMP(1);
     // h_{l-1} leaves from the planes this K loop has just read, in whole lines, behind the loop's last wait for a weight
-    // fragment: the epilogue, two barriers and the plane write pass before the wave waits for a load again
-    if (l >= 1) store_h32(l - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
+    // fragment: the epilogue, two barriers and the plane write pass before the wave waits for a load again (the skip layer,
+    // ragged last tiles and fp16-stored operands; everything else went out inside the K loop)
+    if (l >= 1 && !(h_in_loop && l != L.skip)) store_h32(l - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
     // the bias row comes from the LDS copy made at kernel start: a global load here would open every epilogue with an L2
     // round trip, and its wait would also wait for the stores just issued (vmcnt retires in order)
     f32x4 bl[TW::NT][4];
@@ -497,9 +566,14 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     acc_zero(acc);
     f32x4 be[TW::NT][4];
     load_cols(be, P + L.be, n0, hh);
-    mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, lane);
-    asm volatile("" ::: "memory");  // the bias loads above stay above the stores below
-    store_h32(D - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
+    if (h_in_loop) {
+      PlaneStore<NP, W, TILE, THREADS> ps(Ph, Pl, a.h + ((size_t)(D - 1) * M + m0) * W, pow2f(-ehalf[0]), pow2f(-ehalf[1]), tid);
+      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, lane, ps);
+    } else {
+      mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, lane);
+      asm volatile("" ::: "memory");  // the bias loads above stay above the stores below
+      store_h32(D - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
+    }
     acc_fma_bias_h<false>(acc, pow2f(-(ehalf[0] + wexp[8])), pow2f(-(ehalf[1] + wexp[8])), be);
     const float wm = acc_absmax(acc);
     if (lane == 0) smax[wave] = wm;
@@ -660,6 +734,11 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
   const int ray0 = m0 / S;
   const unsigned long long* __restrict__ hm = (const unsigned long long*)a.hmask + (size_t)blockIdx.x * THREADS + tid;
   const size_t hm_stride = (size_t)gridDim.x * THREADS;
+#ifdef UPNERF_EXP_ASYMPRIO
+  // experiment: ONE of the two waves that share a SIMD (odd hardware wave slot) runs at a raised priority for the whole kernel --
+  // does an asymmetric pair settle into complementary phases (one workgroup's K loop beside the other's epilogue)?
+  if (__builtin_amdgcn_s_getreg(6148 /* HW_REG_HW_ID, wave_id[3:0] */) & 1) __builtin_amdgcn_s_setprio(UPNERF_EXP_ASYMPRIO);
+#endif
 
   if (tid == 64) {
 #pragma unroll
@@ -749,9 +828,10 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
 #pragma unroll
       for (int q = 0; q < EPT; ++q) put_quad<NP, W>(Ph, Pl, er0 + ERS * q, W2 + 4 * eg, vals[q], eg2);
       __syncthreads();
+      const unsigned long long cbits = NT_LOAD(&hm[(size_t)D * hm_stride]);  // arrives under the contraction below
       mma16_lds<NP, W, W2 / 16, AH>(accg, Ph, Pl, hrow0, W2, PT16 + 4 * (size_t)L.t_wc2, W2 / 16, hn0, 0, lane);
       acc_scale(accg, pow2f(-(eg2 + wexp[10])));
-      acc_apply_mask(accg, NT_LOAD(&hm[(size_t)D * hm_stride]));
+      acc_apply_mask(accg, cbits);
       mg1 = acc_absmax(accg);
     }
     f32x4 valr[EPT];

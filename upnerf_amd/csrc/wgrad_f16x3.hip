@@ -47,6 +47,7 @@ __device__ __forceinline__ h4 tr_read(const char* base, int byteoff) {
 // to fp16, one MFMA per block, fp32 accumulate: the "f16" field mode of BASELINE.json configs[3]).
 #define FX_THREADS 512
 #define WG_LOAD(p) NT_LOAD(p)  // operand rows: read once per step (common.cuh: streaming accesses)
+#define WG_OPLOAD(dst, p) dst = WG_LOAD((const f32x4*)(p))
 #ifdef UPNERF_EXP_HALFROW
 #define HALFROW_OK(T, c4) (!((T) == 256 && (c4) >= UPNERF_EXP_HALFROW))
 #else
@@ -106,14 +107,14 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       const int idx = tid + q * FX_THREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
       const int m = mc + row < mlast ? mc + row : mlast;
       const int col = nblk + 4 * c4 < N ? nblk + 4 * c4 : 0;
-      ra[q] = WG_LOAD((const f32x4*)&A[(size_t)m * lda + col]);
+      WG_OPLOAD(ra[q], &A[(size_t)m * lda + col]);
     }
 #pragma unroll
     for (int q = 0; q < B4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
       const int m = mc + row < mlast ? mc + row : mlast;
       const int col = kblk + 4 * c4 < K ? kblk + 4 * c4 : 0;
-      rb[q] = WG_LOAD((const f32x4*)&B[(size_t)m * ldb + col]);
+      WG_OPLOAD(rb[q], &B[(size_t)m * ldb + col]);
     }
   };
   auto split_store = [&](char* hi, char* lo, f32x4 v, float s, int row, int col) {
@@ -196,42 +197,15 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     // rows beyond mend are staged as zeros, so an odd number of chunks simply contracts one all-zero chunk
     // (WG_EXP_*: timing experiments with wrong results -- what is left of the launch without the loads / the staging (which is
     // also the only consumer of the loads: nothing waits for them any more) / the MFMAs; tools/bench_wgrad.py)
-    // Straight-line on purpose: any control flow between the loads of one set and the staging of the other (a reordering of the two
-    // jobs of an interval for half of the waves was tried in round 5: no gain, and its branches brought the vmcnt(0) back).
+    // Straight-line on purpose.  Round 5 tried to run the two jobs of an interval (contract the staged chunk | stage the next one)
+    // in opposite orders in waves 0-3 and 4-7, so that one wave of a SIMD converts while its partner owns the matrix pipe
+    // (MI355X_MICROARCH.md 'Two waves per SIMD' item 9): (a) both orders written out under one wave-uniform branch inside the
+    // loop: 225 spilled registers; (b) one copy of each job in a two-trip loop: no spill, but hipcc waits vmcnt(0) at every join
+    // -- same launch time as before (0.550 against 0.545 ms stand-alone incl. the reduction); (c) a branch around two whole loops:
+    // 47 spills; (d) the loop of (b) with the operand loads hidden in inline asm and hand-counted waits: hipcc re-used the loads'
+    // destination registers for the contraction's operand reads while the loads were in flight (seen in the ISA; never run).
     gload(ra0, rb0, mbeg);
     gload(ra1, rb1, mbeg + FX_CHUNK);
-#ifdef WG_STAGGER
-    // Experiment (make variant EXP=-DWG_STAGGER): between two barriers a wave contracts the staged chunk and stages the next one;
-    // waves 4-7 (the SIMD partners of waves 0-3) do the two jobs in the other order.  The branch sits OUTSIDE the loops: each loop
-    // is straight-line code (see above).
-    auto stage = [&](f32x4 (&ra)[A4], f32x4 (&rb)[B4], int buf, int mnext) {  // the set holds chunk mnext - 2 chunks
-      lstore(ra, rb, buf, mnext - 2 * FX_CHUNK);
-      gload(ra, rb, mnext);
-    };
-    stage(ra0, rb0, 0, mbeg + 2 * FX_CHUNK);  // buffer 0 = chunk 0; set 0 <- chunk 2
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= 4) {
-#pragma unroll 1
-      for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
-        stage(ra1, rb1, 1, mc + 3 * FX_CHUNK);
-        contract(0);
-        __syncthreads();
-        stage(ra0, rb0, 0, mc + 4 * FX_CHUNK);
-        contract(1);
-        __syncthreads();
-      }
-    } else {
-#pragma unroll 1
-      for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
-        contract(0);
-        stage(ra1, rb1, 1, mc + 3 * FX_CHUNK);
-        __syncthreads();
-        contract(1);
-        stage(ra0, rb0, 0, mc + 4 * FX_CHUNK);
-        __syncthreads();
-      }
-    }
-#else
 #pragma unroll 1
     for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
 #ifndef WG_EXP_NOSTAGE
@@ -255,7 +229,6 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       contract(1);
 #endif
     }
-#endif
   } else {
     int buf = 0;
     gload(ra0, rb0, mbeg);
@@ -296,6 +269,156 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       for (int j = 1; j < G; ++j) s += red[tid + j * Q];
       *(f32x4*)&bslabs[((size_t)split * gridDim.y + blockIdx.y) * TN + 4 * tid] = s;
     }
+  }
+}
+
+// ---- 256 x 256 block on FOUR waves, one per SIMD (round 5; f16x3 arithmetic only) ------------------------------------------------
+// The eight-wave kernel above runs its chunk as [stage | barrier | operand reads | MFMAs] with all waves in lockstep: the two
+// waves of a SIMD share the matrix pipe while both contract and leave it idle while both convert, and nothing covers the LDS
+// latency of the operand reads (round 4's elimination: staging + MFMAs alone 0.276 ms, loads + MFMAs alone 0.222, everything
+// 0.381; MFMA busy 0.46).  hipcc would not give the two halves different orders (see that kernel's loop), so this kernel removes
+// the sharing instead: ONE wave per SIMD owns the pipe and 512 registers -- a 128 x 128 quarter of the block in 256 accumulator
+// registers, TWO operand-fragment sets (the reads of chunk c + 1 are issued in front of the MFMAs of chunk c), two register sets
+// of fp32 rows in flight -- and its own instruction stream interleaves the conversion of chunk c + 2 with the MFMAs of chunk c
+// (an MFMA holds the vector issue for 8 of its 32 cycles).  Four LDS images (chunk c + 2 is written while c and c + 1 are read),
+// one barrier per 16-row chunk.  Same arithmetic, same summation order inside a slab as the eight-wave kernel's (a row's products
+// are added in row order either way), so the slabs -- and everything downstream -- are bitwise those of that kernel.
+#define W4_THREADS 256
+template <int NP>
+__global__ __launch_bounds__(W4_THREADS, 1) void wgrad_f16x3_w4_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                                     const float* __restrict__ B, int ldb,
+                                                                     const int* __restrict__ expo_a, const int* __restrict__ expo_b,
+                                                                     float* __restrict__ slabs, float* __restrict__ bslabs,
+                                                                     int rows_per_split, upnerf_wgrad_pending prev) {
+  static_assert(NP == 2, "the one-MFMA form has its own kernel family (wgrad_f16p_kernel)");
+  constexpr int TN = 256, TK = 256, CH = 16, NBUF = 4;
+  constexpr int SZ = 2 * CH * 256;          // bytes per plane (two 128-column panels of 16 rows)
+  constexpr int BUF = 4 * SZ;               // [A hi | A lo | B hi | B lo]
+  constexpr int R4 = CH * TN / 4 / W4_THREADS;  // 16-byte pieces of A (and of B) per thread and chunk: 4
+  constexpr int MT = 4, NT = 4;
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF];  // 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hh = lane >> 5;
+  const int n0 = (wave >> 1) * 128, k0 = (wave & 1) * 128;
+  const int split = blockIdx.x;
+  const int mbeg = split * rows_per_split;
+  const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  if (prev.nsplit > 0) {  // the first prev.rblocks workgroups sum the slabs of the previous launch of the run
+    const int wg = blockIdx.x;
+    if (wg < prev.rblocks) {
+      wgrad_reduce_body<4>(wg, tid, prev, (f32x4(*)[64])lds);
+      __syncthreads();
+    }
+  }
+  const int ea = expo_a[0], eb = expo_b[0];
+  const float sa = ldexpf(1.0f, ea), sb = ldexpf(1.0f, eb);
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const int mlast = mend > mbeg ? mend - 1 : (mbeg < M ? mbeg : M - 1);
+  // this thread's pieces: row r0 + 4 q of the chunk, columns 4 c4 .. 4 c4 + 3 (64 threads per 256-column row)
+  const int r0 = tid >> 6, c4 = tid & 63;
+  const bool cola = 4 * c4 < N, colb = 4 * c4 < K;
+  const float* __restrict__ pa = A + (cola ? 4 * c4 : 0);
+  const float* __restrict__ pb = B + (colb ? 4 * c4 : 0);
+  f32x4 ra[2][R4], rb[2][R4];
+  auto gload = [&](f32x4 (&xa)[R4], f32x4 (&xb)[R4], int mc) {
+#pragma unroll
+    for (int q = 0; q < R4; ++q) {
+      const int m = mc + r0 + 4 * q < mlast ? mc + r0 + 4 * q : mlast;
+      xa[q] = WG_LOAD((const f32x4*)&pa[(size_t)m * lda]);
+      xb[q] = WG_LOAD((const f32x4*)&pb[(size_t)m * ldb]);
+    }
+  };
+  auto split_store = [&](char* hi, char* lo, f32x4 v, float sc, int off) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+    const f2 x0 = f2{v[0], v[1]} * sc, x1 = f2{v[2], v[3]} * sc;
+    const hh2 h0 = __builtin_convertvector(x0, hh2), h1 = __builtin_convertvector(x1, hh2);
+    *(h4*)(hi + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+    const hh2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f2), hh2);
+    const hh2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f2), hh2);
+    *(h4*)(lo + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+  };
+  auto lstore = [&](const f32x4 (&xa)[R4], const f32x4 (&xb)[R4], int buf, int mc) {
+    char* base = lds + buf * BUF;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < R4; ++q) {
+      const int row = r0 + 4 * q, off = himg<CH>(row, 4 * c4);
+      const bool in = mc + row < mend;
+      const f32x4 va = (in && cola) ? xa[q] : z4, vb = (in && colb) ? xb[q] : z4;
+      bsum += va;
+      split_store(base, base + SZ, va, sa, off);
+      split_store(base + 2 * SZ, base + 3 * SZ, vb, sb, off);
+    }
+  };
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int trow = 8 * (g >> 1) + tq, tcol = 16 * (g & 1) + 4 * tp;
+  h8 fah[2][MT], fal[2][MT], fbh[2][NT], fbl[2][NT];
+  auto readfrag = [&](h8 (&ah)[MT], h8 (&al)[MT], h8 (&bh)[NT], h8 (&bl)[NT], int buf) {
+    const char* base = lds + buf * BUF;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int o0 = himg<CH>(trow, n0 + 32 * t + tcol), o1 = himg<CH>(trow + 4, n0 + 32 * t + tcol);
+      ah[t] = __builtin_shufflevector(tr_read(base, o0), tr_read(base, o1), 0, 1, 2, 3, 4, 5, 6, 7);
+      al[t] = __builtin_shufflevector(tr_read(base + SZ, o0), tr_read(base + SZ, o1), 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int o0 = himg<CH>(trow, k0 + 32 * t + tcol), o1 = himg<CH>(trow + 4, k0 + 32 * t + tcol);
+      bh[t] = __builtin_shufflevector(tr_read(base + 2 * SZ, o0), tr_read(base + 2 * SZ, o1), 0, 1, 2, 3, 4, 5, 6, 7);
+      bl[t] = __builtin_shufflevector(tr_read(base + 3 * SZ, o0), tr_read(base + 3 * SZ, o1), 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto mma = [&](const h8 (&ah)[MT], const h8 (&al)[MT], const h8 (&bh)[NT], const h8 (&bl)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+      }
+  };
+  // chunk c lives in image c % 4, fragment set c % 2; its rows travelled in register set c % 2 (rows past mend are staged as zeros)
+  gload(ra[0], rb[0], mbeg);
+  gload(ra[1], rb[1], mbeg + CH);
+  lstore(ra[0], rb[0], 0, mbeg);
+  gload(ra[0], rb[0], mbeg + 2 * CH);
+  __syncthreads();
+  readfrag(fah[0], fal[0], fbh[0], fbl[0], 0);
+  lstore(ra[1], rb[1], 1, mbeg + CH);
+  gload(ra[1], rb[1], mbeg + 3 * CH);
+  __syncthreads();
+#pragma unroll 1
+  for (int mc = mbeg; mc < mend; mc += 4 * CH) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // chunk c = (mc - mbeg) / CH + u: its images / sets are compile-time names
+      readfrag(fah[(u + 1) & 1], fal[(u + 1) & 1], fbh[(u + 1) & 1], fbl[(u + 1) & 1], (u + 1) & 3);  // chunk c + 1
+      mma(fah[u & 1], fal[u & 1], fbh[u & 1], fbl[u & 1]);                                              // chunk c
+      lstore(ra[u & 1], rb[u & 1], (u + 2) & 3, mc + (u + 2) * CH);                                      // chunk c + 2
+      gload(ra[u & 1], rb[u & 1], mc + (u + 4) * CH);                                                    // chunk c + 4
+      __syncthreads();
+    }
+  }
+  const float unscale = ldexpf(1.0f, -(ea + eb));
+  float* slab = slabs + (size_t)split * TN * TK;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        slab[n * TK + k0 + 32 * nt + li] = acc[mt][nt][r] * unscale;
+      }
+  if (bslabs) {  // column sums of A: thread t owns columns 4 * (t % 64) ..+3 of rows t / 64 + 4 q; the four threads sharing them meet in LDS
+    __syncthreads();
+    f32x4* red = (f32x4*)lds;
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 64) *(f32x4*)&bslabs[(size_t)split * TN + 4 * tid] = ((red[tid] + red[tid + 64]) + red[tid + 128]) + red[tid + 192];
   }
 }
 
@@ -624,6 +747,14 @@ int launch_p(int M, int N, int K, const uint16_t* A, int lda, const int* aexp, c
   return (int)hipGetLastError();
 }
 
+#ifndef WG_NO_W4
+// 0 (make variant EXP=-DWG_NO_W4=0): the 256 x 256 block on wgrad_f16x3_w4_kernel (four waves, one per SIMD).  Built in round 5,
+// bitwise the eight-wave kernel's slabs (tests/test_hip_kernels.py runs green on either), measured SLOWER: 0.406 / 0.146 ms against
+// 0.366 / 0.135 ms stand-alone (786 432 / 262 144 rows, launch + reduction, tools/bench_wgrad.py) and 239.8 k against 244.1 k rays/s
+// on the step: a single in-order wave per SIMD hides neither the operand reads' LDS latency nor the conversion under its own MFMAs
+// as well as two waves hide them for each other.  1 = the eight-wave kernel (shipped).
+#define WG_NO_W4 1
+#endif
 template <int MTW, int NTW>
 int launch(int planes, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const int* expo_a, const int* expo_b,
            float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st, const upnerf_wgrad_pending* prevp = nullptr) {
@@ -649,6 +780,13 @@ extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N,
                                           int TK, int planes, const upnerf_wgrad_pending* prev, void* stream) {
   hipStream_t st = (hipStream_t)stream;
 #define WG_ARGS planes, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs, bslabs, nsplit, rows, st, prev
+  if (TN == 256 && TK == 256 && planes == 2 && N <= 256 && K <= 256 && !WG_NO_W4) {  // one wave per SIMD (wgrad_f16x3_w4_kernel)
+    upnerf_wgrad_pending pv = {};
+    if (prev) pv = *prev;
+    hipLaunchKernelGGL((wgrad_f16x3_w4_kernel<2>), dim3(nsplit), dim3(W4_THREADS), 0, st, M, N, K, A, lda, B, ldb, expo_a, expo_b, slabs,
+                       bslabs, rows, pv);
+    return (int)hipGetLastError();
+  }
   if (TN == 256 && TK == 256) return launch<4, 4>(WG_ARGS);
   if (TN == 256 && TK == 128) return launch<4, 2>(WG_ARGS);
   if (TN == 256 && TK == 64) return launch<4, 1>(WG_ARGS);
