@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UPNERF_ABI_VERSION 7
+#define UPNERF_ABI_VERSION 8
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
@@ -411,6 +411,9 @@ typedef struct {
   int32_t n2;                    /* > 0: rows n >= n2 of the result go to dW2[(n - n2) * ldo2 + k], db2[n - n2] */
   float* dW2; float* db2;
   int32_t ldo2, pad;
+  /* a vector head that shares B with the problem (upnerf_wgrad_f16x3_chain_v): per-split partial sums [nsplit][K + 4]
+   * (vslabs: K sums of v[m] B[m][k], then the sum of v) -> dv [K], dbv [1]; NULL: none */
+  const float* vslabs; float* dv; float* dbv;
 } upnerf_wgrad_pending;
 int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
                              float* db, float* slabs, int nsplit, const int* expo_a, const int* expo_b, int planes,
@@ -420,6 +423,14 @@ int upnerf_wgrad_f16x3_chain(int M, const float* A, int lda, int N, const float*
 int upnerf_wgrad_f16x3_chain2(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
                               float* db, int n2, float* dW2, int ldo2, float* db2, float* slabs, int nsplit, const int* expo_a,
                               const int* expo_b, int planes, upnerf_wgrad_pending* pending, void* stream);
+/* upnerf_wgrad_f16x3_chain for a 256 x 256 problem, plus the gradient of a 1-wide head fed by the same B rows, in the same pass
+ * over B:  dv[k] = sum_m v[m] B[m][k],  dbv[0] = sum_m v[m]  (the shared density head: share_sigma reads the last trunk
+ * activation, which is also the B operand of xyz_encoding_final's weight gradient -- models/nerf.py:89, 93 -- so the separate
+ * upnerf_vec_wgrad launch and its second read of that tensor, 1 KB per sample, go away).  fp32 arithmetic for the vector (as
+ * upnerf_vec_wgrad), fixed summation order.  slabs: nsplit * (256 * 256 + 256 + 260) floats.  N = K = 256, planes = 2 only. */
+int upnerf_wgrad_f16x3_chain_v(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
+                               float* db, const float* v, float* dv, float* dbv, float* slabs, int nsplit, const int* expo_a,
+                               const int* expo_b, int planes, upnerf_wgrad_pending* pending, void* stream);
 int upnerf_wgrad_finish(upnerf_wgrad_pending* pending, void* stream);
 
 /* Same contraction for the f16 field mode with fp16-STORED operands: A16 [M][lda] fp16 bits scaled per 64-row tile by

@@ -957,8 +957,9 @@ def test_chained_slab_reductions_are_bitwise_the_separate_ones(hip, field_mode):
     c_rows, a_rows = gen((R, 16), 73).cuda(), gen((R, 48), 74).cuda()
     cfg = rd._PassCfg(pk, 1, True, True, [1.0] * 10, [1.0] * 4)
     res = {}
-    old, old_join = rd.WGRAD_CHAIN, rd.JOIN_HEADS
+    old, old_join, old_ride = rd.WGRAD_CHAIN, rd.JOIN_HEADS, rd.VEC_RIDE
     rd.JOIN_HEADS = 0  # (the joined launch exists only in the chained form)
+    rd.VEC_RIDE = 0    # (and so does the density head riding on the final layer's launch: another summation order, its own test below)
     try:
         for ch in (0, 1):
             rd.WGRAD_CHAIN = ch
@@ -967,9 +968,69 @@ def test_chained_slab_reductions_are_bitwise_the_separate_ones(hip, field_mode):
             sum((t * gen(tuple(t.shape), 80 + i).cuda()).sum() for i, t in enumerate(outs) if t.numel()).backward()
             res[ch] = [cpu(t.grad) for t in leaves]
     finally:
-        rd.WGRAD_CHAIN, rd.JOIN_HEADS = old, old_join
+        rd.WGRAD_CHAIN, rd.JOIN_HEADS, rd.VEC_RIDE = old, old_join, old_ride
     for i in range(5):
         assert torch.equal(res[0][i], res[1][i]), i
+
+
+def test_density_head_gradient_riding_on_the_final_layer_launch_matches_the_separate_one(hip):
+    """upnerf_wgrad_f16x3_chain_v (round 5): the shared density head reads the B operand of the final layer's weight gradient
+    (models/nerf.py:89, 93), so its gradient dw_sigma = sum_m dpre_s[m] h[m][:] is summed inside that launch from the rows as
+    they pass instead of by upnerf_vec_wgrad on a second read of h.  Same fp32 products in another summation order: 2e-6 of
+    the vector's maximum; everything else of the pass bit for bit; and against fp64 on a stand-alone problem with a ragged
+    number of rows."""
+    from upnerf_amd import ops, synth
+    from upnerf_amd.nerf import NeRF
+    rd = hip["rendering"]
+    kw = dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    model = NeRF("coarse", c2f=None, **kw)
+    model.load_state_dict(synth.nerf_state("coarse", seed=3, **kw))
+    model = model.cuda()
+    pk = model.packer
+    R, S = 11, 70
+    o = (gen((R, 3), 70) * 0.3).cuda()
+    d = torch.nn.functional.normalize(gen((R, 3), 71), dim=-1).cuda()
+    z = (torch.sort(gen((R, S), 72).abs() * 3 + 0.1, dim=-1).values).cuda()
+    c_rows, a_rows = gen((R, 16), 73).cuda(), gen((R, 48), 74).cuda()
+    cfg = rd._PassCfg(pk, 1, True, True, [1.0] * 10, [1.0] * 4)
+    res = {}
+    old = rd.VEC_RIDE
+    try:
+        for ride in (0, 1):
+            rd.VEC_RIDE = ride
+            leaves = [t.clone().requires_grad_(True) for t in (o, d, c_rows, a_rows, model.packed().detach())]
+            outs = rd._FieldPass.apply(leaves[0], leaves[1], z, leaves[2], leaves[3], leaves[4], cfg)
+            sum((t * gen(tuple(t.shape), 80 + i).cuda()).sum() for i, t in enumerate(outs) if t.numel()).backward()
+            res[ride] = [cpu(t.grad) for t in leaves]
+    finally:
+        rd.VEC_RIDE = old
+    for i in range(4):
+        assert torch.equal(res[0][i], res[1][i]), i
+    L = pk.L
+    dP0, dP1 = res[0][4], res[1][4]
+    sig = slice(L.wsig, L.wsig + 256)
+    assert float((dP0[sig] - dP1[sig]).abs().max()) <= 2e-6 * float(dP0[sig].abs().max())
+    assert abs(float(dP0[L.bsig] - dP1[L.bsig])) <= 2e-6 * max(abs(float(dP0[L.bsig])), 1e-12)
+    rest = torch.ones_like(dP0, dtype=torch.bool)
+    rest[sig] = False
+    rest[L.bsig] = False
+    assert torch.equal(dP0[rest], dP1[rest])
+    # stand-alone, ragged M, against fp64
+    M = 64 * 37 + 5
+    A, B, v = gen((M, 256), 90).cuda() * 1e-3, torch.relu(gen((M, 256), 91)).cuda(), gen((M,), 92).cuda()
+    dW, db, dv, dbv = (torch.empty(n, device="cuda") for n in (256 * 256, 256, 256, 1))
+    chain = ops.WgradChain(A.device)
+    expo = ops.scale_exponents(A, B)
+    ea, eb = (expo.data_ptr(), expo.data_ptr() + 4) if isinstance(expo, torch.Tensor) else expo
+    chain.wgrad(M, A, 256, 256, B, 256, 256, dW.data_ptr(), 256, db.data_ptr(), ea, eb, v=v, dv_ptr=dv.data_ptr(), dbv_ptr=dbv.data_ptr())
+    chain.finish()
+    torch.cuda.synchronize()
+    ref_v = (v.double()[:, None] * B.double()).sum(0)
+    ref_W = A.double().t() @ B.double()
+    assert float((dv.double() - ref_v).abs().max() / ref_v.abs().max()) < 2e-6
+    assert abs(float(dbv[0]) - float(v.double().sum())) <= 2e-6 * float(v.double().abs().sum())
+    assert float((dW.double().view(256, 256) - ref_W).abs().max() / ref_W.abs().max()) < 2e-6
+    assert float((db.double() - A.double().sum(0)).abs().max() / A.double().sum(0).abs().max()) < 2e-6
 
 
 def test_adam_update_with_gradients_in_place_is_bitwise_the_flat_one(hip):

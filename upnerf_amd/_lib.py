@@ -118,7 +118,7 @@ MAX_ADAM_DESC = 96
 class WgradPending(C.Structure):
     _fields_ = [("slabs", _fp), ("bslabs", _fp), ("dW", _fp), ("db", _fp), ("N", C.c_int32), ("K", C.c_int32), ("TN", C.c_int32),
                 ("TK", C.c_int32), ("nsplit", C.c_int32), ("ldo", C.c_int32), ("rblocks", C.c_int32), ("n2", C.c_int32),
-                ("dW2", _fp), ("db2", _fp), ("ldo2", C.c_int32), ("pad", C.c_int32)]
+                ("dW2", _fp), ("db2", _fp), ("ldo2", C.c_int32), ("pad", C.c_int32), ("vslabs", _fp), ("dv", _fp), ("dbv", _fp)]
 
 
 class WgradGroup(C.Structure):
@@ -171,6 +171,8 @@ _SIGNATURES = {
     "upnerf_wgrad_f16x3": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p],
     "upnerf_wgrad_f16x3_chain": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p],
     "upnerf_wgrad_f16x3_chain2": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p],
+    # (M, A, lda, N, B, ldb, K, dW, ldo, db, v, dv, dbv, slabs, nsplit, expo_a, expo_b, planes, pending, stream)
+    "upnerf_wgrad_f16x3_chain_v": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _p],
     "upnerf_wgrad_finish": [_p, _p],
     "upnerf_transient_fwd": [_p, _p],
     "upnerf_transient_bwd": [_p, _p, _p],
@@ -220,7 +222,7 @@ def _load():
 
 
 lib = _load()
-ABI_VERSION = 7
+ABI_VERSION = 8
 if lib.upnerf_abi_version() != ABI_VERSION:
     raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
 

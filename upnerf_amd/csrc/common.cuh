@@ -474,4 +474,20 @@ __device__ __forceinline__ void wgrad_reduce_body(int bid, int tid, const upnerf
       else if (P.db) P.db[idx] = sb;
     }
   }
+  if (P.vslabs && bid == 0) {  // the vector head that rode on the problem: K sums + the sum of v, per split [K + 4]
+    for (int idx = tid; idx <= K; idx += 64 * PW) {
+      float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* src = P.vslabs + idx;
+      const size_t st = (size_t)K + 4;
+      int sp = 0;
+      for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] += src[(size_t)(sp + u) * st];
+      }
+      for (; sp < nsplit; ++sp) p[0] += src[(size_t)sp * st];
+      const float sv = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      if (idx < K) P.dv[idx] = sv;
+      else if (P.dbv) P.dbv[0] = sv;
+    }
+  }
 }

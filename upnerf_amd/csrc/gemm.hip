@@ -208,7 +208,7 @@ static upnerf_wgrad_pending reduce_desc(int N, int K, int TN, int TK, int nsplit
   const int quads = N * (K / 4);
   int rblocks = (quads + 63) / 64;
   if (rblocks * NTHREADS < N) rblocks = (N + NTHREADS - 1) / NTHREADS;
-  return upnerf_wgrad_pending{slabs, bslabs, dW, db, N, K, TN, TK, nsplit, ldo, rblocks, 0, nullptr, nullptr, 0, 0};
+  return upnerf_wgrad_pending{slabs, bslabs, dW, db, N, K, TN, TK, nsplit, ldo, rblocks, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
 }
 static void launch_reduce(hipStream_t st, const upnerf_wgrad_pending& P) {
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(P.rblocks), dim3(RED_THREADS), 0, st, P);
@@ -815,6 +815,38 @@ extern "C" int upnerf_wgrad_f16x3_chain2(int M, const float* A, int lda, int N, 
   P.dW2 = dW2;
   P.db2 = db2;
   P.ldo2 = ldo2;
+  *pending = P;
+  return 0;
+}
+
+extern "C" int upnerf_wgrad_f16x3_partial_v(int M, const float* A, int lda, const float* B, int ldb, const float* v, const int* expo_a,
+                                            const int* expo_b, float* slabs, float* bslabs, float* vslabs, int nsplit, int rows,
+                                            const upnerf_wgrad_pending* prev, void* stream);  // csrc/wgrad_f16x3.hip
+
+// upnerf_wgrad_f16x3_chain + the 1-wide head that shares B (include/upnerf_hip.h)
+extern "C" int upnerf_wgrad_f16x3_chain_v(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
+                                          float* db, const float* v, float* dv, float* dbv, float* slabs, int nsplit,
+                                          const int* expo_a, const int* expo_b, int planes, upnerf_wgrad_pending* pending,
+                                          void* stream) {
+  if (M <= 0 || !A || !B || !dW || !v || !dv || !slabs || nsplit <= 0 || !expo_a || !expo_b || !pending) return UPNERF_EINVAL;
+  if (N != 256 || K != 256 || planes != 2) return UPNERF_EUNSUP;
+  if ((lda & 3) || (ldb & 3) || (ldo & 3)) return UPNERF_EINVAL;
+  if (pending->nsplit > 0 && pending->slabs == slabs) return UPNERF_EINVAL;
+  const int TN = 256, TK = 256;
+  const int rows = (((M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  float* bslabs = slabs + (size_t)nsplit * TN * TK;
+  float* vslabs = bslabs + (size_t)nsplit * TN;
+  if (pending->nsplit > 0 && pending->rblocks > nsplit) {  // grid too small to carry the previous reduction
+    int rc = upnerf_wgrad_finish(pending, stream);
+    if (rc) return rc;
+  }
+  int rc = upnerf_wgrad_f16x3_partial_v(M, A, lda, B, ldb, v, expo_a, expo_b, slabs, bslabs, vslabs, nsplit, rows,
+                                        pending->nsplit > 0 ? pending : nullptr, stream);
+  if (rc) return rc;
+  upnerf_wgrad_pending P = reduce_desc(N, K, TN, TK, nsplit, slabs, bslabs, dW, ldo, db);
+  P.vslabs = vslabs;
+  P.dv = dv;
+  P.dbv = dbv;
   *pending = P;
   return 0;
 }

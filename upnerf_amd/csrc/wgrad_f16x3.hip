@@ -53,12 +53,16 @@ __device__ __forceinline__ h4 tr_read(const char* base, int byteoff) {
 #else
 #define HALFROW_OK(T, c4) true
 #endif
-template <int NP, int MTW, int NTW>
+// HASV: a 1-wide head that reads the same B rows rides along (upnerf_wgrad_f16x3_chain_v): vsum[k] += v[m] B[m][k] in fp32 on the
+// rows as they pass through the staging registers, sum of v beside it; per-split partials to vslabs[split][K + 4].
+template <int NP, int MTW, int NTW, bool HASV = false>
 __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                                   const float* __restrict__ B, int ldb,
                                                                   const int* __restrict__ expo_a, const int* __restrict__ expo_b,
                                                                   float* __restrict__ slabs, float* __restrict__ bslabs,
-                                                                  int rows_per_split, upnerf_wgrad_pending prev) {
+                                                                  int rows_per_split, upnerf_wgrad_pending prev,
+                                                                  const float* __restrict__ vrow = nullptr,
+                                                                  float* __restrict__ vslabs = nullptr) {
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   constexpr int FX_CHUNK = (MTW * NTW == 16) ? FX_CHUNK_BIG : 32;
   constexpr int PN = (TN + 127) / 128, PK = (TK + 127) / 128;           // 128-column panels per plane
@@ -100,8 +104,11 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
   // one contraction earlier too, i.e. for a full HBM round trip per two chunks (cdna_hip_programming.md, 'Three .s-level traps'
   // (c); round 4's elimination: 0.381 ms with the wait, 0.276 ms of staging + MFMAs without any load).
   f32x4 ra0[A4], rb0[B4], ra1[A4], rb1[B4];
+  float rv0[B4], rv1[B4];           // HASV: v of the B rows in flight
+  f32x4 vsum = {0.f, 0.f, 0.f, 0.f};  // HASV: this thread's 4 columns of sum_m v[m] B[m][k]
+  float vtot = 0.0f;                // HASV: sum of v over this thread's rows (threads of column group 0 only)
   const int mlast = mend > mbeg ? mend - 1 : (mbeg < M ? mbeg : M - 1);
-  auto gload = [&](f32x4 (&ra)[A4], f32x4 (&rb)[B4], int mc) {
+  auto gload = [&](f32x4 (&ra)[A4], f32x4 (&rb)[B4], float (&rv)[B4], int mc) {
 #pragma unroll
     for (int q = 0; q < A4; ++q) {
       const int idx = tid + q * FX_THREADS, row = idx / (TN / 4), c4 = idx - row * (TN / 4);
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       const int m = mc + row < mlast ? mc + row : mlast;
       const int col = kblk + 4 * c4 < K ? kblk + 4 * c4 : 0;
       WG_OPLOAD(rb[q], &B[(size_t)m * ldb + col]);
+      if constexpr (HASV) rv[q] = vrow[m];
     }
   };
   auto split_store = [&](char* hi, char* lo, f32x4 v, float s, int row, int col) {
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     }
   };
   // mc: first row of the chunk the set holds (rows >= mend and columns past the matrix are staged as zeros)
-  auto lstore = [&](const f32x4 (&ra)[A4], const f32x4 (&rb)[B4], int buf, int mc) {
+  auto lstore = [&](const f32x4 (&ra)[A4], const f32x4 (&rb)[B4], const float (&rv)[B4], int buf, int mc) {
     char* base = lds + buf * (2 * SZA + 2 * SZB);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -147,6 +155,11 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       const int idx = tid + q * FX_THREADS, row = idx / (TK / 4), c4 = idx - row * (TK / 4);
       const f32x4 v = (mc + row < mend && kblk + 4 * c4 < K && HALFROW_OK(TK, c4)) ? rb[q] : z4;
       split_store(base + 2 * SZA, base + 2 * SZA + SZB, v, sb, row, 4 * c4);
+      if constexpr (HASV) {
+        const float vm = mc + row < mend ? rv[q] : 0.0f;
+        vsum += v * vm;
+        vtot += c4 == 0 ? vm : 0.0f;
+      }
     }
   };
   // transposed-read address pieces of this lane (cdna_hip_programming.md T10): group g, row q, column quad p
@@ -204,26 +217,26 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     // -- same launch time as before (0.550 against 0.545 ms stand-alone incl. the reduction); (c) a branch around two whole loops:
     // 47 spills; (d) the loop of (b) with the operand loads hidden in inline asm and hand-counted waits: hipcc re-used the loads'
     // destination registers for the contraction's operand reads while the loads were in flight (seen in the ISA; never run).
-    gload(ra0, rb0, mbeg);
-    gload(ra1, rb1, mbeg + FX_CHUNK);
+    gload(ra0, rb0, rv0, mbeg);
+    gload(ra1, rb1, rv1, mbeg + FX_CHUNK);
 #pragma unroll 1
     for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
 #ifndef WG_EXP_NOSTAGE
-      lstore(ra0, rb0, 0, mc);
+      lstore(ra0, rb0, rv0, 0, mc);
 #endif
       __syncthreads();
 #ifndef WG_EXP_NOLOAD
-      gload(ra0, rb0, mc + 2 * FX_CHUNK);
+      gload(ra0, rb0, rv0, mc + 2 * FX_CHUNK);
 #endif
 #ifndef WG_EXP_NOMMA
       contract(0);
 #endif
 #ifndef WG_EXP_NOSTAGE
-      lstore(ra1, rb1, 1, mc + FX_CHUNK);
+      lstore(ra1, rb1, rv1, 1, mc + FX_CHUNK);
 #endif
       __syncthreads();
 #ifndef WG_EXP_NOLOAD
-      gload(ra1, rb1, mc + 3 * FX_CHUNK);
+      gload(ra1, rb1, rv1, mc + 3 * FX_CHUNK);
 #endif
 #ifndef WG_EXP_NOMMA
       contract(1);
@@ -231,12 +244,12 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     }
   } else {
     int buf = 0;
-    gload(ra0, rb0, mbeg);
+    gload(ra0, rb0, rv0, mbeg);
 #pragma unroll 1
     for (int mc = mbeg; mc < mend; mc += FX_CHUNK) {
-      lstore(ra0, rb0, buf, mc);
+      lstore(ra0, rb0, rv0, buf, mc);
       __syncthreads();
-      gload(ra0, rb0, mc + FX_CHUNK);
+      gload(ra0, rb0, rv0, mc + FX_CHUNK);
       contract(buf);
       buf ^= 1;
     }
@@ -268,6 +281,30 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
 #pragma unroll
       for (int j = 1; j < G; ++j) s += red[tid + j * Q];
       *(f32x4*)&bslabs[((size_t)split * gridDim.y + blockIdx.y) * TN + 4 * tid] = s;
+    }
+  }
+  if constexpr (HASV) {
+    // thread t owns columns 4 * (t % (TK/4)) ..+3 of B; the threads sharing them meet in LDS (fixed order); the sums of v live in
+    // the threads of column group 0
+    static_assert(TN == 256 && TK == 256, "the vector head rides on the 256 x 256 block");
+    __syncthreads();
+    f32x4* red = (f32x4*)lds;
+    float* redt = (float*)(red + FX_THREADS);
+    red[tid] = vsum;
+    redt[tid] = vtot;
+    __syncthreads();
+    constexpr int Q = TK / 4, G = FX_THREADS / Q;
+    if (tid < Q) {
+      f32x4 s = red[tid];
+#pragma unroll
+      for (int j = 1; j < G; ++j) s += red[tid + j * Q];
+      *(f32x4*)&vslabs[(size_t)split * (TK + 4) + 4 * tid] = s;
+    }
+    if (tid == 0) {
+      float t = redt[0];
+#pragma unroll
+      for (int j = 1; j < G; ++j) t += redt[j * Q];
+      vslabs[(size_t)split * (TK + 4) + TK] = t;
     }
   }
 }
@@ -797,6 +834,17 @@ extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N,
   if (TN == 64 && TK == 128) return launch<1, 2>(WG_ARGS);
   return launch<1, 1>(WG_ARGS);
 #undef WG_ARGS
+}
+
+// 256 x 256 block with a 1-wide head riding along (upnerf_wgrad_f16x3_chain_v, gemm.hip)
+extern "C" int upnerf_wgrad_f16x3_partial_v(int M, const float* A, int lda, const float* B, int ldb, const float* v, const int* expo_a,
+                                            const int* expo_b, float* slabs, float* bslabs, float* vslabs, int nsplit, int rows,
+                                            const upnerf_wgrad_pending* prevp, void* stream) {
+  upnerf_wgrad_pending prev = {};
+  if (prevp) prev = *prevp;
+  hipLaunchKernelGGL((wgrad_f16x3_kernel<2, 4, 4, true>), dim3(nsplit, 1, 1), dim3(FX_THREADS), 0, (hipStream_t)stream, M, 256, 256, A, lda,
+                     B, ldb, expo_a, expo_b, slabs, bslabs, rows, prev, v, vslabs);
+  return (int)hipGetLastError();
 }
 
 // Packed-operand variant behind upnerf_wgrad_f16p (gemm.hip): blocks of 256 x 256 (both operands fp16-stored) and

@@ -225,11 +225,20 @@ class WgradChain:
 
     def _slabs(self, ns):
         self.flip ^= 1
-        return workspace(f"wgrad_chain{self.flip}", ns * (256 * 256 + 256), self.device)
+        return workspace(f"wgrad_chain{self.flip}", ns * (256 * 256 + 256 + 260), self.device)  # slabs + bias slabs + a riding vector head's
 
-    def wgrad(self, M, A, lda, N, B, ldb, K, dW_ptr, ldo, db_ptr, expo_a, expo_b, a_off=0, b_off=0, planes=2):
+    def wgrad(self, M, A, lda, N, B, ldb, K, dW_ptr, ldo, db_ptr, expo_a, expo_b, a_off=0, b_off=0, planes=2, v=None, dv_ptr=None,
+              dbv_ptr=None):
+        """v / dv_ptr / dbv_ptr: a 1-wide head fed by the same B rows rides on the launch (upnerf_wgrad_f16x3_chain_v: dv[k] =
+        sum_m v[m] B[m][k], dbv = sum_m v[m]) -- 256 x 256 problems of the f16x3 arithmetic only."""
         ns = nsplit_for(M)
         ws = self._slabs(ns)
+        if v is not None:
+            rc = TIMER.run(f"wgrad16_{N}x{K}", lambda: lib.upnerf_wgrad_f16x3_chain_v(
+                M, A.data_ptr() + 4 * a_off, lda, N, B.data_ptr() + 4 * b_off, ldb, K, dW_ptr, ldo, db_ptr, ptr(v), dv_ptr, dbv_ptr,
+                ptr(ws), ns, expo_a, expo_b, planes, C.byref(self.pending), stream()), units=M)
+            check(rc, "upnerf_wgrad_f16x3_chain_v")
+            return
         rc = TIMER.run(f"wgrad16_{N}x{K}", lambda: lib.upnerf_wgrad_f16x3_chain(
             M, A.data_ptr() + 4 * a_off, lda, N, B.data_ptr() + 4 * b_off, ldb, K, dW_ptr, ldo, db_ptr, ptr(ws), ns, expo_a, expo_b,
             planes, C.byref(self.pending), stream()), units=M)

@@ -61,6 +61,8 @@ TILE_PARTIALS = int(__import__("os").environ.get("UPNERF_TILE_PARTIALS", "1"))
 # Slab reductions of the f16x3 weight gradients inside the next weight-gradient launch (upnerf_wgrad_f16x3_chain).
 WGRAD_CHAIN = int(__import__("os").environ.get("UPNERF_WGRAD_CHAIN", "1"))
 # Colour and candidate heads: [gz_r1 | gz_g1] stored as one tensor, one weight-gradient launch against e for both first layers.
+# The shared density head's weight gradient inside the final layer's weight-gradient launch (same B operand); 0 = upnerf_vec_wgrad.
+VEC_RIDE = int(__import__("os").environ.get("UPNERF_VEC_RIDE", "1"))
 if WGRAD_STORE == "f24" and not WGRAD_CHAIN:  # (r4 ADVICE: the 24-bit operands have no un-chained entry point)
     raise RuntimeError("UPNERF_WGRAD_STORE=f24 needs UPNERF_WGRAD_CHAIN=1 (upnerf_wgrad_f24p_chain is the only kernel that reads the hi + lo8 operands)")
 JOIN_HEADS = int(__import__("os").environ.get("UPNERF_JOIN_HEADS", "1"))
@@ -356,10 +358,12 @@ class _FieldPass(torch.autograd.Function):
             # WGRAD_CHAIN: the slab reduction of every f16x3 weight gradient rides on the next one's launch (ops.WgradChain)
             chain = WgradChain(dev) if WGRAD_CHAIN else None
 
-            def wg(gz, lda, N, Bt, ldb, K, off, ldo, boff, ia, ib, b_off=0):
+            def wg(gz, lda, N, Bt, ldb, K, off, ldo, boff, ia, ib, b_off=0, vhead=None):
                 if chain is not None:
+                    v, voff, vboff = vhead if vhead is not None else (None, None, None)
                     chain.wgrad(M, gz, lda, N, Bt, ldb, K, at(off), ldo, None if boff is None else at(boff), EA(ia), EB(ib),
-                                b_off=b_off, planes=ctx.planes)
+                                b_off=b_off, planes=ctx.planes, v=v, dv_ptr=None if v is None else at(voff),
+                                dbv_ptr=None if v is None else at(vboff))
                 else:
                     wgrad_f16x3_into(M, gz, lda, N, Bt, ldb, K, at(off), ldo, None if boff is None else at(boff), dev,
                                      expo_a=EA(ia), expo_b=EB(ib), b_off=b_off, planes=ctx.planes)
@@ -403,8 +407,12 @@ class _FieldPass(torch.autograd.Function):
                 vec_wgrad_frag16_into(M, dpre_s, 1, 1, h16[D - 1], hexp[D - 1], W, at(L.wsig), at(L.bsig), dev)
             else:
                 h_last = h[0] if store16 else h[D - 1]
-                wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1)
-                vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
+                # the shared density head reads the B operand of the final layer's weight gradient: its gradient rides on that
+                # launch (upnerf_wgrad_f16x3_chain_v: one read of h_last instead of two) where the launch is the f16x3 chain's
+                ride = VEC_RIDE and chain is not None and ctx.planes == 2 and W == 256
+                wg(gz_e, W, W, h_last, W, W, L.we, W, L.be, D, D - 1, vhead=(dpre_s, L.wsig, L.bsig) if ride else None)
+                if not ride:
+                    vec_wgrad_into(M, dpre_s, 1, 1, h_last, W, W, at(L.wsig), at(L.bsig), dev)
         rs_c = _empty(R, W2, device=dev) if cfg.use_cand else None
         rs_r = _empty(R, W2, device=dev) if cfg.use_rgb else None
         if tile_part is not None:
