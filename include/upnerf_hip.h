@@ -431,6 +431,11 @@ int upnerf_wgrad_f16x3_chain2(int M, const float* A, int lda, int N, const float
 int upnerf_wgrad_f16x3_chain_v(int M, const float* A, int lda, int N, const float* B, int ldb, int K, float* dW, int ldo,
                                float* db, const float* v, float* dv, float* dbv, float* slabs, int nsplit, const int* expo_a,
                                const int* expo_b, int planes, upnerf_wgrad_pending* pending, void* stream);
+/* the same on the fragment-ordered fp16 operands of the register-resident field kernels (upnerf_wgrad_f16p_chain with
+ * b_is_f16 = 3, N = K = 256): replaces upnerf_vec_wgrad_frag16 for the shared density head of the f16 mode */
+int upnerf_wgrad_f16p_chain_v(int M, const uint16_t* A16, const int32_t* aexp, const uint16_t* B16, const int32_t* bexp, float* dW,
+                              int ldo, float* db, const float* v, float* dv, float* dbv, float* slabs, int nsplit, const int* expo_a,
+                              const int* expo_b, upnerf_wgrad_pending* pending, void* stream);
 int upnerf_wgrad_finish(upnerf_wgrad_pending* pending, void* stream);
 
 /* Same contraction for the f16 field mode with fp16-STORED operands: A16 [M][lda] fp16 bits scaled per 64-row tile by

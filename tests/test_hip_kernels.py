@@ -973,7 +973,8 @@ def test_chained_slab_reductions_are_bitwise_the_separate_ones(hip, field_mode):
         assert torch.equal(res[0][i], res[1][i]), i
 
 
-def test_density_head_gradient_riding_on_the_final_layer_launch_matches_the_separate_one(hip):
+@pytest.mark.parametrize("field_mode", ["f16x3", "f16"], indirect=True)
+def test_density_head_gradient_riding_on_the_final_layer_launch_matches_the_separate_one(hip, field_mode):
     """upnerf_wgrad_f16x3_chain_v (round 5): the shared density head reads the B operand of the final layer's weight gradient
     (models/nerf.py:89, 93), so its gradient dw_sigma = sum_m dpre_s[m] h[m][:] is summed inside that launch from the rows as
     they pass instead of by upnerf_vec_wgrad on a second read of h.  Same fp32 products in another summation order: 2e-6 of
@@ -1009,12 +1010,15 @@ def test_density_head_gradient_riding_on_the_final_layer_launch_matches_the_sepa
     L = pk.L
     dP0, dP1 = res[0][4], res[1][4]
     sig = slice(L.wsig, L.wsig + 256)
+    assert float(dP0[sig].abs().max()) > 0
     assert float((dP0[sig] - dP1[sig]).abs().max()) <= 2e-6 * float(dP0[sig].abs().max())
     assert abs(float(dP0[L.bsig] - dP1[L.bsig])) <= 2e-6 * max(abs(float(dP0[L.bsig])), 1e-12)
     rest = torch.ones_like(dP0, dtype=torch.bool)
     rest[sig] = False
     rest[L.bsig] = False
     assert torch.equal(dP0[rest], dP1[rest])
+    if field_mode != "f16x3":  # (f16: upnerf_wgrad_f16p_chain_v on the register-resident kernels' fragments; the pass above is its test)
+        return
     # stand-alone, ragged M, against fp64
     M = 64 * 37 + 5
     A, B, v = gen((M, 256), 90).cuda() * 1e-3, torch.relu(gen((M, 256), 91)).cuda(), gen((M,), 92).cuda()

@@ -173,6 +173,8 @@ _SIGNATURES = {
     "upnerf_wgrad_f16x3_chain2": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p],
     # (M, A, lda, N, B, ldb, K, dW, ldo, db, v, dv, dbv, slabs, nsplit, expo_a, expo_b, planes, pending, stream)
     "upnerf_wgrad_f16x3_chain_v": [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _p],
+    # (M, A16, aexp, B16, bexp, dW, ldo, db, v, dv, dbv, slabs, nsplit, expo_a, expo_b, pending, stream)
+    "upnerf_wgrad_f16p_chain_v": [_i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "upnerf_wgrad_finish": [_p, _p],
     "upnerf_transient_fwd": [_p, _p],
     "upnerf_transient_bwd": [_p, _p, _p],

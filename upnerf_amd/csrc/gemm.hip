@@ -916,6 +916,36 @@ static int wgrad_f16p_chain_impl(int M, const uint16_t* A16, const uint8_t* Alo,
   return 0;
 }
 
+extern "C" int upnerf_wgrad_f16p_partial_v(int M, const uint16_t* A16, const int* aexp, const uint16_t* B16, const int* bexp, const float* v,
+                                           const int* expo_a, const int* expo_b, float* slabs, float* bslabs, float* vslabs, int nsplit,
+                                           int rows, const upnerf_wgrad_pending* prev, void* stream);  // csrc/wgrad_f16x3.hip
+
+// upnerf_wgrad_f16p_chain on fragment-ordered 256 x 256 operands + the 1-wide head that shares B (include/upnerf_hip.h)
+extern "C" int upnerf_wgrad_f16p_chain_v(int M, const uint16_t* A16, const int32_t* aexp, const uint16_t* B16, const int32_t* bexp,
+                                         float* dW, int ldo, float* db, const float* v, float* dv, float* dbv, float* slabs, int nsplit,
+                                         const int* expo_a, const int* expo_b, upnerf_wgrad_pending* pending, void* stream) {
+  if (M <= 0 || !A16 || !aexp || !B16 || !bexp || !dW || !v || !dv || !slabs || nsplit <= 0 || !expo_a || !expo_b || !pending || (ldo & 3))
+    return UPNERF_EINVAL;
+  if (pending->nsplit > 0 && pending->slabs == slabs) return UPNERF_EINVAL;
+  const int TN = 256, TK = 256;
+  const int rows = (((M + nsplit - 1) / nsplit) + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  float* bslabs = slabs + (size_t)nsplit * TN * TK;
+  float* vslabs = bslabs + (size_t)nsplit * TN;
+  if (pending->nsplit > 0 && pending->rblocks > nsplit) {
+    int rc = upnerf_wgrad_finish(pending, stream);
+    if (rc) return rc;
+  }
+  int rc = upnerf_wgrad_f16p_partial_v(M, A16, aexp, B16, bexp, v, expo_a, expo_b, slabs, bslabs, vslabs, nsplit, rows,
+                                       pending->nsplit > 0 ? pending : nullptr, stream);
+  if (rc) return rc;
+  upnerf_wgrad_pending P = reduce_desc(256, 256, TN, TK, nsplit, slabs, bslabs, dW, ldo, db);
+  P.vslabs = vslabs;
+  P.dv = dv;
+  P.dbv = dbv;
+  *pending = P;
+  return 0;
+}
+
 extern "C" int upnerf_vec_wgrad_frag16(int M, const float* v, int ldv, int nvec, const uint16_t* X16, const int32_t* xexp, int K,
                                        float* dw, float* dbv, float* scratch, int nsplit, void* stream) {
   if (M <= 0 || !v || !X16 || !xexp || !dw || !scratch || nsplit <= 0 || ldv < nvec) return UPNERF_EINVAL;

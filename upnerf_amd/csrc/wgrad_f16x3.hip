@@ -471,14 +471,18 @@ __global__ __launch_bounds__(W4_THREADS, 1) void wgrad_f16x3_w4_kernel(int M, in
 // residual the field kernels' lo plane held, quantised to 1/32 of the tile's scaled unit (byte = round(32 lo) + 128): the
 // operand is hi + lo again to 2^-20 of its tile's maximum, three MFMAs per block as in the f16x3 kernel; a fp32 B operand is
 // split into hi + lo here.  3 bytes per stored element instead of 4.  Row-major operands only (no FRAG).
-template <int MTW, int NTW, int PKB, int FRAG, int NP>
+// HASV (fragment-ordered 256 x 256 problems): a 1-wide head that reads the same B rows rides along (upnerf_wgrad_f16p_chain_v),
+// as in wgrad_f16x3_kernel: vsum[col] += v[m] * B[m][col] in fp32 from the pieces as they pass, per-split partials to vslabs.
+template <int MTW, int NTW, int PKB, int FRAG, int NP, bool HASV = false>
 __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N, int K, const uint16_t* __restrict__ A, int lda,
                                                                  const int* __restrict__ aexp, const void* __restrict__ Bv, int ldb,
                                                                  const int* __restrict__ bexp, const int* __restrict__ expo_a,
                                                                  const int* __restrict__ expo_b, float* __restrict__ slabs,
                                                                  float* __restrict__ bslabs, int rows_per_split,
                                                                  upnerf_wgrad_pending prev, const uint8_t* __restrict__ Alo,
-                                                                 const uint8_t* __restrict__ Blo) {
+                                                                 const uint8_t* __restrict__ Blo, const float* __restrict__ vrow = nullptr,
+                                                                 float* __restrict__ vslabs = nullptr) {
+  static_assert(!HASV || (FRAG && PKB && NP == 1 && MTW == 4 && NTW == 4), "the vector head rides on fragment-ordered 256 x 256 problems");
   constexpr int TN = 64 * MTW, TK = 64 * NTW;
   constexpr int FX_CHUNK = (MTW * NTW == 16) ? FX_CHUNK_BIG : 32;
   constexpr int PN = (TN + 127) / 128, PK = (TK + 127) / 128;
@@ -528,18 +532,20 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
 #ifndef WG_P_SETS
 #define WG_P_SETS 4
 #endif
-  constexpr int NS = NP == 1 ? WG_P_SETS : 2;
+  constexpr int NS = (NP == 1 && !HASV) ? WG_P_SETS : 2;  // (HASV: eight running sums more; four sets spilled 23 registers)
   static_assert(NS % 2 == 0, "the LDS image is double buffered: set u goes to buffer u & 1");
   h8 ra[NS][A8], rbp[NS][B8 ? B8 : 1];
   f32x4 rbf[NS][B4 ? B4 : 1];
   int xa[NS][A8], xb[NS][B8 ? B8 : 1];  // tile exponents of the rows just loaded
+  float rvv[NS][B8 ? B8 : 1];           // HASV: v of the B rows in flight
+  float vsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vtot = 0.0f;  // HASV: this thread's 8 columns of sum_m v[m] B[m][.]; sum of v
   u32x2_t la[NS][A8], lb[NS][B8 ? B8 : 1];  // NP = 2: the residual bytes of the same pieces
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const u32x2_t mid8 = {0x80808080u, 0x80808080u};  // (byte 128 = residual 0)
   // loads are unconditional (clamped rows / columns; see wgrad_f16x3_kernel), out-of-range pieces are zeroed at staging
   const int mlast = mend > mbeg ? mend - 1 : (mbeg < M ? mbeg : M - 1);
   auto gload = [&](h8 (&ra)[A8], int (&xa)[A8], h8 (&rbp)[B8 ? B8 : 1], int (&xb)[B8 ? B8 : 1], f32x4 (&rbf)[B4 ? B4 : 1],
-                   u32x2_t (&la)[A8], u32x2_t (&lb)[B8 ? B8 : 1], int mc) {
+                   u32x2_t (&la)[A8], u32x2_t (&lb)[B8 ? B8 : 1], float (&rv)[B8 ? B8 : 1], int mc) {
 #pragma unroll
     for (int q = 0; q < A8; ++q) {
       if constexpr (FRAG) {
@@ -562,6 +568,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
           const int mr = mc + (tid % RPB) + RPB * q, m = mr < mlast ? mr : mlast, s2 = tid / RPB;
           rbp[q] = NT_LOAD((const h8*)((const char*)Bh + (((size_t)(m >> 5) * (TK / 16) + (s2 >> 1)) * 64 + (s2 & 1) * 32 + (m & 31)) * 16));
           xb[q] = bexp[m >> 5];
+          if constexpr (HASV) rv[q] = vrow[m];
         } else {
           const int idx = tid + q * FX_THREADS, row = idx / (TK / 8), c8 = idx - row * (TK / 8);
           const int m = mc + row < mlast ? mc + row : mlast;
@@ -599,7 +606,8 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   };
   // mc: first row of the chunk the set holds (rows >= mend and columns past the matrix are staged as zeros)
   auto lstore = [&](const h8 (&ra_)[A8], const int (&xa)[A8], const h8 (&rbp_)[B8 ? B8 : 1], const int (&xb)[B8 ? B8 : 1],
-                    const f32x4 (&rbf_)[B4 ? B4 : 1], const u32x2_t (&la_)[A8], const u32x2_t (&lb_)[B8 ? B8 : 1], int buf, int mc) {
+                    const f32x4 (&rbf_)[B4 ? B4 : 1], const u32x2_t (&la_)[A8], const u32x2_t (&lb_)[B8 ? B8 : 1],
+                    const float (&rv)[B8 ? B8 : 1], int buf, int mc) {
     char* base = lds + buf * BUF;
     // the masks (what the conditional loads used to deliver as zeros)
     h8 ra[A8], rbp[B8 ? B8 : 1];
@@ -654,6 +662,13 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
         const int idx = tid + q * FX_THREADS, row = idx / (TK / 8), c8 = idx - row * (TK / 8);
         const _Float16 f = pw2h(eb - xb[q]);
         h8 v = rbp[q];
+        if constexpr (HASV) {  // natural units: fp16 value * 2^-tile exponent, times the row's v (zero past mend: rbp is masked)
+          const bool in = mc + (tid % RPB) + RPB * q < mend;
+          const float sc = in ? ldexpf(rv[q], -xb[q]) : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vsum[j] = fmaf((float)v[j], sc, vsum[j]);
+          vtot += (in && tid < RPB) ? rv[q] : 0.0f;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] * f;
         if constexpr (FRAG) {
@@ -724,14 +739,14 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   // two register sets: the loads of chunk c+2 are in flight while chunk c is contracted (rows beyond mend load as zeros)
   // NS register sets: the loads of chunk c + NS are in flight while chunk c is contracted (rows beyond mend are staged as zeros)
 #pragma unroll
-  for (int u = 0; u < NS; ++u) gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], mbeg + u * FX_CHUNK);
+  for (int u = 0; u < NS; ++u) gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], rvv[u], mbeg + u * FX_CHUNK);
 #pragma unroll 1
   for (int mc = mbeg; mc < mend; mc += NS * FX_CHUNK) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      lstore(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], u & 1, mc + u * FX_CHUNK);
+      lstore(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], rvv[u], u & 1, mc + u * FX_CHUNK);
       __syncthreads();
-      gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], mc + (NS + u) * FX_CHUNK);
+      gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], rvv[u], mc + (NS + u) * FX_CHUNK);
       contract(u & 1);
     }
   }
@@ -767,6 +782,28 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
         for (int t = 0; t < G; ++t) sacc += red[(grp + t * Q) * 8 + j];
       }
       bslabs[((size_t)split * gridDim.y + blockIdx.y) * TN + tid] = sacc;
+    }
+  }
+  if constexpr (HASV) {  // column tid = 16 s + 8 (j / 4) + 4 hh + j % 4 is held, as element j, by the RPB threads with tid / RPB = 2 s + hh
+    __syncthreads();
+    float* red = (float*)lds;
+    float* redt = red + 8 * FX_THREADS;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = vsum[j];
+    if (tid < RPB) redt[tid] = vtot;
+    __syncthreads();
+    if (tid < TK) {
+      const int s2 = 2 * (tid >> 4) + ((tid >> 2) & 1), j = 4 * ((tid >> 3) & 1) + (tid & 3);
+      float sacc = 0.0f;
+#pragma unroll
+      for (int t = 0; t < RPB; ++t) sacc += red[(s2 * RPB + t) * 8 + j];
+      vslabs[(size_t)split * (TK + 4) + tid] = sacc;
+    }
+    if (tid == 0) {
+      float t = 0.0f;
+#pragma unroll
+      for (int r = 0; r < RPB; ++r) t += redt[r];
+      vslabs[(size_t)split * (TK + 4) + TK] = t;
     }
   }
 }
@@ -834,6 +871,17 @@ extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N,
   if (TN == 64 && TK == 128) return launch<1, 2>(WG_ARGS);
   return launch<1, 1>(WG_ARGS);
 #undef WG_ARGS
+}
+
+// the same for the fragment-ordered fp16 operands of the register-resident field kernels (upnerf_wgrad_f16p_chain_v, gemm.hip)
+extern "C" int upnerf_wgrad_f16p_partial_v(int M, const uint16_t* A16, const int* aexp, const uint16_t* B16, const int* bexp, const float* v,
+                                           const int* expo_a, const int* expo_b, float* slabs, float* bslabs, float* vslabs, int nsplit,
+                                           int rows, const upnerf_wgrad_pending* prevp, void* stream) {
+  upnerf_wgrad_pending prev = {};
+  if (prevp) prev = *prevp;
+  hipLaunchKernelGGL((wgrad_f16p_kernel<4, 4, 1, 1, 1, true>), dim3(nsplit, 1, 1), dim3(FX_THREADS), 0, (hipStream_t)stream, M, 256, 256, A16,
+                     256, aexp, (const void*)B16, 256, bexp, expo_a, expo_b, slabs, bslabs, rows, prev, nullptr, nullptr, v, vslabs);
+  return (int)hipGetLastError();
 }
 
 // 256 x 256 block with a 1-wide head riding along (upnerf_wgrad_f16x3_chain_v, gemm.hip)

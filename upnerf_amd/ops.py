@@ -254,11 +254,19 @@ class WgradChain:
         check(rc, "upnerf_wgrad_f16x3_chain2")
 
     def wgrad_p(self, M, A16, lda, aexp, N, B, ldb, bexp, K, dW_ptr, ldo, db_ptr, expo_a, expo_b, frag=False, n2=0, dW2_ptr=None,
-                ldo2=0, db2_ptr=None):
+                ldo2=0, db2_ptr=None, v=None, dv_ptr=None, dbv_ptr=None):
         """wgrad_f16p_into (fp16-stored operands of the f16 field mode) as a link of the run; n2 > 0: rows [n2, N) of the
-        result go to dW2 / db2 (as wgrad2)."""
+        result go to dW2 / db2 (as wgrad2).  v / dv_ptr / dbv_ptr (fragment-ordered 256 x 256 problems): a 1-wide head fed by the
+        same B rows rides on the launch (upnerf_wgrad_f16p_chain_v)."""
         ns = nsplit_for(M)
         ws = self._slabs(ns)
+        if v is not None:
+            assert frag and N == 256 and K == 256 and bexp is not None and n2 == 0
+            rc = TIMER.run(f"wgrad16p_{N}x{K}", lambda: lib.upnerf_wgrad_f16p_chain_v(
+                M, ptr(A16), ptr(aexp), ptr(B), ptr(bexp), dW_ptr, ldo, db_ptr, ptr(v), dv_ptr, dbv_ptr, ptr(ws), ns, expo_a, expo_b,
+                C.byref(self.pending), stream()), units=M)
+            check(rc, "upnerf_wgrad_f16p_chain_v")
+            return
         rc = TIMER.run(f"wgrad16p_{N}x{K}", lambda: lib.upnerf_wgrad_f16p_chain(
             M, ptr(A16), lda, ptr(aexp), N, ptr(B), ldb, ptr(bexp), int(bexp is not None) | (2 if frag else 0), K, dW_ptr, ldo, db_ptr,
             n2, dW2_ptr, ldo2, db2_ptr, ptr(ws), ns, expo_a, expo_b, C.byref(self.pending), stream()), units=M)

@@ -401,10 +401,14 @@ class _FieldPass(torch.autograd.Function):
                 else:
                     wg(gz, W, W, h[l - 1], W, W, L.w[l], W, L.b[l], l, l - 1)
             if rr:  # both operands of the final layer's gradient, and the density head's, as fragments
-                chain.wgrad_p(M, gz16[D], W, gzexp[D], W, h16[D - 1], W, hexp[D - 1], W, at(L.we), W, at(L.be), EA(D), EB(D - 1), frag=True) \
-                    if chain is not None else \
+                ride = VEC_RIDE and chain is not None  # the density head's gradient inside the final layer's launch (same B operand)
+                if chain is not None:
+                    chain.wgrad_p(M, gz16[D], W, gzexp[D], W, h16[D - 1], W, hexp[D - 1], W, at(L.we), W, at(L.be), EA(D), EB(D - 1), frag=True,
+                                  v=dpre_s if ride else None, dv_ptr=at(L.wsig) if ride else None, dbv_ptr=at(L.bsig) if ride else None)
+                else:
                     wgrad_f16p_into(M, gz16[D], W, gzexp[D], W, h16[D - 1], W, hexp[D - 1], W, at(L.we), W, at(L.be), dev, EA(D), EB(D - 1), frag=True)
-                vec_wgrad_frag16_into(M, dpre_s, 1, 1, h16[D - 1], hexp[D - 1], W, at(L.wsig), at(L.bsig), dev)
+                if not ride:
+                    vec_wgrad_frag16_into(M, dpre_s, 1, 1, h16[D - 1], hexp[D - 1], W, at(L.wsig), at(L.bsig), dev)
             else:
                 h_last = h[0] if store16 else h[D - 1]
                 # the shared density head reads the B operand of the final layer's weight gradient: its gradient rides on that
