@@ -557,7 +557,7 @@ def main():
         # HBM bytes per launch come from rocprofv3 PMC passes (tools/pmc_collect.sh; they cannot be collected live): used
         # only when the committed profile was taken from THIS build on THIS workload, otherwise null
         traffic, source, step_bytes = None, None, None
-        meta_p = os.path.join(ROOT, "profiles", "pmc_current.json")
+        meta_p = os.path.join(ROOT, "profiles", "pmc_current_trevi.json" if args.config == "trevi" else "pmc_current.json")
         if os.path.exists(meta_p):
             meta = json.load(open(meta_p))
             if (meta.get("src_sha16") == source_sha16() and meta.get("field") == field and meta.get("config") == args.config

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instruction mix and stall counters of the field kernels (two rocprofv3 PMC passes over a short bench run).
-# usage (GPU box, repo root): [UPNERF_FIELD_TILE=128] bash tools/pmc_field.sh OUTDIR [extra bench args]
+# usage (GPU box, repo root): bash tools/pmc_field.sh OUTDIR [extra bench args]   (--config trevi: the 256-sample register-resident kernels)
 set -u
 OUT=$(realpath -m "$1"); shift
 ROOT=$(pwd)

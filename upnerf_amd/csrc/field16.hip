@@ -790,6 +790,17 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     f32x16 accg[TH::MT][TH::NT];
     acc_zero(accg);
     float mg1 = 0.0f;
+    // the r1 rows of the colour stage further down are requested HERE: they arrive under the candidate stage (its own row
+    // loads, its 128-wide contraction) instead of opening the colour stage with a second HBM round trip
+    f32x4 rv[EPT];
+    if (a.use_rgb) {
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        int m = m0 + er0 + ERS * q;
+        m = m < M ? m : M - 1;
+        rv[q] = NT_LOAD((const f32x4*)&a.r1[(size_t)m * W2 + 4 * eg]);
+      }
+    }
     if (a.use_cand) {
       // d g2 = w_csig * dpre_c + w_cj * g_G_c[ray]   (candidate_sigma / feat_candidate_layer, nerf.py:99-100)
       f32x4 vals[EPT];
@@ -838,15 +849,9 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     float mr1 = 0.0f;
     if (a.use_rgb) {
       // d r1 = W_r2^T (d rgb * rgb (1-rgb))   (rgb_share_layer.2 + sigmoid); loads first, as above
-      f32x4 wr[3], rv[EPT];
+      f32x4 wr[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) wr[c] = *(const f32x4*)&P[L.wr2 + c * W2 + 4 * eg];
-#pragma unroll
-      for (int q = 0; q < EPT; ++q) {
-        int m = m0 + er0 + ERS * q;
-        m = m < M ? m : M - 1;
-        rv[q] = NT_LOAD((const f32x4*)&a.r1[(size_t)m * W2 + 4 * eg]);
-      }
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
         const int row = er0 + ERS * q, m = m0 + row;

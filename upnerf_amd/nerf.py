@@ -36,7 +36,10 @@ class NeRF(nn.Module):
         # reading the device parameter would drain the HIP queue twice per step.  None = unknown (read the parameter).
         self.host_progress = None
         if not encode_feat:
-            raise NotImplementedError("nerf.feat_dim = 0 is not implemented on the HIP path")
+            # decided in round 5: the reference's no-DINO-feature ablation (nerf.py:52-56, 75-78,
+            # 110-123; rendering.py:142-150, 177-190) is outside what this path rebuilds -- no shipped configuration selects it
+            raise NotImplementedError("nerf.feat_dim = 0 (encode_feat=False: colour head on xyz_encoding_final, rgb_candidate_layer, "
+                                      "c_rgb maps) has no HIP path -- see INTEGRATION.md, 'Behavioural notes'")
         for i in range(D):
             k = self.in_channels_xyz if i == 0 else (W + self.in_channels_xyz if i in self.skips else W)
             setattr(self, f"xyz_encoding_{i + 1}", nn.Sequential(nn.Linear(k, W), nn.ReLU(True)))
