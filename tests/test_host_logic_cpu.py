@@ -16,6 +16,9 @@ def test_lazy_results_behave_like_a_dict():
     assert r["b"] == 2 and calls == ["b"]
     assert r["b"] == 2 and calls == ["b"]          # once
     assert dict(r.items()) == {"a": 1, "b": 2, "c": 3} and calls == ["b", "c"]
+    r3 = _LazyResults({"b": 1})
+    r3.lazy("b", lambda: 2)                         # (r4 ADVICE) a pending thunk for a key that already holds a value counts once
+    assert len(r3) == 1 and r3["b"] == 2 and len(r3) == 1
     r2 = _LazyResults({"a": 1})
     r2.lazy("b", lambda: 5)
     r2["b"] = 9                                     # an explicit value replaces the thunk

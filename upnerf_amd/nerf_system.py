@@ -130,7 +130,7 @@ class _LazyResults(dict):
         return super().items()
 
     def __len__(self):
-        return super().__len__() + len([k for k in self._thunks if not super().__contains__(k)])
+        return dict.__len__(self) + sum(1 for k in self._thunks if not dict.__contains__(self, k))
 
     def __eq__(self, other):
         self._force()
