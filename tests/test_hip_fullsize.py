@@ -318,6 +318,7 @@ def test_full_size_forward_and_ray_gradients_match_the_oracle_on_a_slice(mode, r
     from test_hip_parity import GRAD_GATE_CAP, TOL_GRAD, TOL_MAP, TOL_W, build_system
     from golden_util import rel_err
     from upnerf_amd import rendering as rd
+    from upnerf_amd.rendering import ray_gradient, retain_ray_gradient
     c = SynthCase(f"full_{mode}_{progress}", rays, progress, seed=21, n_img=n_img)
     sysm = build_system(c)
     batch = {k: v.cuda() for k, v in c.batch().items()}
@@ -326,7 +327,7 @@ def test_full_size_forward_and_ray_gradients_match_the_oracle_on_a_slice(mode, r
     try:
         keep = {}
         loss, loss_d, res = sysm.compute_loss(batch, u_list=[u.clone() for u in c.u_list], keep=keep)
-        sysm._last_rays.retain_grad()
+        retain_ray_gradient(sysm._last_rays)
         loss.backward()
         torch.cuda.synchronize()
     finally:
@@ -350,7 +351,7 @@ def test_full_size_forward_and_ray_gradients_match_the_oracle_on_a_slice(mode, r
         if not e < (tol_w if "weights" in k else tol_map):
             errs[k] = e
     assert not errs, errs
-    got = sysm._last_rays.grad.detach().cpu()[idx].double() * (rays / n)  # batch mean -> slice mean
+    got = ray_gradient(sysm._last_rays).detach().cpu()[idx].double() * (rays / n)  # batch mean -> slice mean
     for tag, cs in (("rays_o", slice(0, 3)), ("rays_d", slice(3, 6))):
         a, b = got[:, cs], gr32[:, cs].double()
         if mode == "f16x3":

@@ -53,3 +53,41 @@ def test_lazy_results_follow_the_whole_dict_protocol():
     r, _ = make()
     r.update({"b": 5})
     assert r["b"] == 5
+
+
+def test_zero_pool_serves_one_arena_per_step_and_falls_back_off_plan():
+    """zero_pool: the second step's requests are slices of one zeroed arena (256-byte aligned, disjoint); a request that
+    leaves the previous step's sequence, and any request outside a step, is a plain torch.zeros."""
+    import torch
+    from upnerf_amd import zero_pool
+    zero_pool._S.plan = None
+    dev = torch.device("cpu")
+    assert zero_pool.zeros(5, dev).shape == (5,)  # outside a step
+    with zero_pool.step(dev):
+        a, b = zero_pool.zeros(10, dev), zero_pool.zeros(100, dev)
+        assert a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()  # nothing planned yet: two fills
+    with zero_pool.step(dev):
+        a, b = zero_pool.zeros(10, dev), zero_pool.zeros(100, dev)
+        assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+        assert b.data_ptr() - a.data_ptr() == 256 and a.numel() == 10 and b.numel() == 100
+        a += 1.0
+        assert float(b.abs().max()) == 0.0
+        c = zero_pool.zeros(7, dev)  # one more than planned
+        assert c.untyped_storage().data_ptr() != a.untyped_storage().data_ptr() and float(c.abs().max()) == 0.0
+    with zero_pool.step(dev):
+        a = zero_pool.zeros(10, dev)
+        x = zero_pool.zeros(33, dev)  # off the plan (100 was next): fills from here on
+        y = zero_pool.zeros(7, dev)
+        assert x.untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
+        assert y.untyped_storage().data_ptr() not in (a.untyped_storage().data_ptr(), x.untyped_storage().data_ptr())
+    with zero_pool.step(dev):  # ... and the new sequence is the plan now
+        a, x, y = zero_pool.zeros(10, dev), zero_pool.zeros(33, dev), zero_pool.zeros(7, dev)
+        assert a.untyped_storage().data_ptr() == x.untyped_storage().data_ptr() == y.untyped_storage().data_ptr()
+        assert float(torch.cat([a, x, y]).abs().max()) == 0.0
+    try:
+        with zero_pool.step(dev):
+            zero_pool.zeros(3, dev)
+            raise KeyError("a step that raised")
+    except KeyError:
+        pass
+    assert zero_pool._S.rec is None and zero_pool._S.plan[1] == (10, 33, 7)  # the failed step changed nothing

@@ -985,16 +985,38 @@ extern "C" int upnerf_wgrad_f24p_chain(int M, const uint16_t* A16, const uint8_t
 }
 
 // ---- small matrix-vector products of the folded colour layer (packing): y[m] = add[m] + sum_k A[m][k] x[k] (trans = 0, one wave
-// per row, lane-strided partial sums + a shuffle tree: fixed order) or y[k] = sum_m A[m][k] x[m] (trans = 1, one thread per
-// column walking the rows in order).  128 x 384: one 5 us launch where a 64 x 64-tile GEMM launch plus two copies stood.
+// per row, lane-strided partial sums + a shuffle tree: fixed order) or y[k] = sum_m A[m][k] x[m] (trans = 1: 16 columns per
+// workgroup, 16 row classes m = p (mod 16) per column with all of a class's loads in flight at once, the classes added in order
+// out of LDS -- one thread per column walking the 128 rows one dependent load at a time was a 33 us launch).
 __global__ __launch_bounds__(256) void matvec_kernel(int M, int K, const float* __restrict__ A, int lda, const float* __restrict__ x,
                                                      const float* __restrict__ add, float* __restrict__ y, int trans) {
   if (trans) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ float part[16][17];
+    const int c = threadIdx.x & 15, p = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + c;
     float s = 0.0f;
-    for (int m = 0; m < M; ++m) s += A[(size_t)m * lda + k] * x[m];
-    y[k] = s + (add ? add[k] : 0.0f);
+    if (k < K) {
+      for (int m0 = p; m0 < M; m0 += 16 * 8) {
+        float a[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int m = m0 + 16 * u;
+          const int mc = m < M ? m : M - 1;
+          a[u] = A[(size_t)mc * lda + k];
+          xv[u] = m < M ? x[mc] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u] * xv[u];
+      }
+    }
+    part[p][c] = s;
+    __syncthreads();
+    if (p == 0 && k < K) {
+      float t = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += part[q][c];
+      y[k] = t + (add ? add[k] : 0.0f);
+    }
     return;
   }
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1008,7 +1030,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(int M, int K, const float* 
 extern "C" int upnerf_matvec(int M, int K, const float* A, int lda, const float* x, const float* add, float* y, int trans,
                              void* stream) {
   if (M <= 0 || K <= 0 || !A || !x || !y || lda < K) return UPNERF_EINVAL;
-  const int blocks = trans ? (K + 255) / 256 : (M + 3) / 4;
+  const int blocks = trans ? (K + 15) / 16 : (M + 3) / 4;
   hipLaunchKernelGGL(matvec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, K, A, lda, x, add, y, trans);
   return (int)hipGetLastError();
 }

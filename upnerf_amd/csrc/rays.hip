@@ -445,45 +445,53 @@ struct EmbedGroups {
   int n;
 };
 
-__global__ void embed_bwd_grouped_kernel(int R, int N, const long long* __restrict__ idx, EmbedGroups T) {
+// The workgroup's four table rows scan the SAME indices: they are staged in LDS once (coalesced, 4096 rays per trip) and each
+// wave ballots its row out of LDS -- every wave walking idx through its own chain of global loads was most of a 52 us launch
+// for a batch in which a table row is hit five times.  The rows a wave adds up are still taken in ray order.
+#define EMB_CHUNK 4096
+__global__ __launch_bounds__(NTHREADS) void embed_bwd_grouped_kernel(int R, int N, const long long* __restrict__ idx, EmbedGroups T) {
+  __shared__ int idx_s[EMB_CHUNK];
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (n >= N) return;
+  const int n = blockIdx.x * (NTHREADS >> 6) + (threadIdx.x >> 6);
   float acc[UPNERF_MAX_EMBED_GROUPS][4];
 #pragma unroll
   for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[t][q] = 0.f;
-  // the index scan runs eight 64-ray groups ahead of the accumulation (one load per group would be a chain of 64 L2 round
-  // trips for a table row that, typically, no ray of the batch hits)
-  constexpr int U = 8;
-  for (int base0 = 0; base0 < R; base0 += 64 * U) {
-    long long iv[U];
+  for (int c0 = 0; c0 < R; c0 += EMB_CHUNK) {
+    if (c0) __syncthreads();
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = base0 + 64 * u + lane;
-      iv[u] = r < R ? idx[r] : -1;
+    for (int u = 0; u < EMB_CHUNK / NTHREADS; ++u) {
+      const int r = c0 + u * NTHREADS + (int)threadIdx.x;
+      const long long v = r < R ? idx[r] : -1;
+      idx_s[u * NTHREADS + threadIdx.x] = (v >= 0 && v < N) ? (int)v : -1;
     }
+    __syncthreads();
+    const int cnt = (R - c0) < EMB_CHUNK ? (R - c0) : EMB_CHUNK;
+    if (n < N) {
+      for (int base = 0; base < cnt; base += 64) {
+        unsigned long long m = __ballot(idx_s[base + lane] == n);
+        while (m) {
+          const int j = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const size_t ray = (size_t)(c0 + base + j);
+          float v[UPNERF_MAX_EMBED_GROUPS][4];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int base = base0 + 64 * u;
-      unsigned long long m = __ballot(iv[u] == (long long)n);
-      while (m) {
-        const int j = __ffsll((long long)m) - 1;
-        m &= m - 1;
+          for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t) {
+            const int dim = T.dim[t];  // 0 for an unused slot
+            const float* __restrict__ row = T.g[t] + ray * dim;
 #pragma unroll
-        for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t) {
-          if (t < T.n) {
-            const int dim = T.dim[t];
-            const float* __restrict__ row = T.g[t] + (size_t)(base + j) * dim;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (lane + 64 * q < dim) acc[t][q] += row[lane + 64 * q];
+            for (int q = 0; q < 4; ++q) v[t][q] = (lane + 64 * q < dim) ? row[lane + 64 * q] : 0.f;
           }
+#pragma unroll
+          for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] += v[t][q];
         }
       }
     }
   }
+  if (n >= N) return;
 #pragma unroll
   for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t) {
     if (t < T.n) {

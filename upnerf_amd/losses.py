@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 from torch import nn
 
-from . import step_scalars
+from . import step_scalars, zero_pool
 from ._lib import LossArgs, LossGrads, check, lib, ptr, stream
 
 TERMS = ("l_depth_c", "l_feat_c", "l_rgb_c", "l_depth_f", "l_feat_f", "l_rgb_f", "l_beta", "l_alpha")
@@ -50,7 +50,7 @@ class _LossFn(torch.autograd.Function):
         want = [(x, ok) for x, ok in ((dd, need[0]), (rows, need[2]), (sdc, need[3]), (sdf, need[4]), (fc, need[7]), (ff, need[8]),
                                       (rc, need[10]), (rf, need[11]), (beta, need[13]), (alpha, need[14]))]
         pad = lambda n: (n + 63) // 64 * 64
-        arena = torch.zeros(sum(pad(x.numel()) for x, ok in want if x is not None and ok) or 1, device=g_terms.device)
+        arena = zero_pool.zeros(sum(pad(x.numel()) for x, ok in want if x is not None and ok) or 1, g_terms.device)
         cursor = [0]
 
         def new(x, ok):

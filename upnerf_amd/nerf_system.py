@@ -17,14 +17,14 @@ from collections import defaultdict
 import torch
 from torch import nn
 
-from . import step_scalars
+from . import step_scalars, zero_pool
 from .camera import refine_and_get_rays
 from .losses import UPNeRFLoss
 from .nerf import NeRF, fp32_round
 from .ops import embed_rows, reset_deferred
 from .optim import get_learning_rate, get_optimizer, get_scheduler
 from .parallel import GradSync
-from .rendering import render_rays
+from .rendering import join_rays, render_rays
 from .transient_net import TransientNet
 
 try:  # pragma: no cover - Lightning is absent in the build image
@@ -246,7 +246,7 @@ class NeRFSystem(_Base):
             for v in t_side.values():
                 v.record_stream(cur)  # consumed by the blend / loss on the main stream
         for i in range(0, B, chunk):
-            out = render_rays(models=self.models, embeddings=self.embeddings, rays=rays[i:i + chunk],
+            out = render_rays(models=self.models, embeddings=self.embeddings, rays=rays if chunk >= B else rays[i:i + chunk],
                               img_idx=img_idx[i:i + chunk], sched_mult=sched_mult, sched_phase=sched_phase,
                               N_samples=hp["nerf.N_samples"], use_disp=hp["nerf.use_disp"],
                               perturb=hp["nerf.perturb"] if train else 0, N_importance=hp["nerf.N_importance"],
@@ -294,7 +294,7 @@ class NeRFSystem(_Base):
         idx = batch["img_idx"]
         se3 = embed_rows(self.se3_refine, idx, defer_grad=True) if self.hparams["pose.optimize"] else None
         rays_o, rays_d = refine_and_get_rays(se3, batch["c2w"], batch["directions"])
-        return torch.cat([rays_o, rays_d, batch["ray_infos"]], 1)
+        return join_rays(rays_o, rays_d, batch["ray_infos"])
 
     def depth_targets(self, batch):
         """Affine-corrected mono-depth prior (nerf_system.py:169-177)."""
@@ -332,15 +332,16 @@ class NeRFSystem(_Base):
     # (and put the gradient all-reduce between them) and replay them with the host bookkeeping done beside the replays
     def _step_backward(self, batch, u_list=None):
         """Forward, loss and backward; gradients are left in the parameters' .grad."""
-        loss, loss_d, _ = self.compute_loss(batch, u_list=u_list)
-        for o in self._opts_scheds()[0]:
-            o.zero_grad()
-        if self.grad_sync is not None and step_scalars.current() is None:
-            # eager step: the fine field's gradients are all-reduced while the rest of backward runs.  (Under graph capture
-            # the collective stays between the two graphs of a step, graph_step.py.)
-            sm = self.get_schedule_mult(self._host_progress)
-            self.grad_sync.begin(0 if sm == 0 else (2 if sm == 1 else 1))
-        self.manual_backward(loss)
+        with zero_pool.step(batch["img_idx"].device):  # the step's zeroed buffers: slices of one arena, one fill launch
+            loss, loss_d, _ = self.compute_loss(batch, u_list=u_list)
+            for o in self._opts_scheds()[0]:
+                o.zero_grad()
+            if self.grad_sync is not None and step_scalars.current() is None:
+                # eager step: the fine field's gradients are all-reduced while the rest of backward runs.  (Under graph
+                # capture the collective stays between the two graphs of a step, graph_step.py.)
+                sm = self.get_schedule_mult(self._host_progress)
+                self.grad_sync.begin(0 if sm == 0 else (2 if sm == 1 else 1))
+            self.manual_backward(loss)
         return loss, loss_d
 
     def _step_update(self):

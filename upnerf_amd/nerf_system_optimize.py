@@ -16,11 +16,12 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from . import zero_pool
 from .camera import refine_and_get_rays
 from .nerf_system import NeRFSystem
 from .ops import embed_rows
 from .optim import get_optimizer
-from .rendering import render_rays
+from .rendering import join_rays, render_rays
 
 
 class NeRFSystemOptimize(NeRFSystem):
@@ -68,7 +69,8 @@ class NeRFSystemOptimize(NeRFSystem):
         chunk = rays.shape[0] if train else hp["val.chunk_size"]
         outs = []
         for i in range(0, rays.shape[0], chunk):
-            outs.append(render_rays(models=self.models, embeddings=self.embeddings, rays=rays[i:i + chunk],
+            outs.append(render_rays(models=self.models, embeddings=self.embeddings,
+                                    rays=rays if chunk >= rays.shape[0] else rays[i:i + chunk],
                                     img_idx=img_idx[i:i + chunk], sched_mult=1.0, N_samples=hp["nerf.N_samples"],
                                     use_disp=hp["nerf.use_disp"], perturb=hp["nerf.perturb"] if train else 0,
                                     N_importance=hp["nerf.N_importance"], encode_feat=True, u_list=u_list,
@@ -78,7 +80,7 @@ class NeRFSystemOptimize(NeRFSystem):
     def rays_from_batch(self, batch):
         se3 = embed_rows(self.se3_refine, batch["img_idx"], defer_grad=True) if self.pose_optimize else None
         o, d = refine_and_get_rays(se3, batch["c2w"], batch["directions"])
-        return torch.cat([o, d, batch["ray_infos"]], 1)
+        return join_rays(o, d, batch["ray_infos"])
 
     def compute_loss(self, batch, u_list=None):
         rays = self.rays_from_batch(batch)
@@ -89,10 +91,11 @@ class NeRFSystemOptimize(NeRFSystem):
 
     # the three pieces of a step (NeRFSystem.training_step composes them; graph_step.GraphedTrainingStep captures the first two)
     def _step_backward(self, batch, u_list=None):
-        loss, loss_d, _ = self.compute_loss(batch, u_list=u_list)
-        for o in self._opts_scheds()[0]:
-            o.zero_grad()
-        self.manual_backward(loss)
+        with zero_pool.step(batch["img_idx"].device):
+            loss, loss_d, _ = self.compute_loss(batch, u_list=u_list)
+            for o in self._opts_scheds()[0]:
+                o.zero_grad()
+            self.manual_backward(loss)
         return loss, loss_d
 
     def _step_host(self, loss, loss_d, done):

@@ -17,6 +17,7 @@ from typing import Dict
 import torch
 import torch.nn.functional as F
 
+from . import zero_pool
 from ._lib import AUXK, CK, MAX_D, X0, Frag16Desc, FragDesc, Layout
 
 
@@ -31,7 +32,7 @@ class _PackFn(torch.autograd.Function):
         L, W, W2, Fd = packer.L, packer.W, packer.W2, packer.feat_dim
         p = {n: t.detach().contiguous() for n, t in zip(names, tensors)}
         dev = tensors[0].device
-        buf = torch.zeros(L.total + W2 * Fd, device=dev, dtype=torch.float32)  # P followed by a copy of W_r1[:, :F]
+        buf = zero_pool.zeros(L.total + W2 * Fd, dev)  # P followed by a copy of W_r1[:, :F]
         st = stream()
         descs = packer._pack_descs(p, lambda n: p[n].data_ptr(), L.total)
         arr = (PackDesc * len(descs))(*descs)
@@ -63,7 +64,7 @@ class _PackFn(torch.autograd.Function):
         st = stream()
         # one flat buffer for all parameter gradients
         sizes = [math.prod(s) for s in ctx.shapes]
-        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        flat = zero_pool.zeros(sum(sizes), dev)
         grads, off = {}, 0
         for n, s_, k in zip(names, ctx.shapes, sizes):
             grads[n] = flat[off:off + k].view(s_)
@@ -331,7 +332,7 @@ class NerfPacker:
         from ._lib import check, lib, ptr, stream
         fd, nf, bd, nb = self._descs16()
         t0 = (self.L.total + 63) // 64 * 64  # the transposed set starts on a 256-byte boundary
-        both = torch.zeros(t0 + self.L.t_total, device=P.device, dtype=torch.float32)  # one fill for the two sets
+        both = zero_pool.zeros(t0 + self.L.t_total, P.device)  # one fill for the two sets
         P16, PT16 = both[:self.L.total], both[t0:]
         scratch = torch.empty(16, device=P.device, dtype=torch.float32)
         wexp = torch.empty(16, device=P.device, dtype=torch.int32)

@@ -17,13 +17,13 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import _lib, step_scalars
+from . import _lib, step_scalars, zero_pool
 from ._lib import (CompositeBwdArgs, CompositeFwdArgs, FieldBwdArgs, FieldFwdArgs, AUXK, CK, RR_PART_STRIDE, TILE_PART_STRIDE, X0, check, lib,
                    ptr, stream)
 from .ops import (TIMER, WgradChain, embed_rows, hip_linear, linear_kn_view, linear_raw, nsplit_for, vec_wgrad_frag16_into, vec_wgrad_into, wgrad_f16p_into,
                   wgrad_f16x3_into, wgrad_into, workspace)
 
-__all__ = ["render_rays", "sample_pdf", "band_weights"]
+__all__ = ["render_rays", "sample_pdf", "band_weights", "join_rays", "retain_ray_gradient", "ray_gradient"]
 
 # Arithmetic of the field contractions (all HIP kernels of libupnerf_hip.so; there is no non-HIP path):
 #   "f16x3"  3-term fp16 hi/lo split on the f16 matrix cores, fp32-level accuracy (csrc/field16.hip; needs W = 256 and
@@ -63,6 +63,7 @@ WGRAD_CHAIN = int(__import__("os").environ.get("UPNERF_WGRAD_CHAIN", "1"))
 # Colour and candidate heads: [gz_r1 | gz_g1] stored as one tensor, one weight-gradient launch against e for both first layers.
 # The shared density head's weight gradient inside the final layer's weight-gradient launch (same B operand); 0 = upnerf_vec_wgrad.
 VEC_RIDE = int(__import__("os").environ.get("UPNERF_VEC_RIDE", "1"))
+JOIN_RAYS = int(__import__("os").environ.get("UPNERF_JOIN_RAYS", "1"))  # (0: render_rays slices the [R][8] rows back apart, for A/B runs)
 if WGRAD_STORE == "f24" and not WGRAD_CHAIN:  # (r4 ADVICE: the 24-bit operands have no un-chained entry point)
     raise RuntimeError("UPNERF_WGRAD_STORE=f24 needs UPNERF_WGRAD_CHAIN=1 (upnerf_wgrad_f24p_chain is the only kernel that reads the hi + lo8 operands)")
 JOIN_HEADS = int(__import__("os").environ.get("UPNERF_JOIN_HEADS", "1"))
@@ -191,7 +192,7 @@ class _FieldPass(torch.autograd.Function):
                              dtype=torch.int64) if train else None)  # 64 bits per lane and tile, either tiling (rr: 128 per lane)
         # running max|.| of the stored tensors (scales of the f16x3 weight gradients): slots [0, 16) filled by this pass, [16, 32)
         # by the backward kernel -- one zero fill and, later, one exponent launch for both
-        mx32 = torch.zeros(32, device=dev) if train else None
+        mx32 = zero_pool.zeros(32, dev) if train else None
         amax = mx32[:16] if train else None
         g1 = _empty(Mp, W2, device=dev)[:M] if (cfg.use_cand and train and not e_frag) else None
         g1_16 = torch.empty(Mp, W2, device=dev, dtype=torch.float16) if (cfg.use_cand and train and e_frag) else None
@@ -341,7 +342,7 @@ class _FieldPass(torch.autograd.Function):
                                gz_g2=gz_g2 if gz_g2 is not None else (dequant16(gz_g2_16[None], gzg2exp[None], frag=True)[0, :M] if g2f else None),
                                dpre_s=dpre_s, dpre_c=dpre_c, dpre_rgb=dpre_rgb, dxyz=dxyz)
         # ---- weight gradients, written straight into a buffer with P's layout
-        dP = torch.zeros(L.total, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
+        dP = zero_pool.zeros(L.total, dev) if ctx.needs_input_grad[5] else None
         d_c_rows = d_a_rows = None
         if dP is not None:
             base = dP.data_ptr()
@@ -610,6 +611,35 @@ def _project_feat(model, E_s, sum_sfeat, G_c=None, t_weight=None):
     return _ProjectFeat.apply(len(xs), *xs, *ws)
 
 
+def join_rays(rays_o, rays_d, near_far):
+    """The [R][8] rows render_rays takes (o | d | near far; models/nerf_system.py:166), remembering the tensors they were
+    concatenated from: render_rays then reads origins and directions from those instead of slicing them back out of the rows
+    (two copy launches forward; backward two zero fills, two copies, an add and two more copies to hand contiguous gradients
+    to the pose kernel).  The values are the same; the gradient then reaches `rays_o` / `rays_d` directly and `rays.grad`
+    stays empty -- `ray_gradient(rays)` returns it either way."""
+    rays = torch.cat([rays_o, rays_d, near_far], 1)
+    if JOIN_RAYS and rays_o.dtype == torch.float32 and rays_o.dim() == 2 and rays_o.shape[1] == 3 and rays_d.shape == rays_o.shape:
+        rays._upnerf_parts = (rays_o, rays_d, near_far)
+    return rays
+
+
+def retain_ray_gradient(rays):
+    """Ask for the gradient w.r.t. the rows of `rays` (call before backward; tests)."""
+    for t in (rays,) + tuple(getattr(rays, "_upnerf_parts", ())[:2]):
+        if t.requires_grad and not t.is_leaf:
+            t.retain_grad()
+
+
+def ray_gradient(rays):
+    """d loss / d rays [R][8] after a backward preceded by retain_ray_gradient, or None."""
+    parts = getattr(rays, "_upnerf_parts", None)
+    if parts is not None and (parts[0].grad is not None or parts[1].grad is not None):
+        z = lambda t, g: torch.zeros_like(t) if g is None else g
+        g = torch.cat([z(parts[0], parts[0].grad), z(parts[1], parts[1].grad), torch.zeros_like(parts[2])], 1)
+        return g if rays.grad is None else g + rays.grad
+    return rays.grad
+
+
 def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use_disp=False, perturb=0,
                 N_importance=0, test_time=False, encode_feat=True, **kwargs):
     """Drop-in for the reference's render_rays (models/rendering.py:53-66): same positional/keyword arguments,
@@ -663,8 +693,13 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
               "upnerf_uniform_keyed")
         return t
 
-    rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()  # once, not once per field pass
-    near_far = rays[:, 6:8].detach().contiguous()
+    parts = getattr(rays, "_upnerf_parts", None)
+    if parts is not None and parts[0].shape == (R, 3) and parts[0].is_contiguous() and parts[1].is_contiguous():
+        rays_o, rays_d = parts[0], parts[1]  # join_rays: the tensors `rays` was concatenated from, no slice copies
+        near_far = parts[2].detach().contiguous()
+    else:
+        rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()  # once, not once per field pass
+        near_far = rays[:, 6:8].detach().contiguous()
     z = _empty(R, N_samples, device=dev)
     u0 = draw(N_samples) if perturb > 0 else None
     check(lib.upnerf_sample_coarse(R, N_samples, ptr(near_far), ptr(_linspace01(N_samples, dev)), ptr(u0),
