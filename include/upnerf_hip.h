@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UPNERF_ABI_VERSION 8
+#define UPNERF_ABI_VERSION 9
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
@@ -514,6 +514,16 @@ typedef struct {
   int32_t dim;                   /* <= 256 */
 } upnerf_embed_group;
 int upnerf_embed_bwd_grouped(int R, int N, const int64_t* idx, const upnerf_embed_group* groups, int ngroups, void* stream);
+/* The forward side of the same tables (nn.Embedding.forward, models/nerf_system.py:79-91 called at :160, :170 and in
+ * rendering.py:177-181 / transient_net.py:31): rows[r][:] = table[idx[r]][:] for up to UPNERF_MAX_EMBED_GROUPS tables of N
+ * rows in one launch instead of an index_select launch per table.  An index outside [0, N) is UPNERF_EINVAL-free on the host
+ * (it lives in device memory): its row is written as NaN, which no test or loss survives unnoticed. */
+typedef struct {
+  const float* table;            /* [N][dim] */
+  float* rows;                   /* [R][dim] gathered rows */
+  int32_t dim;                   /* <= 256 */
+} upnerf_embed_rows_group;
+int upnerf_embed_fwd_grouped(int R, int N, const int64_t* idx, const upnerf_embed_rows_group* groups, int ngroups, void* stream);
 
 
 /* ---- generic fp32 MFMA linear layer: C[M][N] = act(A[M][K] . B[N][K]^T + bias) --------------------

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(dll, n), f"{n} declared in include/upnerf_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "ctypes binding and header disagree"
-    assert _lib.lib.upnerf_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.lib.upnerf_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_struct_sizes_match_the_c_layout():

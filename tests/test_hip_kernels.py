@@ -200,6 +200,51 @@ def test_deferred_embedding_gradients_share_one_launch_and_equal_the_immediate_o
         assert torch.equal(a, b)
 
 
+def test_one_gather_launch_serves_every_table_of_a_step(hip):
+    """ops.EMBED_PREFETCH: inside a scope the first embed_rows() gathers every registered table of the same height with ONE
+    upnerf_embed_fwd_grouped launch (<= 8 tables each); values, gradients and a second request of a table equal nn.Embedding's."""
+    ops = hip["ops"]
+    g = torch.Generator().manual_seed(11)
+    R, N = 777, 41
+    dims = [6, 2, 48, 16, 128, 200, 256, 64, 3, 5]  # ten tables: two launches
+    mods = [torch.nn.Embedding(N, d).cuda() for d in dims]
+    other = torch.nn.Embedding(N + 1, 7).cuda()  # another height: not in the group
+    idx = torch.randint(0, N, (R,), generator=g).cuda()
+    weights = [torch.randn(R, d, generator=g).cuda() for d in dims]
+    launches = []
+    real = ops.lib.upnerf_embed_fwd_grouped
+
+    def counted(*a):
+        launches.append(a[4])
+        return real(*a)
+
+    ops.lib.upnerf_embed_fwd_grouped = counted
+    try:
+        with ops.EMBED_PREFETCH.scope(mods + [other, None]):
+            rows = [ops.embed_rows(m, idx) for m in mods]
+            again = ops.embed_rows(mods[2], idx)
+            o = ops.embed_rows(other, idx)
+            loss = sum((r * w).sum() for r, w in zip(rows, weights)) + (again * weights[2]).sum() * 0.5 + o.sum()
+            loss.backward()
+        assert ops.EMBED_PREFETCH.tables is None and not ops.EMBED_PREFETCH.cache
+    finally:
+        ops.lib.upnerf_embed_fwd_grouped = real
+    assert launches == [8, 2]
+    for m, r in zip(mods, rows):
+        assert torch.equal(r, m.weight.detach()[idx])
+    assert torch.equal(again, rows[2]) and again is not rows[2]
+    assert torch.equal(o, other.weight.detach()[idx])
+    for j, (m, w) in enumerate(zip(mods, weights)):
+        ref = torch.zeros_like(m.weight).index_add_(0, idx, w * (1.5 if j == 2 else 1.0))
+        assert torch.allclose(m.weight.grad, ref, rtol=1e-5, atol=1e-5), j
+    # an index outside the table poisons its row instead of reading out of bounds
+    bad = idx.clone()
+    bad[5] = N
+    with ops.EMBED_PREFETCH.scope(mods[:2]):
+        r0 = ops.embed_rows(mods[0], bad)
+    assert torch.isnan(r0[5]).all() and not torch.isnan(r0[:5]).any()
+
+
 # ------------------------------------------------------------------------------------------ generic GEMMs
 @pytest.mark.parametrize("M,N,K,relu", [(300, 256, 384, True), (129, 384, 256, False), (64, 1, 256, False),
                                         (500, 3, 128, False), (77, 128, 384, True), (4096, 16, 128, False)])

@@ -252,13 +252,14 @@ def test_joined_rays_and_plain_rows_render_the_same_step(name, monkeypatch):
     if name not in CASES:
         pytest.skip("fixture not present")
     import upnerf_amd.nerf_system as ns
-    from upnerf_amd import zero_pool
+    from upnerf_amd import ops, zero_pool
     c = Case(name)
     outs = []
     for plain in (False, True):
         if plain:
             monkeypatch.setattr(ns, "join_rays", lambda o, d, nf: torch.cat([o, d, nf], 1))
             monkeypatch.setattr(zero_pool, "zeros", lambda n, device: torch.zeros(int(n), device=device))
+            monkeypatch.setattr(ops, "ENABLE_EMBED_PREFETCH", False)  # ... and an index_select per table
         sysm = build_system(c)
         batch = {k: v.cuda() for k, v in c.batch().items()}
         for _ in range(2):  # the second step is the one served from the pool

@@ -2,8 +2,8 @@
 # round 5, launch diet: parity of the touched pieces, then old-vs-new step rate alternating on one box, then the launch count
 out=gpurun_out/diet; mkdir -p $out
 timeout 1500 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py tests/test_graph_step.py -q -x -m gpu > $out/pytest.log 2>&1; tail -4 $out/pytest.log
-one() {  # label, lib suffix, knobs
-  UPNERF_LIB=$PWD/upnerf_amd/libupnerf_hip$2.so UPNERF_ZERO_POOL=$3 UPNERF_JOIN_RAYS=$3 timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline ${EXTRA:-} 2>/dev/null | tail -1 > $out/b_$1.json
+one() {  # label, (unused), knobs on / off
+  UPNERF_ZERO_POOL=$3 UPNERF_JOIN_RAYS=$3 UPNERF_EMBED_PREFETCH=$3 timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline ${EXTRA:-} 2>/dev/null | tail -1 > $out/b_$1.json
   python - $out/b_$1.json $1 <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); print(sys.argv[2], round(d['value']), 'rays/s', round(d['ms_per_step'],3), 'ms', d.get('launches_per_step'))

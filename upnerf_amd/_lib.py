@@ -135,6 +135,10 @@ class EmbedGroup(C.Structure):
     _fields_ = [("g", _fp), ("out", _fp), ("dim", C.c_int32)]
 
 
+class EmbedRowsGroup(C.Structure):
+    _fields_ = [("table", _fp), ("rows", _fp), ("dim", C.c_int32)]
+
+
 MAX_EMBED_GROUPS = 8
 
 
@@ -195,6 +199,7 @@ _SIGNATURES = {
     "upnerf_gather_rays": [C.POINTER(GatherRaysArgs), _p],
     "upnerf_embed_bwd": [_i, _i, _i, _p, _p, _p, _p],
     "upnerf_embed_bwd_grouped": [_i, _i, _p, C.POINTER(EmbedGroup), _i, _p],
+    "upnerf_embed_fwd_grouped": [_i, _i, _p, C.POINTER(EmbedRowsGroup), _i, _p],
     "upnerf_linear": [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p],
     "upnerf_loss_fwd": [C.POINTER(LossArgs), _p, _p, _p, _p],
     "upnerf_loss_bwd": [C.POINTER(LossArgs), _p, C.POINTER(LossGrads), _p],
@@ -224,7 +229,7 @@ def _load():
 
 
 lib = _load()
-ABI_VERSION = 8
+ABI_VERSION = 9
 if lib.upnerf_abi_version() != ABI_VERSION:
     raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
 

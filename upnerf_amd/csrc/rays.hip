@@ -666,6 +666,48 @@ extern "C" int upnerf_embed_bwd_grouped(int R, int N, const int64_t* idx, const 
   return (int)hipGetLastError();
 }
 
+// Forward gathers of the per-image tables: one wave per ray copies its row of every table.
+struct EmbedRowGroups {
+  const float* table[UPNERF_MAX_EMBED_GROUPS];
+  float* rows[UPNERF_MAX_EMBED_GROUPS];
+  int dim[UPNERF_MAX_EMBED_GROUPS];
+  int n;
+};
+__global__ __launch_bounds__(NTHREADS) void embed_fwd_grouped_kernel(int R, int N, const long long* __restrict__ idx, EmbedRowGroups T) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (NTHREADS >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const long long i = idx[r];
+  const bool ok = i >= 0 && i < N;
+#pragma unroll
+  for (int t = 0; t < UPNERF_MAX_EMBED_GROUPS; ++t) {
+    if (t < T.n) {
+      const int dim = T.dim[t];
+      const float* __restrict__ src = T.table[t] + (size_t)(ok ? i : 0) * dim;
+      float* __restrict__ dst = T.rows[t] + (size_t)r * dim;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lane + 64 * q < dim) dst[lane + 64 * q] = ok ? src[lane + 64 * q] : __builtin_nanf("");
+    }
+  }
+}
+extern "C" int upnerf_embed_fwd_grouped(int R, int N, const int64_t* idx, const upnerf_embed_rows_group* groups, int ngroups,
+                                        void* stream) {
+  if (R <= 0 || N <= 0 || !idx || !groups || ngroups <= 0 || ngroups > UPNERF_MAX_EMBED_GROUPS) return UPNERF_EINVAL;
+  EmbedRowGroups T;
+  T.n = ngroups;
+  for (int j = 0; j < UPNERF_MAX_EMBED_GROUPS; ++j) {
+    const bool live = j < ngroups;
+    if (live && (!groups[j].table || !groups[j].rows || groups[j].dim <= 0 || groups[j].dim > 256)) return UPNERF_EINVAL;
+    T.table[j] = live ? groups[j].table : nullptr;
+    T.rows[j] = live ? groups[j].rows : nullptr;
+    T.dim[j] = live ? groups[j].dim : 0;
+  }
+  hipLaunchKernelGGL(embed_fwd_grouped_kernel, dim3((R + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, N,
+                     (const long long*)idx, T);
+  return (int)hipGetLastError();
+}
+
 extern "C" int upnerf_gather_rays(const upnerf_gather_rays_args* a, void* stream) {
   if (!a || a->R <= 0 || !a->idx || !a->all_ray_infos || !a->all_directions || !a->all_rgbs || !a->poses || !a->ray_infos ||
       !a->directions || !a->img_idx || !a->c2w || !a->rgbs)

@@ -39,10 +39,13 @@ class _LossFn(torch.autograd.Function):
         check(lib.upnerf_loss_fwd(C.byref(a), ptr(depth), ptr(terms), ptr(scratch), stream()), "upnerf_loss_fwd")
         ctx.args, ctx.keep = a, t  # `t` keeps the device buffers referenced by `a` alive
         ctx.mark_non_differentiable(depth)
+        ctx.set_materialize_grads(False)  # (no zero tensor -- a fill launch -- for the output nothing differentiates)
         return terms, depth
 
     @staticmethod
     def backward(ctx, g_terms, _g_depth):
+        if g_terms is None:
+            return (None,) * 16
         a, t = ctx.args, ctx.keep
         (dd, inv, rows, sdc, sdf, twc, twf, fc, ff, fg, rc, rf, rg, beta, alpha) = t
         need = ctx.needs_input_grad[1:]
@@ -84,7 +87,7 @@ class _SumSelected(torch.autograd.Function):
     @staticmethod
     def forward(ctx, terms, mask):
         ctx.save_for_backward(mask)
-        return torch.where(mask, terms, 0.0).sum()
+        return torch.where(mask, terms, _const(0.0, terms.device)).sum()  # (a Python 0.0 is a scalar_tensor fill per call)
 
     @staticmethod
     def backward(ctx, g):
@@ -93,6 +96,18 @@ class _SumSelected(torch.autograd.Function):
 
 
 _MASKS = {}
+_CONSTS = {}
+
+
+def _const(value: float, device):
+    """A cached 0-dim fp32 constant on `device` (allocated once, outside any graph capture after the first eager step)."""
+    key = (float(value), torch.device(device))
+    if key not in _CONSTS:
+        t = torch.full((), float(value), device=device, dtype=torch.float32)
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            return t  # memory of the capturing graph's pool: not to be kept beyond it
+        _CONSTS[key] = t
+    return _CONSTS[key]
 
 
 def _term_mask(m, fine, device):

@@ -19,9 +19,9 @@ from torch import nn
 
 from . import step_scalars, zero_pool
 from .camera import refine_and_get_rays
-from .losses import UPNeRFLoss
+from .losses import UPNeRFLoss, _const
 from .nerf import NeRF, fp32_round
-from .ops import embed_rows, reset_deferred
+from .ops import EMBED_PREFETCH, embed_rows, reset_deferred
 from .optim import get_learning_rate, get_optimizer, get_scheduler
 from .parallel import GradSync
 from .rendering import join_rays, render_rays
@@ -61,8 +61,8 @@ except Exception:
             self._ensure_optim()
             return self._scheds if len(self._scheds) > 1 else self._scheds[0]
 
-        def manual_backward(self, loss):
-            loss.backward()
+        def manual_backward(self, loss, *args, **kwargs):
+            loss.backward(*args, **kwargs)
 
 
 class _LazyResults(dict):
@@ -332,7 +332,8 @@ class NeRFSystem(_Base):
     # (and put the gradient all-reduce between them) and replay them with the host bookkeeping done beside the replays
     def _step_backward(self, batch, u_list=None):
         """Forward, loss and backward; gradients are left in the parameters' .grad."""
-        with zero_pool.step(batch["img_idx"].device):  # the step's zeroed buffers: slices of one arena, one fill launch
+        # the step's zeroed buffers are slices of one arena (one fill launch), its per-image table rows come from one gather launch
+        with zero_pool.step(batch["img_idx"].device), EMBED_PREFETCH.scope(self._per_image_tables()):
             loss, loss_d, _ = self.compute_loss(batch, u_list=u_list)
             for o in self._opts_scheds()[0]:
                 o.zero_grad()
@@ -341,8 +342,14 @@ class NeRFSystem(_Base):
                 # capture the collective stays between the two graphs of a step, graph_step.py.)
                 sm = self.get_schedule_mult(self._host_progress)
                 self.grad_sync.begin(0 if sm == 0 else (2 if sm == 1 else 1))
-            self.manual_backward(loss)
+            self.manual_backward(loss, gradient=_const(1.0, loss.device))  # (the default seed is a ones_like fill launch)
         return loss, loss_d
+
+    def _per_image_tables(self):
+        """nn.Embedding modules a training step gathers with batch["img_idx"] (models/nerf_system.py:79-91)."""
+        t = [getattr(self, "se3_refine", None), getattr(self, "depth_scale", None)] + list(self.embeddings.values())
+        tn = getattr(self, "transient_net", None)
+        return t + [getattr(tn, "embedding_t", None)]
 
     def _step_update(self):
         """Both optimiser updates (device work only for FlatAdam; returns what _step_host needs to advance its counters)."""

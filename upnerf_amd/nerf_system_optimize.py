@@ -18,8 +18,9 @@ from torch import nn
 
 from . import zero_pool
 from .camera import refine_and_get_rays
+from .losses import _const
 from .nerf_system import NeRFSystem
-from .ops import embed_rows
+from .ops import EMBED_PREFETCH, embed_rows
 from .optim import get_optimizer
 from .rendering import join_rays, render_rays
 
@@ -91,11 +92,11 @@ class NeRFSystemOptimize(NeRFSystem):
 
     # the three pieces of a step (NeRFSystem.training_step composes them; graph_step.GraphedTrainingStep captures the first two)
     def _step_backward(self, batch, u_list=None):
-        with zero_pool.step(batch["img_idx"].device):
+        with zero_pool.step(batch["img_idx"].device), EMBED_PREFETCH.scope(self._per_image_tables()):
             loss, loss_d, _ = self.compute_loss(batch, u_list=u_list)
             for o in self._opts_scheds()[0]:
                 o.zero_grad()
-            self.manual_backward(loss)
+            self.manual_backward(loss, gradient=_const(1.0, loss.device))
         return loss, loss_d
 
     def _step_host(self, loss, loss_d, done):

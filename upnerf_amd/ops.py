@@ -4,7 +4,9 @@ PyTorch is used here for device memory, streams and autograd bookkeeping only; t
 libupnerf_hip.so.  Nothing in this file falls back to ATen matmuls."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -457,6 +459,67 @@ class _DeferredEmbeds:
 DEFERRED_EMBEDS = _DeferredEmbeds()
 
 
+class _EmbedPrefetch:
+    """Forward gathers of a training step's per-image tables in ONE launch (upnerf_embed_fwd_grouped) instead of an
+    index_select launch per table: inside `with EMBED_PREFETCH.scope(modules):` the first embed_rows() of a registered table
+    gathers the rows of every registered table of the same height for that index tensor; the later calls with the same index
+    tensor are handed their slice.  The tables do not change inside the scope (the optimisers run after it).  Outside a
+    scope, and for any table or index the scope does not know, embed_rows gathers on its own as before."""
+
+    def __init__(self):
+        self.tables, self.cache = None, {}
+
+    @contextlib.contextmanager
+    def scope(self, modules):
+        if self.tables is not None or not ENABLE_EMBED_PREFETCH:  # (nested: the outer scope keeps the cache)
+            yield
+            return
+        self.tables = [m.weight for m in modules if m is not None and getattr(m, "weight", None) is not None]
+        self.cache = {}
+        try:
+            yield
+        finally:
+            self.tables, self.cache = None, {}
+
+    def rows(self, table, idx):
+        if self.tables is None:
+            return None
+        key = (idx.data_ptr(), idx.numel())
+        hit = self.cache.get(key)
+        if hit is None:
+            ok = lambda w: (w.is_cuda and w.device == idx.device and w.dtype == torch.float32 and w.dim() == 2
+                            and w.shape[1] <= 256 and w.shape[0] == table.shape[0] and w.is_contiguous())
+            live, seen = [], set()
+            for w in self.tables:
+                if ok(w) and w.data_ptr() not in seen:
+                    seen.add(w.data_ptr())
+                    live.append(w)
+            if table.data_ptr() not in seen:
+                return None
+            R = idx.numel()
+            arena = torch.empty(R * sum(w.shape[1] for w in live), device=idx.device, dtype=torch.float32)
+            hit, off = {"_keep": (idx, arena)}, 0  # (idx kept alive: its address is the cache key)
+            for w in live:
+                hit[w.data_ptr()] = (off, w.shape[1])
+                off += R * w.shape[1]
+            for lo in range(0, len(live), _lib.MAX_EMBED_GROUPS):
+                part = live[lo:lo + _lib.MAX_EMBED_GROUPS]
+                arr = (_lib.EmbedRowsGroup * len(part))(*[_lib.EmbedRowsGroup(table=w.data_ptr(), rows=arena.data_ptr() + 4 * hit[w.data_ptr()][0],
+                                                                              dim=w.shape[1]) for w in part])
+                check(lib.upnerf_embed_fwd_grouped(R, table.shape[0], ptr(idx), arr, len(part), stream()),
+                      "upnerf_embed_fwd_grouped")
+            self.cache[key] = hit
+        at = hit.get(table.data_ptr())
+        if at is None:
+            return None
+        # a fresh view per request: autograd attaches the calling node to the tensor object a forward returns
+        return hit["_keep"][1][at[0]:at[0] + idx.numel() * at[1]].view(idx.numel(), at[1])
+
+
+ENABLE_EMBED_PREFETCH = os.environ.get("UPNERF_EMBED_PREFETCH", "1") != "0"  # (0: one gather launch per table, for A/B runs)
+EMBED_PREFETCH = _EmbedPrefetch()
+
+
 class _EmbedRows(torch.autograd.Function):
     """table[idx] whose backward is one HIP kernel (dense, deterministic) instead of ATen's sort-based embedding
     backward (14 small launches per table and step)."""
@@ -467,7 +530,8 @@ class _EmbedRows(torch.autograd.Function):
         ctx.shape, ctx.defer = tuple(table.shape), defer
         ctx.owner = table if defer else None
         ctx.tokens = _defer_token(table) if defer else None
-        return table.detach().index_select(0, idx)
+        rows = EMBED_PREFETCH.rows(table, idx)
+        return rows if rows is not None else table.detach().index_select(0, idx)
 
     @staticmethod
     def backward(ctx, g):

@@ -36,6 +36,7 @@ class _TransientFn(torch.autograd.Function):
                                **{n: ptr(q) for n, q in zip(_TransientFn.NAMES, p)})
         check(lib.upnerf_transient_fwd(C.byref(a), stream()), "upnerf_transient_fwd")
         ctx.args, ctx.keep = a, (feat, t_emb, p, h, ee, t, alpha, rgb, beta, spre)
+        ctx.set_materialize_grads(False)  # the training loss reads alpha and beta only: no zero-filled d_rgb (a fill launch)
         return alpha, rgb, beta
 
     @staticmethod
