@@ -226,6 +226,9 @@ typedef struct {
   const int32_t* eexp;
   const uint16_t* g2_16;         /* with e16 (modes 0, 1): g2 the same way, 128 wide = 8 k-blocks per 32 samples (then `g2` is ignored) */
   const int32_t* g2exp;
+  /* encode_feat = False (models/rendering.py:177-190): the shared colour composited with the JOINT-transmittance weights,
+   * sum_i w_sj rgb_i -- the shared half of `c_rgb`.  NULL = not wanted; modes 0, 1 with has_rgb only.  (ABI 9) */
+  float* rgb_joint_map;          /* [R][3] */
 } upnerf_composite_fwd_args;
 
 int upnerf_composite_fwd(const upnerf_composite_fwd_args* a, void* stream);
@@ -254,6 +257,7 @@ typedef struct {
   const int32_t* eexp;
   const uint16_t* g2_16;
   const int32_t* g2exp;
+  const float* g_rgb_joint_map;  /* [R][3] upstream gradient of upnerf_composite_fwd_args.rgb_joint_map, or NULL (ABI 9) */
 } upnerf_composite_bwd_args;
 
 int upnerf_composite_bwd(const upnerf_composite_bwd_args* a, void* stream);

@@ -147,8 +147,6 @@ def _lin(p: Params, name: str, x: Tensor) -> Tensor:
 def nerf_field(p: Params, cfg: NerfCfg, xyz: Tensor, view_dir: Tensor, a: Optional[Tensor],
                c: Optional[Tensor], sched_mult: float, progress: float) -> Dict[str, Tensor]:
     """Per-sample field evaluation; returns s_sigma[M,1], s_feat, (c_sigma, c_feat), (s_rgb)."""
-    if not cfg.encode_feat:
-        raise NotImplementedError("oracle restates the feature-encoding configuration only")
     x0 = posenc(xyz, cfg.xyz_L, progress, cfg.c2f)
     h = x0
     for i in range(cfg.D):  # nerf.py:84-87
@@ -157,6 +155,18 @@ def nerf_field(p: Params, cfg: NerfCfg, xyz: Tensor, view_dir: Tensor, a: Option
         h = torch.relu(_lin(p, f"xyz_encoding_{i + 1}.0", h))
     out = {"s_sigma": F.softplus(_lin(p, "share_sigma.0", h))}  # nerf.py:89
     e = _lin(p, "xyz_encoding_final", h)  # nerf.py:93
+    if not cfg.encode_feat:  # nerf.py:110-123: colour head on e in every phase, candidate head whenever sched_mult < 1
+        parts = [e, posenc(view_dir, cfg.dir_L, progress, cfg.c2f)]
+        if cfg.encode_appearance:
+            parts.append(a)
+        r = torch.relu(_lin(p, "rgb_share_layer.0", torch.cat(parts, 1)))
+        out["s_rgb"] = torch.sigmoid(_lin(p, "rgb_share_layer.2", r))
+        if sched_mult < 1:
+            g = torch.relu(_lin(p, "candidate_encoding.0", torch.cat([e, c], 1)))
+            g = torch.relu(_lin(p, "candidate_encoding.2", g))
+            out["c_sigma"] = F.softplus(_lin(p, "candidate_sigma.0", g))
+            out["c_rgb"] = _lin(p, "rgb_candidate_layer", g)
+        return out
     out["s_feat"] = _lin(p, "feat_share_layer", e)  # nerf.py:95
     if sched_mult < 1 and cfg.encode_candidate:  # nerf.py:96-100
         g = torch.relu(_lin(p, "candidate_encoding.0", torch.cat([e, c], 1)))
@@ -182,12 +192,14 @@ def _excl_cumprod(one_minus_alpha: Tensor) -> Tensor:
 
 
 def composite(res: Dict[str, Tensor], typ: str, f: Dict[str, Tensor], z: Tensor, sched_mult: float,
-              encode_candidate: bool) -> None:
+              encode_candidate: bool, encode_feat: bool = True) -> None:
     """Fills res[...] in place with the keys of SURVEY 8a 'outputs by phase'."""
     delta = torch.cat([z[:, 1:] - z[:, :-1], 1e2 * torch.ones_like(z[:, :1])], -1)
     a_s = 1 - torch.exp(-delta * f["s_sigma"])
     if sched_mult < 1:
         if not encode_candidate:  # rendering.py:134-150
+            if not encode_feat:
+                raise NotImplementedError("rendering.py:149-150 (`raise NotImplemented`): no candidate-free path without features")
             w = a_s * _excl_cumprod(1 - a_s)
             res[f"s_weights_{typ}"] = w
             res[f"feat_{typ}"] = (w[..., None] * f["s_feat"]).sum(1)
@@ -198,7 +210,10 @@ def composite(res: Dict[str, Tensor], typ: str, f: Dict[str, Tensor], z: Tensor,
             s_w, c_w, w = a_s * T, a_c * T, a_all * T
             res[f"c_weights_{typ}"] = w
             res[f"c_depth_{typ}"] = (w * z).sum(1)
-            res[f"feat_{typ}"] = (s_w[..., None] * f["s_feat"]).sum(1) + (c_w[..., None] * f["c_feat"]).sum(1)
+            if encode_feat:
+                res[f"feat_{typ}"] = (s_w[..., None] * f["s_feat"]).sum(1) + (c_w[..., None] * f["c_feat"]).sum(1)
+            else:  # rendering.py:177-189
+                res[f"c_rgb_{typ}"] = (s_w[..., None] * f["s_rgb"]).sum(1) + (c_w[..., None] * f["c_rgb"]).sum(1)
             res[f"t_weight_{typ}"] = c_w.sum(1)
     w_s = a_s * _excl_cumprod(1 - a_s)
     if sched_mult > 0:  # rendering.py:195-209
@@ -296,7 +311,7 @@ def render_rays(models: Dict[str, Params], cfgs: Dict[str, NerfCfg], embeddings:
             c = embeddings[f"{cfg.typ}_c"][img_idx][:, None, :].expand(R, S, -1).reshape(R * S, -1)
         f = nerf_field(p, cfg, xyz, vdir, a, c, sched_mult, progress)
         f = {k: (v.reshape(R, S) if "sigma" in k else v.reshape(R, S, -1)) for k, v in f.items()}
-        composite(res, cfg.typ, f, zz, sched_mult, cfg.encode_candidate)
+        composite(res, cfg.typ, f, zz, sched_mult, cfg.encode_candidate, cfg.encode_feat)
 
     run("nerf_coarse", z)
     if keep is not None:
@@ -375,7 +390,7 @@ def blend_transient(res: Dict[str, Tensor], t: Dict[str, Tensor], fine: bool) ->
 
 # a17: UPNeRFLoss  (losses.py:21-64)
 def upnerf_loss(res: Dict[str, Tensor], rgb: Tensor, feat: Tensor, depth: Tensor, m: float,
-                depth_mult: float = 1e-3, alpha_reg: float = 1.0, fine: bool = True) -> Dict[str, Tensor]:
+                depth_mult: float = 1e-3, alpha_reg: float = 1.0, fine: bool = True, encode_feat: bool = True) -> Dict[str, Tensor]:
     out = {}
     for typ, tag in (("coarse", "c"), ("fine", "f")):
         if typ == "fine" and not fine:
@@ -385,7 +400,10 @@ def upnerf_loss(res: Dict[str, Tensor], rgb: Tensor, feat: Tensor, depth: Tensor
             if f"t_weight_{typ}" in res:
                 l = l * (1 - res[f"t_weight_{typ}"].detach())
             out[f"l_depth_{tag}"] = l.mean() * depth_mult * (1 - m)
-            out[f"l_feat_{tag}"] = ((res[f"feat_{typ}"] - feat) ** 2).mean() * (1 - m)
+            if encode_feat:
+                out[f"l_feat_{tag}"] = ((res[f"feat_{typ}"] - feat) ** 2).mean() * (1 - m)
+            else:  # losses.py:33-35, 54-56
+                out[f"l_c_rgb_{tag}"] = ((res[f"c_rgb_{typ}"] - rgb) ** 2).mean() * (1 - m)
         if m > 0:
             sq = (res[f"s_rgb_{typ}"] - rgb) ** 2
             if typ == "coarse":
@@ -429,7 +447,7 @@ def training_forward(state: Dict[str, Params], cfgs: Dict[str, NerfCfg], batch: 
         t = transient_net(state["transient_net"], batch["feats"], idx, hp.get("t_net.beta_min", 0.1))
         blend_transient(res, t, fine)
     losses = upnerf_loss(res, batch["rgbs"], batch["feats"], depth, m, hp.get("loss.depth_mult", 1e-3),
-                         hp.get("loss.alpha_reg", 1.0), fine)
+                         hp.get("loss.alpha_reg", 1.0), fine, encode_feat=cfgs["nerf_coarse"].encode_feat)
     return losses, res
 
 

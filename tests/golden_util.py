@@ -18,6 +18,8 @@ CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f no
 
 
 class Case:
+    encode_feat = True  # (subclasses that do not load a fixture: the feature-head configuration)
+
     def __init__(self, name):
         self.name = name
         self.g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
@@ -33,6 +35,7 @@ class Case:
         c2f = self.g["cfg_c2f"]
         self.c2f = None if c2f[0] < 0 else (float(c2f[0]), float(c2f[1]))
         self.encode_candidate = None if "cfg_encode_candidate" not in self.g else bool(c("encode_candidate"))
+        self.encode_feat = bool(c("encode_feat", 1))  # False: nerf.feat_dim = 0 (nerf_system.py:373-374)
         self.sched = float(self.g["meta_sched"])
         if self.sched in (0.0, 1.0):
             self.sched = int(self.sched)
@@ -42,14 +45,16 @@ class Case:
         self.z_fine = torch.from_numpy(self.g["z_fine"]) if "z_fine" in self.g else None
 
     def nerf_kw(self):
-        return dict(D=self.D, W=self.W, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+        return dict(D=self.D, W=self.W, feat_dim=384 if self.encode_feat else 0, xyz_L=10, dir_L=4, appearance_dim=48,
+                    candidate_dim=16)
 
     def state(self, requires_grad=True, dtype=torch.float32):
         """{"nerf_coarse": params, ..., "embedding_*": weight, "se3_refine": weight, "depth_scale": weight}."""
         st = {}
         for typ in ("coarse", "fine") if self.fine else ("coarse",):
             sd = synth.nerf_state(typ, seed=self.seed, progress=self.progress, sigma_bias=self.sigma_bias,
-                                  sigma_gain=self.sigma_gain, trunk_gain=self.trunk_gain, **self.nerf_kw())
+                                  sigma_gain=self.sigma_gain, trunk_gain=self.trunk_gain, encode_feat=self.encode_feat,
+                                  **self.nerf_kw())
             sd.pop("progress")
             st[f"nerf_{typ}"] = {k: v.to(dtype).requires_grad_(requires_grad) for k, v in sd.items()}
         st["transient_net"] = {k: v.to(dtype).requires_grad_(requires_grad)

@@ -40,10 +40,10 @@ def test_step_scalars_slots_and_values():
     assert t.values() == [1.0, 2.0, 3.0, 7.0, 8.0, 9.0]
 
 
-def _system(perturb, steps):
+def _system(perturb, steps, feat_dim=384):
     from upnerf_amd.nerf_system import NeRFSystem, SyntheticDataset, default_hparams
     hp = default_hparams(**{"nerf.N_samples": 32, "nerf.N_importance": 32, "train.batch_size": 192, "max_steps": steps,
-                            "nerf.perturb": perturb})
+                            "nerf.perturb": perturb, "nerf.feat_dim": feat_dim})
     torch.manual_seed(0)
     s = NeRFSystem(hp, SyntheticDataset(7))
     s.setup()
@@ -62,15 +62,16 @@ def _state(s):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("perturb", [0.0, 1.0])
-def test_replayed_steps_are_bitwise_the_eager_steps(perturb):
+@pytest.mark.parametrize("perturb,feat_dim", [(0.0, 384), (1.0, 384), (1.0, 0)])
+def test_replayed_steps_are_bitwise_the_eager_steps(perturb, feat_dim):
+    """(feat_dim = 0: the reference's configuration without DINO features -- encode_feat = False, c_rgb maps.)"""
     from upnerf_amd import synth
     from upnerf_amd.graph_step import GraphedTrainingStep
     STEPS = 120  # progress advances by 1/120 per iteration: phase 0 until 0.1, then n_s = 0, 0, 1, 1, 1, 2, ... (repeats)
     batches = [{k: v.cuda() for k, v in synth.batch(192, 7, seed=40 + i).items()} for i in range(3)]
     runs = {}
     for mode in ("eager", "graph"):
-        s = _system(perturb, STEPS)
+        s = _system(perturb, STEPS, feat_dim)
         s.global_step = 12  # progress 0.05: eight iterations of phase 0, then the candidate schedule starts
         s.set_progress(s.global_step / (2 * STEPS))
         step = GraphedTrainingStep(s) if mode == "graph" else s.training_step

@@ -1212,14 +1212,16 @@ def test_frag16_layout_and_exponents(hip):
         assert 2 ** 13 <= mx * 2.0 ** int(wexp[eid]) < 2 ** 14
 
 
-@pytest.mark.parametrize("W,D,cand", [(256, 8, 16), (64, 4, 16), (256, 8, 0)])
-def test_hip_pack_matches_torch_pack_forward_and_backward(hip, W, D, cand):
-    """NerfPacker.pack_hip (upnerf_pack + upnerf_linear, hand-written backward) against the torch restatement pack()."""
+@pytest.mark.parametrize("W,D,cand,feat", [(256, 8, 16, True), (64, 4, 16, True), (256, 8, 0, True), (256, 8, 16, False),
+                                           (64, 4, 16, False)])
+def test_hip_pack_matches_torch_pack_forward_and_backward(hip, W, D, cand, feat):
+    """NerfPacker.pack_hip (upnerf_pack + upnerf_linear, hand-written backward) against the torch restatement pack();
+    feat = False: the module without feature layers (encode_feat = False: one pack launch, nothing to fold)."""
     from upnerf_amd import synth
     from upnerf_amd.nerf import NeRF
-    kw = dict(D=D, W=W, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=cand)
-    m = NeRF("coarse", c2f=None, **kw)
-    m.load_state_dict(synth.nerf_state("coarse", seed=4, **kw))
+    kw = dict(D=D, W=W, feat_dim=384 if feat else 0, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=cand)
+    m = NeRF("coarse", c2f=None, encode_feat=feat, **kw)
+    m.load_state_dict(synth.nerf_state("coarse", seed=4, encode_feat=feat, **kw))
     pk = m.packer
     ref_p = {n: t.detach().clone().requires_grad_(True) for n, t in m.named_parameters()}
     P_ref = pk.pack(ref_p)
@@ -1233,8 +1235,8 @@ def test_hip_pack_matches_torch_pack_forward_and_backward(hip, W, D, cand):
     (P * up.cuda()).sum().backward()
     for n in pk.pack_names():
         assert rel_err(cpu(gp[n].grad), ref_p[n].grad) < 2e-6, n
-    if cand:  # not part of P: feat_candidate_layer (projected per ray by the caller)
-        assert gp["feat_candidate_layer.weight"].grad is None
+    if cand:  # not part of P: feat_candidate_layer / rgb_candidate_layer (projected per ray by the caller)
+        assert gp["feat_candidate_layer.weight" if feat else "rgb_candidate_layer.weight"].grad is None
 
 
 # ------------------------------------------------------------------------------------------ parameter re-layout

@@ -49,7 +49,10 @@ KNOWN_FLIPPED = frozenset({"cfg1_small_fine", "cfg2_det_phase1", "cfg2_phase0", 
                            "cfg2_trained_p08", "small_nocand",  # round 3, both field tilings
                            # round 4's cases at the reference's 128 + 128 samples: new here, and held to the strict gate at the
                            # reference's own depths by test_training_step_matches_reference_golden_at_the_reference_depths
-                           "yaml_phase0", "yaml_phase1"})
+                           "yaml_phase0", "yaml_phase1",
+                           # round 5's cases without the feature head (encode_feat = False): new here, strict at the reference's
+                           # own depths by the same test
+                           "nofeat_phase0", "nofeat_phase2", "nofeat_w256_phase1"})
 _FLIPPED_SEEN = {}
 
 
@@ -97,7 +100,8 @@ def build_system(c):
     from upnerf_amd.nerf_system import NeRFSystem, SyntheticDataset, default_hparams
     hp = default_hparams(**{"nerf.N_samples": c.Nc, "nerf.N_importance": c.Nf, "nerf.use_disp": c.use_disp,
                             "nerf.perturb": c.perturb, "pose.optimize": c.pose_opt, "pose.c2f": c.c2f,
-                            "nerf.D": c.D, "nerf.W": c.W, "max_steps": 1000})
+                            "nerf.D": c.D, "nerf.W": c.W, "max_steps": 1000,
+                            "nerf.feat_dim": 384 if getattr(c, "encode_feat", True) else 0})
     sysm = NeRFSystem(hp, SyntheticDataset(c.n_img))
     sysm.setup()
     st = c.state(requires_grad=False)
@@ -123,7 +127,7 @@ def build_system(c):
     return sysm
 
 
-@pytest.mark.parametrize("name", ["cfg2_phase0", "cfg2_phase1", "cfg2_phase2", "cfg2_det_phase1"])
+@pytest.mark.parametrize("name", ["cfg2_phase0", "cfg2_phase1", "cfg2_phase2", "cfg2_det_phase1", "nofeat_w256_phase1"])
 def test_f16_mode_matches_reference_golden_at_its_stated_gate(name):
     """BASELINE.json configs[3] arithmetic (FIELD_MODE "f16": fp16 MLP weights / activations on MFMA, fp32 accumulate) on the
     config-#2-shaped goldens, all three schedule phases.  Stated gates (SURVEY 8d "Config 4": ~1e-2 on maps), max-normalised:

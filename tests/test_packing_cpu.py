@@ -101,3 +101,26 @@ def test_state_dict_keys_and_shapes_match_the_reference_modules():
         m = TransientNet(**item["kwargs"]) if tag.startswith("transient") else NeRF("coarse", c2f=(0.1, 0.5), **item["kwargs"])
         mine = {k: list(v.shape) for k, v in m.state_dict().items()}
         assert mine == item["state"], (tag, set(mine) ^ set(item["state"]))
+
+
+def test_pack_without_the_feature_layer_places_the_colour_matrix_as_it_stands():
+    """encode_feat = False (nerf.py:52-56): rgb_share_layer.0 reads [xyz_encoding_final | PE(dir) | appearance] itself, so the
+    layout's "folded" colour matrix is W_r1[:, :W] and its side columns W_r1[:, W:], unchanged; its bias is b_r1."""
+    import torch
+    from upnerf_amd._lib import AUXK
+    from upnerf_amd.nerf import NeRF
+    m = NeRF("coarse", D=4, W=64, encode_feat=False, feat_dim=0, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    p = dict(m.named_parameters())
+    assert "feat_share_layer.weight" not in p and "rgb_candidate_layer.weight" in p
+    assert "feat_share_layer.weight" not in m.packer.pack_names()
+    P = m.packer.pack(p).detach()
+    L, W, W2 = m.packer.L, 64, 32
+    wr1 = P[L.wr1:L.wr1 + W2 * (W + AUXK)].view(W2, W + AUXK)
+    w = p["rgb_share_layer.0.weight"].detach()
+    assert w.shape == (W2, W + 27 + 48)
+    assert torch.equal(wr1[:, :W + 75], w) and float(wr1[:, W + 75:].abs().max()) == 0.0
+    assert torch.equal(P[L.br1:L.br1 + W2], p["rgb_share_layer.0.bias"].detach())
+    # gradients flow straight back
+    (m.packer.pack(p) * torch.arange(L.total, dtype=torch.float32)).sum().backward()
+    g = p["rgb_share_layer.0.weight"].grad
+    assert torch.equal(g[3, :5], torch.arange(L.wr1 + 3 * (W + AUXK), L.wr1 + 3 * (W + AUXK) + 5, dtype=torch.float32))

@@ -87,6 +87,8 @@ def schedule_mult(progress, sched):  # nerf_system.py:452-461 (cannot import: ne
 def build(case):
     n_img = case["n_img"]
     kw = dict(D=case["D"], W=case["W"], feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16)
+    if case.get("encode_feat") is False:  # nerf_system.py:373-374: encode_feat = feat_dim > 0, feat_dim = 0
+        kw.update(encode_feat=False, feat_dim=0)
     models, sds = {}, {}
     for typ in ("coarse", "fine") if case["Nf"] > 0 else ("coarse",):
         m = ref_nerf.NeRF(typ, c2f=case["c2f"], **kw)
@@ -129,7 +131,7 @@ def run_case(name, case):
         res = ref_rendering.render_rays(models=models, embeddings=embeddings, rays=rays, img_idx=idx, sched_mult=m,
                                         sched_phase=0, N_samples=case["Nc"], use_disp=case.get("use_disp", False),
                                         perturb=case["perturb"], N_importance=case["Nf"], white_back=False,
-                                        encode_feat=True, validation=False)
+                                        encode_feat=case.get("encode_feat", True), validation=False)
     # NeRFSystem.forward transient blend (nerf_system.py:128-146)
     if m > 0:
         t = tn(b["feats"], idx)
@@ -137,7 +139,7 @@ def run_case(name, case):
         if fine:
             res["rgb_fine"] = res["s_rgb_fine"] * (1 - t["alpha"]) + t["rgb"] * t["alpha"]
         res["t_beta"], res["t_alpha"] = t["beta"], t["alpha"]
-    loss_fn = ref_losses.UPNeRFLoss(depth_mult=1e-3, alpha_reg=1.0, encode_feat=True, fine=fine)
+    loss_fn = ref_losses.UPNeRFLoss(depth_mult=1e-3, alpha_reg=1.0, encode_feat=case.get("encode_feat", True), fine=fine)
     loss_d = loss_fn(res, b["rgbs"], b["feats"], depth, m)
     loss = sum(l for l in loss_d.values())
     if rays.requires_grad:
@@ -228,6 +230,14 @@ CASES = {
     # non-candidate branch with sched<1 (rendering.py:134-150)
     "small_nocand": dict(BASE, R=9, D=4, W=64, Nc=32, Nf=32, c2f=(0.1, 0.5), progress=0.3, sched=0.5, perturb=1.0,
                          pose_opt=True, encode_candidate=False),
+    # encode_feat = False (nerf.feat_dim = 0: colour head on xyz_encoding_final, rgb_candidate_layer, c_rgb maps and the l_c_rgb
+    # terms -- nerf.py:52-56, 75-78, 110-123; rendering.py:177-190; losses.py:33-35, 54-56), the three schedule phases; the
+    # 256-wide one runs the f16x3 / f16 kernels
+    "nofeat_phase0": dict(BASE, R=8, D=4, W=64, Nc=32, Nf=32, c2f=(0.1, 0.5), progress=0.05, perturb=1.0, pose_opt=True, encode_feat=False),
+    "nofeat_phase1": dict(BASE, R=8, D=4, W=64, Nc=32, Nf=32, c2f=(0.1, 0.5), progress=0.3, perturb=1.0, pose_opt=True, encode_feat=False),
+    "nofeat_phase2": dict(BASE, R=8, D=4, W=64, Nc=32, Nf=32, c2f=(0.1, 0.5), progress=0.8, perturb=1.0, pose_opt=True, encode_feat=False),
+    "nofeat_w256_phase1": dict(BASE, R=5, D=8, W=256, Nc=64, Nf=128, c2f=(0.1, 0.5), progress=0.3, perturb=1.0, pose_opt=True,
+                               encode_feat=False),
     # all PE bands masked (progress < c2f start), zero se3 is covered by test_pose (separate fixture)
     "small_allmasked": dict(BASE, R=8, D=4, W=64, Nc=32, Nf=32, c2f=(0.1, 0.5), progress=0.02, perturb=1.0, pose_opt=True),
 }
@@ -419,7 +429,10 @@ def state_key_fixture():
     for tag, kw in {"nerf_d8_w256": dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16),
                     "nerf_d4_w64": dict(D=4, W=64, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48, candidate_dim=16),
                     "nerf_d8_w256_nocand": dict(D=8, W=256, feat_dim=384, xyz_L=10, dir_L=4, appearance_dim=48,
-                                                candidate_dim=0)}.items():
+                                                candidate_dim=0),
+                    # nerf.feat_dim = 0 (nerf_system.py:373-374): no feature layers, rgb_candidate_layer
+                    "nerf_d8_w256_nofeat": dict(D=8, W=256, encode_feat=False, feat_dim=0, xyz_L=10, dir_L=4, appearance_dim=48,
+                                                candidate_dim=16)}.items():
         m = ref_nerf.NeRF("coarse", c2f=(0.1, 0.5), **kw)
         out[tag] = {"kwargs": kw, "state": {k: list(v.shape) for k, v in m.state_dict().items()},
                     "param_order": [k for k, _ in m.named_parameters()]}

@@ -46,7 +46,8 @@ class CompositeFwdArgs(C.Structure):
                 ("e", _fp), ("g2", _fp),
                 ("w_all", _fp), ("w_sj", _fp), ("w_cj", _fp), ("w_s", _fp),
                 ("E_s", _fp), ("G_c", _fp), ("sum_sfeat", _fp), ("t_weight", _fp), ("c_depth", _fp),
-                ("s_depth", _fp), ("rgb_map", _fp), ("e16", _fp), ("eexp", _fp), ("g2_16", _fp), ("g2exp", _fp)]
+                ("s_depth", _fp), ("rgb_map", _fp), ("e16", _fp), ("eexp", _fp), ("g2_16", _fp), ("g2exp", _fp),
+                ("rgb_joint_map", _fp)]
 
 
 class CompositeBwdArgs(C.Structure):
@@ -55,7 +56,8 @@ class CompositeBwdArgs(C.Structure):
                 ("w_all", _fp), ("w_sj", _fp), ("w_cj", _fp), ("w_s", _fp),
                 ("g_E_s", _fp), ("g_G_c", _fp), ("g_sum_sfeat", _fp), ("g_t_weight", _fp), ("g_c_depth", _fp),
                 ("g_s_depth", _fp), ("g_rgb_map", _fp), ("g_w_all", _fp), ("g_w_s", _fp),
-                ("d_sigma_s", _fp), ("d_sigma_c", _fp), ("d_rgb", _fp), ("e16", _fp), ("eexp", _fp), ("g2_16", _fp), ("g2exp", _fp)]
+                ("d_sigma_s", _fp), ("d_sigma_c", _fp), ("d_rgb", _fp), ("e16", _fp), ("eexp", _fp), ("g2_16", _fp), ("g2exp", _fp),
+                ("g_rgb_joint_map", _fp)]
 
 
 class FieldBwdArgs(C.Structure):

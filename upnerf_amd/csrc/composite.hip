@@ -182,7 +182,8 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
   const bool feat_from_ws = a.mode == 3;       // feature map weighted by the shared-only weights
   const bool want_feat = a.mode != 2;
   float carryT = 1.0f, carryTs = 1.0f;
-  float acc_cd = 0.f, acc_sd = 0.f, acc_tw = 0.f, acc_sf = 0.f, acc_rgb[3] = {0.f, 0.f, 0.f};
+  float acc_cd = 0.f, acc_sd = 0.f, acc_tw = 0.f, acc_sf = 0.f, acc_rgb[3] = {0.f, 0.f, 0.f}, acc_rgbj[3] = {0.f, 0.f, 0.f};
+  const bool rgb_joint = joint && a.has_rgb && a.rgb_joint_map;  // encode_feat = False: the shared half of c_rgb
   f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accG = {0.f, 0.f, 0.f, 0.f};
   const bool laneE = lane < W / 4, laneG = lane < W2 / 4;
   for (int c0 = 0; c0 < S; c0 += 64) {
@@ -206,6 +207,10 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
       }
       acc_cd += w_all * zi;
       acc_tw += w_cj;
+      if (rgb_joint && valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc_rgbj[c] += w_sj * a.rgb[(base + i) * 3 + c];
+      }
     }
     const float Ts = carryTs * excl_prod_scan(valid ? 1.0f - A.a_s : 1.0f, lane, tot);
     carryTs *= tot;
@@ -264,6 +269,12 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
     if (joint) { a.c_depth[r] = cd; a.t_weight[r] = tw; }
     if (want_feat) a.sum_sfeat[r] = sf;
     if (a.has_rgb) { a.rgb_map[r * 3] = rg[0]; a.rgb_map[r * 3 + 1] = rg[1]; a.rgb_map[r * 3 + 2] = rg[2]; }
+  }
+  if (rgb_joint) {  // (wave-uniform)
+    float rj[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rj[c] = wave_sum(acc_rgbj[c]);
+    if (lane == 0) { a.rgb_joint_map[r * 3] = rj[0]; a.rgb_joint_map[r * 3 + 1] = rj[1]; a.rgb_joint_map[r * 3 + 2] = rj[2]; }
   }
   if constexpr (EFRAG) {
     if (want_feat) {
@@ -328,6 +339,9 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
   const float g_sd = a.g_s_depth ? a.g_s_depth[r] : 0.f;
   float g_rm[3] = {0.f, 0.f, 0.f};
   if (a.has_rgb && a.g_rgb_map) { g_rm[0] = a.g_rgb_map[r * 3]; g_rm[1] = a.g_rgb_map[r * 3 + 1]; g_rm[2] = a.g_rgb_map[r * 3 + 2]; }
+  float g_rj[3] = {0.f, 0.f, 0.f};  // encode_feat = False: gradient of the joint-weight colour map (the shared half of c_rgb)
+  const bool rgb_joint = joint && a.has_rgb && a.g_rgb_joint_map;
+  if (rgb_joint) { g_rj[0] = a.g_rgb_joint_map[r * 3]; g_rj[1] = a.g_rgb_joint_map[r * 3 + 1]; g_rj[2] = a.g_rgb_joint_map[r * 3 + 2]; }
   const bool need_dots = want_feat && (a.g_E_s || (joint && a.g_G_c));
   const bool g_frag = EFRAG && joint && a.g_G_c && a.g2_16;
   if constexpr (EFRAG) {
@@ -392,11 +406,17 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
       A = alphas_at(a.z, a.sigma_s, a.sigma_c, base, i, S, joint);
       zi = a.z[base + i];
     }
-    double tot, ds = 0.0, dc = 0.0;
+    double tot, ds = 0.0, dc = 0.0, w_sj_d = 0.0;
     if (joint) {
       const double om = valid ? (double)(1.0f - A.a_all) : 1.0;
       const double T = carry_s[wave][0][c] * excl_prod_scan_d(om, lane, tot);
-      const double Gs = (double)dotE + g_sf, Gc = (double)dotG + g_tw;
+      double Gs = (double)dotE + g_sf;
+      const double Gc = (double)dotG + g_tw;
+      if (rgb_joint && valid) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) Gs += (double)g_rj[ch] * (double)a.rgb[(base + i) * 3 + ch];
+        w_sj_d = (double)A.a_s * T;
+      }
       const double Gw = (double)g_cd * zi + ((a.g_w_all && valid) ? (double)a.g_w_all[base + i] : 0.0);
       const double X = valid ? ((double)A.a_s * Gs + (double)A.a_c * Gc + (double)A.a_all * Gw) * T : 0.0;
       const double suf = excl_suffix_sum_d(X, lane, tot) + sufX;
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
       ds += (double)A.delta * (oms * Ts * Gws - suf);
       if (a.has_rgb && valid) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) a.d_rgb[(base + i) * 3 + ch] = (float)w_s * g_rm[ch];
+        for (int ch = 0; ch < 3; ++ch) a.d_rgb[(base + i) * 3 + ch] = rgb_joint ? (float)(w_s * g_rm[ch] + w_sj_d * g_rj[ch]) : (float)w_s * g_rm[ch];
       }
     }
     if (valid) {

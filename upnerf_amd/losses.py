@@ -118,19 +118,20 @@ def _term_mask(m, fine, device):
     return _MASKS[key]
 
 
-def _terms_to_dict(terms, m, fine):
+def _terms_to_dict(terms, m, fine, encode_feat=True):
     out = {}
+    fc, ff = ("l_feat_c", "l_feat_f") if encode_feat else ("l_c_rgb_c", "l_c_rgb_f")  # losses.py:30-35, 51-56
     if m < 1:
-        out["l_depth_c"], out["l_feat_c"] = terms[0], terms[1]
+        out["l_depth_c"], out[fc] = terms[0], terms[1]
     if m > 0:
         out["l_rgb_c"] = terms[2]
     if fine:
         if m < 1:
-            out["l_depth_f"], out["l_feat_f"] = terms[3], terms[4]
+            out["l_depth_f"], out[ff] = terms[3], terms[4]
         if m > 0:
             out["l_rgb_f"], out["l_beta"], out["l_alpha"] = terms[5], terms[6], terms[7]
     # the reference's dict order (losses.py:24-63): coarse terms, then fine terms
-    order = ["l_depth_c", "l_feat_c", "l_rgb_c", "l_depth_f", "l_feat_f", "l_rgb_f", "l_beta", "l_alpha"]
+    order = ["l_depth_c", fc, "l_rgb_c", "l_depth_f", ff, "l_rgb_f", "l_beta", "l_alpha"]
     return {k: out[k] for k in order if k in out}
 
 
@@ -139,25 +140,26 @@ class UPNeRFLoss(nn.Module):
         super().__init__()
         self.depth_mult, self.alpha_reg, self.encode_feat, self.fine = depth_mult, alpha_reg, encode_feat, fine
         self.near, self.far = near, far
-        if not encode_feat:
-            raise NotImplementedError("nerf.feat_dim = 0 is not implemented on the HIP path")
 
     def _run(self, inputs, rgb, feat, m, depth_direct=None, inv_depth=None, scale_rows=None):
         g = inputs.get
         beta = g("t_beta")
         alpha = g("t_alpha")
         fine = self.fine
+        # encode_feat = False (losses.py:33-35, 54-56): the candidate colour map against the colour targets takes the place of
+        # the feature map against the feature targets -- the same mean squared difference, three columns wide
+        fk, ft = ("feat_", feat) if self.encode_feat else ("c_rgb_", rgb)
         cfg = (m, self.depth_mult, self.alpha_reg, self.near, self.far, fine)
         terms, depth = _LossFn.apply(
             cfg, depth_direct, inv_depth, scale_rows,
             g("s_depth_coarse") if m < 1 else None, g("s_depth_fine") if (m < 1 and fine) else None,
             g("t_weight_coarse") if m < 1 else None, g("t_weight_fine") if (m < 1 and fine) else None,
-            g("feat_coarse") if m < 1 else None, g("feat_fine") if (m < 1 and fine) else None, feat if m < 1 else None,
+            g(fk + "coarse") if m < 1 else None, g(fk + "fine") if (m < 1 and fine) else None, ft if m < 1 else None,
             g("s_rgb_coarse") if m > 0 else None, g("s_rgb_fine") if (m > 0 and fine) else None, rgb if m > 0 else None,
             beta.reshape(-1) if (beta is not None and m > 0 and fine) else None,
             alpha.reshape(-1) if (alpha is not None and m > 0 and fine) else None)
         self.last_terms = (terms, m, fine)
-        return _terms_to_dict(terms, m, fine), depth
+        return _terms_to_dict(terms, m, fine, self.encode_feat), depth
 
     def total(self):
         """Sum of the terms of the last call as one autograd node (what `sum(loss_d.values())` computes; the summation order,

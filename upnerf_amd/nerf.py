@@ -35,27 +35,28 @@ class NeRF(nn.Module):
         # Host mirror of `progress`: render_rays needs the value on the host (band weights are kernel arguments) and
         # reading the device parameter would drain the HIP queue twice per step.  None = unknown (read the parameter).
         self.host_progress = None
-        if not encode_feat:
-            # decided in round 5: the reference's no-DINO-feature ablation (nerf.py:52-56, 75-78,
-            # 110-123; rendering.py:142-150, 177-190) is outside what this path rebuilds -- no shipped configuration selects it
-            raise NotImplementedError("nerf.feat_dim = 0 (encode_feat=False: colour head on xyz_encoding_final, rgb_candidate_layer, "
-                                      "c_rgb maps) has no HIP path -- see INTEGRATION.md, 'Behavioural notes'")
         for i in range(D):
             k = self.in_channels_xyz if i == 0 else (W + self.in_channels_xyz if i in self.skips else W)
             setattr(self, f"xyz_encoding_{i + 1}", nn.Sequential(nn.Linear(k, W), nn.ReLU(True)))
         self.xyz_encoding_final = nn.Linear(W, W)
         self.share_sigma = nn.Sequential(nn.Linear(W, 1), nn.Softplus())
-        self.feat_share_layer = nn.Linear(W, feat_dim)
-        in_rgb = feat_dim + self.in_channels_dir + (appearance_dim if self.encode_appearance else 0)
+        # encode_feat = False (nerf.py:52-56, 75-78): no feature layer -- the colour head reads xyz_encoding_final itself and
+        # the candidate head ends in a 3-wide colour layer instead of the feature one
+        if encode_feat:
+            self.feat_share_layer = nn.Linear(W, feat_dim)
+        in_rgb = (feat_dim if encode_feat else W) + self.in_channels_dir + (appearance_dim if self.encode_appearance else 0)
         self.rgb_share_layer = nn.Sequential(nn.Linear(in_rgb, W // 2), nn.ReLU(True), nn.Linear(W // 2, 3),
                                              nn.Sigmoid())
         if self.encode_candidate:
             self.candidate_encoding = nn.Sequential(nn.Linear(W + candidate_dim, W // 2), nn.ReLU(True),
                                                     nn.Linear(W // 2, W // 2), nn.ReLU(True))
             self.candidate_sigma = nn.Sequential(nn.Linear(W // 2, 1), nn.Softplus())
-            self.feat_candidate_layer = nn.Linear(W // 2, feat_dim)
+            if encode_feat:
+                self.feat_candidate_layer = nn.Linear(W // 2, feat_dim)
+            else:
+                self.rgb_candidate_layer = nn.Linear(W // 2, 3)
         self.packer = NerfPacker(W, D, self.skips, self.in_channels_xyz, self.in_channels_dir, feat_dim,
-                                 appearance_dim, candidate_dim)
+                                 appearance_dim, candidate_dim, encode_feat=encode_feat)
 
     def set_progress(self, progress: float):
         """Write `progress` (device parameter, as the reference does through .data) and its host mirror.  The mirror
@@ -100,14 +101,18 @@ class NeRF(nn.Module):
         if sigma_only:
             return ret
         e = lin(self.xyz_encoding_final, h)
-        ret["s_feat"] = lin(self.feat_share_layer, e)
-        if sched_mult < 1 and self.encode_candidate:
+        if self.encode_feat:
+            ret["s_feat"] = lin(self.feat_share_layer, e)
+        if sched_mult < 1 and (self.encode_candidate or not self.encode_feat):  # (nerf.py:97 / 119: no flag check without features)
             g = lin(self.candidate_encoding[0], torch.cat([e, inputs["input_c"]], 1), True)
             g = lin(self.candidate_encoding[2], g, True)
             ret["c_sigma"] = torch.nn.functional.softplus(lin(self.candidate_sigma[0], g))
-            ret["c_feat"] = lin(self.feat_candidate_layer, g)
-        if sched_mult > 0:
-            parts = [ret["s_feat"], self.positional_encoding(inputs["input_dir"], self.dir_L)]
+            if self.encode_feat:
+                ret["c_feat"] = lin(self.feat_candidate_layer, g)
+            else:
+                ret["c_rgb"] = lin(self.rgb_candidate_layer, g)
+        if sched_mult > 0 or not self.encode_feat:  # (nerf.py:110-117: always, without features)
+            parts = [ret["s_feat"] if self.encode_feat else e, self.positional_encoding(inputs["input_dir"], self.dir_L)]
             if self.encode_appearance:
                 parts.append(inputs["input_a"])
             r = lin(self.rgb_share_layer[0], torch.cat(parts, 1), True)

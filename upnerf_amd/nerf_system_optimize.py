@@ -74,7 +74,7 @@ class NeRFSystemOptimize(NeRFSystem):
                                     rays=rays if chunk >= rays.shape[0] else rays[i:i + chunk],
                                     img_idx=img_idx[i:i + chunk], sched_mult=1.0, N_samples=hp["nerf.N_samples"],
                                     use_disp=hp["nerf.use_disp"], perturb=hp["nerf.perturb"] if train else 0,
-                                    N_importance=hp["nerf.N_importance"], encode_feat=True, u_list=u_list,
+                                    N_importance=hp["nerf.N_importance"], encode_feat=hp["nerf.feat_dim"] > 0, u_list=u_list,
                                     coarse_sigma_only=self.coarse_sigma_only))
         return {k: (outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], 0)) for k in outs[0]}
 

@@ -32,6 +32,14 @@ class _PackFn(torch.autograd.Function):
         L, W, W2, Fd = packer.L, packer.W, packer.W2, packer.feat_dim
         p = {n: t.detach().contiguous() for n, t in zip(names, tensors)}
         dev = tensors[0].device
+        if not packer.encode_feat:  # no feature layer to fold into the colour head: the pack launch is the whole job
+            buf = zero_pool.zeros(L.total, dev)
+            descs = packer._pack_descs(p, lambda n: p[n].data_ptr())
+            arr = (PackDesc * len(descs))(*descs)
+            check(lib.upnerf_pack(ptr(buf), arr, len(descs), 0, stream()), "upnerf_pack")
+            ctx.packer, ctx.names, ctx.buf = packer, names, None
+            ctx.shapes = [tuple(t.shape) for t in tensors]
+            return buf
         buf = zero_pool.zeros(L.total + W2 * Fd, dev)  # P followed by a copy of W_r1[:, :F]
         st = stream()
         descs = packer._pack_descs(p, lambda n: p[n].data_ptr(), L.total)
@@ -58,7 +66,6 @@ class _PackFn(torch.autograd.Function):
         from .ops import wgrad_blocks_into, wgrad_into
         packer, names, buf = ctx.packer, ctx.names, ctx.buf
         L, W, W2, Fd = packer.L, packer.W, packer.W2, packer.feat_dim
-        feat_w, feat_b = ctx.saved_tensors
         dP = dP.contiguous()
         dev = dP.device
         st = stream()
@@ -72,6 +79,9 @@ class _PackFn(torch.autograd.Function):
         descs = packer._pack_descs(grads, lambda n: grads[n].data_ptr())
         arr = (PackDesc * len(descs))(*descs)
         check(lib.upnerf_pack(ptr(dP), arr, len(descs), 1, st), "upnerf_pack")
+        if not packer.encode_feat:
+            return (None, None) + tuple(grads[n] for n in names)
+        feat_w, feat_b = ctx.saved_tensors
         base = dP.data_ptr()
         gbr1 = dP[L.br1:L.br1 + W2]
         g_wr = grads["rgb_share_layer.0.weight"]          # [W2][F + 27 + A]
@@ -94,7 +104,10 @@ class _PackFn(torch.autograd.Function):
 
 class NerfPacker:
     def __init__(self, W: int, D: int, skips, in_xyz: int, in_dir: int, feat_dim: int, appearance_dim: int,
-                 candidate_dim: int):
+                 candidate_dim: int, encode_feat: bool = True):
+        # encode_feat = False (models/nerf.py:52-56, 110-123): the colour head reads xyz_encoding_final itself, so the
+        # "folded" first colour matrix of the layout is W_r1[:, :W] as it stands -- same layout, no fold launches
+        self.encode_feat = bool(encode_feat)
         if W not in (64, 256):
             raise ValueError(f"HIP field kernels support W in (64, 256), got {W}")
         if not 1 <= D <= MAX_D:
@@ -183,13 +196,14 @@ class NerfPacker:
         else:
             for n in (W2 * (W + CK), W2, W2 * W2, W2, W2, 4):
                 put(torch.zeros(n, device=dev, dtype=dt), n)
-        Fd = self.feat_dim
-        wr = p["rgb_share_layer.0.weight"]  # [W2][F + 27 + A]
-        fold = wr[:, :Fd] @ p["feat_share_layer.weight"]  # [W2][W]
+        Fd = self.feat_dim if self.encode_feat else W
+        wr = p["rgb_share_layer.0.weight"]  # [W2][F + 27 + A]  (encode_feat = False: [W2][W + 27 + A])
+        fold = wr[:, :Fd] @ p["feat_share_layer.weight"] if self.encode_feat else wr[:, :W]  # [W2][W]
         aux_w = F.pad(wr[:, Fd:], (0, AUXK - (self.in_dir + self.A))) if self.A else \
             F.pad(wr[:, Fd:], (0, AUXK - self.in_dir))
         put(torch.cat([fold, aux_w], 1), W2 * (W + AUXK))
-        put(wr[:, :Fd] @ p["feat_share_layer.bias"] + p["rgb_share_layer.0.bias"], W2)
+        put(wr[:, :Fd] @ p["feat_share_layer.bias"] + p["rgb_share_layer.0.bias"] if self.encode_feat
+            else p["rgb_share_layer.0.bias"], W2)
         put(F.pad(p["rgb_share_layer.2.weight"], (0, 0, 0, 1)), 4 * W2)
         put(F.pad(p["rgb_share_layer.2.bias"], (0, 1)), 4)
         P = torch.cat(pieces)
@@ -232,9 +246,13 @@ class NerfPacker:
             add("candidate_sigma.0.weight", 0, 1, W2, L.wcsig, W2)
             add("candidate_sigma.0.bias", 0, 1, 1, L.bcsig, 1)
         naux = self.in_dir + self.A
-        add("rgb_share_layer.0.weight", Fd, W2, naux, L.wr1 + W, W + AUXK)       # [PE(dir) | appearance] columns
-        if scratch_off is not None:
-            add("rgb_share_layer.0.weight", 0, W2, Fd, scratch_off, Fd)           # contiguous copy of W_r1[:, :F]
+        if not self.encode_feat:  # W_r1 = [W | PE(dir) | appearance] columns go where the folded matrix and its side columns sit
+            add("rgb_share_layer.0.weight", 0, W2, W + naux, L.wr1, W + AUXK)
+            add("rgb_share_layer.0.bias", 0, 1, W2, L.br1, W2)
+        else:
+            add("rgb_share_layer.0.weight", Fd, W2, naux, L.wr1 + W, W + AUXK)   # [PE(dir) | appearance] columns
+            if scratch_off is not None:
+                add("rgb_share_layer.0.weight", 0, W2, Fd, scratch_off, Fd)       # contiguous copy of W_r1[:, :F]
         add("rgb_share_layer.2.weight", 0, 3, W2, L.wr2, W2)
         add("rgb_share_layer.2.bias", 0, 1, 3, L.br2, 3)
         return out
@@ -246,7 +264,8 @@ class NerfPacker:
                        "candidate_encoding.2.bias", "candidate_sigma.0.weight", "candidate_sigma.0.bias"]
 
     def pack_names(self):
-        names = [f"xyz_encoding_{l + 1}.0.{k}" for l in range(self.D) for k in ("weight", "bias")] + self.PACK_NAMES_BASE
+        base = [n for n in self.PACK_NAMES_BASE if self.encode_feat or not n.startswith("feat_share_layer")]
+        names = [f"xyz_encoding_{l + 1}.0.{k}" for l in range(self.D) for k in ("weight", "bias")] + base
         return names + (self.PACK_NAMES_CAND if self.has_cand else [])
 
     def pack_hip(self, p: Dict[str, torch.Tensor]) -> torch.Tensor:

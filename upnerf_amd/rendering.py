@@ -115,8 +115,9 @@ def _empty(*shape, device):
 class _PassCfg:
     """Static (non-tensor) description of one field pass."""
 
-    def __init__(self, packer, mode: int, use_cand: bool, use_rgb: bool, wk_xyz, wk_dir):
+    def __init__(self, packer, mode: int, use_cand: bool, use_rgb: bool, wk_xyz, wk_dir, rgb_joint: bool = False):
         self.packer, self.mode, self.use_cand, self.use_rgb = packer, mode, use_cand, use_rgb
+        self.rgb_joint = bool(rgb_joint and mode <= 1 and use_rgb)  # encode_feat = False: the shared colour under the joint weights too
         self.wk_xyz, self.wk_dir = wk_xyz, wk_dir
         # ctx.needs_input_grad reports requires_grad of the inputs even under torch.no_grad(); whether a backward pass
         # can follow is decided where the pass is configured (Function.forward itself always runs with grad disabled)
@@ -229,11 +230,13 @@ class _FieldPass(torch.autograd.Function):
         c_depth = _empty(R, device=dev) if joint else None
         s_depth = _empty(R, device=dev)
         rgb_map = _empty(R, 3, device=dev) if cfg.use_rgb else None
+        rgbj_map = _empty(R, 3, device=dev) if cfg.rgb_joint else None
         ca = CompositeFwdArgs(R=R, S=S, W=W, mode=cfg.mode, z=ptr(z), sigma_s=ptr(sigma_s), sigma_c=ptr(sigma_c),
                               rgb=ptr(rgb), has_rgb=int(cfg.use_rgb), e=ptr(e), g2=ptr(g2), w_all=ptr(w_all),
                               w_sj=ptr(w_sj), w_cj=ptr(w_cj), w_s=ptr(w_s), E_s=ptr(E_s), G_c=ptr(G_c),
                               sum_sfeat=ptr(sum_sfeat), t_weight=ptr(t_weight), c_depth=ptr(c_depth),
-                              s_depth=ptr(s_depth), rgb_map=ptr(rgb_map), e16=ptr(e16), eexp=ptr(eexp), g2_16=ptr(g2_16), g2exp=ptr(g2exp))
+                              s_depth=ptr(s_depth), rgb_map=ptr(rgb_map), e16=ptr(e16), eexp=ptr(eexp), g2_16=ptr(g2_16), g2exp=ptr(g2exp),
+                              rgb_joint_map=ptr(rgbj_map))
         check(TIMER.run("composite_fwd", lambda: lib.upnerf_composite_fwd(C.byref(ca), st), units=M),
               "upnerf_composite_fwd")
 
@@ -245,11 +248,11 @@ class _FieldPass(torch.autograd.Function):
                          w_all=w_all, w_sj=w_sj,
                          w_cj=w_cj, w_s=w_s, wnorm=wnorm)
         z0 = torch.zeros(0, device=dev)
-        outs = (E_s, G_c, sum_sfeat, t_weight, c_depth, s_depth, rgb_map, w_all, w_s)
+        outs = (E_s, G_c, sum_sfeat, t_weight, c_depth, s_depth, rgb_map, w_all, w_s, rgbj_map)
         return tuple(o if o is not None else z0 for o in outs)
 
     @staticmethod
-    def backward(ctx, gE, gG, gsf, gtw, gcd, gsd, grm, gwall, gws):
+    def backward(ctx, gE, gG, gsf, gtw, gcd, gsd, grm, gwall, gws, grj):
         cfg, (R, S), sv = ctx.cfg, ctx.dims, ctx.saved
         pk, L = cfg.packer, cfg.packer.L
         W, W2, D = pk.W, pk.W2, pk.D
@@ -263,7 +266,7 @@ class _FieldPass(torch.autograd.Function):
 
         gE, gsf = g(gE, want_feat), g(gsf, want_feat)
         gG, gtw, gcd, gwall = g(gG, joint), g(gtw, joint), g(gcd, joint), g(gwall, joint)
-        gsd, gws, grm = g(gsd), g(gws), g(grm, cfg.use_rgb)
+        gsd, gws, grm, grj = g(gsd), g(gws), g(grm, cfg.use_rgb), g(grj, cfg.rgb_joint)
 
         d_sigma_s = _empty(M, device=dev)
         d_sigma_c = _empty(M, device=dev) if joint else None
@@ -275,7 +278,7 @@ class _FieldPass(torch.autograd.Function):
                               g_sum_sfeat=ptr(gsf), g_t_weight=ptr(gtw), g_c_depth=ptr(gcd), g_s_depth=ptr(gsd),
                               g_rgb_map=ptr(grm), g_w_all=ptr(gwall), g_w_s=ptr(gws), d_sigma_s=ptr(d_sigma_s),
                               d_sigma_c=ptr(d_sigma_c), d_rgb=ptr(d_rgb), e16=ptr(sv.get("e16")), eexp=ptr(sv.get("eexp")),
-                              g2_16=ptr(sv.get("g2_16")), g2exp=ptr(sv.get("g2exp")))
+                              g2_16=ptr(sv.get("g2_16")), g2exp=ptr(sv.get("g2exp")), g_rgb_joint_map=ptr(grj))
         check(TIMER.run("composite_bwd", lambda: lib.upnerf_composite_bwd(C.byref(cb), st), units=M),
               "upnerf_composite_bwd")
 
@@ -611,6 +614,16 @@ def _project_feat(model, E_s, sum_sfeat, G_c=None, t_weight=None):
     return _ProjectFeat.apply(len(xs), *xs, *ws)
 
 
+def _project_rgb(model, G_c, t_weight):
+    """The candidate half of `c_rgb` (encode_feat = False, rendering.py:183-188): sum_i w_cj (W_rc g2_i + b_rc) =
+    W_rc (sum w_cj g2) + b_rc sum w_cj -- the same composite-then-project algebra as _project_feat, three columns wide."""
+    rc = model.rgb_candidate_layer
+    # (eight output columns, five of them zero: the data-gradient GEMM of _ProjectFeat contracts over them in blocks of eight)
+    w8 = torch.nn.functional.pad(rc.weight, (0, 0, 0, 5))
+    b8 = torch.nn.functional.pad(rc.bias, (0, 5))
+    return _ProjectFeat.apply(2, G_c, t_weight[:, None], w8, b8[:, None])[:, :3]
+
+
 def join_rays(rays_o, rays_d, near_far):
     """The [R][8] rows render_rays takes (o | d | near far; models/nerf_system.py:166), remembering the tensors they were
     concatenated from: render_rays then reads origins and directions from those instead of slicing them back out of the rows
@@ -662,8 +675,6 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
     `s_depth_coarse` for it; the fine pass is unchanged, bit for bit."""
     if not rays.is_cuda:
         raise RuntimeError("upnerf_amd.render_rays runs on the GPU only (no CPU fallback)")
-    if not encode_feat:
-        raise NotImplementedError("nerf.feat_dim = 0 (rgb-only candidate head) is not implemented on the HIP path")
     draws = list(kwargs["u_list"]) if kwargs.get("u_list") is not None else None
     dev = rays.device
     R = rays.shape[0]
@@ -723,12 +734,17 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
         # leaves it None and pays a device read here
         hp = getattr(model, "host_progress", None)
         progress = float(model.progress.data) if hp is None else float(torch.tensor(hp, dtype=torch.float32))
+        if bool(getattr(model, "encode_feat", True)) != bool(encode_feat):
+            raise ValueError(f"render_rays(encode_feat={encode_feat}) with a {typ} field built with encode_feat={model.encode_feat}")
+        if not encode_feat and sched_mult < 1 and not model.encode_candidate:
+            # the reference has no such path either: `raise NotImplemented` (rendering.py:149-150)
+            raise NotImplementedError("encode_feat=False needs the candidate head while sched_mult < 1 (models/rendering.py:149-150)")
         use_cand = bool(sched_mult < 1 and model.encode_candidate)
-        use_rgb = bool(sched_mult > 0)
+        use_rgb = bool(sched_mult > 0 or not encode_feat)  # without features the colour head always runs (nerf.py:110-117)
         mode = (1 if use_rgb else 0) if use_cand else (3 if sched_mult < 1 else 2)
         cfg = _PassCfg(model.packer, mode, use_cand, use_rgb, band_weights(model.xyz_L, progress, model.c2f),
-                       band_weights(model.dir_L, progress, model.c2f))
-        E_s, G_c, sum_sf, t_w, c_dep, s_dep, rgb_map, w_all, w_s = _FieldPass.apply(
+                       band_weights(model.dir_L, progress, model.c2f), rgb_joint=not encode_feat)
+        E_s, G_c, sum_sf, t_w, c_dep, s_dep, rgb_map, w_all, w_s, rgbj_map = _FieldPass.apply(
             rays_o, rays_d, zz, c_rows, a_rows, model.packed(), cfg)
         if sched_mult < 1:
             if not model.encode_candidate:  # rendering.py:134-150
@@ -737,7 +753,10 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
             else:  # rendering.py:151-182
                 results[f"c_weights_{typ}"] = w_all
                 results[f"c_depth_{typ}"] = c_dep
-                results[f"feat_{typ}"] = _project_feat(model, E_s, sum_sf, G_c, t_w)
+                if encode_feat:
+                    results[f"feat_{typ}"] = _project_feat(model, E_s, sum_sf, G_c, t_w)
+                else:  # rendering.py:177-190: c_rgb = sum w_sj s_rgb + sum w_cj c_rgb, the candidate half projected per ray
+                    results[f"c_rgb_{typ}"] = rgbj_map + _project_rgb(model, G_c, t_w)
                 results[f"t_weight_{typ}"] = t_w
         if sched_mult > 0:  # rendering.py:195-209
             results[f"s_weights_{typ}"] = w_s

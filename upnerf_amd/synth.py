@@ -48,7 +48,8 @@ def _linear(prefix: str, out_f: int, in_f: int, seed: int, gain: float = 1.0) ->
 
 def nerf_state(typ: str, D: int = 8, W: int = 256, skips=(4,), feat_dim: int = 384, xyz_L: int = 10, dir_L: int = 4,
                appearance_dim: int = 48, candidate_dim: int = 16, seed: int = 0, progress: float = 0.0,
-               sigma_bias: float = 0.0, sigma_gain: float = 1.0, trunk_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+               sigma_bias: float = 0.0, sigma_gain: float = 1.0, trunk_gain: float = 1.0,
+               encode_feat: bool = True) -> Dict[str, torch.Tensor]:
     """state_dict of one reference NeRF (nerf.py:39-78).  `sigma_bias` shifts the density heads so that
     alphas are not all tiny (useful to exercise the compositing); `sigma_gain` scales their weights and `trunk_gain` the
     trunk weights ("trained-like" statistics: densities from 0 to tens, saturated alphas, activations over several decades)."""
@@ -60,14 +61,18 @@ def nerf_state(typ: str, D: int = 8, W: int = 256, skips=(4,), feat_dim: int = 3
         sd.update(_linear(pre + f"xyz_encoding_{i + 1}.0", W, k, seed, gain=trunk_gain))
     sd.update(_linear(pre + "xyz_encoding_final", W, W, seed))
     sd.update(_linear(pre + "share_sigma.0", 1, W, seed))
-    sd.update(_linear(pre + "feat_share_layer", feat_dim, W, seed))
-    sd.update(_linear(pre + "rgb_share_layer.0", W // 2, feat_dim + in_dir + appearance_dim, seed))
+    if encode_feat:
+        sd.update(_linear(pre + "feat_share_layer", feat_dim, W, seed))
+    sd.update(_linear(pre + "rgb_share_layer.0", W // 2, (feat_dim if encode_feat else W) + in_dir + appearance_dim, seed))
     sd.update(_linear(pre + "rgb_share_layer.2", 3, W // 2, seed))
     if candidate_dim > 0:
         sd.update(_linear(pre + "candidate_encoding.0", W // 2, W + candidate_dim, seed))
         sd.update(_linear(pre + "candidate_encoding.2", W // 2, W // 2, seed))
         sd.update(_linear(pre + "candidate_sigma.0", 1, W // 2, seed))
-        sd.update(_linear(pre + "feat_candidate_layer", feat_dim, W // 2, seed))
+        if encode_feat:
+            sd.update(_linear(pre + "feat_candidate_layer", feat_dim, W // 2, seed))
+        else:  # nerf.py:77-78
+            sd.update(_linear(pre + "rgb_candidate_layer", 3, W // 2, seed))
     out = {k[len(pre):] if k.startswith(pre) else k: v for k, v in sd.items()}
     out["share_sigma.0.weight"] = out["share_sigma.0.weight"] * sigma_gain
     out["share_sigma.0.bias"] = out["share_sigma.0.bias"] + sigma_bias
