@@ -558,6 +558,13 @@ typedef struct {
   const float* beta; const float* alpha;                             /* [R] */
   const float* sched_dev;                /* [1] DEVICE or NULL: the multiplier m of the terms is read from here at execution
                                             time (graph replay); `sched` then only selects the phase (== 0, in (0,1), == 1) */
+  /* (ABI 9) the sum of the terms a phase uses, as part of the same two launches instead of a select + reduce + product on the
+   * caller's side: bit k of term_mask = term k counts (`sum(loss_d.values())`, models/nerf_system.py:183).  upnerf_loss_fwd
+   * writes total[0] = sum of the masked terms in term order when `total` is given; upnerf_loss_bwd adds g_total[0] to the
+   * upstream gradient of every masked term when `g_total` is given (g_terms may then be NULL). */
+  int32_t term_mask, reserved_;
+  float* total;                          /* [1] or NULL */
+  const float* g_total;                  /* [1] DEVICE or NULL (backward only) */
 } upnerf_loss_args;
 int upnerf_loss_fwd(const upnerf_loss_args* a, float* depth_out /*[R]*/, float* terms /*[8]*/,
                     float* scratch /*[64*8]*/, void* stream);

@@ -1313,6 +1313,48 @@ def test_fused_loss_and_depth_prior(hip, m, fine, has_tw):
                 assert rel_err(cpu(rw.grad), rw_ref.grad) < 1e-5
 
 
+@pytest.mark.parametrize("m,fine", [(0, True), (0.5, True), (1, True), (0.5, False)])
+def test_loss_total_comes_from_the_loss_launches_and_takes_its_gradient_there(hip, m, fine):
+    """UPNeRFLoss.total(): the sum of the phase's terms written by upnerf_loss_fwd itself (term_mask / total), its gradient added
+    to the masked terms' upstream gradients inside upnerf_loss_bwd (g_total) -- alone and together with a gradient that reaches
+    a term through the dict."""
+    from upnerf_amd.losses import UPNeRFLoss
+    R, F = 301, 384
+    res = {}
+    for typ in ("coarse", "fine") if fine else ("coarse",):
+        res[f"s_depth_{typ}"] = gen((R,), 70, 0.2, 4.0)
+        if m < 1:
+            res[f"feat_{typ}"] = gen((R, F), 71)
+            res[f"t_weight_{typ}"] = gen((R,), 72, 0.0, 1.0)
+        if m > 0:
+            res[f"s_rgb_{typ}"] = gen((R, 3), 73, 0.0, 1.0)
+    if m > 0 and fine:
+        res["t_beta"], res["t_alpha"] = gen((R, 1), 74, 0.1, 1.0), gen((R, 1), 75, 0.0, 1.0)
+    rgb, feat = gen((R, 3), 76, 0.0, 1.0), gen((R, F), 77)
+    depth = gen((R,), 78, 0.2, 4.5)
+    first = "l_depth_c" if m < 1 else "l_rgb_c"
+
+    def run(dev, mixed):
+        r = {k: v.clone().to(dev).requires_grad_(not k.startswith("t_weight")) for k, v in res.items()}
+        if dev == "cpu":
+            out = orc.upnerf_loss(r, rgb, feat, depth, m, 1e-3, 1.0, fine)
+            total = sum(out.values())
+        else:
+            lf = UPNeRFLoss(depth_mult=1e-3, alpha_reg=1.0, fine=fine, near=0.1, far=5.0)
+            out = lf(r, rgb.cuda(), feat.cuda(), depth.cuda(), m)
+            total = lf.total()
+        (total * 0.7 + out[first] * 0.3 if mixed else total).backward()
+        return total.detach(), r
+
+    for mixed in (False, True):
+        t_ref, r_ref = run("cpu", mixed)
+        t, r = run("cuda", mixed)
+        assert abs(float(t) - float(t_ref)) <= 2e-6 * max(1e-2, abs(float(t_ref)))
+        for k in r_ref:
+            if r_ref[k].grad is not None:
+                assert rel_err(cpu(r[k].grad), r_ref[k].grad) < 1e-5, (k, mixed)
+
+
 # ------------------------------------------------------------------------------------------ a18
 def test_flat_adam_follows_torch_adam_including_skipped_parameters():
     from upnerf_amd.optim import FlatAdam

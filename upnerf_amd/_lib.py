@@ -81,7 +81,8 @@ class LossArgs(C.Structure):
                 ("depth_direct", _fp), ("inv_depth", _fp), ("depth_scale_rows", _fp),
                 ("s_depth_c", _fp), ("s_depth_f", _fp), ("t_weight_c", _fp), ("t_weight_f", _fp),
                 ("feat_c", _fp), ("feat_f", _fp), ("feat_gt", _fp),
-                ("rgb_c", _fp), ("rgb_f", _fp), ("rgb_gt", _fp), ("beta", _fp), ("alpha", _fp), ("sched_dev", _fp)]
+                ("rgb_c", _fp), ("rgb_f", _fp), ("rgb_gt", _fp), ("beta", _fp), ("alpha", _fp), ("sched_dev", _fp),
+                ("term_mask", C.c_int32), ("reserved_", C.c_int32), ("total", _fp), ("g_total", _fp)]
 
 
 class LossGrads(C.Structure):

@@ -140,12 +140,26 @@ __global__ void loss_finish_kernel(upnerf_loss_args a, const float* __restrict__
     case T_BETA: scale = m / R; break;
     case T_ALPHA: scale = a.alpha_reg * m / R; break;
   }
-  terms[k] = s * scale;
+  const float t = s * scale;
+  terms[k] = t;
+  if (a.total) {  // (one wave: the masked terms are added in term order by lane 0)
+    const float v = ((a.term_mask >> k) & 1) ? t : 0.f;
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < T_N; ++j) tot += __shfl(v, j);
+    if (k == 0) a.total[0] = tot;
+  }
 }
 
-__global__ __launch_bounds__(NTHREADS) void loss_bwd_kernel(upnerf_loss_args a, const float* __restrict__ gt,
+__global__ __launch_bounds__(NTHREADS) void loss_bwd_kernel(upnerf_loss_args a, const float* __restrict__ gt_in,
                                                            upnerf_loss_grads g) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  float gt[T_N];  // upstream gradient of every term: the caller's vector + the total's gradient on the masked terms
+  {
+    const float gtot = a.g_total ? a.g_total[0] : 0.f;
+#pragma unroll
+    for (int k = 0; k < T_N; ++k) gt[k] = (gt_in ? gt_in[k] : 0.f) + (((a.term_mask >> k) & 1) ? gtot : 0.f);
+  }
   const float m = a.sched_dev ? *a.sched_dev : a.sched, R = (float)a.R;
   const bool p0 = a.sched < 1.0f, p1 = a.sched > 0.0f;  // the phase is static; only the multiplier follows the step
   if (idx < a.R) {
@@ -234,7 +248,7 @@ extern "C" int upnerf_loss_fwd(const upnerf_loss_args* a, float* depth_out, floa
 extern "C" int upnerf_loss_bwd(const upnerf_loss_args* a, const float* g_terms, const upnerf_loss_grads* g, void* stream) {
   int rc = check(a);
   if (rc) return rc;
-  if (!g_terms || !g) return UPNERF_EINVAL;
+  if ((!g_terms && !a->g_total) || !g) return UPNERF_EINVAL;
   const long long n = (long long)a->R * (a->sched < 1.f ? a->F : 1);
   int blocks = (int)((n + NTHREADS - 1) / NTHREADS);
   if (blocks > 2048) blocks = 2048;

@@ -16,11 +16,14 @@ TERMS = ("l_depth_c", "l_feat_c", "l_rgb_c", "l_depth_f", "l_feat_f", "l_rgb_f",
 
 class _LossFn(torch.autograd.Function):
     """inputs (any may be None): depth_direct, inv_depth, scale_rows, s_depth_c, s_depth_f, t_weight_c, t_weight_f,
-    feat_c, feat_f, feat_gt, rgb_c, rgb_f, rgb_gt, beta, alpha; returns (terms[8], depth_targets[R])."""
+    feat_c, feat_f, feat_gt, rgb_c, rgb_f, rgb_gt, beta, alpha; returns (terms[8], depth_targets[R], total): `total` = the
+    sum of the terms the phase uses (`sum(loss_d.values())`, nerf_system.py:183), written by the same two launches -- and its
+    gradient enters the backward kernel directly (no select + reduce forward, no mask product backward)."""
 
     @staticmethod
     def forward(ctx, cfg, *tensors):
         m, depth_mult, alpha_reg, near, far, fine = cfg
+        on = [m < 1, m < 1, m > 0, fine and m < 1, fine and m < 1, fine and m > 0, fine and m > 0, fine and m > 0]
         t = [None if x is None else x.detach().contiguous().float() for x in tensors]
         (dd, inv, rows, sdc, sdf, twc, twf, fc, ff, fg, rc, rf, rg, beta, alpha) = t
         ref = next(x for x in (dd, inv) if x is not None)
@@ -34,17 +37,19 @@ class _LossFn(torch.autograd.Function):
                      rgb_gt=ptr(rg), beta=ptr(beta), alpha=ptr(alpha),
                      sched_dev=dyn.ptr_named("sched", 1) if dyn else None)
         depth = torch.empty(R, device=dev)
-        terms = torch.empty(8, device=dev)
+        terms, total = torch.empty(8, device=dev), torch.empty((), device=dev)
+        a.term_mask = sum(1 << k for k, b in enumerate(on) if b)
+        a.total = ptr(total)
         scratch = torch.empty(64 * 8, device=dev)
         check(lib.upnerf_loss_fwd(C.byref(a), ptr(depth), ptr(terms), ptr(scratch), stream()), "upnerf_loss_fwd")
         ctx.args, ctx.keep = a, t  # `t` keeps the device buffers referenced by `a` alive
         ctx.mark_non_differentiable(depth)
         ctx.set_materialize_grads(False)  # (no zero tensor -- a fill launch -- for the output nothing differentiates)
-        return terms, depth
+        return terms, depth, total
 
     @staticmethod
-    def backward(ctx, g_terms, _g_depth):
-        if g_terms is None:
+    def backward(ctx, g_terms, _g_depth, g_total):
+        if g_terms is None and g_total is None:
             return (None,) * 16
         a, t = ctx.args, ctx.keep
         (dd, inv, rows, sdc, sdf, twc, twf, fc, ff, fg, rc, rf, rg, beta, alpha) = t
@@ -53,7 +58,7 @@ class _LossFn(torch.autograd.Function):
         want = [(x, ok) for x, ok in ((dd, need[0]), (rows, need[2]), (sdc, need[3]), (sdf, need[4]), (fc, need[7]), (ff, need[8]),
                                       (rc, need[10]), (rf, need[11]), (beta, need[13]), (alpha, need[14]))]
         pad = lambda n: (n + 63) // 64 * 64
-        arena = zero_pool.zeros(sum(pad(x.numel()) for x, ok in want if x is not None and ok) or 1, g_terms.device)
+        arena = zero_pool.zeros(sum(pad(x.numel()) for x, ok in want if x is not None and ok) or 1, (g_terms if g_terms is not None else g_total).device)
         cursor = [0]
 
         def new(x, ok):
@@ -69,8 +74,13 @@ class _LossFn(torch.autograd.Function):
         g = LossGrads(d_depth_scale_rows=ptr(d_rows), d_depth=ptr(d_dd), d_s_depth_c=ptr(d_sdc), d_s_depth_f=ptr(d_sdf),
                       d_feat_c=ptr(d_fc), d_feat_f=ptr(d_ff), d_rgb_c=ptr(d_rc), d_rgb_f=ptr(d_rf), d_beta=ptr(d_beta),
                       d_alpha=ptr(d_alpha))
-        gt = g_terms.contiguous().float()
-        check(lib.upnerf_loss_bwd(C.byref(a), ptr(gt), C.byref(g), stream()), "upnerf_loss_bwd")
+        gt = g_terms.contiguous().float() if g_terms is not None else None
+        gtot = g_total.contiguous().float() if g_total is not None else None
+        a.g_total = ptr(gtot)
+        try:
+            check(lib.upnerf_loss_bwd(C.byref(a), ptr(gt), C.byref(g), stream()), "upnerf_loss_bwd")
+        finally:
+            a.g_total = None
         shp = lambda d, x: None if d is None else d.view_as(x)
         return (None, d_dd, None, d_rows, d_sdc, d_sdf, None, None, d_fc, d_ff, None, d_rc, d_rf, None,
                 shp(d_beta, tensors_like(ctx, 13)), shp(d_alpha, tensors_like(ctx, 14)))
@@ -80,22 +90,6 @@ def tensors_like(ctx, i):
     return ctx.keep[i]
 
 
-class _SumSelected(torch.autograd.Function):
-    """Sum of the terms a phase uses, as ONE node of the autograd graph (the reference sums the dict's values with Python's
-    `sum`: eight adds forward and, backward, eight one-hot gradients of the `terms[i]` views added up again)."""
-
-    @staticmethod
-    def forward(ctx, terms, mask):
-        ctx.save_for_backward(mask)
-        return torch.where(mask, terms, _const(0.0, terms.device)).sum()  # (a Python 0.0 is a scalar_tensor fill per call)
-
-    @staticmethod
-    def backward(ctx, g):
-        (mask,) = ctx.saved_tensors
-        return g * mask, None
-
-
-_MASKS = {}
 _CONSTS = {}
 
 
@@ -108,14 +102,6 @@ def _const(value: float, device):
             return t  # memory of the capturing graph's pool: not to be kept beyond it
         _CONSTS[key] = t
     return _CONSTS[key]
-
-
-def _term_mask(m, fine, device):
-    key = (m < 1, m > 0, bool(fine), device)
-    if key not in _MASKS:
-        on = [m < 1, m < 1, m > 0, fine and m < 1, fine and m < 1, fine and m > 0, fine and m > 0, fine and m > 0]
-        _MASKS[key] = torch.tensor(on, dtype=torch.bool, device=device)
-    return _MASKS[key]
 
 
 def _terms_to_dict(terms, m, fine, encode_feat=True):
@@ -150,7 +136,7 @@ class UPNeRFLoss(nn.Module):
         # the feature map against the feature targets -- the same mean squared difference, three columns wide
         fk, ft = ("feat_", feat) if self.encode_feat else ("c_rgb_", rgb)
         cfg = (m, self.depth_mult, self.alpha_reg, self.near, self.far, fine)
-        terms, depth = _LossFn.apply(
+        terms, depth, total = _LossFn.apply(
             cfg, depth_direct, inv_depth, scale_rows,
             g("s_depth_coarse") if m < 1 else None, g("s_depth_fine") if (m < 1 and fine) else None,
             g("t_weight_coarse") if m < 1 else None, g("t_weight_fine") if (m < 1 and fine) else None,
@@ -158,14 +144,13 @@ class UPNeRFLoss(nn.Module):
             g("s_rgb_coarse") if m > 0 else None, g("s_rgb_fine") if (m > 0 and fine) else None, rgb if m > 0 else None,
             beta.reshape(-1) if (beta is not None and m > 0 and fine) else None,
             alpha.reshape(-1) if (alpha is not None and m > 0 and fine) else None)
-        self.last_terms = (terms, m, fine)
+        self.last_terms, self.last_total = (terms, m, fine), total
         return _terms_to_dict(terms, m, fine, self.encode_feat), depth
 
     def total(self):
         """Sum of the terms of the last call as one autograd node (what `sum(loss_d.values())` computes; the summation order,
         hence the last bit of the value, may differ -- the gradients do not)."""
-        terms, m, fine = self.last_terms
-        return _SumSelected.apply(terms, _term_mask(m, fine, terms.device))
+        return self.last_total  # (written by the loss launches themselves: _LossFn)
 
     def forward(self, inputs, rgb_targets, feat_targets, depth_targets, schedule_mult):
         """Reference calling convention (losses.py:21): depth targets already computed by the caller."""

@@ -98,7 +98,6 @@ class _PackFn(torch.autograd.Function):
         else:
             wgrad_into(W2, wrF, Fd, Fd, dP, W + AUXK, W, g_fw.data_ptr(), W, None, dev, b_off=L.wr1)
         check(lib.upnerf_matvec(W2, Fd, ptr(wrF), Fd, ptr(gbr1), None, ptr(grads["feat_share_layer.bias"]), 1, st), "upnerf_matvec")
-        grads["rgb_share_layer.0.bias"].copy_(gbr1)
         return (None, None) + tuple(grads[n] for n in names)
 
 
@@ -253,6 +252,8 @@ class NerfPacker:
             add("rgb_share_layer.0.weight", Fd, W2, naux, L.wr1 + W, W + AUXK)   # [PE(dir) | appearance] columns
             if scratch_off is not None:
                 add("rgb_share_layer.0.weight", 0, W2, Fd, scratch_off, Fd)       # contiguous copy of W_r1[:, :F]
+            else:  # backward: d b_r1 = d br1 (forward, br1 = W_r1[:, :F] b_feat + b_r1 is the mat-vec's output, not a copy)
+                add("rgb_share_layer.0.bias", 0, 1, W2, L.br1, W2)
         add("rgb_share_layer.2.weight", 0, 3, W2, L.wr2, W2)
         add("rgb_share_layer.2.bias", 0, 1, 3, L.br2, 3)
         return out
