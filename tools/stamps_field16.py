@@ -1,6 +1,7 @@
 """Per-phase shader-clock breakdown of the f16x3 forward trunk loop (diagnostic build: make -C upnerf_amd/csrc stamps).
 
     UPNERF_LIB=upnerf_amd/libupnerf_hip_stamps.so python tools/stamps_field16.py
+    ... --heads   (build: make -C upnerf_amd/csrc stamps EXP=-DUPNERF_STAMPS_HEADS): eight pieces of the forward kernel's head stage
 """
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,6 +34,16 @@ for i, n in enumerate(names):
     print(f"  {n:40s} {buf[i] / waves / 8:9.0f}   {100 * buf[i] / tot:5.1f} %")
 print(f"  {'sum':40s} {tot / waves / 8:9.0f}")
 
+if "--heads" in sys.argv:
+    hn = ["colour: 256-deep K loop + store of e", "colour: side-input contraction + bias / relu / max", "candidate: 256-deep K loop",
+          "candidate: side inputs + relu / sign bits / max", "barrier, exponent, two plane writes, barrier", "r1 store + three colour outputs",
+          "g1 store, candidate_encoding.2, epilogue, planes", "g2 store + candidate density"]
+    ht = sum(buf[8:16])
+    print("forward kernel, head stage, cycles per wave per tile:")
+    for i, n in enumerate(hn):
+        print(f"  {n:52s} {buf[8 + i] / waves:9.0f}   {100 * buf[8 + i] / ht:5.1f} %")
+    print(f"  {'sum':52s} {ht / waves:9.0f}")
+    sys.exit(0)
 print(f"forward kernel outside the trunk, cycles per wave per tile: prologue + encoding {buf[7] / waves:.0f}, "
       f"density head + final layer {buf[13] / waves:.0f}, colour / candidate heads {buf[14] / waves:.0f}")
 bnames = ["head stages (d g2, d r1, 128-wide contraction)", "d e (256-wide + rank-1 feature term)", "d h_{D-1}",

@@ -444,6 +444,43 @@ __device__ __forceinline__ void plane_row8(const char* Ph, const char* Pl, int r
   }
 }
 
+// ---- the 1- and 3-wide heads on the matrix pipe (round 5; nerf.py:89, 98, 108).  rowdot16 below costs a wave ~3k cycles per
+// output column of a 128-deep head (weights from L2, 64 conversions and 32 FMAs per lane, the plane row read once per column): the
+// three heads of a tile were 18k of a forward kernel's 293k cycles for 0.1 % of its MACs.  Here the heads' weights are split into
+// scaled fp16 (hi, lo) ONCE per workgroup in the prologue (head_stage: [768] = w_sigma | W_r2 rows 0..2 | w_csigma, one common
+// power-of-two exponent) and a wave contracts ITS 16 rows of the tile against them with v_mfma_f32_16x16x32_f16:
+//   D[n][m] = sum_k Wh[n][k] X[m][k]  (+ Wl . Xh + Wh . Xl),   n < NOUT <= 16 head outputs, m = 16 rows, K / 32 blocks;
+// the weight fragment (A operand: lane l holds row n = l & 15, eight k of group l >> 4) comes from the LDS staging (lanes n >=
+// NOUT hold zeros), the activation fragment (B operand: row m = l & 15, the same eight k) from the planes.  Both operands use
+// the same lane -> k assignment, so the sum is over all k whatever k the hardware calls them.  Result: lanes 0..15 hold, in
+// acc[0 .. NOUT), the outputs of row  row16 + lane.
+#define HEAD_STAGE_N 768  // 256 (w_sigma) + 3 x 128 (W_r2) + 128 (w_csigma)
+template <int NP, int W, int K, int NOUT>
+__device__ __forceinline__ f32x4 head16_mfma(const char* Ph, const char* Pl, int row16, int c0, const _Float16* sh, const _Float16* sl,
+                                             int lane) {
+  static_assert(K % 32 == 0 && NOUT <= 4, "one 16 x 16 x 32 block per 32 columns; outputs in the first register quad");
+  const int n = lane & 15, g = lane >> 4;
+  const bool live = n < NOUT;
+  const int nn = live ? n : 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int b = 0; b < K / 32; ++b) {
+    const int k = 32 * b + 8 * g;
+    h8 wh = *(const h8*)(sh + nn * K + k), wl = *(const h8*)(sl + nn * K + k);
+    wh = live ? wh : zero;
+    wl = live ? wl : zero;
+    const h8 xh = *(const h8*)(Ph + poff<W>(row16 + n, c0 + k));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);
+    if constexpr (NP == 2) {
+      const h8 xl = *(const h8*)(Pl + poff<W>(row16 + n, c0 + k));
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
 // dot of plane row segment [c0, c0+K) with w[0..K), split over the TPR adjacent threads that share a row; K is a
 // compile-time constant and the weight loads are issued before anything consumes them.
 template <int NP, int W, int TPR, int K>

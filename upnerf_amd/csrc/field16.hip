@@ -83,6 +83,21 @@ __device__ unsigned long long upnerf_stamp_acc[16];  // [0..7] forward trunk pha
 #define STAMP_FLUSH
 #define STAMP_FLUSH_AT(base)
 #endif
+// make stamps EXP=-DUPNERF_STAMPS_HEADS: slots 8..15 hold eight pieces of the FORWARD kernel's head stage instead of the backward
+// kernel's stages (tools/stamps_field16.py --heads)
+#if defined(UPNERF_STAMPS) && defined(UPNERF_STAMPS_HEADS)
+#define HSTAMP(i) STAMP(i)
+#define HSTAMP_RESET                               \
+  do {                                             \
+    for (int _i = 0; _i < 8; ++_i) _t_acc[_i] = 0; \
+    _t_prev = __builtin_amdgcn_s_memtime();        \
+  } while (0)
+#define BSTAMP_FLUSH_AT(base)
+#else
+#define HSTAMP(i)
+#define HSTAMP_RESET
+#define BSTAMP_FLUSH_AT(base) STAMP_FLUSH_AT(base)
+#endif
 
 namespace {
 
@@ -334,7 +349,6 @@ template <int NP, int TILE, int NW>
 __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(upnerf_layout L, upnerf_field_fwd_args a) {
   constexpr int W = 256, W2 = 128, THREADS = 64 * NW;
   constexpr int AH = NP == 2 ? F16_AHEAD_X3 : F16_AHEAD_F16;  // weight k-blocks in flight (common16.cuh:mma16_lds)
-  constexpr int TPR = THREADS / TILE;
   __shared__ __attribute__((aligned(16))) char planes[NP * TILE * W * 2];
   __shared__ float smax[NW], smaxb[NW];
   __shared__ unsigned int mx_s[16];  // running maxima of this workgroup (track / track_flush)
@@ -350,6 +364,10 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   __shared__ float wk_s[10];
   // trunk biases [D][W]: the epilogues read them from LDS
   __shared__ __attribute__((aligned(16))) float bias_s[UPNERF_MAX_D * W];
+  // the 1- and 3-wide heads' weights as scaled fp16 (hi, lo), split once per workgroup (common16.cuh: head16_mfma)
+  __shared__ __attribute__((aligned(16))) _Float16 hw_hi[HEAD_STAGE_N], hw_lo[HEAD_STAGE_N];
+  __shared__ float hw_max[NW];
+  static_assert(HEAD_STAGE_N == W + 4 * W2 && HEAD_STAGE_N == 3 * THREADS && TILE == 16 * NW, "head staging: three weights per thread, 16 rows per wave");
   char* Ph = planes;
   char* Pl = planes + (NP - 1) * TILE * W * 2;  // NP == 1: never dereferenced
   using TW = WaveTile16<W, TILE, NW>;
@@ -390,6 +408,11 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     if (l < D)
       for (int c = tid; c < W; c += THREADS) bias_s[l * W + c] = P[L.b[l] + c];
 
+  // the head weights of this thread (staging index tid, tid + 256, tid + 512): requested here, split behind the barrier below
+  float hwv[3];
+  hwv[0] = P[L.wsig + tid];
+  hwv[1] = P[L.wr2 + tid];                                             // W_r2 rows 0, 1 (256 of its 384 entries)
+  hwv[2] = tid < W2 ? P[L.wr2 + 2 * W2 + tid] : P[L.wcsig + tid - W2];  // W_r2 row 2 | w_csigma
   // ---- sample positions (rendering.py:251 / 308) and the maxima that bound the side inputs of this tile
   {
     float xm = 0.0f;
@@ -417,13 +440,26 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
       for (int idx = tid; idx < nr * UPNERF_CK; idx += THREADS) sm = fmaxf(sm, fabsf(a.c_rows[(size_t)ray0 * UPNERF_CK + idx]));
     xm = wave_max(xm);
     sm = wave_max(sm);
+    const float hm = wave_max(fmaxf(fmaxf(fabsf(hwv[0]), fabsf(hwv[1])), fabsf(hwv[2])));
     if (lane == 0) {
       smax[wave] = xm;
       smaxb[wave] = sm;
+      hw_max[wave] = hm;
     }
   }
   __syncthreads();
   const float x0max = wg_max<NW>(smax), sidemax = wg_max<NW>(smaxb);
+  const int hwexp = scale_exp(wg_max<NW>(hw_max));  // one exponent for the three heads: largest |w| -> [2^13, 2^14)
+  {
+    const float sc = pow2f(hwexp);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      _Float16 h, l;
+      split16(hwv[j] * sc, h, l);
+      hw_hi[tid + j * THREADS] = h;
+      hw_lo[tid + j * THREADS] = l;
+    }
+  }  // (visible behind the barrier that closes the encoding)
   track(mx_s, D + 4, x0max, tid);
   int ecur = scale_exp(x0max);
   // ---- BARF-masked encoding (nerf.py:126-147) straight into the planes
@@ -547,11 +583,12 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   for (int _i = 0; _i < 8; ++_i) _t_acc[_i] = 0;
   _t_prev = __builtin_amdgcn_s_memtime();
 #endif
-  const int prow = tid / TPR, phalf = tid % TPR, pm = m0 + prow;
+  const int hrow16 = 16 * wave, hm = m0 + hrow16 + (lane & 15);  // the 1- / 3-wide heads: lanes 0..15 of a wave own its 16 rows
   // ---- shared density head (nerf.py:89): softplus(w . h + b)
   {
-    const float pre = rowdot16<NP, W, TPR, W>(Ph, Pl, prow, phalf, 0, P + L.wsig, pow2f(-(prow >= TILE / 2 ? ehalf[1] : ehalf[0]))) + P[L.bsig];
-    if (phalf == 0 && pm < M) a.sigma_s[pm] = softplus_f(pre);
+    const f32x4 pre = head16_mfma<NP, W, W, 1>(Ph, Pl, hrow16, 0, hw_hi, hw_lo, lane);
+    const float us = pow2f(-((hrow16 >= TILE / 2 ? ehalf[1] : ehalf[0]) + hwexp));
+    if (lane < 16 && hm < M) a.sigma_s[hm] = softplus_f(pre[0] * us + P[L.bsig]);
   }
   // density-only pass (nerf.py:90-91 `sigma_only`): nobody consumes e, so the pass ends here
   if (!a.e && !a.use_rgb && !a.use_cand) {
@@ -599,6 +636,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   }
 
   // ---- first layer of the colour head (folded, nerf.py:95+102-109) and of the candidate head (nerf.py:97-98)
+  HSTAMP_RESET;
   f32x16 accr[TH::MT][TH::NT], accc[TH::MT][TH::NT];
   int rayrow[TH::MT];
 #pragma unroll
@@ -614,12 +652,14 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     load_cols(br, P + L.br1, hn0, hh);
     mma16_lds<NP, W, W / 16, AH>(accr, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, 0, lane);
     store_e();
+    HSTAMP(0);  // colour: 256-deep K loop + the store of e
     const float* ap[TH::MT];
 #pragma unroll
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.aux + (size_t)rayrow[mt] * UPNERF_AUXK + 8 * hh;
     mma16_glb<NP, UPNERF_AUXK>(accr, ap, ecur, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, W, lane);
     acc_fma_bias<true>(accr, pow2f(-(ecur + wexp[11])), br);
     mr = acc_absmax(accr);
+    HSTAMP(1);  // colour: side-input contraction (rows from global) + bias / relu / max
   }
   if (a.use_cand) {
     acc_zero(accc);
@@ -627,6 +667,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     load_cols(bc, P + L.bc1, hn0, hh);
     mma16_lds<NP, W, W / 16, AH>(accc, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, 0, lane);
     store_e();
+    HSTAMP(2);  // candidate: 256-deep K loop
     const float* ap[TH::MT];
 #pragma unroll
     for (int mt = 0; mt < TH::MT; ++mt) ap[mt] = a.c_rows + (size_t)rayrow[mt] * UPNERF_CK + 8 * hh;
@@ -634,6 +675,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     const unsigned long long bits = acc_fma_relu_pack(accc, pow2f(-(ecur + wexp[9])), bc);
     if (a.hmask) NT_STORE(&((unsigned long long*)a.hmask)[((size_t)D * gridDim.x + blockIdx.x) * THREADS + tid], bits);
     mc = acc_absmax(accc);
+    HSTAMP(3);  // candidate: side-input contraction + relu / sign bits / max
   }
   if (lane == 0) {
     smax[wave] = mr;
@@ -649,14 +691,19 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   if (a.use_rgb) acc_to_planes<NP, W>(accr, Ph, Pl, hrow0, hn0, 0, ecur, lane);
   if (a.use_cand) acc_to_planes<NP, W>(accc, Ph, Pl, hrow0, hn0, W2, ecur, lane);
   __syncthreads();
+  HSTAMP(4);  // barrier, exponent, both plane writes, barrier
   if (a.use_rgb) {
     if (a.r1) tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, 0, pow2f(-ecur), a.r1, W2, m0, M, tid);
     // rgb_share_layer.2 + sigmoid (nerf.py:56-61)
+    {
+      const f32x4 pre = head16_mfma<NP, W, W2, 3>(Ph, Pl, hrow16, 0, hw_hi + W, hw_lo + W, lane);
+      const float us = pow2f(-(ecur + hwexp));
+      if (lane < 16 && hm < M) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float pre = rowdot16<NP, W, TPR, W2>(Ph, Pl, prow, phalf, 0, P + L.wr2 + c * W2, pow2f(-ecur)) + P[L.br2 + c];
-      if (phalf == 0 && pm < M) a.rgb[(size_t)pm * 3 + c] = sigmoid_f(pre);
+        for (int c = 0; c < 3; ++c) a.rgb[(size_t)hm * 3 + c] = sigmoid_f(pre[c] * us + P[L.br2 + c]);
+      }
     }
+    HSTAMP(5);  // r1 store + the three colour outputs
   }
   if (a.use_cand) {
     if (a.g1) tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-ecur), a.g1, W2, m0, M, tid);
@@ -672,11 +719,15 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     ecur = scale_exp(wg_max<NW>(smax));
     acc_to_planes<NP, W>(acc, Ph, Pl, hrow0, hn0, W2, ecur, lane);
     __syncthreads();
+    HSTAMP(6);  // g1 store, candidate_encoding.2 (128-deep K loop), epilogue, barrier, plane write, barrier
     if (a.g2) tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-ecur), a.g2, W2, m0, M, tid);
-    const float pre = rowdot16<NP, W, TPR, W2>(Ph, Pl, prow, phalf, W2, P + L.wcsig, pow2f(-ecur)) + P[L.bcsig];
-    if (phalf == 0 && pm < M) a.sigma_c[pm] = softplus_f(pre);
+    const f32x4 pre = head16_mfma<NP, W, W2, 1>(Ph, Pl, hrow16, W2, hw_hi + W + 3 * W2, hw_lo + W + 3 * W2, lane);
+    if (lane < 16 && hm < M) a.sigma_c[hm] = softplus_f(pre[0] * pow2f(-(ecur + hwexp)) + P[L.bcsig]);
+    HSTAMP(7);  // g2 store + candidate density
   }
+#if !(defined(UPNERF_STAMPS) && defined(UPNERF_STAMPS_HEADS))
   STAMP(6);  // colour / candidate heads
+#endif
   STAMP_FLUSH_AT(8);
   track_flush(mx_s, a.amax, tid);
 }
@@ -1071,7 +1122,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
   STAMP(3);  // D-1 trunk layers
   if (D > 1) store_gz32(0, pow2f(-ecur), pow2f(-ecur));  // gz_0: still in the planes
   if (!a.need_dxyz) {
-    STAMP_FLUSH_AT(8);
+    BSTAMP_FLUSH_AT(8);
     track_flush(mx_s, a.gmax, tid);
     return;
   }
@@ -1108,7 +1159,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     a.dxyz[(size_t)m * 3 + n] = g;
   }
   STAMP(4);  // d x0 -> d xyz
-  STAMP_FLUSH_AT(8);
+  BSTAMP_FLUSH_AT(8);
   track_flush(mx_s, a.gmax, tid);
 }
 
