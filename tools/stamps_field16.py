@@ -2,6 +2,7 @@
 
     UPNERF_LIB=upnerf_amd/libupnerf_hip_stamps.so python tools/stamps_field16.py
     ... --heads   (build: make -C upnerf_amd/csrc stamps EXP=-DUPNERF_STAMPS_HEADS): eight pieces of the forward kernel's head stage
+    ... --bheads  (build: ... EXP=-DUPNERF_STAMPS_BHEADS): seven pieces of the backward kernel's head stage
 """
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,6 +44,16 @@ if "--heads" in sys.argv:
     for i, n in enumerate(hn):
         print(f"  {n:52s} {buf[8 + i] / waves:9.0f}   {100 * buf[8 + i] / ht:5.1f} %")
     print(f"  {'sum':52s} {ht / waves:9.0f}")
+    sys.exit(0)
+if "--bheads" in sys.argv:
+    hn = ["candidate: row loads (g2, g_G_c), d g2, store, column sums", "barrier, plane write, barrier",
+          "candidate_encoding.2^T: 128-deep contraction, scale, mask, max", "colour: d r1 (rank 3), store, column / ray sums",
+          "barrier, exponent, two plane writes, barrier", "gz_g1 store (+ its per-ray sums)", "partial sums: folds through LDS, three barriers"]
+    ht = sum(buf[8:15])
+    print("backward kernel, head stage, cycles per wave per tile:")
+    for i, n in enumerate(hn):
+        print(f"  {n:62s} {buf[8 + i] / waves:9.0f}   {100 * buf[8 + i] / ht:5.1f} %")
+    print(f"  {'sum':62s} {ht / waves:9.0f}")
     sys.exit(0)
 print(f"forward kernel outside the trunk, cycles per wave per tile: prologue + encoding {buf[7] / waves:.0f}, "
       f"density head + final layer {buf[13] / waves:.0f}, colour / candidate heads {buf[14] / waves:.0f}")

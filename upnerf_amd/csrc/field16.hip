@@ -85,6 +85,14 @@ __device__ unsigned long long upnerf_stamp_acc[16];  // [0..7] forward trunk pha
 #endif
 // make stamps EXP=-DUPNERF_STAMPS_HEADS: slots 8..15 hold eight pieces of the FORWARD kernel's head stage instead of the backward
 // kernel's stages (tools/stamps_field16.py --heads)
+// ... EXP=-DUPNERF_STAMPS_BHEADS: slots 8..15 hold seven pieces of the BACKWARD kernel's head stage (--bheads)
+#if defined(UPNERF_STAMPS) && defined(UPNERF_STAMPS_BHEADS)
+#define BHSTAMP(i) STAMP(i)
+#define BH_ONLY 1
+#else
+#define BHSTAMP(i)
+#define BH_ONLY 0
+#endif
 #if defined(UPNERF_STAMPS) && defined(UPNERF_STAMPS_HEADS)
 #define HSTAMP(i) STAMP(i)
 #define HSTAMP_RESET                               \
@@ -96,7 +104,11 @@ __device__ unsigned long long upnerf_stamp_acc[16];  // [0..7] forward trunk pha
 #else
 #define HSTAMP(i)
 #define HSTAMP_RESET
+#if BH_ONLY
+#define BSTAMP_FLUSH_AT(base)
+#else
 #define BSTAMP_FLUSH_AT(base) STAMP_FLUSH_AT(base)
+#endif
 #endif
 
 namespace {
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   // density-only pass (nerf.py:90-91 `sigma_only`): nobody consumes e, so the pass ends here
   if (!a.e && !a.use_rgb && !a.use_cand) {
     store_h32(D - 1, pow2f(-ehalf[0]), pow2f(-ehalf[1]));
-    STAMP_FLUSH_AT(8);
+    if (!BH_ONLY) STAMP_FLUSH_AT(8);
     track_flush(mx_s, a.amax, tid);
     return;
   }
@@ -630,7 +642,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
   };
   if (!a.use_rgb && !a.use_cand) {
     store_e();
-    STAMP_FLUSH_AT(8);
+    if (!BH_ONLY) STAMP_FLUSH_AT(8);
     track_flush(mx_s, a.amax, tid);
     return;
   }
@@ -728,7 +740,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
 #if !(defined(UPNERF_STAMPS) && defined(UPNERF_STAMPS_HEADS))
   STAMP(6);  // colour / candidate heads
 #endif
-  STAMP_FLUSH_AT(8);
+  if (!BH_ONLY) STAMP_FLUSH_AT(8);
   track_flush(mx_s, a.amax, tid);
 }
 
@@ -883,6 +895,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
       }
       lmax = wave_max(lmax);
       if (lane == 0) smax[wave] = lmax;
+      BHSTAMP(0);  // candidate: row loads (g2, g_G_c), d g2, store, column sums
       __syncthreads();
       const float mx = wg_max<NW>(smax);
       track(mx_s, D + 2, mx, tid);
@@ -890,11 +903,13 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
 #pragma unroll
       for (int q = 0; q < EPT; ++q) put_quad<NP, W>(Ph, Pl, er0 + ERS * q, W2 + 4 * eg, vals[q], eg2);
       __syncthreads();
+      BHSTAMP(1);  // barrier, plane write, barrier
       const unsigned long long cbits = NT_LOAD(&hm[(size_t)D * hm_stride]);  // arrives under the contraction below
       mma16_lds<NP, W, W2 / 16, AH>(accg, Ph, Pl, hrow0, W2, PT16 + 4 * (size_t)L.t_wc2, W2 / 16, hn0, 0, lane);
       acc_scale(accg, pow2f(-(eg2 + wexp[10])));
       acc_apply_mask(accg, cbits);
       mg1 = acc_absmax(accg);
+      BHSTAMP(2);  // candidate_encoding.2^T: 128-deep contraction, scale, mask, max
     }
     f32x4 valr[EPT];
     float mr1 = 0.0f;
@@ -927,6 +942,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
         mr1 = fmaxf(mr1, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
       }
       mr1 = wave_max(mr1);
+      BHSTAMP(3);  // colour: d r1 (rank 3), store, column / ray sums
     }
     if (lane == 0) {
       smax[wave] = mg1;
@@ -946,10 +962,12 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
       for (int q = 0; q < EPT; ++q) put_quad<NP, W>(Ph, Pl, er0 + ERS * q, 4 * eg, valr[q], erg);
     }
     __syncthreads();
+    BHSTAMP(4);  // barrier, exponent, two plane writes, barrier
     if (a.use_cand) {
       if (tp) tile_store16_sum<NP, W, TILE, THREADS, W2, MAXRAYS>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, gld, m0, M, tid, slot_s, tp_sg);
       else tile_store16<NP, W, TILE, THREADS, W2>(Ph, Pl, W2, pow2f(-erg), a.gz_g1, gld, m0, M, tid);
     }
+    BHSTAMP(5);  // gz_g1 store (+ its per-ray sums)
     if (tp) {
       // A thread holds four columns (eg) of 2 * EPT rows' worth of sums; the two halves of a wave fold first, then the
       // waves through LDS, in a fixed order (bitwise reproducible).  Two rounds of at most 24 floats per column group.
@@ -999,7 +1017,12 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
       __syncthreads();
       if (k < 6) *(f32x4*)&part[4 * W2 + 8 + W2 * k + 4 * g] = readout(k);
     }
+    BHSTAMP(6);  // partial sums: folds through LDS, three barriers
   }
+#if BH_ONLY
+  STAMP_FLUSH_AT(8);
+  for (int _i = 0; _i < 8; ++_i) _t_acc[_i] = 0;
+#endif
 
   STAMP(0);  // head stages (elementwise d g2 / d r1, 128-wide contraction, plane writes)
   int ecur;
