@@ -411,45 +411,61 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     }
   }
   if (tid < 16) mx_s[tid] = 0u;
-  if (tid >= 64 && tid < 64 + WEXP_SLOTS) wexp_s[tid - 64] = a.wexp[tid - 64];
+  // ---- every load of the prologue, requested back to back and UNCONDITIONALLY (clamped indices, values masked afterwards).
+  // Behind `if (tid in range)` / `if (l < D)` hipcc branches around each load and waits for it before the next one: the ISA of
+  // round 5 opened this kernel with eleven `global_load_dword ; s_waitcnt vmcnt(0)` pairs in a row (weight exponents, band
+  // weights, eight bias rows) and three more waits for the sample positions and the side-input maxima -- ~9k of the prologue's
+  // 21.7k cycles per tile were L2 / HBM round trips taken one at a time.
+  static_assert(W == THREADS && TILE <= THREADS && WEXP_SLOTS <= THREADS, "one bias column, one sample row per thread");
+  const int wexp_v = a.wexp[tid & (WEXP_SLOTS - 1)];
   // the ten band weights of this step (device table under graph replay): one request here instead of one L2 round trip per trip
   // of the encoding loop below (round 5 stamps: the stage took 24.9k cycles per tile with five of ten bands skipped, as with none)
-  if (tid >= 128 && tid < 138) wk_s[tid - 128] = a.wk_xyz_dev ? a.wk_xyz_dev[tid - 128] : a.wk_xyz[tid - 128];
+  const float* __restrict__ wk_src = a.wk_xyz_dev ? a.wk_xyz_dev : P;
+  float wk_v = wk_src[tid < 10 ? tid : 9];
+  float bias_v[UPNERF_MAX_D];
 #pragma unroll
-  for (int l = 0; l < UPNERF_MAX_D; ++l)
-    if (l < D)
-      for (int c = tid; c < W; c += THREADS) bias_s[l * W + c] = P[L.b[l] + c];
-
-  // the head weights of this thread (staging index tid, tid + 256, tid + 512): requested here, split behind the barrier below
+  for (int l = 0; l < UPNERF_MAX_D; ++l) bias_v[l] = P[(l < D ? L.b[l] : L.b[0]) + tid];
+  // the head weights of this thread (staging index tid, tid + 256, tid + 512): split behind the barrier below
   float hwv[3];
   hwv[0] = P[L.wsig + tid];
   hwv[1] = P[L.wr2 + tid];                                             // W_r2 rows 0, 1 (256 of its 384 entries)
-  hwv[2] = tid < W2 ? P[L.wr2 + 2 * W2 + tid] : P[L.wcsig + tid - W2];  // W_r2 row 2 | w_csigma
-  // ---- sample positions (rendering.py:251 / 308) and the maxima that bound the side inputs of this tile
+  hwv[2] = P[tid < W2 ? L.wr2 + 2 * W2 + tid : L.wcsig + tid - W2];     // W_r2 row 2 | w_csigma
+  // sample positions (rendering.py:251 / 308): row tid % TILE, clamped to the last sample
+  const int ms = m0 + (tid & (TILE - 1)), msc = ms < M ? ms : M - 1, rs = msc / S;
+  const float zz = a.z[msc];
+  const float ox = a.rays_o[3 * rs + 0], oy = a.rays_o[3 * rs + 1], oz = a.rays_o[3 * rs + 2];
+  const float dx = a.rays_d[3 * rs + 0], dy = a.rays_d[3 * rs + 1], dz = a.rays_d[3 * rs + 2];
+  // the maxima that bound the side inputs of this tile: the rows of its rays (one pass of the workgroup unless S < 32)
+  const int mlast = (m0 + TILE < M ? m0 + TILE : M) - 1;
+  const int ray0 = m0 / S, nr = mlast / S - ray0 + 1;
+  const float* __restrict__ aux_src = a.use_rgb ? a.aux + (size_t)ray0 * UPNERF_AUXK : P;   // (a pointer select, not a branch around the load)
+  const float* __restrict__ crow_src = a.use_cand ? a.c_rows + (size_t)ray0 * UPNERF_CK : P;
+  const float av = aux_src[a.use_rgb && tid < nr * UPNERF_AUXK ? tid : 0];
+  const float cv = crow_src[a.use_cand && tid < nr * UPNERF_CK ? tid : 0];
+  if (!a.wk_xyz_dev) wk_v = a.wk_xyz[tid < 10 ? tid : 9];
+  if (tid < WEXP_SLOTS) wexp_s[tid] = wexp_v;
+  if (tid < 10) wk_s[tid] = wk_v;
+#pragma unroll
+  for (int l = 0; l < UPNERF_MAX_D; ++l) bias_s[l * W + tid] = bias_v[l];  // (rows >= D: copies of row 0, never read)
   {
     float xm = 0.0f;
     if (tid < TILE) {
-      const int m = m0 + tid;
       float x = 0.f, y = 0.f, zc = 0.f;
-      if (m < M) {
-        const int r = m / S;
-        const float zz = a.z[m];
-        x = mul_then_add(a.rays_o[3 * r + 0], a.rays_d[3 * r + 0], zz);
-        y = mul_then_add(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], zz);
-        zc = mul_then_add(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], zz);
+      if (ms < M) {
+        x = mul_then_add(ox, dx, zz);
+        y = mul_then_add(oy, dy, zz);
+        zc = mul_then_add(oz, dz, zz);
       }
       xyz_s[tid * 3 + 0] = x;
       xyz_s[tid * 3 + 1] = y;
       xyz_s[tid * 3 + 2] = zc;
       xm = fmaxf(fmaxf(fabsf(x), fabsf(y)), fmaxf(fabsf(zc), 1.0f));  // |sin|, |cos| <= 1
     }
-    float sm = 0.0f;
-    const int mlast = (m0 + TILE < M ? m0 + TILE : M) - 1;
-    const int ray0 = m0 / S, nr = mlast / S - ray0 + 1;
+    float sm = fmaxf(a.use_rgb && tid < nr * UPNERF_AUXK ? fabsf(av) : 0.0f, a.use_cand && tid < nr * UPNERF_CK ? fabsf(cv) : 0.0f);
     if (a.use_rgb)
-      for (int idx = tid; idx < nr * UPNERF_AUXK; idx += THREADS) sm = fmaxf(sm, fabsf(a.aux[(size_t)ray0 * UPNERF_AUXK + idx]));
+      for (int idx = tid + THREADS; idx < nr * UPNERF_AUXK; idx += THREADS) sm = fmaxf(sm, fabsf(a.aux[(size_t)ray0 * UPNERF_AUXK + idx]));
     if (a.use_cand)
-      for (int idx = tid; idx < nr * UPNERF_CK; idx += THREADS) sm = fmaxf(sm, fabsf(a.c_rows[(size_t)ray0 * UPNERF_CK + idx]));
+      for (int idx = tid + THREADS; idx < nr * UPNERF_CK; idx += THREADS) sm = fmaxf(sm, fabsf(a.c_rows[(size_t)ray0 * UPNERF_CK + idx]));
     xm = wave_max(xm);
     sm = wave_max(sm);
     const float hm = wave_max(fmaxf(fmaxf(fabsf(hwv[0]), fabsf(hwv[1])), fabsf(hwv[2])));
