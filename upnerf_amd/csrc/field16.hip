@@ -824,29 +824,63 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     for (int l = 0; l < UPNERF_MAX_D; ++l) loff_s[l] = L.t_w[l];
   }
   if (tid >= 64 && tid < 80) mx_s[tid - 64] = 0u;
-  if (tid >= 128 && tid < 128 + WEXP_SLOTS) wexp_s[tid - 128] = a.wexp[tid - 128];
+  // ---- every load of the prologue AND the row loads of the head stages, requested back to back and unconditionally (clamped
+  // rows, pointer selects for absent inputs, values masked afterwards).  Behind `if (m < M)`, `if (a.use_cand)`, `ptr ? load : 0`
+  // hipcc branches around each load and waits for it before the next: this kernel opened with five to six HBM round trips in a
+  // row for the per-row scalars, and its candidate stage carried a `s_waitcnt vmcnt(0)` in the middle of its sixteen row loads
+  // (the g_G_c rows behind a null check) -- 21.8k cycles per tile for a stage that moves 1.5 KB per sample (round 5 stamps).
+  static_assert(TILE <= THREADS && WEXP_SLOTS <= THREADS, "one sample row per thread");
+  const int wexp_v = a.wexp[tid & (WEXP_SLOTS - 1)];
+  const int ms = m0 + (tid & (TILE - 1)), msc = ms < M ? ms : M - 1;
+  const bool has_gc = a.use_cand && a.g_G_c != nullptr;
+  const float dss_v = a.d_sigma_s[msc], ss_v = a.sigma_s[msc];
+  const float wf_v = (a.g_E_s ? a.w_feat_s : P)[a.g_E_s ? msc : 0];
+  const float dsc_v = (a.use_cand ? a.d_sigma_c : P)[a.use_cand ? msc : 0], sc_v = (a.use_cand ? a.sigma_c : P)[a.use_cand ? msc : 0];
+  const float cw_v = (has_gc ? a.w_cj : P)[has_gc ? msc : 0];
+  float y_v[3], dy_v[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    y_v[c] = (a.use_rgb ? a.rgb : P)[a.use_rgb ? (size_t)msc * 3 + c : 0];
+    dy_v[c] = (a.use_rgb ? a.d_rgb : P)[a.use_rgb ? (size_t)msc * 3 + c : 0];
+  }
+  // column group and first row of this thread in the elementwise head stages (row advances by THREADS / GPR per step)
+  const int eg = tid % GPR, er0 = tid / GPR;
+  constexpr int ERS = THREADS / GPR;
+  // the r1 / g2 rows of the head stages and the per-ray candidate-feature gradient rows: they travel under the prologue
+  f32x4 rv[EPT], gv[EPT], gg[EPT];
+  {
+    const float* __restrict__ r1p = a.use_rgb ? a.r1 : P;
+    const float* __restrict__ g2p = a.use_cand ? a.g2 : P;
+    const float* __restrict__ ggp = has_gc ? a.g_G_c : P;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      int m = m0 + er0 + ERS * q;
+      m = m < M ? m : M - 1;
+      rv[q] = NT_LOAD((const f32x4*)&r1p[a.use_rgb ? (size_t)m * W2 + 4 * eg : 0]);
+      gv[q] = NT_LOAD((const f32x4*)&g2p[a.use_cand ? (size_t)m * W2 + 4 * eg : 0]);
+      gg[q] = *(const f32x4*)&ggp[has_gc ? (size_t)(m / S) * W2 + 4 * eg : 0];
+    }
+  }
+  if (tid < WEXP_SLOTS) wexp_s[tid] = wexp_v;
   // softplus'(x) = 1 - exp(-softplus(x)); per-row feature weight on its ray slot; per-row scalars of the head stages
   if (tid < TILE) {
-    const int m = m0 + tid;
+    const int m = ms;
     float v = 0.0f, wf = 0.0f, dpc = 0.0f, cwj = 0.0f;
     f32x4 dprgb = {0.f, 0.f, 0.f, 0.f};
     int j = 0;
     if (m < M) {
-      v = a.d_sigma_s[m] * (1.0f - expf(-a.sigma_s[m]));
+      v = dss_v * (1.0f - expf(-ss_v));
       a.dpre_sig_s[m] = v;
-      if (a.g_E_s) wf = a.w_feat_s[m];
+      if (a.g_E_s) wf = wf_v;
       j = m / S - ray0;
       if (a.use_cand) {
-        dpc = a.d_sigma_c[m] * (1.0f - expf(-a.sigma_c[m]));
+        dpc = dsc_v * (1.0f - expf(-sc_v));
         a.dpre_sig_c[m] = dpc;
-        if (a.g_G_c) cwj = a.w_cj[m];
+        if (has_gc) cwj = cw_v;
       }
       if (a.use_rgb) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float y = a.rgb[(size_t)m * 3 + c];
-          dprgb[c] = a.d_rgb[(size_t)m * 3 + c] * (y * (1.0f - y));
-        }
+        for (int c = 0; c < 3; ++c) dprgb[c] = dy_v[c] * (y_v[c] * (1.0f - y_v[c]));
         *(f32x4*)&a.dpre_rgb[(size_t)m * 4] = dprgb;
       }
     }
@@ -859,9 +893,6 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     for (int q = 0; q < MAXRAYS; ++q) wfj[q][tid] = (q == j) ? wf : 0.0f;
   }
   __syncthreads();
-  // column group and first row of this thread in the elementwise head stages (row advances by THREADS / GPR per step)
-  const int eg = tid % GPR, er0 = tid / GPR;
-  constexpr int ERS = THREADS / GPR;
 
   STAMP_DECL;
   int erg = 0;  // exponent of the [gz_r1 | gz_g1] planes
@@ -869,33 +900,13 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
     f32x16 accg[TH::MT][TH::NT];
     acc_zero(accg);
     float mg1 = 0.0f;
-    // the r1 rows of the colour stage further down are requested HERE: they arrive under the candidate stage (its own row
-    // loads, its 128-wide contraction) instead of opening the colour stage with a second HBM round trip
-    f32x4 rv[EPT];
-    if (a.use_rgb) {
-#pragma unroll
-      for (int q = 0; q < EPT; ++q) {
-        int m = m0 + er0 + ERS * q;
-        m = m < M ? m : M - 1;
-        rv[q] = NT_LOAD((const f32x4*)&a.r1[(size_t)m * W2 + 4 * eg]);
-      }
-    }
     if (a.use_cand) {
       // d g2 = w_csig * dpre_c + w_cj * g_G_c[ray]   (candidate_sigma / feat_candidate_layer, nerf.py:99-100)
       f32x4 vals[EPT];
       float lmax = 0.0f;
       {
-        // all loads first, unconditionally (rows past M are clamped and masked afterwards): a branch around each load
-        // makes hipcc wait for every one of them in turn
+        // (the g2 / g_G_c rows were requested in the prologue; without a feature gradient cw is zero and gg finite: P's first words)
         const f32x4 wv = *(const f32x4*)&P[L.wcsig + 4 * eg];
-        f32x4 gv[EPT], gg[EPT];
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) {
-          int m = m0 + er0 + ERS * q;
-          m = m < M ? m : M - 1;
-          gv[q] = NT_LOAD((const f32x4*)&a.g2[(size_t)m * W2 + 4 * eg]);
-          gg[q] = a.g_G_c ? *(const f32x4*)&a.g_G_c[(size_t)(m / S) * W2 + 4 * eg] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
           const int row = er0 + ERS * q, m = m0 + row;
