@@ -579,6 +579,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
   constexpr int W = 256, W2 = 128;
   using C = RRCfg<NW>;
   __shared__ __attribute__((aligned(16))) char lds[C::LDS];  // ONE object: [ring | transposers | vectors | ray rows | tables]
+  __shared__ float wk_w[NW][16];                             // the ten band weights, one row per wave (encoding loop)
   char* ring = lds;
   float* vec_s = (float*)(lds + C::VEC0);
   float* rows_s = (float*)(lds + C::ROW0);
@@ -605,7 +606,43 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
   const bool train = a.h16 != nullptr;
   const int last_stage = (!a.e && !a.e16 && !use_rgb && !use_cand) ? D - 1 : ((!use_rgb && !use_cand) ? D : D + 3);
 
-  // ---- stage tables, vectors, per-ray rows (ordinary loads: all of them BEFORE the first DMA is in flight)
+  // ---- every ordinary load of the prologue, requested back to back and UNCONDITIONALLY (clamped indices, pointer selects for
+  // absent inputs; the values are masked when they are stored).  One workgroup owns a CU here, so nothing hides a prologue that
+  // takes its loads one at a time -- and behind `l < D ? P[..] : 0`, `use_rgb ? P[..] : 0`, `if (tid < n)` hipcc branches around
+  // every load and waits for it before the next: the ISA of round 5 had twenty `global_load ; s_waitcnt vmcnt(0)` pairs in a row
+  // in front of this kernel's first barrier, and three more per trip of the encoding loop (the band weights).
+  static_assert(C::THREADS >= 3 * W2 && C::THREADS >= W, "one thread per vector element");
+  const int tw = tid & (W - 1), th = tid & (W2 - 1);
+  float bias_v[UPNERF_MAX_D];
+#pragma unroll
+  for (int l = 0; l < UPNERF_MAX_D; ++l) bias_v[l] = P[(l < D ? L.b[l] : L.b[0]) + tw];
+  const float be_v = P[L.be + tw], wsig_v = P[L.wsig + tw];
+  const float br1_v = P[L.br1 + th], bc1_v = P[L.bc1 + th], bc2_v = P[L.bc2 + th], wcsig_v = P[L.wcsig + th];
+  const float wr2_v = P[L.wr2 + (tid < 3 * W2 ? tid : 0)];
+  const float bsig_v = P[L.bsig], bcsig_v = P[L.bcsig];               // (head biases: the layout has them whatever heads run)
+  const float br2_v[3] = {P[L.br2], P[L.br2 + 1], P[L.br2 + 2]};
+  const int wexp_v = a.wexp[tid < RR_MAXSTAGE ? tid : 0];
+  const float wnorm_v = a.wnorm[tid < RR_MAXSTAGE ? tid : 0];
+  const int mlast = (blockIdx.x * C::TILE + C::TILE < M ? blockIdx.x * C::TILE + C::TILE : M) - 1;
+  const int nr = mlast / S - ray0 + 1;
+  const float* __restrict__ aux_src = use_rgb ? a.aux + (size_t)ray0 * UPNERF_AUXK : P;
+  const float* __restrict__ crow_src = use_cand ? a.c_rows + (size_t)ray0 * UPNERF_CK : P;
+  const float aux_v = aux_src[use_rgb && tid < nr * UPNERF_AUXK ? tid : 0];
+  const float crow_v = crow_src[use_cand && tid < nr * UPNERF_CK ? tid : 0];
+  const float zz = a.z[mc];
+  float ro_v[3], rd_v[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    ro_v[n] = a.rays_o[3 * ray + n];
+    rd_v[n] = a.rays_d[3 * ray + n];
+  }
+  // the ten band weights (device table under graph replay): one request per wave here, read from a wave-private LDS row inside the
+  // encoding loop
+  const float* __restrict__ wk_src = a.wk_xyz_dev ? a.wk_xyz_dev : P;
+  float wk_v = wk_src[lane < 10 ? lane : 9];
+  if (!a.wk_xyz_dev) wk_v = a.wk_xyz[lane < 10 ? lane : 9];
+
+  // ---- stage tables, vectors, per-ray rows
   if (tid < RR_MAXSTAGE) {
     int off = 0, kb = 16, tiles = 0;
     const int st = tid;
@@ -630,36 +667,42 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
     int_s[16 + st] = kb;
     int_s[32 + st] = tiles;
     mx_s[st] = 0u;
-    int_s[64 + st] = a.wexp[st];
-    ((float*)int_s)[80 + st] = a.wnorm[st];
+    int_s[64 + st] = wexp_v;
+    ((float*)int_s)[80 + st] = wnorm_v;
   }
+  if (tid < W) {
 #pragma unroll
-  for (int l = 0; l < UPNERF_MAX_D; ++l)
-    for (int c = tid; c < W; c += C::THREADS) vec_s[256 * l + c] = l < D ? P[L.b[l] + c] : 0.0f;
-  for (int c = tid; c < W; c += C::THREADS) {
-    vec_s[RR_V_BE + c] = P[L.be + c];
-    vec_s[RR_V_WSIG + c] = P[L.wsig + c];
+    for (int l = 0; l < UPNERF_MAX_D; ++l) vec_s[256 * l + tid] = l < D ? bias_v[l] : 0.0f;
+    vec_s[RR_V_BE + tid] = be_v;
+    vec_s[RR_V_WSIG + tid] = wsig_v;
   }
-  for (int c = tid; c < W2; c += C::THREADS) {
-    vec_s[RR_V_BR1 + c] = use_rgb ? P[L.br1 + c] : 0.0f;
-    vec_s[RR_V_BC1 + c] = use_cand ? P[L.bc1 + c] : 0.0f;
-    vec_s[RR_V_BC2 + c] = use_cand ? P[L.bc2 + c] : 0.0f;
-    vec_s[RR_V_WCSIG + c] = use_cand ? P[L.wcsig + c] : 0.0f;
+  if (tid < W2) {
+    vec_s[RR_V_BR1 + tid] = use_rgb ? br1_v : 0.0f;
+    vec_s[RR_V_BC1 + tid] = use_cand ? bc1_v : 0.0f;
+    vec_s[RR_V_BC2 + tid] = use_cand ? bc2_v : 0.0f;
+    vec_s[RR_V_WCSIG + tid] = use_cand ? wcsig_v : 0.0f;
   }
-  for (int c = tid; c < 3 * W2; c += C::THREADS) vec_s[RR_V_WR2 + c] = use_rgb ? P[L.wr2 + c] : 0.0f;
+  if (tid < 3 * W2) vec_s[RR_V_WR2 + tid] = use_rgb ? wr2_v : 0.0f;
+  if (lane < 10) wk_w[wave][lane] = wk_v;
   // per-ray side inputs of the heads: [aux 80 | candidate row 16] per ray slot; their largest magnitude bounds the exponent of e
   float sidemax = 0.0f;
   {
-    const int mlast = (blockIdx.x * C::TILE + C::TILE < M ? blockIdx.x * C::TILE + C::TILE : M) - 1;
-    const int nr = mlast / S - ray0 + 1;
-    if (use_rgb)
-      for (int i = tid; i < nr * UPNERF_AUXK; i += C::THREADS) {
+    if (use_rgb && tid < nr * UPNERF_AUXK) {
+      rows_s[(tid / UPNERF_AUXK) * C::ROWF + tid % UPNERF_AUXK] = aux_v;
+      sidemax = fabsf(aux_v);
+    }
+    if (use_cand && tid < nr * UPNERF_CK) {
+      rows_s[(tid / UPNERF_CK) * C::ROWF + 96 + tid % UPNERF_CK] = crow_v;
+      sidemax = fmaxf(sidemax, fabsf(crow_v));
+    }
+    if (use_rgb)  // (more rows than threads: S < 64 only)
+      for (int i = tid + C::THREADS; i < nr * UPNERF_AUXK; i += C::THREADS) {
         const float v = a.aux[(size_t)ray0 * UPNERF_AUXK + i];
         rows_s[(i / UPNERF_AUXK) * C::ROWF + i % UPNERF_AUXK] = v;
         sidemax = fmaxf(sidemax, fabsf(v));
       }
     if (use_cand)
-      for (int i = tid; i < nr * UPNERF_CK; i += C::THREADS) {
+      for (int i = tid + C::THREADS; i < nr * UPNERF_CK; i += C::THREADS) {
         const float v = a.c_rows[(size_t)ray0 * UPNERF_CK + i];
         rows_s[(i / UPNERF_CK) * C::ROWF + 96 + i % UPNERF_CK] = v;
         sidemax = fmaxf(sidemax, fabsf(v));
@@ -669,13 +712,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
   // (coordinate, band) pairs of ITS sample once; the halves meet in an LDS scratch (the ring, not yet in use)
   float xm;
   {
-    const float zz = a.z[mc];
     float xyz[3];
 #pragma unroll
-    for (int n = 0; n < 3; ++n) xyz[n] = mul_then_add(a.rays_o[3 * ray + n], a.rays_d[3 * ray + n], zz);
+    for (int n = 0; n < 3; ++n) xyz[n] = mul_then_add(ro_v[n], rd_v[n], zz);
     xm = fmaxf(fmaxf(fabsf(xyz[0]), fabsf(xyz[1])), fmaxf(fabsf(xyz[2]), 1.0f));  // |sin|, |cos| <= 1
     float* pe = (float*)ring + (32 * wave + li) * RR_PE_LD;
-    const float* __restrict__ wkd = a.wk_xyz_dev;
+    const float* wkw = wk_w[wave];  // (written by this wave above: LDS operations of a wave execute in order)
+    asm volatile("" ::: "memory");
     if (hh == 0) {
       pe[0] = xyz[0];
       pe[1] = xyz[1];
@@ -690,8 +733,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
     for (int p = 0; p < 15; ++p) {
       const int n = p < 10 ? hh : 2, k = p < 10 ? p : 2 * (p - 10) + hh;
       const int ku = p < 10 ? p : 2 * (p - 10);  // wave-uniform: the (first) band of this trip
-      const float wk = wkd ? wkd[k] : a.wk_xyz[k];
-      const float wu0 = wkd ? wkd[ku] : a.wk_xyz[ku], wu1 = wkd ? wkd[ku + (p >= 10)] : a.wk_xyz[ku + (p >= 10)];
+      const float wk = wkw[k];
+      const float wu0 = wkw[ku], wu1 = wkw[ku + (p >= 10)];
       float sv = 0.0f, cv = 0.0f;
       if ((__builtin_amdgcn_readfirstlane(__float_as_uint(wu0)) | __builtin_amdgcn_readfirstlane(__float_as_uint(wu1))) != 0u) {
         const float xv = n == 0 ? xyz[0] : (n == 1 ? xyz[1] : xyz[2]);
@@ -743,13 +786,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_fwd_kernel(upnerf_layout
   __syncthreads();  // scratch reads done (the ring is free for the weight stream), tables / vector maxima visible
   sidemax = __uint_as_float(mx_s[15]);
 
-  const float bsig = P[L.bsig];
-  float br2[3] = {0.f, 0.f, 0.f}, bcsig = 0.0f;
-  if (use_rgb) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) br2[c] = P[L.br2 + c];
-  }
-  if (use_cand) bcsig = P[L.bcsig];
+  const float bsig = bsig_v;
+  float br2[3] = {use_rgb ? br2_v[0] : 0.f, use_rgb ? br2_v[1] : 0.f, use_rgb ? br2_v[2] : 0.f};
+  const float bcsig = use_cand ? bcsig_v : 0.0f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ordinary load / store of the prologue has retired: the counter starts at 0
 
   Ring<NW> rg;
@@ -1090,6 +1129,39 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
   float* __restrict__ rpart = a.tile_part ? a.tile_part + t32 * UPNERF_RR_PART_STRIDE : nullptr;
   const int rb = __builtin_amdgcn_readfirstlane((m0 / S + 1) * S - m0);  // first row of this wave's second ray (>= 32: none)
 
+  // ---- every ordinary load of the prologue, requested back to back and unconditionally (see the forward kernel: one workgroup
+  // per CU, nothing hides a prologue that takes its ~25 loads one round trip at a time)
+  static_assert(C::THREADS >= 3 * W2 && C::THREADS >= W, "one thread per vector element");
+  const bool has_ge = a.g_E_s != nullptr, has_gc = use_cand && a.g_G_c != nullptr;
+  const int wexp_v = a.wexp[tid < 16 ? tid : 0];
+  const float wnorm_v = a.wnorm[32 + (tid < 16 ? tid : 0)];
+  const float wsig_v = P[L.wsig + (tid & (W - 1))], wcsig_v = P[L.wcsig + (tid & (W2 - 1))], wr2_v = P[L.wr2 + (tid < 3 * W2 ? tid : 0)];
+  const int mlast = (blockIdx.x * C::TILE + C::TILE < M ? blockIdx.x * C::TILE + C::TILE : M) - 1;
+  const int nr = mlast / S - ray0 + 1;
+  const float* __restrict__ ge_src = has_ge ? a.g_E_s + (size_t)ray0 * W : P;
+  const float* __restrict__ gc_src = has_gc ? a.g_G_c + (size_t)ray0 * W2 : P;
+  float ge_v[3], gc_v[2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) ge_v[j] = ge_src[has_ge && tid + j * C::THREADS < nr * W ? tid + j * C::THREADS : 0];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) gc_v[j] = gc_src[has_gc && tid + j * C::THREADS < nr * W2 ? tid + j * C::THREADS : 0];
+  const float dss_v = a.d_sigma_s[mc], ss_v = a.sigma_s[mc];
+  const float wf_v = (has_ge ? a.w_feat_s : P)[has_ge ? mc : 0];
+  const float dsc_v = (use_cand ? a.d_sigma_c : P)[use_cand ? mc : 0], sc_v = (use_cand ? a.sigma_c : P)[use_cand ? mc : 0];
+  const float cw_v = (has_gc ? a.w_cj : P)[has_gc ? mc : 0];
+  float y_v[3], dy_v[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    y_v[c] = (use_rgb ? a.rgb : P)[use_rgb ? (size_t)mc * 3 + c : 0];
+    dy_v[c] = (use_rgb ? a.d_rgb : P)[use_rgb ? (size_t)mc * 3 + c : 0];
+  }
+  // sign bits of g2 / r1 (forward slots D + 1, D + 2): ordinary loads, nothing is in flight yet
+  const char* __restrict__ hm_src = (use_cand || use_rgb) ? (const char*)a.hmask : (const char*)P;
+  u32x4_t bits_g2 = *(const u32x4_t*)(hm_src + (use_cand ? (((size_t)(D + 1) * nt32 + t32) * 64 + lane) * 16 : 0));
+  u32x4_t bits_r1 = *(const u32x4_t*)(hm_src + (use_rgb ? (((size_t)(D + 2) * nt32 + t32) * 64 + lane) * 16 : 0));
+  if (!use_cand) bits_g2 = u32x4_t{0u, 0u, 0u, 0u};
+  if (!use_rgb) bits_r1 = u32x4_t{0u, 0u, 0u, 0u};
+
   // ---- stage tables.  Order of consumption: [t_wc2] [t_head] t_we, then for l = D-1 .. 1: [t_skipx at l == skip] t_w[l], then
   // [t_w[0]].  Stage ids: 0 wc2, 1 head, 2 we, 3 + 2 i (skipx) / 4 + 2 i (trunk) for l = D-1-i, 3 + 2 (D-1) = layer 0.
   if (tid < RB_NSTAGE) {
@@ -1120,25 +1192,41 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
     int_s[3 * RB_NSTAGE + st] = wrap;
     if (st < 16) {
       mx_s[st] = 0u;
-      int_s[4 * RB_NSTAGE + 16 + st] = a.wexp[st];
-      ((float*)int_s)[4 * RB_NSTAGE + 32 + st] = a.wnorm[32 + st];
+      int_s[4 * RB_NSTAGE + 16 + st] = wexp_v;
+      ((float*)int_s)[4 * RB_NSTAGE + 32 + st] = wnorm_v;
     }
   }
-  for (int c = tid; c < W; c += C::THREADS) vec_s[RB_V_WSIG + c] = P[L.wsig + c];
-  for (int c = tid; c < W2; c += C::THREADS) vec_s[RB_V_WCSIG + c] = use_cand ? P[L.wcsig + c] : 0.0f;
-  for (int c = tid; c < 3 * W2; c += C::THREADS) vec_s[RB_V_WR2 + c] = use_rgb ? P[L.wr2 + c] : 0.0f;
+  if (tid < W) vec_s[RB_V_WSIG + tid] = wsig_v;
+  if (tid < W2) vec_s[RB_V_WCSIG + tid] = use_cand ? wcsig_v : 0.0f;
+  if (tid < 3 * W2) vec_s[RB_V_WR2 + tid] = use_rgb ? wr2_v : 0.0f;
   // upstream gradients of the per-ray sums (rank-1 terms of d e and d g2), one row per ray slot; absent = zero
   float gEmax = 0.0f, gGmax = 0.0f;
   {
-    const int mlast = (blockIdx.x * C::TILE + C::TILE < M ? blockIdx.x * C::TILE + C::TILE : M) - 1;
-    const int nr = mlast / S - ray0 + 1;
-    for (int i = tid; i < nr * W; i += C::THREADS) {
-      const float v = a.g_E_s ? a.g_E_s[(size_t)ray0 * W + i] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = tid + j * C::THREADS;
+      if (i < nr * W) {
+        const float v = has_ge ? ge_v[j] : 0.0f;
+        rows_s[(i >> 8) * C::ROWF + (i & 255)] = v;
+        gEmax = fmaxf(gEmax, fabsf(v));
+      }
+    }
+    for (int i = tid + 3 * C::THREADS; i < nr * W; i += C::THREADS) {  // (more than six rays per tile: S < 64 only)
+      const float v = has_ge ? a.g_E_s[(size_t)ray0 * W + i] : 0.0f;
       rows_s[(i >> 8) * C::ROWF + (i & 255)] = v;
       gEmax = fmaxf(gEmax, fabsf(v));
     }
-    for (int i = tid; i < nr * W2; i += C::THREADS) {
-      const float v = (use_cand && a.g_G_c) ? a.g_G_c[(size_t)ray0 * W2 + i] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = tid + j * C::THREADS;
+      if (i < nr * W2) {
+        const float v = has_gc ? gc_v[j] : 0.0f;
+        rows_s[(i >> 7) * C::ROWF + 256 + (i & 127)] = v;
+        gGmax = fmaxf(gGmax, fabsf(v));
+      }
+    }
+    for (int i = tid + 2 * C::THREADS; i < nr * W2; i += C::THREADS) {
+      const float v = has_gc ? a.g_G_c[(size_t)ray0 * W2 + i] : 0.0f;
       rows_s[(i >> 7) * C::ROWF + 256 + (i & 127)] = v;
       gGmax = fmaxf(gGmax, fabsf(v));
     }
@@ -1147,18 +1235,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
   float dps = 0.0f, dpc = 0.0f, wf = 0.0f, cwj = 0.0f;
   f32x4 dprgb = {0.f, 0.f, 0.f, 0.f};
   if (valid) {
-    dps = a.d_sigma_s[m] * (1.0f - expf(-a.sigma_s[m]));
-    if (a.g_E_s) wf = a.w_feat_s[m];
+    dps = dss_v * (1.0f - expf(-ss_v));
+    if (has_ge) wf = wf_v;
     if (use_cand) {
-      dpc = a.d_sigma_c[m] * (1.0f - expf(-a.sigma_c[m]));
-      if (a.g_G_c) cwj = a.w_cj[m];
+      dpc = dsc_v * (1.0f - expf(-sc_v));
+      if (has_gc) cwj = cw_v;
     }
     if (use_rgb) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float y = a.rgb[(size_t)m * 3 + c];
-        dprgb[c] = a.d_rgb[(size_t)m * 3 + c] * (y * (1.0f - y));
-      }
+      for (int c = 0; c < 3; ++c) dprgb[c] = dy_v[c] * (y_v[c] * (1.0f - y_v[c]));
     }
     if (hh == 0) {
       a.dpre_sig_s[m] = dps;
@@ -1166,10 +1251,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
       if (use_rgb) *(f32x4*)&a.dpre_rgb[(size_t)m * 4] = dprgb;
     }
   }
-  // sign bits of g2 / r1 (forward slots D + 1, D + 2): ordinary loads, nothing is in flight yet
-  u32x4_t bits_g2 = {0u, 0u, 0u, 0u}, bits_r1 = {0u, 0u, 0u, 0u};
-  if (use_cand) bits_g2 = *(const u32x4_t*)((const char*)a.hmask + (((size_t)(D + 1) * nt32 + t32) * 64 + lane) * 16);
-  if (use_rgb) bits_r1 = *(const u32x4_t*)((const char*)a.hmask + (((size_t)(D + 2) * nt32 + t32) * 64 + lane) * 16);
   gEmax = wave_max_rr(gEmax);
   gGmax = wave_max_rr(gGmax);
   __syncthreads();  // tables written
