@@ -185,6 +185,10 @@ typedef struct {
   uint8_t* h_lo8;                /* f16x3 mode with h16, or NULL: [D][M][W] bytes, the rounding residual of every h16 element in 1/32 of
                                     its tile's scaled unit (byte = round(32 lo) + 128): h16 + h_lo8 = the trunk activation to 2^-20
                                     of its tile's maximum in 3 bytes ("24-bit" weight-gradient operands, upnerf_wgrad_f24p_chain) */
+  int64_t rows_capacity;         /* (ABI 9) tile_rows = 256: the number of rows every per-sample tensor passed here was allocated with.
+                                    The register-resident kernels write whole 256-sample tiles: tensors need ceil(M / 256) * 256 rows.
+                                    A caller that says so here gets UPNERF_EINVAL instead of a write past the end when it is less;
+                                    0 = not stated (unchecked, as before) */
 } upnerf_field_fwd_args;
 
 int upnerf_field_fwd(const upnerf_layout* L, const upnerf_field_fwd_args* a, void* stream);
@@ -315,6 +319,7 @@ typedef struct {
   uint16_t* gz_g2_16;            /* tile_rows = 256, or NULL: gz_g2 as 128-wide fp16 operand fragments (then gz_g2 may be NULL) */
   int32_t* gzg2exp;
   uint8_t* gz_lo8;               /* f16x3 mode with gz16, or NULL: [D][M][W] residual bytes of gz16 (as upnerf_field_fwd_args.h_lo8) */
+  int64_t rows_capacity;         /* (ABI 9) as in upnerf_field_fwd_args */
 } upnerf_field_bwd_args;
 
 /* Layout of one row of tile_part (floats): d w_csig [W/2] | d w_r2 [3][W/2] | sum dpre_sig_c, sum dpre_rgb[0..2] | 4 pad |

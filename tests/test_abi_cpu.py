@@ -67,6 +67,13 @@ def test_argument_errors_are_reported_not_crashed():
     L = _lib.Layout()
     L.W, L.D, L.skip = 100, 8, 4
     assert _lib.lib.upnerf_field_fwd(ctypes.byref(L), ctypes.byref(_lib.FieldFwdArgs()), None) == -2
+    # the register-resident kernels write whole 256-sample tiles: a caller that states how many rows its tensors have is refused
+    # when that is less than ceil(M / 256) * 256 (r4 ADVICE) -- before anything is launched
+    L.W, L.D, L.skip = 256, 8, 4
+    one = ctypes.cast(ctypes.c_void_p(16), ctypes.c_void_p)  # (non-null, never dereferenced on the host)
+    fa = _lib.FieldFwdArgs(R=10, S=64, planes=1, tile_rows=256, rays_o=one, rays_d=one, z=one, P=one, P16=one, wexp=one, x0=one,
+                           sigma_s=one, wnorm=one, rows_capacity=640)
+    assert _lib.lib.upnerf_field_fwd_f16x3(ctypes.byref(L), ctypes.byref(fa), None) == -1  # 640 rows < 768
 
 
 def test_host_wrappers_refuse_or_fall_back_cleanly_without_a_gpu():

@@ -37,7 +37,8 @@ class FieldFwdArgs(C.Structure):
                 ("x0", _fp), ("h", _fp), ("hmask", _fp), ("amax", _fp), ("e", _fp), ("g1", _fp), ("g2", _fp), ("r1", _fp),
                 ("P16", _fp), ("wexp", _fp), ("wk_xyz_dev", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("wnorm", _fp),
                 ("h16", _fp), ("hexp", _fp), ("h_last_only", C.c_int32), ("x0f", _fp), ("e16", _fp), ("eexp", _fp),
-                ("g2_16", _fp), ("g2exp", _fp), ("r1_16", _fp), ("r1exp", _fp), ("g1_16", _fp), ("g1exp", _fp), ("h_lo8", _fp)]
+                ("g2_16", _fp), ("g2exp", _fp), ("r1_16", _fp), ("r1exp", _fp), ("g1_16", _fp), ("g1exp", _fp), ("h_lo8", _fp),
+                ("rows_capacity", C.c_int64)]
 
 
 class CompositeFwdArgs(C.Structure):
@@ -71,7 +72,8 @@ class FieldBwdArgs(C.Structure):
                 ("gz_h", _fp), ("gz_e", _fp), ("gz_g1", _fp), ("gz_g2", _fp), ("gz_r1", _fp),
                 ("dpre_sig_s", _fp), ("dpre_sig_c", _fp), ("dpre_rgb", _fp), ("dxyz", _fp),
                 ("PT16", _fp), ("wexp", _fp), ("planes", C.c_int32), ("tile_rows", C.c_int32), ("gz16", _fp), ("gzexp", _fp), ("xs", _fp), ("tile_part", _fp), ("gz_rg_ld", C.c_int32), ("reserved_", C.c_int32), ("wnorm", _fp),
-                ("gz_rg16", _fp), ("gzrgexp", _fp), ("gz_g2_16", _fp), ("gzg2exp", _fp), ("gz_lo8", _fp)]
+                ("gz_rg16", _fp), ("gzrgexp", _fp), ("gz_g2_16", _fp), ("gzg2exp", _fp), ("gz_lo8", _fp),
+                ("rows_capacity", C.c_int64)]
 
 
 class LossArgs(C.Structure):

@@ -1264,6 +1264,7 @@ extern "C" int upnerf_field_fwd_f16x3(const upnerf_layout* L, const upnerf_field
     if (a->planes != 1) return UPNERF_EUNSUP;
     if (a->S < 32) return UPNERF_EUNSUP;  // at most 9 rays per 256-sample tile
     if (!a->wnorm) return UPNERF_EINVAL;
+    if (a->rows_capacity != 0 && a->rows_capacity < (M + 255) / 256 * 256) return UPNERF_EINVAL;  // whole tiles are written
     if ((a->e16 && !a->eexp) || (a->g2_16 && !a->g2exp) || (a->r1_16 && !a->r1exp) || (a->g1_16 && !a->g1exp)) return UPNERF_EINVAL;
     if (a->h16 && !a->hmask) return UPNERF_EINVAL;
     if (a->use_cand && !a->g2 && !a->g2_16) return UPNERF_EINVAL;
@@ -1304,6 +1305,7 @@ extern "C" int upnerf_field_bwd_f16x3(const upnerf_layout* L, const upnerf_field
   if (a->tile_rows == 256) {  // register-resident kernels (csrc/field16rr.hip)
     if (a->planes != 1) return UPNERF_EUNSUP;
     if (!a->wnorm || !a->gz16) return UPNERF_EINVAL;
+    if (a->rows_capacity != 0 && a->rows_capacity < (M + 255) / 256 * 256) return UPNERF_EINVAL;  // whole tiles are written
     return upnerf_rr16_bwd_launch(L, a, stream);
   }
   if (a->wnorm) return UPNERF_EUNSUP;

@@ -215,7 +215,8 @@ class _FieldPass(torch.autograd.Function):
                           P16=ptr(P16), wexp=ptr(wexp), wk_xyz_dev=dyn.ptr_named("wk_xyz", 10) if dyn else None,
                           planes=_planes(), tile_rows=tile, wnorm=ptr(wnorm), h16=ptr(h16), hexp=ptr(hexp),
                           h_last_only=int(store16), x0f=ptr(x0f), e16=ptr(e16), eexp=ptr(eexp),
-                          g2_16=ptr(g2_16), g2exp=ptr(g2exp), r1_16=ptr(r1_16), r1exp=ptr(r1exp), g1_16=ptr(g1_16), g1exp=ptr(g1exp), h_lo8=ptr(h_lo8))
+                          g2_16=ptr(g2_16), g2exp=ptr(g2exp), r1_16=ptr(r1_16), r1exp=ptr(r1exp), g1_16=ptr(g1_16), g1exp=ptr(g1exp), h_lo8=ptr(h_lo8),
+                          rows_capacity=Mp if rr else 0)  # (rr: every per-sample tensor above was allocated with Mp rows)
         fwd_fn = lib.upnerf_field_fwd_f16x3 if use16 else lib.upnerf_field_fwd
         check(TIMER.run("field_fwd", lambda: fwd_fn(C.byref(L), C.byref(fa), st), units=M), "upnerf_field_fwd")
 
@@ -332,7 +333,8 @@ class _FieldPass(torch.autograd.Function):
                           gz_r1=ptr(gz_rg) if gz_rg is not None else ptr(gz_r1), gz_rg_ld=W if gz_rg is not None else 0,
                           gz_rg16=ptr(gz_rg16), gzrgexp=ptr(gzrgexp), gz_g2_16=ptr(gz_g2_16), gzg2exp=ptr(gzg2exp), gz_lo8=ptr(gz_lo8), dpre_sig_s=ptr(dpre_s), dpre_sig_c=ptr(dpre_c), dpre_rgb=ptr(dpre_rgb),
                           dxyz=ptr(dxyz), PT16=ptr(sv["PT16"]), wexp=ptr(sv["wexp"]), planes=ctx.planes, tile_rows=ctx.tile_rows, xs=ptr(sv.get("x0f")), gz16=ptr(gz16),
-                          gzexp=ptr(gzexp), tile_part=ptr(ray_part if rr else tile_part), wnorm=ptr(sv.get("wnorm")))
+                          gzexp=ptr(gzexp), tile_part=ptr(ray_part if rr else tile_part), wnorm=ptr(sv.get("wnorm")),
+                          rows_capacity=Mp if rr else 0)
         bwd_fn = lib.upnerf_field_bwd_f16x3 if use16 else lib.upnerf_field_bwd
         check(TIMER.run("field_bwd", lambda: bwd_fn(C.byref(L), C.byref(fb), st), units=M), "upnerf_field_bwd")
 
