@@ -440,6 +440,70 @@ def test_only_the_known_goldens_take_the_flipped_branch():
     assert took <= KNOWN_FLIPPED, f"new cases on the loose gradient gate: {sorted(took - KNOWN_FLIPPED)}"
 
 
+def test_feature_less_fields_validate_and_optimise_at_test_time():
+    """encode_feat = False beyond the training step: the chunked no-grad validation render (nerf_system.py:231-269) and one
+    test-time-optimisation step on frozen fields (nerf_system_optmize.py:84-129, sched 1) of the `nofeat_phase2` golden's system
+    -- the maps against the reference's golden / the oracle, the TTO gradients against the oracle."""
+    from golden_util import orc
+    from upnerf_amd.nerf_system import SyntheticDataset, default_hparams
+    from upnerf_amd.nerf_system_optimize import NeRFSystemOptimize
+    c = Case("nofeat_phase2")
+    assert not c.encode_feat
+    sysm = build_system(c)
+    sysm.hparams["val.chunk_size"] = 3  # 8 rays: three chunks
+    b = c.batch()
+    val = {k: v.cuda()[None] for k, v in b.items()}
+    log = sysm.validation_step(val)
+    res = log["results"]
+    # perturb = 0 in validation: compare with the oracle's deterministic render of the same rays
+    with torch.no_grad():
+        real = orc.schedule_mult
+        orc.schedule_mult = lambda p, s_: c.sched
+        try:
+            hp = dict(c.hparams(), **{"nerf.perturb": 0.0})
+            _, ref = orc.training_forward(c.state(requires_grad=False), c.cfgs(), c.batch(), hp, c.progress)
+        finally:
+            orc.schedule_mult = real
+    for k in ("s_rgb_coarse", "s_rgb_fine", "s_depth_fine", "rgb_fine"):
+        assert rel_err(res[k].cpu().numpy(), ref[k].numpy()) < (TOL_MAP if "depth" not in k else 5e-3), k
+    assert torch.isfinite(log["val_psnr"]).all()
+    # one TTO step on the frozen feature-less fields
+    hp = default_hparams(**{"nerf.N_samples": c.Nc, "nerf.N_importance": c.Nf, "nerf.perturb": 0.0, "pose.c2f": c.c2f,
+                            "nerf.D": c.D, "nerf.W": c.W, "nerf.feat_dim": 0, "val.chunk_size": 4})
+    tto = NeRFSystemOptimize(hp, SyntheticDataset(c.n_img), pose_optimize=True)
+    tto.train_dataset = SyntheticDataset(c.n_img)
+    tto.model_setup(trained_state=sysm.state_dict(), n_test_images=1)
+    tto.cuda()
+    with torch.no_grad():
+        tto.embedding_fine_a.weight.copy_(sysm.embedding_fine_a.weight[3:4])
+        tto.se3_refine.weight.copy_(sysm.se3_refine.weight[5:6])
+    batch = {k: v.cuda() for k, v in b.items()}
+    batch["img_idx"] = torch.zeros_like(batch["img_idx"])
+    loss, _, r2 = tto.compute_loss(batch)
+    loss.backward()
+    assert all(p.grad is None for p in tto.nerf_fine.parameters())
+    st = c.state(requires_grad=False)
+    a_row = st["embedding_fine_a"][3:4].clone().requires_grad_(True)
+    se3_row = st["se3_refine"][5:6].clone().requires_grad_(True)
+    st["embedding_fine_a"], st["embedding_coarse_a"] = a_row.expand(c.n_img, -1), st["embedding_coarse_a"]
+    st["se3_refine"] = se3_row.expand(c.n_img, -1)
+    cf = c.cfgs()
+    for v in cf.values():
+        v.encode_candidate = False
+    pose = orc.compose_pair(orc.se3_exp(st["se3_refine"][b["img_idx"]]), b["c2w"])
+    o, d = orc.get_rays(b["directions"], pose)
+    rays = torch.cat([o, d, b["ray_infos"]], 1)
+    emb = {k[len("embedding_"):]: v for k, v in st.items() if k.startswith("embedding_")}
+    ro = orc.render_rays({k: st[k] for k in ("nerf_coarse", "nerf_fine")}, cf, emb, rays, b["img_idx"], 1.0, N_samples=c.Nc,
+                         perturb=0.0, N_importance=c.Nf, progress=c.progress)
+    lo = ((ro["s_rgb_fine"] - b["rgbs"]) ** 2).mean()
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < TOL_MAP * max(1e-2, abs(float(lo)))
+    assert rel_err(r2["s_rgb_fine"].detach().cpu().numpy(), ro["s_rgb_fine"].detach().numpy()) < TOL_MAP
+    assert rel_err(tto.embedding_fine_a.weight.grad.cpu().numpy(), a_row.grad.numpy()) < 2e-3
+    assert rel_err(tto.se3_refine.weight.grad.cpu().numpy(), se3_row.grad.numpy()) < 1.5e-2
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     """The product path must not fall back: without the .so, importing the binding raises ImportError."""
     import importlib
