@@ -103,18 +103,36 @@ def executed_mac(sched, direction="fwd", pose=True):
 HBM_COPY_TBS = 6.29  # /opt/skills/guides/MI355X_MICROARCH.md: measured float4 copy rate (8.0 TB/s spec)
 
 
-def step_object(tflop_alg, tflop_exec, ms_per_step, field, step_bytes):
+def step_object(tflop_alg, tflop_exec, ms_per_step, field, step_bytes, comm_ms=None):
     """`roofline.step`: the whole step against its two floors -- algorithmic FLOPs at the dense peak of the field arithmetic,
     and the step's measured HBM bytes (PMC, all kernels; null without a profile of these sources) at the measured copy rate."""
     mfma_ms = tflop_alg / PEAK[field] * 1e3
     hbm_ms = None if step_bytes is None else step_bytes / (HBM_COPY_TBS * 1e12) * 1e3
     floor = max(mfma_ms, hbm_ms or 0.0)
+    if comm_ms is not None:  # N > 1: the exchange is not the kernels' time -- the floors are compared with the step minus it
+        compute_ms = max(ms_per_step - comm_ms, 1e-9)
+        return {"algorithmic_tflop": tflop_alg, "algorithmic_tflops": tflop_alg / (compute_ms * 1e-3),
+                "executed_tflop": tflop_exec, "mfma_floor_ms": mfma_ms, "hbm_bytes": step_bytes, "hbm_floor_ms": hbm_ms,
+                "binding_floor": None if hbm_ms is None else ("hbm" if hbm_ms >= mfma_ms else "mfma"),
+                "frac_of_floor": floor / compute_ms, "ms_per_step": ms_per_step, "comm_ms": comm_ms, "compute_ms": compute_ms,
+                "note": "per rank; compute_ms = ms_per_step - comm.allreduce_ms (the serial exchange of a replayed step); floors as "
+                        "at N = 1: algorithmic TFLOP / dense peak, PMC bytes / 6.29 TB/s; frac_of_floor = larger floor / compute_ms"}
     return {"algorithmic_tflop": tflop_alg, "algorithmic_tflops": tflop_alg / (ms_per_step * 1e-3),
             "executed_tflop": tflop_exec, "mfma_floor_ms": mfma_ms, "hbm_bytes": step_bytes, "hbm_floor_ms": hbm_ms,
             "binding_floor": None if hbm_ms is None else ("hbm" if hbm_ms >= mfma_ms else "mfma"),
             "frac_of_floor": floor / ms_per_step, "ms_per_step": ms_per_step,
             "note": "mfma_floor = algorithmic TFLOP / dense peak of the field arithmetic (2.4 GHz); hbm_floor = PMC bytes of "
                     "every kernel of a step / 6.29 TB/s (measured copy rate); frac_of_floor = the larger floor / the step"}
+
+
+def comm_object(c, graph):
+    """`comm` of an N > 1 line: what the gradient exchange cost per step, so that a scaling shortfall can be attributed without
+    a second run.  allreduce_ms = time inside the all-reduce calls (max over ranks; includes waiting for the slowest rank to
+    arrive), bytes = fp32 gradient bytes a rank contributes per step."""
+    return {"allreduce_ms": c["allreduce_ms"], "bytes": c["bytes"], "allreduces_per_step": c["allreduces_per_step"],
+            "early_launches": c["early_launches"], "late_only": c["late_only"], "clock": c["clock"],
+            "placement": "between the two HIP graphs of a replayed step, in series (DESIGN.md section 7)" if graph
+                         else "eager: fine-field bucket on a side stream under the rest of backward, the rest at its end"}
 
 
 def source_sha16():
@@ -241,6 +259,9 @@ class Bench:
         TIMER.reset()
         TIMER.enabled, TIMER.only = timer_only is not None, timer_only or None
         calls0 = _lib.CALLS[0]
+        sync = sysm.grad_sync if self.world > 1 else None
+        if sync is not None:
+            sync.comm_reset(timing=True)  # HIP events around every all-reduce of the timed steps (read back after the barrier)
         # no cyclic garbage collection inside the timed region: a generation-2 pass over the module / ctypes objects of a freshly
         # built system costs tens of ms of host time and lands wherever the allocation counters put it (seen inside a 4-step
         # region: 134 k instead of 240 k rays/s); collected here instead, re-enabled after the last repeat
@@ -255,13 +276,19 @@ class Bench:
             self.barrier()
             dt = time.perf_counter() - t0
             TIMER.enabled = False
+            comm = None
+            if sync is not None:
+                comm = sync.comm_summary(steps)
+                sync.comm_reset(timing=False)
             if self.world > 1:
-                t = torch.tensor([dt, host], device=self.dev, dtype=torch.float64)
+                t = torch.tensor([dt, host, comm["allreduce_ms"]], device=self.dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt, host = float(t[0]), float(t[1])
+                dt, host, comm["allreduce_ms"] = float(t[0]), float(t[1]), float(t[2])
             out = {"value": self.world * self.rays * steps / dt, "ms_per_step": dt / steps * 1e3,
                    "host_issue_ms_per_step": host / steps * 1e3, "c_abi_calls_per_step": (_lib.CALLS[0] - calls0) / steps,
                    "sched_mult": sysm.get_schedule_mult(progress), "graph": bool(graph)}
+            if comm is not None:
+                out["comm"] = comm_object(comm, graph)
             if repeats > 1 and timer_only is None:
                 vals = [out["value"]]
                 for _ in range(repeats - 1):
@@ -448,19 +475,38 @@ def main():
 
     if args.dry_run:  # plumbing only: same barriers / max-over-ranks / one line from rank 0
         t = torch.zeros(1)
-        if world > 1:
+        sync = None
+        if world > 1:  # ... and the gradient exchange of the real step at its real size (2.25 M floats, fine-field bucket early)
+            n_fine, n_rest = 823_000, 1_426_577
+            ps = [torch.nn.Parameter(torch.zeros(n_fine)), torch.nn.Parameter(torch.zeros(n_rest))]
+            sync = parallel.GradSync(ps, early=ps[:1])
+            sync.comm_reset(timing=True)
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             t += 1
+            if sync is not None:
+                sync.begin(1)
+                for q in ps:
+                    q.grad = torch.full_like(q, float(rank))
+                    if q is ps[0]:
+                        sync._on_grad(q)  # (what the post-accumulate-grad hook does inside a backward pass)
+                sync()
         if world > 1:
             dist.barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dt = torch.tensor([time.perf_counter() - t0, sync.comm_summary(args.steps)["allreduce_ms"] if sync else 0.0], dtype=torch.float64)
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            assert float(ps[1].grad[0]) == (world - 1) / 2.0  # the mean over ranks arrived
+        comm = None
+        if sync is not None:
+            c = sync.comm_summary(args.steps)
+            c["allreduce_ms"] = float(dt[1])
+            comm = comm_object(c, False)
         if rank == 0:
             print(json.dumps({"metric": "training rays/sec", "value": 0.0, "unit": "rays/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(dt) / args.steps * 1e3,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(dt[0]) / args.steps * 1e3,
+                              **({"comm": comm, "roofline": {"step": step_object(0.0, 0.0, float(dt[0]) / args.steps * 1e3, field, None, comm["allreduce_ms"])}} if comm else {}),
                               "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
                               "dtype": DTYPE[field], "data": "synthetic", "dry_run": True, "world_size_observed": observed, "backend": backend,
                               "config": {"workload": cfg["workload"], "parallelism": f"dp{world}"}}))
@@ -540,6 +586,8 @@ def main():
     }
     if "graph_stats" in main_leg:
         line["graph_stats"] = main_leg["graph_stats"]
+    if "comm" in main_leg:
+        line["comm"] = main_leg["comm"]
     line.update(extras)
     if summ:
         per_sample = {"field_fwd": 2 * mac, "field_bwd": 2 * mac, "wgrad_256x256": 2 * 256 * 256,
@@ -578,7 +626,8 @@ def main():
                             "executed_frac": exe / peak,
                             "step": step_object(line["algorithmic_tflop_per_step"],
                                                 2 * (2 * executed_mac(sched, "fwd") + executed_mac(sched, "bwd")) * spr / 1e12,
-                                                main_leg["ms_per_step"], field, step_bytes),
+                                                main_leg["ms_per_step"], field, step_bytes,
+                                                main_leg["comm"]["allreduce_ms"] if "comm" in main_leg else None),
                             "traffic": traffic, "traffic_source": source,
                             "hbm_bytes_per_step": step_bytes,  # all kernels of a step, same PMC passes (null with traffic)
                             "avg_launch_ms": kern[dom]["avg_ms"],

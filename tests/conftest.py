@@ -26,3 +26,19 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The widened-gate report of the golden / mid-size gradient comparisons (tests/test_hip_parity.py:widened_lines): one line per
+    comparison whose gate stood above the flat 1e-3, with the measured error.  Copied per round to profiles/rNN_parity_widened.txt."""
+    m = sys.modules.get("test_hip_parity")
+    if m is None or not getattr(m, "_WIDENED", None):
+        return
+    path = os.environ.get("UPNERF_WIDENED_OUT", os.path.join(ROOT, "gpurun_out", "parity_widened.txt"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write("# case\tparameter\tgate\tmeasured error\tneeded its widening?  (gate = max(1e-3, min(4 x reference noise, 3e-2)))\n")
+            f.write("\n".join(m.widened_lines()) + "\n")
+    except OSError:
+        pass

@@ -104,6 +104,15 @@ def test_eight_ranks_dry_run_is_the_line_the_scale_run_expects():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["world_size_observed"] == 8 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
     assert d["backend"] == "gloo" and d["dry_run"] is True and d["steps"] == 2
+    # an N > 1 line attributes its communication -- time inside the all-reduces, bytes per rank and step, how
+    # often the early (fine-field) bucket went out -- and roofline.step subtracts it
+    c = d["comm"]
+    assert set(c) >= {"allreduce_ms", "bytes", "allreduces_per_step", "early_launches", "late_only", "clock", "placement"}
+    assert c["bytes"] == 4 * (823_000 + 1_426_577) and c["allreduce_ms"] > 0
+    # the first step of a phase learns the early count (late only), the second launches the early bucket
+    assert c["late_only"] == 1 and c["early_launches"] == 1 and c["allreduces_per_step"] == 1.5
+    st = d["roofline"]["step"]
+    assert abs(st["compute_ms"] - (d["ms_per_step"] - c["allreduce_ms"])) < 1e-9 and st["comm_ms"] == c["allreduce_ms"]
 
 
 def test_a_dead_rank_is_a_nonzero_exit():
@@ -151,3 +160,6 @@ def test_two_ranks_spawned_on_one_device_run_the_real_step():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["world_size_observed"] == 2 and d["graph_stats"]["replays"] >= 4
     assert abs(d["value"] - 2 * 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    c = d["comm"]  # the exchange of the replayed step: one flat all-reduce between the two graphs
+    assert 8.0e6 < c["bytes"] < 9.5e6 and c["allreduces_per_step"] == 1.0 and 0 < c["allreduce_ms"] < d["ms_per_step"]
+    assert c["placement"].startswith("between the two HIP graphs")

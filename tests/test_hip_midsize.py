@@ -7,7 +7,7 @@ agreement here is agreement with the reference at a batch size the committed fix
      99.9 % (the inverse CDF divides by the bin mass, and the reference's `denom < eps -> 1` rule, rendering.py:44-46, lets a
      draw in a bin of mass ~eps hop a bin under 1e-7 perturbations of the coarse weights);
   2. everything else with the oracle evaluated AT the GPU's fine depths: per-ray maps and losses 1e-4, per-sample weights
-     2e-4, every parameter gradient max(1e-3, 4 x the reference's own fp32-vs-fp64 noise on that tensor) -- the gates of
+     2e-4, every parameter gradient max(1e-3, min(4 x the reference's own fp32-vs-fp64 noise on that tensor, 3e-2)) -- the gates of
      tests/test_hip_parity.py;
   3. the fp16 field mode (BASELINE.json configs[3]) at its stated gates: maps 1e-2, per-sample weights 3e-2, gradients --
      INCLUDING every NeRF weight gradient -- relative L2 6e-2."""
@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from golden_util import Case, named_grads, orc, rel_err
-from test_hip_parity import TOL_GRAD, TOL_MAP, TOL_W, build_system
+from test_hip_parity import TOL_GRAD, TOL_MAP, TOL_W, build_system, grad_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -122,7 +122,9 @@ def test_mid_size_batch_matches_the_oracle(name):
                 bad[n] = "expected no gradient"
             continue
         e = rel_err(g.detach().cpu().numpy(), r.numpy())
-        if not e < TOL_GRAD and not e < 4 * reference_noise().get(n, 0.0):
+        # (the gate of tests/test_hip_parity.py: widened by the reference's own noise, never beyond GRAD_GATE_CAP; listed in the
+        # session's widened-gate report under "mid:<case>")
+        if not e < TOL_GRAD and not e < grad_gate(reference_noise().get(n, 0.0), "mid:" + name, n, e):
             bad[n] = (e, noise.get(n, 0.0))
     assert not bad, bad
 

@@ -14,6 +14,7 @@ ap.add_argument("--field", default="f16x3")
 ap.add_argument("--config", default="brandenburg")
 ap.add_argument("--progress", type=float, default=0.3)
 ap.add_argument("--out", default="pmc_current.json", help="file name under profiles/ (bench.py reads pmc_current.json for the headline, pmc_current_trevi.json for the trevi object)")
+ap.add_argument("--name", default=None, help="name the PMC json is committed under in profiles/ (e.g. r06_pmc.json): what `roofline.traffic_source` cites; default: the input file's name")
 a = ap.parse_args()
 pmc = json.load(open(a.pmc_json))
 np_ = "1" if a.field == "f16" else "2"
@@ -36,6 +37,6 @@ if steps:
     step_bytes = sum((t.get("fetch_bytes_per_launch", 0) + t.get("write_bytes_per_launch", 0)) * t.get("dispatches", 0)
                      for t in pmc.values() if isinstance(t, dict)) / steps
 out = {"src_sha16": bench.source_sha16(), "hbm_bytes_per_step": step_bytes, "field": a.field, "config": a.config, "progress": a.progress,
-       "file": os.path.basename(a.pmc_json), "kernels": kern}
+       "file": a.name or os.path.basename(a.pmc_json), "kernels": kern}
 json.dump(out, open(os.path.join(ROOT, "profiles", a.out), "w"), indent=1)
 print(json.dumps(out, indent=1))

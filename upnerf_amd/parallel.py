@@ -11,6 +11,7 @@ checked (cheaply, by count and total size) in debug mode."""
 from __future__ import annotations
 
 import os
+import time
 from typing import Iterable, List, Optional
 
 import torch
@@ -62,6 +63,11 @@ class GradSync:
         self._early_flat, self._early_live, self._stream = None, [], None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.early]
         self.stats = {"early_launches": 0, "late_only": 0}
+        # communication attribution (bench.py `comm`): with `timing` on, every all-reduce is bracketed -- by HIP events on the
+        # stream it is enqueued on (no host synchronisation: the pairs are read back in comm_summary()), by the host clock for a
+        # CPU group -- and the floats it moved are counted
+        self.timing = False
+        self._pairs, self._host_s, self._floats, self._reduces = [], 0.0, 0, 0
 
     # ---- early bucket ------------------------------------------------------------------------------------------------------
     def begin(self, key) -> None:
@@ -93,10 +99,13 @@ class GradSync:
             self._stream.wait_stream(torch.cuda.current_stream(dev))  # the gradients are complete on the compute stream
             with torch.cuda.stream(self._stream):
                 torch._foreach_copy_(views, [p.grad for p in live])
+                ev = self._mark(dev)
                 self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._mark_end(ev, dev, n)
         else:
             torch._foreach_copy_(views, [p.grad for p in live])
             self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._mark_end(None, dev, n)  # (asynchronous on a CPU group: its wait is timed in _finish_early)
         self._early_live, self._early_views = live, views
         self.stats["early_launches"] += 1
 
@@ -104,7 +113,10 @@ class GradSync:
         """Wait for the early all-reduce and write the averages back; returns the ids of the parameters it covered."""
         if self._work is None:
             return set()
+        t0 = time.perf_counter()
         self._work.wait()
+        if self.timing and not self._early_flat.is_cuda:
+            self._host_s += time.perf_counter() - t0
         flat = self._early_flat[:sum(v.numel() for v in self._early_views)]
         if flat.is_cuda:
             torch.cuda.current_stream(flat.device).wait_stream(self._stream)
@@ -152,8 +164,48 @@ class GradSync:
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
             if not (torch.equal(lo, sig) and torch.equal(hi, sig)):
                 raise RuntimeError("ranks disagree on which parameters received gradients")
+        ev = self._mark(flat.device)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._mark_end(ev, flat.device, n)
         flat.mul_(1.0 / self.world)
+
+    # ---- communication attribution -------------------------------------------------------------------------------------------
+    def _mark(self, dev):
+        if not self.timing:
+            return None
+        if dev.type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(dev))
+            return ev
+        return time.perf_counter()
+
+    def _mark_end(self, start, dev, n) -> None:
+        if not self.timing:
+            return
+        self._floats += n
+        self._reduces += 1
+        if start is None:
+            return
+        if dev.type == "cuda":
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream(dev))
+            self._pairs.append((start, end))
+        else:
+            self._host_s += time.perf_counter() - start
+
+    def comm_reset(self, timing: bool = True) -> None:
+        self.timing = timing
+        self._pairs, self._host_s, self._floats, self._reduces = [], 0.0, 0, 0
+        self.stats["early_launches"] = self.stats["late_only"] = 0
+
+    def comm_summary(self, steps: int) -> dict:
+        """Per-step communication of the steps since comm_reset(): time inside the all-reduce calls (HIP events on their stream;
+        the caller has synchronised the device), bytes they moved, how many of the steps launched the early bucket."""
+        ms = sum(a.elapsed_time(b) for a, b in self._pairs) + self._host_s * 1e3
+        steps = max(steps, 1)
+        return {"allreduce_ms": ms / steps, "bytes": 4 * self._floats / steps, "allreduces_per_step": self._reduces / steps,
+                "early_launches": self.stats["early_launches"], "late_only": self.stats["late_only"], "world": self.world,
+                "clock": "HIP events around each all-reduce on the stream it is enqueued on" if self._pairs else "host clock around each all-reduce (CPU group)"}
 
     def unpack(self) -> None:
         """Averaged gradients back into the parameters' .grad tensors."""
