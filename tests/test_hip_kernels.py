@@ -7,6 +7,8 @@ Tolerances (max-normalised error, golden_util.rel_err): fp32 MFMA vs fp32 CPU BL
 import ctypes as C
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -237,12 +239,58 @@ def test_one_gather_launch_serves_every_table_of_a_step(hip):
     for j, (m, w) in enumerate(zip(mods, weights)):
         ref = torch.zeros_like(m.weight).index_add_(0, idx, w * (1.5 if j == 2 else 1.0))
         assert torch.allclose(m.weight.grad, ref, rtol=1e-5, atol=1e-5), j
-    # an index outside the table poisons its row instead of reading out of bounds
+    # an index outside the table poisons its row instead of reading out of bounds ...
     bad = idx.clone()
     bad[5] = N
-    with ops.EMBED_PREFETCH.scope(mods[:2]):
-        r0 = ops.embed_rows(mods[0], bad)
-    assert torch.isnan(r0[5]).all() and not torch.isnan(r0[:5]).any()
+    old = os.environ.get("UPNERF_CHECK_EMBED_IDX")
+    try:
+        os.environ["UPNERF_CHECK_EMBED_IDX"] = "0"
+        with ops.EMBED_PREFETCH.scope(mods[:2]):
+            r0 = ops.embed_rows(mods[0], bad)
+        assert torch.isnan(r0[5]).all() and not torch.isnan(r0[:5]).any()
+        # ... and the host-side range check (the first prefetch of a process; every one with UPNERF_CHECK_EMBED_IDX=1) raises where
+        # nn.Embedding / index_select raised a device-side assert (r5 ADVICE)
+        os.environ["UPNERF_CHECK_EMBED_IDX"] = "1"
+        with ops.EMBED_PREFETCH.scope(mods[:2]):
+            with pytest.raises(IndexError):
+                ops.embed_rows(mods[0], bad)
+    finally:
+        if old is None:
+            os.environ.pop("UPNERF_CHECK_EMBED_IDX", None)
+        else:
+            os.environ["UPNERF_CHECK_EMBED_IDX"] = old
+
+
+def test_a_prefetched_arena_is_served_only_on_the_stream_that_filled_it(hip):
+    """r5 ADVICE: the gather arena belongs to the stream of the first embed_rows(); a request on another stream gathers its own rows
+    there (index_select on the consuming stream) instead of reading slices that stream was never ordered behind."""
+    ops = hip["ops"]
+    g = torch.Generator().manual_seed(12)
+    N, R = 23, 500
+    mods = [torch.nn.Embedding(N, d).cuda() for d in (48, 128)]
+    idx = torch.randint(0, N, (R,), generator=g).cuda()
+    side = torch.cuda.Stream()
+    launches = []
+    real = ops.lib.upnerf_embed_fwd_grouped
+
+    def counted(*a):
+        launches.append(a[4])
+        return real(*a)
+
+    ops.lib.upnerf_embed_fwd_grouped = counted
+    try:
+        with ops.EMBED_PREFETCH.scope(mods):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                first = ops.embed_rows(mods[1], idx)  # fills the arena ON THE SIDE STREAM
+                assert ops.EMBED_PREFETCH.rows(mods[0].weight, idx) is not None  # same stream: served
+            assert ops.EMBED_PREFETCH.rows(mods[0].weight, idx) is None  # main stream: not served from the side stream's arena
+            second = ops.embed_rows(mods[0], idx)  # ... so this is an index_select on the main stream
+            torch.cuda.current_stream().wait_stream(side)
+    finally:
+        ops.lib.upnerf_embed_fwd_grouped = real
+    assert launches == [2]
+    assert torch.equal(first, mods[1].weight.detach()[idx]) and torch.equal(second, mods[0].weight.detach()[idx])
 
 
 # ------------------------------------------------------------------------------------------ generic GEMMs

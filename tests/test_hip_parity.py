@@ -537,6 +537,36 @@ def test_feature_less_fields_validate_and_optimise_at_test_time():
     assert rel_err(tto.se3_refine.weight.grad.cpu().numpy(), se3_row.grad.numpy()) < 1.5e-2
 
 
+@pytest.mark.parametrize("pose_opt", [True, False])
+def test_side_stream_transient_net_step_equals_the_single_stream_step(pose_opt):
+    """r5 ADVICE: hparams["hip.side_stream"] runs the TransientNet (and its table gather) on a side stream.  With the pose frozen
+    its embed_rows() is the FIRST of the step (the prefetch arena then belongs to the side stream and the main stream's tables
+    gather on their own); with the pose optimised the main stream fills the arena first and the side stream gathers its own rows.
+    Either way every loss term and every gradient is bitwise the single-stream step's."""
+    c = Case("cfg2_phase1")
+    c.pose_opt = pose_opt
+    out = []
+    for side in (False, True):
+        sysm = build_system(c)
+        sysm.hparams["hip.side_stream"] = side
+        batch = {k: v.cuda() for k, v in c.batch().items()}
+        from upnerf_amd.ops import EMBED_PREFETCH
+        with EMBED_PREFETCH.scope(sysm._per_image_tables()):  # (the scope of NeRFSystem._step_backward)
+            loss, loss_d, _ = sysm.compute_loss(batch, u_list=[u.clone() for u in c.u_list])
+            loss.backward()
+        torch.cuda.synchronize()
+        out.append((float(loss), {k: float(v) for k, v in loss_d.items()},
+                    {n: (None if p.grad is None else p.grad.clone()) for n, p in sysm.named_parameters()}))
+    (l0, d0, g0), (l1, d1, g1) = out
+    assert l0 == l1 and d0 == d1
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert (g0[n] is None) == (g1[n] is None), n
+        if g0[n] is not None:
+            assert torch.equal(g0[n], g1[n]), n
+    assert (g0["se3_refine.weight"] is not None) == pose_opt
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     """The product path must not fall back: without the .so, importing the binding raises ImportError."""
     import importlib

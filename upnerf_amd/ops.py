@@ -464,10 +464,20 @@ class _EmbedPrefetch:
     index_select launch per table: inside `with EMBED_PREFETCH.scope(modules):` the first embed_rows() of a registered table
     gathers the rows of every registered table of the same height for that index tensor; the later calls with the same index
     tensor are handed their slice.  The tables do not change inside the scope (the optimisers run after it).  Outside a
-    scope, and for any table or index the scope does not know, embed_rows gathers on its own as before."""
+    scope, and for any table or index the scope does not know, embed_rows gathers on its own as before.
+
+    Stream rule (r5 ADVICE): the arena belongs to the stream that filled it.  A request issued on ANOTHER stream (the
+    TransientNet's side stream of hparams["hip.side_stream"]) is not served from it -- it gathers its own rows with an
+    index_select on the consuming stream, as before the prefetch existed -- so no slice is ever read by a stream that has not
+    been ordered behind the gather, and the allocator never hands the arena's block to one stream while another still reads it.
+
+    Index range (r5 ADVICE): the grouped kernel writes NaN rows for an out-of-range index where index_select raised a device-side
+    assert; the first prefetch of a process (and every prefetch with UPNERF_CHECK_EMBED_IDX=1; never with =0, never under graph
+    capture) checks min / max of the index tensor against the table height on the host and raises IndexError."""
 
     def __init__(self):
         self.tables, self.cache = None, {}
+        self.checked = 0
 
     @contextlib.contextmanager
     def scope(self, modules):
@@ -486,6 +496,9 @@ class _EmbedPrefetch:
             return None
         key = (idx.data_ptr(), idx.numel())
         hit = self.cache.get(key)
+        cur = torch.cuda.current_stream(idx.device) if idx.is_cuda else None
+        if hit is not None and hit["_stream"] != cur:
+            return None  # filled on another stream: the caller gathers on its own stream
         if hit is None:
             ok = lambda w: (w.is_cuda and w.device == idx.device and w.dtype == torch.float32 and w.dim() == 2
                             and w.shape[1] <= 256 and w.shape[0] == table.shape[0] and w.is_contiguous())
@@ -497,8 +510,14 @@ class _EmbedPrefetch:
             if table.data_ptr() not in seen:
                 return None
             R = idx.numel()
+            mode = os.environ.get("UPNERF_CHECK_EMBED_IDX")
+            if R and mode != "0" and (mode == "1" or self.checked == 0) and not torch.cuda.is_current_stream_capturing():
+                self.checked += 1
+                lo_i, hi_i = int(idx.min()), int(idx.max())
+                if lo_i < 0 or hi_i >= table.shape[0]:
+                    raise IndexError(f"embedding index out of range: [{lo_i}, {hi_i}] for a table of {table.shape[0]} rows")
             arena = torch.empty(R * sum(w.shape[1] for w in live), device=idx.device, dtype=torch.float32)
-            hit, off = {"_keep": (idx, arena)}, 0  # (idx kept alive: its address is the cache key)
+            hit, off = {"_keep": (idx, arena), "_stream": cur}, 0  # (idx kept alive: its address is the cache key)
             for w in live:
                 hit[w.data_ptr()] = (off, w.shape[1])
                 off += R * w.shape[1]
