@@ -298,6 +298,48 @@ def test_joined_rays_and_plain_rows_render_the_same_step(name, monkeypatch):
             assert torch.equal(ga[n], gb[n]), n
 
 
+def test_gradients_of_consecutive_eager_steps_do_not_alias():
+    """r5 ADVICE (zero_pool lifetime): parameter gradients may be views of a step's zero arena; a gradient kept from step k must not
+    be touched by step k + 1 (fresh arena per step)."""
+    c = Case("cfg2_phase1")
+    sysm = build_system(c)
+    batch = {k: v.cuda() for k, v in c.batch().items()}
+    sysm._step_backward(batch, u_list=[u.clone() for u in c.u_list])
+    kept = {n: p.grad for n, p in sysm.named_parameters() if p.grad is not None}
+    copies = {n: g.clone() for n, g in kept.items()}
+    for p in sysm.parameters():
+        p.grad = None
+    sysm._step_backward(batch, u_list=[u.clone() for u in c.u_list])
+    torch.cuda.synchronize()
+    new = {n: p.grad for n, p in sysm.named_parameters() if p.grad is not None}
+    for n, g in kept.items():
+        assert torch.equal(g, copies[n]), n  # untouched by the second step
+        if n in new:
+            assert new[n].data_ptr() != g.data_ptr(), n
+
+
+def test_an_in_place_edit_of_joined_rays_is_rendered():
+    """r5 ADVICE: join_rays remembers the tensors the rows were concatenated from, render_rays reads those -- but only while
+    nobody has written to the rows since (the tensor's version counter).  After `rays[:, 6:8] = ...` (a near / far rescale, the
+    edit a caller of the reference's render_rays(rays=...) may make) the rows themselves are rendered."""
+    from upnerf_amd.rendering import join_rays, render_rays
+    c = Case("cfg2_phase2")
+    sysm = build_system(c)
+    batch = {k: v.cuda() for k, v in c.batch().items()}
+    kw = dict(models=sysm.models, embeddings=sysm.embeddings, img_idx=batch["img_idx"], sched_mult=1.0, N_samples=c.Nc,
+              perturb=0, N_importance=c.Nf)
+    with torch.no_grad():
+        rays = sysm.rays_from_batch(batch)
+        assert getattr(rays, "_upnerf_parts", None) is not None
+        a = render_rays(rays=rays, **kw)["s_depth_fine"].clone()
+        edited = rays.clone()                       # a plain tensor with the edit: what the rows say
+        edited[:, 6:8] = edited[:, 6:8] * torch.tensor([1.5, 0.8], device=rays.device)
+        want = render_rays(rays=edited, **kw)["s_depth_fine"].clone()
+        rays[:, 6:8] = rays[:, 6:8] * torch.tensor([1.5, 0.8], device=rays.device)   # the same edit, in place, on the joined tensor
+        got = render_rays(rays=rays, **kw)["s_depth_fine"]
+    assert torch.equal(got, want) and not torch.equal(got, a)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_training_step_matches_reference_golden(name):
     c = Case(name)

@@ -634,7 +634,10 @@ def join_rays(rays_o, rays_d, near_far):
     stays empty -- `ray_gradient(rays)` returns it either way."""
     rays = torch.cat([rays_o, rays_d, near_far], 1)
     if JOIN_RAYS and rays_o.dtype == torch.float32 and rays_o.dim() == 2 and rays_o.shape[1] == 3 and rays_d.shape == rays_o.shape:
-        rays._upnerf_parts = (rays_o, rays_d, near_far)
+        # ... as long as nobody has written to the rows since (r5 ADVICE): render_rays takes the parts only while the tensor's
+        # version counter still says so; an in-place edit of `rays` (rays[:, 3:6] = ..., a near / far rescale) sends it back to
+        # slicing the rows, which is the drop-in contract of render_rays(rays=...)
+        rays._upnerf_parts = (rays_o, rays_d, near_far, rays._version)
     return rays
 
 
@@ -707,7 +710,8 @@ def render_rays(models, embeddings, rays, img_idx, sched_mult, N_samples=64, use
         return t
 
     parts = getattr(rays, "_upnerf_parts", None)
-    if parts is not None and parts[0].shape == (R, 3) and parts[0].is_contiguous() and parts[1].is_contiguous():
+    if (parts is not None and parts[3] == rays._version and parts[0].shape == (R, 3) and parts[0].is_contiguous()
+            and parts[1].is_contiguous()):
         rays_o, rays_d = parts[0], parts[1]  # join_rays: the tensors `rays` was concatenated from, no slice copies
         near_far = parts[2].detach().contiguous()
     else:

@@ -6,7 +6,14 @@ the requests are served as 256-byte aligned slices of ONE arena zeroed by one la
 sequence the previous step made; a request that does not match that sequence (another schedule phase, another shape) and
 every request outside a step fall back to `torch.zeros`, so a caller never sees anything but zeros.  Under graph capture the
 arena is one allocation of the graph's pool like any other tensor of the step (graph_step.py runs one eager step per shape
-signature before it captures, which is where the capture's plan comes from)."""
+signature before it captures, which is where the capture's plan comes from).
+
+Lifetime (r5 ADVICE).  The slices are views that may outlive the step: the flat parameter gradient of packing._PackFn.backward is
+one of them and autograd's AccumulateGrad may adopt it as a parameter's .grad.  Every step allocates a FRESH arena (`_S.arena` is
+dropped when the scope closes; nothing is ever handed out twice), so a retained view can never be overwritten by a later step --
+its cost is memory: one kept .grad pins the whole arena of its step (packed images, dP, the loss arena: ~20 MB at the headline
+shape) until the next zero_grad(set_to_none=True).  tests/test_hip_parity.py::test_gradients_of_consecutive_eager_steps_do_not_alias
+holds the no-aliasing half of this."""
 from __future__ import annotations
 
 import contextlib
