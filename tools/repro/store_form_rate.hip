@@ -27,7 +27,7 @@ __global__ __launch_bounds__(512) void push(char* __restrict__ dst, int iters, i
   f32x16 acc = {0};
   const h8 ha = {1, 1, 1, 1, 1, 1, 1, 1};
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, window, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)base, 16, window, 0x00820000);  // stride 16, ADD_TID_ENABLE
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)base, 16, window, 0x00800000);  // stride 16, ADD_TID_ENABLE (bit 23); DATA_FORMAT must be 0: with add_tid its bits extend the stride
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void push(char* __restrict__ dst, int iters, i
 int main() {
   const int window = 256 << 10, iters = 2000;
   char* dst;
-  hipMalloc(&dst, 8 * window);
+  hipMalloc(&dst, 8 * window + (256 << 20));  // (slack behind the windows: a mis-built descriptor then corrupts nothing and the check below reports it)
   hipMemset(dst, 0, 8 * window);
   unsigned long long* cyc;
   float* sink;

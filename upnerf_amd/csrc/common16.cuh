@@ -164,6 +164,15 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
     // out of the caller's layer loop and spill them.
     int li = lane & 31, lh = lane >> 5;
     asm volatile("" : "+v"(li), "+v"(lh));
+#ifdef UPNERF_EXP_KROT
+    // experiment (round 6): every workgroup walks the K dimension from its own starting block -- the CUs of an XCD then ask the L2
+    // for DIFFERENT fragments at any moment instead of all for the same one (same products, another summation order)
+    static_assert((T & (T - 1)) == 0, "rotation: power-of-two trip counts");
+    const int rot = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) & (T - 1));
+#define KR(t) (((t) + rot) & (T - 1))
+#else
+#define KR(t) (t)
+#endif
     const char* bpu[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bpu[nt] = Wf + ((size_t)((n0 >> 5) + nt) * Kp16 + (kB0 >> 4)) * 2048 + (li + 32 * lh) * 16;
@@ -171,14 +180,14 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
     auto ldw = [&](int t) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        uwh[t % SETS][nt] = W_LOAD(bpu[nt], t);
-        if constexpr (NP == 2) uwl[t % SETS][nt] = W_LOAD_LO(bpu[nt], t);
+        uwh[t % SETS][nt] = W_LOAD(bpu[nt], KR(t));
+        if constexpr (NP == 2) uwl[t % SETS][nt] = W_LOAD_LO(bpu[nt], KR(t));
       }
     };
     auto ldx = [&](int t) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int o = poff<W>(row0 + 32 * mt + li, kA0 + 16 * t + 8 * lh);
+        const int o = poff<W>(row0 + 32 * mt + li, kA0 + 16 * KR(t) + 8 * lh);
         uxh[t & 1][mt] = *(const h8*)(Ph + o);
         if constexpr (NP == 2) uxl[t & 1][mt] = *(const h8*)(Pl + o);
       }
@@ -195,6 +204,7 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
       mma16_step<NP>(acc, uxh[t & 1], uxl[t & 1], uwh[t % SETS], uwl[t % SETS]);
       __builtin_amdgcn_sched_barrier(0);
     }
+#undef KR
     return;
   }
   static_assert(F16_FORCE_UNROLLED_K || SETS % 2 != 0 || T % SETS != 0 || std::is_same<typename std::remove_reference<PIECE>::type, NoPiece>::value,
