@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UPNERF_ABI_VERSION 9
+#define UPNERF_ABI_VERSION 10
 #define UPNERF_EINVAL (-1)   /* bad size / null pointer */
 #define UPNERF_EUNSUP (-2)   /* unsupported width/depth combination */
 
@@ -64,6 +64,20 @@ int upnerf_sample_coarse(int R, int S, const float* near_far, const float* steps
 int upnerf_uniform_keyed(int R, int n, uint64_t seed, int step, const float* step_dev, int row0, int row_stride, int draw,
                          float* out, void* stream);
 
+/* Key of the uniform draws, for kernels that GENERATE their draws instead of reading a buffer upnerf_uniform_keyed wrote (round
+ * 6: one launch less per consumer).  Same fields, same numbers: u(seed, step, row0 + r * row_stride, draw, column). */
+typedef struct upnerf_rng {
+  uint64_t seed;
+  int32_t step;           /* optimisation step; overridden by step_dev[0] when step_dev != NULL (graph replay) */
+  int32_t row0, row_stride;
+  const float* step_dev;  /* DEVICE [1] float or NULL */
+} upnerf_rng;
+
+/* a5 with the jitter draws generated in the kernel (draw 0 of upnerf_uniform_keyed): z_out as upnerf_sample_coarse would compute
+ * it from u = upnerf_uniform_keyed(R, S, ..., draw 0), bit for bit.  perturb > 0. */
+int upnerf_sample_coarse_keyed(int R, int S, const float* near_far, const float* steps, const upnerf_rng* rng, float perturb,
+                               int use_disp, float* z_out, void* stream);
+
 /* ---- a11: inverse-CDF resampling (models/rendering.py:7-50 sample_pdf) ---------------------------
  * z [R][S] coarse depths (bins = midpoints, computed inside), weights [R][S] (only [1:S-1] used),
  * u [u_rows][n] with u_rows == R, or u_rows == 1 for the deterministic linspace; writes n values per
@@ -73,6 +87,16 @@ int upnerf_sample_pdf(int R, int S, const float* z, const float* weights, const 
 
 /* ---- a12: ascending sort of each row (models/rendering.py:275,290,298,307 torch.sort values) ----- */
 int upnerf_sort_rows(int R, int S, float* z, void* stream);
+
+/* ---- a11 + a12 in one launch (models/rendering.py:262-308): zf[r] = sort(z[r] | set A | set B), S = Nc + n_a + n_b columns.
+ * z [R][Nc] coarse depths; set X = n_x inverse-CDF samples of the weights w_x [R][Nc] (entries 1..Nc-2 used, as upnerf_sample_pdf)
+ * that upnerf_sample_pdf would write to columns [col_x, col_x + n_x) of zf before upnerf_sort_rows sorts the row -- the same
+ * arithmetic call for call, so zf equals the three-launch sequence bit for bit.  n_b may be 0 (one set).  Uniforms: u_x
+ * [u_rows][n_x] (u_rows = R, or 1 for the deterministic linspace) or, where u_x is NULL, generated from `rng` as draw number
+ * draw_x of upnerf_uniform_keyed (the caller numbers its draws in call order; draw 0 is the coarse jitter). */
+int upnerf_resample_sort(int R, int Nc, const float* z, const float* w_a, int n_a, int col_a, const float* u_a, int draw_a,
+                         const float* w_b, int n_b, int col_b, const float* u_b, int draw_b, int u_rows, const upnerf_rng* rng,
+                         float* zf, void* stream);
 
 /* ---- per-ray rgb-head side input: [PE(rays_d, L=4, masked) | appearance row | 0]  (nerf.py:102-107;
  *      the reference repeats it per sample, rendering.py:104-109) ---------------------------------- */
@@ -544,6 +568,11 @@ int upnerf_linear(int M, int N, int K, const float* A, int lda, const float* B, 
 /* Matrix-vector products in a fixed summation order (the bias fold of the colour layer, both directions):
  * trans = 0: y[m] = add[m] + sum_k A[m][k] x[k], m < M;  trans = 1: y[k] = add[k] + sum_m A[m][k] x[m], k < K.  add may be NULL. */
 int upnerf_matvec(int M, int K, const float* A, int lda, const float* x, const float* add, float* y, int trans, void* stream);
+/* The backward of the bias fold in one launch: y[k] = sum_m A[m][k] x[m] (upnerf_matvec, trans = 1, add = NULL, bit for bit) AND the
+ * rank-1 update R[m][k] += x[m] v[k] (m < M, k < K; row stride ldr) that the caller used to issue as a separate addr_ launch
+ * (d W_r1[:, :F] += g_br1 (x) b_feat, the second term of the folded colour layer's gradient). */
+int upnerf_matvec_rank1(int M, int K, const float* A, int lda, const float* x, float* y, float* R, int ldr, const float* v,
+                        void* stream);
 
 /* ---- a15 + a17: depth-prior affine (models/nerf_system.py:169-177) fused with UPNeRFLoss (losses.py:21-64) --------
  * Per-ray inputs only ([R], [R,3], [R,F]); any absent tensor is NULL.  `terms` receives the 8 loss terms in the order

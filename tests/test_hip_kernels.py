@@ -153,6 +153,95 @@ def test_sort_rows(hip, S):
     assert np.array_equal(cpu(zd).numpy(), torch.sort(z, -1)[0].numpy())
 
 
+@pytest.mark.parametrize("Nc,na,nb,mode", [(64, 128, 0, "keyed"), (64, 90, 38, "keyed"), (64, 0, 128, "keyed"), (128, 128, 0, "buf"),
+                                           (64, 38, 90, "buf"), (64, 128, 0, "det"), (64, 64, 64, "det"), (5, 3, 0, "keyed")])
+def test_fused_resample_and_sort_equals_the_launch_per_piece_sequence(hip, Nc, na, nb, mode):
+    """upnerf_resample_sort (round 6: coarse depths | inverse-CDF set A | set B -> sorted fine depths in one launch, keyed uniforms
+    generated in the kernel) against the sequence it replaces -- strided copy, upnerf_uniform_keyed + upnerf_sample_pdf per set,
+    upnerf_sort_rows -- bit for bit; sets of width zero keep their draw number (the reference draws rand(R, 0) too)."""
+    L = hip["lib"]
+    lib, ptr, st = L.lib, L.ptr, L.stream
+    R, S = 333, Nc + na + nb
+    g = torch.Generator().manual_seed(Nc * 1000 + na)
+    z = torch.sort(torch.rand(R, Nc, generator=g) * 4 + 0.1, -1)[0].cuda().contiguous()
+    wa = (torch.rand(R, Nc, generator=g) ** 4).cuda().contiguous()
+    wb = (torch.rand(R, Nc, generator=g) ** 8).cuda().contiguous()
+    wa[3] = 0.0  # an all-eps cdf row
+    seed, step, row0, stride = 0x1234567887654321, 17, 5, 3
+    # set A sits BEHIND set B in the row, as render_rays places the candidate-weight samples (rendering.py:283-290)
+    col_a, col_b = Nc + nb, Nc
+    draws = {}
+    ref = torch.empty(R, S, device="cuda")
+    ref[:, :Nc] = z
+    for d, (w, n, col) in enumerate(((wa, na, col_a), (wb, nb, col_b)), start=1):
+        if n == 0:
+            continue
+        if mode == "det":
+            u, rows = torch.linspace(0, 1, n, device="cuda"), 1
+        elif mode == "buf":
+            u, rows = torch.rand(R, n, generator=g).cuda().contiguous(), R
+        else:
+            u, rows = torch.empty(R, n, device="cuda"), R
+            L.check(lib.upnerf_uniform_keyed(R, n, seed, step, None, row0, stride, d, ptr(u), st()), "uniform_keyed")
+        draws[d] = u
+        L.check(lib.upnerf_sample_pdf(R, Nc, ptr(z), ptr(w), ptr(u), rows, n, ref.data_ptr() + 4 * col, S, st()), "sample_pdf")
+    L.check(lib.upnerf_sort_rows(R, S, ptr(ref), st()), "sort_rows")
+    got = torch.full((R, S), float("nan"), device="cuda")
+    rng = L.Rng(seed=seed, step=step, row0=row0, row_stride=stride, step_dev=None)
+    ua, ub = (draws.get(1), draws.get(2)) if mode != "keyed" else (None, None)
+    L.check(lib.upnerf_resample_sort(R, Nc, ptr(z), ptr(wa), na, col_a, ptr(ua), 1, ptr(wb), nb, col_b, ptr(ub), 2,
+                                     1 if mode == "det" else R, C.byref(rng) if mode == "keyed" else None, ptr(got), st()), "resample_sort")
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    # ... and the step counter from device memory (graph replay) draws the same numbers
+    if mode == "keyed":
+        sd = torch.tensor([float(step)], device="cuda")
+        rng2 = L.Rng(seed=seed, step=0, row0=row0, row_stride=stride, step_dev=sd.data_ptr())
+        got2 = torch.empty_like(got)
+        L.check(lib.upnerf_resample_sort(R, Nc, ptr(z), ptr(wa), na, col_a, None, 1, ptr(wb), nb, col_b, None, 2, R, C.byref(rng2),
+                                         ptr(got2), st()), "resample_sort")
+        assert torch.equal(got2, ref)
+
+
+@pytest.mark.parametrize("disp", [0, 1])
+def test_coarse_depths_with_the_jitter_generated_in_the_kernel(hip, disp):
+    """upnerf_sample_coarse_keyed == upnerf_sample_coarse fed by upnerf_uniform_keyed(draw 0), bit for bit."""
+    L = hip["lib"]
+    lib, ptr, st = L.lib, L.ptr, L.stream
+    R, S = 517, 64
+    g = torch.Generator().manual_seed(3)
+    nf = torch.stack([0.1 + torch.rand(R, generator=g), 4 + torch.rand(R, generator=g)], 1).cuda().contiguous()
+    steps = torch.linspace(0, 1, S, device="cuda")
+    seed, step, row0, stride = 77, 123456, 2, 8
+    u = torch.empty(R, S, device="cuda")
+    L.check(lib.upnerf_uniform_keyed(R, S, seed, step, None, row0, stride, 0, ptr(u), st()), "uniform_keyed")
+    ref, got = torch.empty(R, S, device="cuda"), torch.empty(R, S, device="cuda")
+    L.check(lib.upnerf_sample_coarse(R, S, ptr(nf), ptr(steps), ptr(u), 1.0, disp, ptr(ref), st()), "sample_coarse")
+    rng = L.Rng(seed=seed, step=step, row0=row0, row_stride=stride, step_dev=None)
+    L.check(lib.upnerf_sample_coarse_keyed(R, S, ptr(nf), ptr(steps), C.byref(rng), 1.0, disp, ptr(got), st()), "sample_coarse_keyed")
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+
+
+def test_matvec_with_the_rank_one_update_riding_along(hip):
+    """upnerf_matvec_rank1: y = A^T x exactly as upnerf_matvec(trans = 1) and R += x (x) v -- the bias fold's backward in one launch."""
+    L = hip["lib"]
+    lib, ptr, st = L.lib, L.ptr, L.stream
+    M, K, ldr = 128, 384, 459
+    A, x, v = gen((M, K), 1).cuda(), gen((M,), 2).cuda(), gen((K,), 3).cuda()
+    R0 = gen((M, ldr), 4).cuda()
+    y_ref, y = torch.empty(K, device="cuda"), torch.empty(K, device="cuda")
+    L.check(lib.upnerf_matvec(M, K, ptr(A), K, ptr(x), None, ptr(y_ref), 1, st()), "matvec")
+    Rg = R0.clone()
+    L.check(lib.upnerf_matvec_rank1(M, K, ptr(A), K, ptr(x), ptr(y), ptr(Rg), ldr, ptr(v), st()), "matvec_rank1")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    want = R0.clone()
+    want[:, :K] += x[:, None] * v[None, :]
+    assert torch.equal(Rg[:, K:], R0[:, K:])
+    assert rel_err(cpu(Rg[:, :K]), cpu(want[:, :K])) < 1e-6
+
+
 @pytest.mark.parametrize("R,N,dim", [(4096, 763, 48), (100, 7, 6), (5000, 1200, 128), (64, 3, 2), (300, 10, 200)])
 def test_embedding_gradient_kernel(hip, R, N, dim):
     """Dense embedding gradient (one HIP kernel) against ATen's nn.Embedding backward; also bitwise run-to-run."""

@@ -282,6 +282,8 @@ def test_joined_rays_and_plain_rows_render_the_same_step(name, monkeypatch):
             monkeypatch.setattr(ns, "join_rays", lambda o, d, nf: torch.cat([o, d, nf], 1))
             monkeypatch.setattr(zero_pool, "zeros", lambda n, device: torch.zeros(int(n), device=device))
             monkeypatch.setattr(ops, "ENABLE_EMBED_PREFETCH", False)  # ... and an index_select per table
+            import upnerf_amd.rendering as rd_
+            monkeypatch.setattr(rd_, "FUSE_RESAMPLE", 0)  # ... and a launch per piece of the fine-depth resampling
         sysm = build_system(c)
         batch = {k: v.cuda() for k, v in c.batch().items()}
         for _ in range(2):  # the second step is the one served from the pool
@@ -296,6 +298,26 @@ def test_joined_rays_and_plain_rows_render_the_same_step(name, monkeypatch):
             assert float((ga[n] - gb[n]).abs().max()) <= 1e-6 * float(gb[n].abs().max()), n
         else:
             assert torch.equal(ga[n], gb[n]), n
+
+
+@pytest.mark.parametrize("name", ["cfg2_phase0", "cfg2_phase1", "cfg2_phase2"])
+def test_keyed_draws_generated_by_their_consumers_are_the_draws_of_the_uniform_kernel(name, monkeypatch):
+    """Round 6: with keyed jitter (the training default) the coarse-depth kernel and the fused resample + sort kernel generate
+    their uniforms themselves.  Same depths, same loss, bit for bit, as the sequence that drew them with upnerf_uniform_keyed."""
+    import upnerf_amd.rendering as rd_
+    c = Case(name)
+    outs = []
+    for fuse in (1, 0):
+        monkeypatch.setattr(rd_, "FUSE_RESAMPLE", fuse)
+        sysm = build_system(c)
+        assert sysm.hparams.get("rng.keyed", True) and sysm.hparams["nerf.perturb"] > 0
+        sysm.global_step = 7
+        batch = {k: v.cuda() for k, v in c.batch().items()}
+        keep = {}
+        loss, _, _ = sysm.compute_loss(batch, keep=keep)
+        outs.append((loss.detach().clone(), keep["z_coarse"].clone(), keep["z_fine"].clone()))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0])
+    assert float((outs[0][1][:, 1:] - outs[0][1][:, :-1]).min()) >= 0.0 and float(outs[0][2].std()) > 0.0
 
 
 def test_gradients_of_consecutive_eager_steps_do_not_alias():

@@ -159,6 +159,11 @@ class Frag16Desc(C.Structure):
     _fields_ = FragDesc._fields_ + [("exp_id", C.c_int32)]
 
 
+class Rng(C.Structure):
+    """upnerf_rng: key of the uniform draws a kernel generates itself."""
+    _fields_ = [("seed", C.c_uint64), ("step", C.c_int32), ("row0", C.c_int32), ("row_stride", C.c_int32), ("step_dev", _fp)]
+
+
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
 _SIGNATURES = {
     "upnerf_abi_version": [],
@@ -168,6 +173,9 @@ _SIGNATURES = {
     "upnerf_uniform_keyed": [_i, _i, C.c_uint64, _i, _p, _i, _i, _i, _p, _p],
     "upnerf_sample_pdf": [_i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     "upnerf_sort_rows": [_i, _i, _p, _p],
+    "upnerf_sample_coarse_keyed": [_i, _i, _p, _p, C.POINTER(Rng), _f, _i, _p, _p],
+    # (R, Nc, z, w_a, n_a, col_a, u_a, draw_a, w_b, n_b, col_b, u_b, draw_b, u_rows, rng, zf, stream)
+    "upnerf_resample_sort": [_i, _i, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, C.POINTER(Rng), _p, _p],
     "upnerf_ray_aux": [_i, _p, _p, C.POINTER(C.c_float), _p, _p, _p],
     "upnerf_field_fwd": [C.POINTER(Layout), C.POINTER(FieldFwdArgs), _p],
     "upnerf_composite_fwd": [C.POINTER(CompositeFwdArgs), _p],
@@ -195,6 +203,7 @@ _SIGNATURES = {
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
     "upnerf_matvec": [_i, _i, _p, _i, _p, _p, _p, _i, _p],
+    "upnerf_matvec_rank1": [_i, _i, _p, _i, _p, _p, _p, _i, _p, _p],
     "upnerf_vec_wgrad_frag16": [_i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_part_finish": [_i, _i, _p, _p, _p, _p],
@@ -234,7 +243,7 @@ def _load():
 
 
 lib = _load()
-ABI_VERSION = 9
+ABI_VERSION = 10
 if lib.upnerf_abi_version() != ABI_VERSION:
     raise ImportError("libupnerf_hip.so ABI version mismatch; rebuild it")
 

@@ -989,7 +989,8 @@ extern "C" int upnerf_wgrad_f24p_chain(int M, const uint16_t* A16, const uint8_t
 // workgroup, 16 row classes m = p (mod 16) per column with all of a class's loads in flight at once, the classes added in order
 // out of LDS -- one thread per column walking the 128 rows one dependent load at a time was a 33 us launch).
 __global__ __launch_bounds__(256) void matvec_kernel(int M, int K, const float* __restrict__ A, int lda, const float* __restrict__ x,
-                                                     const float* __restrict__ add, float* __restrict__ y, int trans) {
+                                                     const float* __restrict__ add, float* __restrict__ y, int trans,
+                                                     float* __restrict__ R1 = nullptr, int ldr = 0, const float* __restrict__ v1 = nullptr) {
   if (trans) {
     __shared__ float part[16][17];
     const int c = threadIdx.x & 15, p = threadIdx.x >> 4;
@@ -1007,6 +1008,14 @@ __global__ __launch_bounds__(256) void matvec_kernel(int M, int K, const float* 
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += a[u] * xv[u];
+        if (R1) {  // upnerf_matvec_rank1: R[m][k] += x[m] v[k] on the elements this thread visits anyway (each exactly once)
+          const float vk = v1[k];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int m = m0 + 16 * u;
+            if (m < M) R1[(size_t)m * ldr + k] += xv[u] * vk;
+          }
+        }
       }
     }
     part[p][c] = s;
@@ -1032,6 +1041,14 @@ extern "C" int upnerf_matvec(int M, int K, const float* A, int lda, const float*
   if (M <= 0 || K <= 0 || !A || !x || !y || lda < K) return UPNERF_EINVAL;
   const int blocks = trans ? (K + 15) / 16 : (M + 3) / 4;
   hipLaunchKernelGGL(matvec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, K, A, lda, x, add, y, trans);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_matvec_rank1(int M, int K, const float* A, int lda, const float* x, float* y, float* R, int ldr, const float* v,
+                                   void* stream) {
+  if (M <= 0 || K <= 0 || !A || !x || !y || !R || !v || lda < K || ldr < K) return UPNERF_EINVAL;
+  hipLaunchKernelGGL(matvec_kernel, dim3((K + 15) / 16), dim3(256), 0, (hipStream_t)stream, M, K, A, lda, x, (const float*)nullptr, y, 1, R,
+                     ldr, v);
   return (int)hipGetLastError();
 }
 

@@ -210,14 +210,31 @@ __device__ __forceinline__ float base_z(float near, float far, float s, int use_
   return 1.f / (1.f / near * (1.f - s) + 1.f / far * s);
 }
 
+__device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int k0, unsigned int k1);
+__device__ __forceinline__ float keyed_uniform(unsigned int seed_lo, unsigned int seed_hi, int step, unsigned int grow, int draw, int col);
+// rng (by value; seed_lo == seed_hi == 0 and row_stride == 0: none): the jitter draws are GENERATED here (draw 0 of
+// upnerf_uniform_keyed, the same numbers) instead of read from `u` -- one launch less per step
+struct RngKey {
+  unsigned int seed_lo, seed_hi;
+  int step, row0, row_stride;
+  const float* step_dev;
+};
 __global__ void sample_coarse_kernel(int R, int S, const float* __restrict__ near_far, const float* __restrict__ steps,
-                                     const float* __restrict__ u, float perturb, int use_disp, float* __restrict__ z) {
+                                     const float* __restrict__ u, float perturb, int use_disp, float* __restrict__ z, RngKey rng) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * S) return;
   const int r = idx / S, i = idx - r * S;
   const float near = near_far[2 * r], far = near_far[2 * r + 1];
   const float zi = base_z(near, far, steps[i], use_disp);
-  if (perturb > 0.f && u) {
+  if (perturb > 0.f && rng.row_stride > 0) {
+    const int step = rng.step_dev ? (int)rng.step_dev[0] : rng.step;
+    const float uk = keyed_uniform(rng.seed_lo, rng.seed_hi, step, (unsigned int)(rng.row0 + r * rng.row_stride), 0, i);
+    const float zl = i > 0 ? base_z(near, far, steps[i - 1], use_disp) : zi;
+    const float zr = i < S - 1 ? base_z(near, far, steps[i + 1], use_disp) : zi;
+    const float upper = i < S - 1 ? 0.5f * (zi + zr) : zi;
+    const float lower = i > 0 ? 0.5f * (zl + zi) : zi;
+    z[idx] = lower + (upper - lower) * (perturb * uk);
+  } else if (perturb > 0.f && u) {
     const float zl = i > 0 ? base_z(near, far, steps[i - 1], use_disp) : zi;
     const float zr = i < S - 1 ? base_z(near, far, steps[i + 1], use_disp) : zi;
     const float upper = i < S - 1 ? 0.5f * (zi + zr) : zi;
@@ -239,6 +256,20 @@ __device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int 
   c[3] = (unsigned int)p0;
   c[0] = n0;
   c[2] = n2;
+}
+// u(seed, step, global row, draw, column c): the value uniform_keyed_kernel writes to out[r][c] (element c & 3 of block c >> 2)
+__device__ __forceinline__ float keyed_uniform(unsigned int seed_lo, unsigned int seed_hi, int step, unsigned int grow, int draw, int col) {
+  unsigned int c[4] = {grow, (unsigned int)(col >> 2), (unsigned int)step, (unsigned int)draw};
+  unsigned int k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const int j = col & 3;
+  const unsigned int x = j == 0 ? c[0] : (j == 1 ? c[1] : (j == 2 ? c[2] : c[3]));
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 __global__ void uniform_keyed_kernel(int R, int n, unsigned int seed_lo, unsigned int seed_hi, int step,
                                      const float* __restrict__ step_dev, int row0, int row_stride, int draw,
@@ -263,26 +294,20 @@ __global__ void uniform_keyed_kernel(int R, int n, unsigned int seed_lo, unsigne
 
 // ---- a11: sample_pdf (rendering.py:7-50); one wave per ray, cdf kept in LDS.
 #define PDF_MAXS 1024
-__global__ __launch_bounds__(NTHREADS) void sample_pdf_kernel(int R, int S, const float* __restrict__ z,
-                                                             const float* __restrict__ weights,
-                                                             const float* __restrict__ u, int u_rows, int n,
-                                                             float* __restrict__ out, int out_stride) {
-  __shared__ float cdf_s[4][PDF_MAXS];
-  __shared__ float bins_s[4][PDF_MAXS];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + wave;
-  if (r >= R) return;
-  float* cdf = cdf_s[wave];
-  float* bins = bins_s[wave];
+// One ray by one wave: the cdf of weights[1 .. S-1) over the mid-points of z (both rows of S entries), n inverse-CDF samples to
+// out[0 .. n).  U(k) yields the k-th uniform (a buffer read or a keyed Philox value); out may be global or LDS.
+template <class U>
+__device__ __forceinline__ void pdf_row(int S, const float* __restrict__ zrow, const float* __restrict__ wrow, int n, U&& uget,
+                                        float* out, float* cdf, float* bins, int lane) {
   const int B = S - 2;  // number of weights; cdf and bins have B+1 entries
   const float eps = 1e-5f;
   double part = 0.0;
   for (int j = lane; j < B; j += 64) {
-    const float w = weights[(size_t)r * S + 1 + j] + eps;
+    const float w = wrow[1 + j] + eps;
     cdf[j + 1] = w;  // staged; turned into the running sum below
     part += (double)w;
   }
-  for (int j = lane; j <= B; j += 64) bins[j] = 0.5f * (z[(size_t)r * S + j] + z[(size_t)r * S + j + 1]);
+  for (int j = lane; j <= B; j += 64) bins[j] = 0.5f * (zrow[j] + zrow[j + 1]);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
   const float total = (float)part;  // correctly rounded sum of the row
@@ -299,7 +324,7 @@ __global__ __launch_bounds__(NTHREADS) void sample_pdf_kernel(int R, int S, cons
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   for (int k = lane; k < n; k += 64) {
-    const float uk = u[(size_t)(u_rows == 1 ? 0 : r) * n + k];
+    const float uk = uget(k);
     // searchsorted(cdf, u, right=True): number of entries <= u
     int lo = 0, hi = B + 1;
     while (lo < hi) {
@@ -311,7 +336,67 @@ __global__ __launch_bounds__(NTHREADS) void sample_pdf_kernel(int R, int S, cons
     const float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
     float den = c1 - c0;
     if (den < eps) den = 1.f;
-    out[(size_t)r * out_stride + k] = b0 + (uk - c0) / den * (b1 - b0);
+    out[k] = b0 + (uk - c0) / den * (b1 - b0);
+  }
+  __builtin_amdgcn_wave_barrier();  // (the next call of this wave rewrites cdf / bins)
+}
+
+__global__ __launch_bounds__(NTHREADS) void sample_pdf_kernel(int R, int S, const float* __restrict__ z,
+                                                             const float* __restrict__ weights,
+                                                             const float* __restrict__ u, int u_rows, int n,
+                                                             float* __restrict__ out, int out_stride) {
+  __shared__ float cdf_s[4][PDF_MAXS];
+  __shared__ float bins_s[4][PDF_MAXS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const float* __restrict__ urow = u + (size_t)(u_rows == 1 ? 0 : r) * n;
+  pdf_row(S, z + (size_t)r * S, weights + (size_t)r * S, n, [&](int k) { return urow[k]; }, out + (size_t)r * out_stride,
+          cdf_s[wave], bins_s[wave], lane);
+}
+
+// ---- a11 + a12 in one launch (rendering.py:262-308): the fine depths of a ray = sort(z_coarse | samples of set A | samples of
+// set B).  One wave per ray: both inverse-CDF sets (sample_pdf_kernel's arithmetic, call for call) land in an LDS row next to
+// the coarse depths, the rank-counting sort of sort_rows_kernel writes the row out.  Uniforms: buffers (u_a / u_b, the
+// parity tests inject them) or, with a key, generated here (draws 1, 2 of upnerf_uniform_keyed in call order: set A is drawn
+// first).  Replaces a strided copy, two sample_pdf launches, a sort and two uniform launches of a training step.
+struct ResampleSet {
+  const float* w;  // [R][Nc] weights (detached)
+  const float* u;  // [R or 1][n] uniforms, or NULL with a key
+  int n, col, u_rows, draw;
+};
+__global__ __launch_bounds__(NTHREADS) void resample_sort_kernel(int R, int Nc, int S, const float* __restrict__ z, ResampleSet A,
+                                                                ResampleSet Bs, RngKey rng, float* __restrict__ zf) {
+  __shared__ float cdf_s[4][PDF_MAXS];
+  __shared__ float bins_s[4][PDF_MAXS];
+  __shared__ float v_s[4][PDF_MAXS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  float* v = v_s[wave];
+  const float* __restrict__ zrow = z + (size_t)r * Nc;
+  for (int j = lane; j < Nc; j += 64) v[j] = zrow[j];
+  const int step = rng.step_dev ? (int)rng.step_dev[0] : rng.step;
+  const unsigned int grow = (unsigned int)(rng.row0 + r * rng.row_stride);
+  auto one = [&](const ResampleSet& q) {
+    if (q.n <= 0) return;
+    const float* __restrict__ urow = q.u ? q.u + (size_t)(q.u_rows == 1 ? 0 : r) * q.n : nullptr;
+    pdf_row(Nc, zrow, q.w + (size_t)r * Nc, q.n,
+            [&](int k) { return urow ? urow[k] : keyed_uniform(rng.seed_lo, rng.seed_hi, step, grow, q.draw, k); }, v + q.col,
+            cdf_s[wave], bins_s[wave], lane);
+  };
+  one(A);
+  one(Bs);
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  for (int e = lane; e < S; e += 64) {
+    const float x = v[e];
+    int rank = 0;
+    for (int j = 0; j < S; ++j) {
+      const float y = v[j];
+      rank += (y < x || (y == x && j < e)) ? 1 : 0;
+    }
+    zf[(size_t)r * S + rank] = x;
   }
 }
 
@@ -569,7 +654,24 @@ extern "C" int upnerf_sample_coarse(int R, int S, const float* near_far, const f
   if (perturb > 0.f && !u) return UPNERF_EINVAL;
   const long long n = (long long)R * S;
   hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R, S,
-                     near_far, steps, u, perturb, use_disp, z_out);
+                     near_far, steps, u, perturb, use_disp, z_out, RngKey{0u, 0u, 0, 0, 0, nullptr});
+  return (int)hipGetLastError();
+}
+
+static int rng_key(const upnerf_rng* g, RngKey* k) {
+  if (!g || g->step < 0 || g->row0 < 0 || g->row_stride < 1) return UPNERF_EINVAL;
+  *k = RngKey{(unsigned int)g->seed, (unsigned int)(g->seed >> 32), g->step, g->row0, g->row_stride, g->step_dev};
+  return 0;
+}
+
+extern "C" int upnerf_sample_coarse_keyed(int R, int S, const float* near_far, const float* steps, const upnerf_rng* rng,
+                                          float perturb, int use_disp, float* z_out, void* stream) {
+  if (R <= 0 || S <= 0 || !near_far || !steps || !z_out || !(perturb > 0.f)) return UPNERF_EINVAL;
+  RngKey k;
+  if (rng_key(rng, &k)) return UPNERF_EINVAL;
+  const long long n = (long long)R * S;
+  hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R, S,
+                     near_far, steps, (const float*)nullptr, perturb, use_disp, z_out, k);
   return (int)hipGetLastError();
 }
 
@@ -589,6 +691,26 @@ extern "C" int upnerf_sample_pdf(int R, int S, const float* z, const float* weig
   if (!u || (u_rows != 1 && u_rows != R) || out_stride < n) return UPNERF_EINVAL;
   hipLaunchKernelGGL(sample_pdf_kernel, dim3((R + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, S, z, weights, u,
                      u_rows, n, out, out_stride);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_resample_sort(int R, int Nc, const float* z, const float* w_a, int n_a, int col_a, const float* u_a, int draw_a,
+                                    const float* w_b, int n_b, int col_b, const float* u_b, int draw_b, int u_rows,
+                                    const upnerf_rng* rng, float* zf, void* stream) {
+  const long long S = (long long)Nc + n_a + n_b;
+  if (R <= 0 || Nc < 3 || n_a < 0 || n_b < 0 || S > PDF_MAXS || !z || !zf) return UPNERF_EINVAL;
+  if ((n_a > 0 && !w_a) || (n_b > 0 && !w_b)) return UPNERF_EINVAL;
+  // the sets tile the columns behind the coarse depths
+  if (n_a > 0 && (col_a < Nc || col_a + n_a > S)) return UPNERF_EINVAL;
+  if (n_b > 0 && (col_b < Nc || col_b + n_b > S)) return UPNERF_EINVAL;
+  if (n_a > 0 && n_b > 0 && !(col_a + n_a <= col_b || col_b + n_b <= col_a)) return UPNERF_EINVAL;
+  RngKey k{0u, 0u, 0, 0, 0, nullptr};
+  const bool need_key = (n_a > 0 && !u_a) || (n_b > 0 && !u_b);
+  if (need_key && rng_key(rng, &k)) return UPNERF_EINVAL;
+  if (!need_key && (u_rows != 1 && u_rows != R)) return UPNERF_EINVAL;
+  if (draw_a < 0 || draw_b < 0) return UPNERF_EINVAL;
+  ResampleSet A{w_a, u_a, n_a, col_a, u_rows, draw_a}, B{w_b, u_b, n_b, col_b, u_rows, draw_b};
+  hipLaunchKernelGGL(resample_sort_kernel, dim3((R + 3) / 4), dim3(NTHREADS), 0, (hipStream_t)stream, R, Nc, (int)S, z, A, B, k, zf);
   return (int)hipGetLastError();
 }
 

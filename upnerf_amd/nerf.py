@@ -62,12 +62,25 @@ class NeRF(nn.Module):
         """Write `progress` (device parameter, as the reference does through .data) and its host mirror.  The mirror
         holds the fp32-rounded value -- what the reference reads back with `progress.data.item()` (nerf.py:94,
         nerf_system.py:180) and what a checkpoint restores."""
-        self.progress.data.fill_(float(progress))
         self.host_progress = fp32_round(progress)
+        # The device parameter is written ON DEMAND (flush_progress): every reader inside this package uses the host mirror, so a
+        # fill launch per model and step bought nothing; state_dict() / checkpoints / the nn.Module forward flush first.
+        self._progress_stale = True
+
+    def flush_progress(self):
+        """Bring the device parameter `progress` up to date with the host mirror (state_dict, checkpoints, module forward)."""
+        if getattr(self, "_progress_stale", False) and self.host_progress is not None:
+            self.progress.data.fill_(float(self.host_progress))
+        self._progress_stale = False
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_progress()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
         self.host_progress = None  # a checkpoint may carry another progress value
+        self._progress_stale = False
 
     def packed(self) -> torch.Tensor:
         """Flat kernel-layout parameter buffer, differentiable w.r.t. the parameters."""
@@ -83,6 +96,7 @@ class NeRF(nn.Module):
         enc = torch.stack([arg.sin(), arg.cos()], dim=-2)
         if self.c2f is not None:
             start, end = self.c2f
+            self.flush_progress()
             alpha = (self.progress.data - start) / (end - start) * L
             k = torch.arange(L, dtype=torch.float32, device=x.device)
             enc = enc * ((1 - ((alpha - k).clamp(min=0, max=1) * torch.pi).cos()) / 2)

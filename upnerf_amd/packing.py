@@ -89,7 +89,7 @@ class _PackFn(torch.autograd.Function):
         # d W_r1[:, :F] = gfold . W_feat^T + gbr1 (x) b_feat
         check(lib.upnerf_linear(W2, Fd, W, base + 4 * L.wr1, W + AUXK, ptr(feat_w), W, None, ptr(g_wr), in_rgb, 0, st),
               "upnerf_linear")
-        g_wr[:, :Fd].addr_(gbr1, feat_b)
+        # (the second term, g_wr[:, :F] += gbr1 (x) b_feat, rides on the matrix-vector launch below: upnerf_matvec_rank1)
         # d W_feat = W_r1[:, :F]^T . gfold ; d b_feat = W_r1[:, :F]^T . gbr1 ; d b_r1 = gbr1
         wrF = buf[L.total:].view(W2, Fd)
         g_fw = grads["feat_share_layer.weight"]
@@ -97,7 +97,8 @@ class _PackFn(torch.autograd.Function):
             wgrad_blocks_into(W2, wrF, Fd, Fd, dP, W + AUXK, W, g_fw.data_ptr(), W, None, dev, b_off=L.wr1)
         else:
             wgrad_into(W2, wrF, Fd, Fd, dP, W + AUXK, W, g_fw.data_ptr(), W, None, dev, b_off=L.wr1)
-        check(lib.upnerf_matvec(W2, Fd, ptr(wrF), Fd, ptr(gbr1), None, ptr(grads["feat_share_layer.bias"]), 1, st), "upnerf_matvec")
+        check(lib.upnerf_matvec_rank1(W2, Fd, ptr(wrF), Fd, ptr(gbr1), ptr(grads["feat_share_layer.bias"]), ptr(g_wr), in_rgb,
+                                      ptr(feat_b), st), "upnerf_matvec_rank1")
         return (None, None) + tuple(grads[n] for n in names)
 
 
