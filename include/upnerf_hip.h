@@ -568,6 +568,18 @@ int upnerf_linear(int M, int N, int K, const float* A, int lda, const float* B, 
 /* Matrix-vector products in a fixed summation order (the bias fold of the colour layer, both directions):
  * trans = 0: y[m] = add[m] + sum_k A[m][k] x[k], m < M;  trans = 1: y[k] = add[k] + sum_m A[m][k] x[m], k < K.  add may be NULL. */
 int upnerf_matvec(int M, int K, const float* A, int lda, const float* x, const float* add, float* y, int trans, void* stream);
+/* p[0 .. n) = 0 (p 16-byte aligned): the one fill of a training step's zero arena (upnerf_amd/zero_pool.py). */
+int upnerf_zero(float* p, long long n, void* stream);
+/* out_j[i] = a_j[i] + b_j[i], i < n_j, for up to UPNERF_MAX_ADD_PAIRS tensors in one launch (the gradient sum of a tensor with two
+ * consumers: ops._Fanout; fp32 addition is commutative, so the result is autograd's own a + b bit for bit). */
+#define UPNERF_MAX_ADD_PAIRS 8
+typedef struct upnerf_add_pair {
+  const float* a;
+  const float* b;
+  float* out;   /* may alias a or b */
+  int32_t n;
+} upnerf_add_pair;
+int upnerf_add_pairs(const upnerf_add_pair* pairs, int npairs, void* stream);
 /* The backward of the bias fold in one launch: y[k] = sum_m A[m][k] x[m] (upnerf_matvec, trans = 1, add = NULL, bit for bit) AND the
  * rank-1 update R[m][k] += x[m] v[k] (m < M, k < K; row stride ldr) that the caller used to issue as a separate addr_ launch
  * (d W_r1[:, :F] += g_br1 (x) b_feat, the second term of the folded colour layer's gradient). */

@@ -36,11 +36,11 @@ def test_struct_sizes_match_the_c_layout():
     prog = r'''
     #include <stdio.h>
     #include "upnerf_hip.h"
-    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(upnerf_layout), sizeof(upnerf_field_fwd_args),
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(upnerf_layout), sizeof(upnerf_field_fwd_args),
       sizeof(upnerf_composite_fwd_args), sizeof(upnerf_composite_bwd_args), sizeof(upnerf_field_bwd_args),
       sizeof(upnerf_loss_args), sizeof(upnerf_loss_grads), sizeof(upnerf_frag_desc), sizeof(upnerf_frag16_desc),
       sizeof(upnerf_gather_rays_args), sizeof(upnerf_pack_desc), sizeof(upnerf_wgrad_group), sizeof(upnerf_embed_group),
-      sizeof(upnerf_embed_rows_group), sizeof(upnerf_rng)); return 0; }'''
+      sizeof(upnerf_embed_rows_group), sizeof(upnerf_rng), sizeof(upnerf_add_pair)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         src, exe = os.path.join(d, "s.c"), os.path.join(d, "s")
         open(src, "w").write(prog)
@@ -49,7 +49,7 @@ def test_struct_sizes_match_the_c_layout():
     mine = [ctypes.sizeof(t) for t in (_lib.Layout, _lib.FieldFwdArgs, _lib.CompositeFwdArgs, _lib.CompositeBwdArgs,
                                        _lib.FieldBwdArgs, _lib.LossArgs, _lib.LossGrads, _lib.FragDesc, _lib.Frag16Desc,
                                        _lib.GatherRaysArgs, _lib.PackDesc, _lib.WgradGroup, _lib.EmbedGroup,
-                                       _lib.EmbedRowsGroup, _lib.Rng)]
+                                       _lib.EmbedRowsGroup, _lib.Rng, _lib.AddPair)]
     assert sizes == mine
 
 

@@ -223,6 +223,35 @@ def test_coarse_depths_with_the_jitter_generated_in_the_kernel(hip, disp):
     assert torch.equal(got, ref)
 
 
+def test_fanout_sums_the_gradients_of_all_pairs_in_one_launch(hip):
+    """ops.fanout: two aliases per tensor; the backward adds every pair with ONE upnerf_add_pairs launch -- the bits of autograd's own
+    a + b -- and passes a lone gradient through."""
+    ops = hip["ops"]
+    xs = [gen(s_, 40 + i).cuda().requires_grad_(True) for i, s_ in enumerate([(300, 3), (300, 3), (384, 257), (384,)])]
+    frozen = gen((5,), 50).cuda()
+    launches = []
+    real = ops.lib.upnerf_add_pairs
+
+    def counted(*a):
+        launches.append(a[1])
+        return real(*a)
+
+    ops.lib.upnerf_add_pairs = counted
+    try:
+        A, B = ops.fanout(*xs, frozen)
+        assert A[4] is frozen and B[4] is frozen
+        ws = [gen(tuple(x.shape), 60 + i).cuda() for i, x in enumerate(xs)]
+        vs = [gen(tuple(x.shape), 70 + i).cuda() for i, x in enumerate(xs)]
+        loss = sum((a * w).sum() for a, w in zip(A[:3], ws)) + sum((b * b * v).sum() for b, v in zip(B[:4], vs))  # xs[3]: one consumer only
+        loss.backward()
+    finally:
+        ops.lib.upnerf_add_pairs = real
+    assert launches == [3]
+    for i, x in enumerate(xs):
+        ref = (ws[i] if i < 3 else 0) + 2 * x.detach() * vs[i]
+        assert torch.equal(x.grad, ref if i < 3 else 2 * x.detach() * vs[i]), i
+
+
 def test_matvec_with_the_rank_one_update_riding_along(hip):
     """upnerf_matvec_rank1: y = A^T x exactly as upnerf_matvec(trans = 1) and R += x (x) v -- the bias fold's backward in one launch."""
     L = hip["lib"]

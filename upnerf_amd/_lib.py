@@ -159,6 +159,13 @@ class Frag16Desc(C.Structure):
     _fields_ = FragDesc._fields_ + [("exp_id", C.c_int32)]
 
 
+class AddPair(C.Structure):
+    _fields_ = [("a", _fp), ("b", _fp), ("out", _fp), ("n", C.c_int32)]
+
+
+MAX_ADD_PAIRS = 8
+
+
 class Rng(C.Structure):
     """upnerf_rng: key of the uniform draws a kernel generates itself."""
     _fields_ = [("seed", C.c_uint64), ("step", C.c_int32), ("row0", C.c_int32), ("row_stride", C.c_int32), ("step_dev", _fp)]
@@ -204,6 +211,8 @@ _SIGNATURES = {
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],
     "upnerf_matvec": [_i, _i, _p, _i, _p, _p, _p, _i, _p],
     "upnerf_matvec_rank1": [_i, _i, _p, _i, _p, _p, _p, _i, _p, _p],
+    "upnerf_add_pairs": [C.POINTER(AddPair), _i, _p],
+    "upnerf_zero": [_p, C.c_longlong, _p],
     "upnerf_vec_wgrad_frag16": [_i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p],
     "upnerf_ray_sum": [_i, _i, _p, _i, _p, _p],
     "upnerf_ray_part_finish": [_i, _i, _p, _p, _p, _p],

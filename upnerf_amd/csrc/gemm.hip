@@ -525,6 +525,23 @@ __global__ void unpack_kernel(const float* __restrict__ dP, PackDescs D) {
   ((float*)q.ptr)[(size_t)r * q.src_ld + c] = dP[q.dst_off + (size_t)r * q.dst_ld + c];
 }
 
+// ---- out_j = a_j + b_j for up to UPNERF_MAX_ADD_PAIRS tensors in one launch: the sum autograd forms when a tensor feeds two
+// consumers (ray origins / directions into the coarse and the fine pass; feat_share_layer into the folded colour matrix and the
+// per-ray projection), taken over by ops._Fanout so that a step carries ONE such launch per fan-out instead of an ATen add per tensor
+struct AddPairs {
+  upnerf_add_pair d[UPNERF_MAX_ADD_PAIRS];
+  int start[UPNERF_MAX_ADD_PAIRS + 1];
+  int n;
+};
+__global__ void add_pairs_kernel(AddPairs D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.start[D.n]) return;
+  int j = 0;
+  while (idx >= D.start[j + 1]) ++j;
+  const int e = idx - D.start[j];
+  D.d[j].out[e] = D.d[j].a[e] + D.d[j].b[e];
+}
+
 // ---- f16x3 weight re-layout (hi/lo fp16, fragment order, one power-of-two exponent per matrix id)
 struct Frag16Descs {
   upnerf_frag16_desc d[UPNERF_MAX_FRAG_DESC];
@@ -1115,15 +1132,14 @@ extern "C" int upnerf_vec_wgrad(int M, const float* v, int ldv, int nvec, const 
 #define TP_NS 128      // first-stage splits
 namespace {
 // rs[which][r][:] = sum over the tiles that hold rows of ray r of the tile's sums for that ray's slot (ascending tile order)
-__global__ void tile_part_rays_kernel(int R, int S, const float* __restrict__ part, float* __restrict__ rs_g1,
-                                      float* __restrict__ rs_r1) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  float* __restrict__ out = blockIdx.y == 0 ? rs_g1 : rs_r1;
+__device__ __forceinline__ void tile_part_rays_body(int idx, int which, int R, int S, const float* __restrict__ part,
+                                                    float* __restrict__ rs_g1, float* __restrict__ rs_r1) {
+  float* __restrict__ out = which == 0 ? rs_g1 : rs_r1;
   if (idx >= R * 32 || !out) return;
   const int r = idx >> 5, g = idx & 31;
   const long long b = (long long)r * S, e = b + S - 1;
   const int t0 = (int)(b / 64), t1 = (int)(e / 64);
-  const int base = TP_WCOLS + (blockIdx.y == 0 ? 0 : 384) + 4 * g;
+  const int base = TP_WCOLS + (which == 0 ? 0 : 384) + 4 * g;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int t = t0; t <= t1; ++t) {
     const int j = r - (int)(((long long)t * 64) / S);
@@ -1131,12 +1147,15 @@ __global__ void tile_part_rays_kernel(int R, int S, const float* __restrict__ pa
   }
   *(f32x4*)&out[(size_t)r * 128 + 4 * g] = s;
 }
+__global__ void tile_part_rays_kernel(int R, int S, const float* __restrict__ part, float* __restrict__ rs_g1,
+                                      float* __restrict__ rs_r1) {
+  tile_part_rays_body(blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, R, S, part, rs_g1, rs_r1);
+}
 // out1[split][0..519] = sum of the weight part over the split's tiles: two row groups of 130 16-byte columns, 8 rows in flight
-__global__ __launch_bounds__(320) void tile_part_sum1_kernel(int ntiles, int per, const float* __restrict__ part,
-                                                             float* __restrict__ out1) {
-  __shared__ __attribute__((aligned(16))) float red[TP_WCOLS];
+__device__ __forceinline__ void tile_part_sum1_body(int blk, int ntiles, int per, const float* __restrict__ part, float* __restrict__ out1,
+                                                    float* red) {
   const int tid = threadIdx.x, c4 = tid % 130, rg = tid / 130;
-  const int tb = blockIdx.x * per, te = (tb + per < ntiles) ? tb + per : ntiles;
+  const int tb = blk * per, te = (tb + per < ntiles) ? tb + per : ntiles;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (rg < 2) {
     constexpr int U = 8;
@@ -1154,7 +1173,25 @@ __global__ __launch_bounds__(320) void tile_part_sum1_kernel(int ntiles, int per
   }
   if (rg == 1) *(f32x4*)&red[4 * c4] = acc;
   __syncthreads();
-  if (rg == 0) *(f32x4*)&out1[(size_t)blockIdx.x * TP_WCOLS + 4 * c4] = acc + *(const f32x4*)&red[4 * c4];
+  if (rg == 0) *(f32x4*)&out1[(size_t)blk * TP_WCOLS + 4 * c4] = acc + *(const f32x4*)&red[4 * c4];
+}
+__global__ __launch_bounds__(320) void tile_part_sum1_kernel(int ntiles, int per, const float* __restrict__ part,
+                                                             float* __restrict__ out1) {
+  __shared__ __attribute__((aligned(16))) float red[TP_WCOLS];
+  tile_part_sum1_body(blockIdx.x, ntiles, per, part, out1, red);
+}
+// both first stages in ONE launch (round 6): blocks [0, nsu) sum the weight part of their split, the rest the per-ray rows -- the
+// two read the same table and do not depend on each other
+__global__ __launch_bounds__(320) void tile_part_stage1_kernel(int nsu, int nrb, int ntiles, int per, int R, int S,
+                                                               const float* __restrict__ part, float* __restrict__ out1,
+                                                               float* __restrict__ rs_g1, float* __restrict__ rs_r1) {
+  __shared__ __attribute__((aligned(16))) float red[TP_WCOLS];
+  if ((int)blockIdx.x < nsu) {
+    tile_part_sum1_body(blockIdx.x, ntiles, per, part, out1, red);
+    return;
+  }
+  const int b = blockIdx.x - nsu, which = b >= nrb ? 1 : 0;
+  if (threadIdx.x < 256) tile_part_rays_body((b - which * nrb) * 256 + threadIdx.x, which, R, S, part, rs_g1, rs_r1);
 }
 // column c of the weight part summed over the splits (four groups of splits per column, folded in a fixed order)
 __global__ __launch_bounds__(256) void tile_part_sum2_kernel(int ns, const float* __restrict__ out1, float* __restrict__ d_wcsig,
@@ -1192,13 +1229,18 @@ extern "C" int upnerf_tile_part_finish(int R, int S, const float* tile_part, flo
   if (M > 0x7fffffffLL) return UPNERF_EINVAL;
   const int ntiles = (int)((M + 63) / 64);
   const hipStream_t st = (hipStream_t)stream;
-  if (rs_g1 || rs_r1)
-    hipLaunchKernelGGL(tile_part_rays_kernel, dim3((R * 32 + 255) / 256, 2), dim3(256), 0, st, R, S, tile_part, rs_g1, rs_r1);
-  if (d_wcsig || d_bcsig || d_wr2 || d_br2) {
-    if (!scratch) return UPNERF_EINVAL;
-    const int ns = ntiles < TP_NS ? ntiles : TP_NS, per = (ntiles + ns - 1) / ns;
-    const int nsu = (ntiles + per - 1) / per;  // splits that hold at least one tile
-    hipLaunchKernelGGL(tile_part_sum1_kernel, dim3(nsu), dim3(320), 0, st, ntiles, per, tile_part, scratch);
+  const bool rays = rs_g1 || rs_r1, wsum = d_wcsig || d_bcsig || d_wr2 || d_br2;
+  if (wsum && !scratch) return UPNERF_EINVAL;
+  const int ns = ntiles < TP_NS ? ntiles : TP_NS, per = (ntiles + ns - 1) / ns;
+  const int nsu = (ntiles + per - 1) / per;  // splits that hold at least one tile
+  const int nrb = (R * 32 + 255) / 256;
+  if (rays && wsum)
+    hipLaunchKernelGGL(tile_part_stage1_kernel, dim3(nsu + 2 * nrb), dim3(320), 0, st, nsu, nrb, ntiles, per, R, S, tile_part, scratch,
+                       rs_g1, rs_r1);
+  else if (rays)
+    hipLaunchKernelGGL(tile_part_rays_kernel, dim3(nrb, 2), dim3(256), 0, st, R, S, tile_part, rs_g1, rs_r1);
+  if (wsum) {
+    if (!rays) hipLaunchKernelGGL(tile_part_sum1_kernel, dim3(nsu), dim3(320), 0, st, ntiles, per, tile_part, scratch);
     hipLaunchKernelGGL(tile_part_sum2_kernel, dim3((TP_WCOLS + 63) / 64), dim3(256), 0, st, nsu, scratch, d_wcsig, d_bcsig, d_wr2,
                        d_br2);
   }
@@ -1247,6 +1289,35 @@ extern "C" int upnerf_pack(float* P, const upnerf_pack_desc* descs, int ndesc, i
     hipLaunchKernelGGL(unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)P, D);
   else
     hipLaunchKernelGGL(pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D);
+  return (int)hipGetLastError();
+}
+
+// n floats of zeros, 16 bytes per thread and trip (the step's zero arena: zero_pool.py)
+__global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) ((f32x4*)p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
+}
+extern "C" int upnerf_zero(float* p, long long n, void* stream) {
+  if (!p || n <= 0 || ((uintptr_t)p & 15)) return UPNERF_EINVAL;
+  const long long want = ((n >> 2) + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int upnerf_add_pairs(const upnerf_add_pair* pairs, int npairs, void* stream) {
+  if (!pairs || npairs <= 0 || npairs > UPNERF_MAX_ADD_PAIRS) return UPNERF_EINVAL;
+  AddPairs D;
+  D.n = npairs;
+  D.start[0] = 0;
+  for (int j = 0; j < npairs; ++j) {
+    if (!pairs[j].a || !pairs[j].b || !pairs[j].out || pairs[j].n <= 0) return UPNERF_EINVAL;
+    D.d[j] = pairs[j];
+    D.start[j + 1] = D.start[j] + pairs[j].n;
+  }
+  hipLaunchKernelGGL(add_pairs_kernel, dim3((D.start[npairs] + 255) / 256), dim3(256), 0, (hipStream_t)stream, D);
   return (int)hipGetLastError();
 }
 

@@ -82,9 +82,12 @@ class NeRF(nn.Module):
         self.host_progress = None  # a checkpoint may carry another progress value
         self._progress_stale = False
 
-    def packed(self) -> torch.Tensor:
-        """Flat kernel-layout parameter buffer, differentiable w.r.t. the parameters."""
+    def packed(self, override=None) -> torch.Tensor:
+        """Flat kernel-layout parameter buffer, differentiable w.r.t. the parameters.  override: name -> tensor standing in for the
+        parameter of that name (aliases from ops.fanout for parameters that have a second consumer in the step)."""
         p = dict(self.named_parameters())
+        if override:
+            p.update(override)
         if p["xyz_encoding_1.0.weight"].is_cuda:
             return self.packer.pack_hip(p)  # 4 HIP launches; hand-written backward
         return self.packer.pack(p)  # torch restatement (CPU tests)

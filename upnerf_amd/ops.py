@@ -535,6 +535,55 @@ class _EmbedPrefetch:
         return hit["_keep"][1][at[0]:at[0] + idx.numel() * at[1]].view(idx.numel(), at[1])
 
 
+class _Fanout(torch.autograd.Function):
+    """Two aliases of each input, for tensors that feed two consumers inside a step.  Autograd would add the two gradients of every
+    such tensor with an ATen launch each; here the backward adds ALL pairs of the fan-out in one upnerf_add_pairs launch (a + b in
+    fp32 either way: same bits).  A missing gradient passes the other one through."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.set_materialize_grads(False)  # an alias nobody differentiated hands back None, not a zero tensor to be added
+        return tuple(x.view_as(x) for x in xs) + tuple(x.view_as(x) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = len(gs) // 2
+        outs, pairs = [None] * n, []
+        for j in range(n):
+            a, b = gs[j], gs[n + j]
+            if a is None or b is None:
+                outs[j] = a if b is None else b
+                continue
+            a, b = a.contiguous(), b.contiguous()
+            if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape):
+                outs[j] = a + b
+                continue
+            out = torch.empty_like(a)
+            outs[j] = out
+            pairs.append(_lib.AddPair(a=a.data_ptr(), b=b.data_ptr(), out=out.data_ptr(), n=a.numel()))
+            ctx_keep = (a, b)  # noqa: F841  (alive until the launch below is enqueued; the caching allocator is stream-ordered)
+        for lo in range(0, len(pairs), _lib.MAX_ADD_PAIRS):
+            part = pairs[lo:lo + _lib.MAX_ADD_PAIRS]
+            arr = (_lib.AddPair * len(part))(*part)
+            check(lib.upnerf_add_pairs(arr, len(part), stream()), "upnerf_add_pairs")
+        return tuple(outs)
+
+
+def fanout(*xs):
+    """(x_1a, ..., x_na), (x_1b, ..., x_nb): two aliases of every tensor that requires a gradient and lives on the GPU (others are
+    handed through twice): consumer A takes the first tuple, consumer B the second."""
+    live = [i for i, x in enumerate(xs) if isinstance(x, torch.Tensor) and x.is_cuda and x.requires_grad and ENABLE_FANOUT
+            and torch.is_grad_enabled()]
+    if not live:
+        return tuple(xs), tuple(xs)
+    res = _Fanout.apply(*[xs[i] for i in live])
+    a, b = list(xs), list(xs)
+    for k, i in enumerate(live):
+        a[i], b[i] = res[k], res[len(live) + k]
+    return tuple(a), tuple(b)
+
+
+ENABLE_FANOUT = os.environ.get("UPNERF_FANOUT", "1") != "0"  # (0: autograd's own accumulation, for A/B runs)
 ENABLE_EMBED_PREFETCH = os.environ.get("UPNERF_EMBED_PREFETCH", "1") != "0"  # (0: one gather launch per table, for A/B runs)
 EMBED_PREFETCH = _EmbedPrefetch()
 

@@ -57,6 +57,17 @@ def step(device):
         _S.rec, _S.arena = None, None
 
 
+def _zeroed(n: int, device) -> torch.Tensor:
+    """n zeroed floats by the library's own fill (upnerf_zero) on the GPU, torch.zeros elsewhere."""
+    dev = torch.device(device)
+    if dev.type != "cuda" or n <= 0:
+        return torch.zeros(max(n, 0), device=dev, dtype=torch.float32)
+    from ._lib import check, lib, stream
+    t = torch.empty(n, device=dev, dtype=torch.float32)
+    check(lib.upnerf_zero(t.data_ptr(), n, stream()), "upnerf_zero")
+    return t
+
+
 def zeros(n: int, device) -> torch.Tensor:
     """n zeroed floats (1-D, fp32)."""
     n = int(n)
@@ -65,7 +76,7 @@ def zeros(n: int, device) -> torch.Tensor:
     first = not _S.rec
     _S.rec.append(n)
     if first and _S.plan is not None and _S.plan[0] == torch.device(device) == _S.device:
-        _S.arena = torch.zeros(sum(_padded(k) for k in _S.plan[1]), device=device, dtype=torch.float32)
+        _S.arena = _zeroed(sum(_padded(k) for k in _S.plan[1]), device)
     if _S.arena is not None:
         sizes = _S.plan[1]
         if _S.i < len(sizes) and sizes[_S.i] == n and torch.device(device) == _S.device:
