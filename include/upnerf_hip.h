@@ -486,6 +486,15 @@ int upnerf_wgrad_f16p_chain(int M, const uint16_t* A16, int lda, const int32_t* 
                             float* db2, float* slabs, int nsplit, const int* expo_a, const int* expo_b,
                             upnerf_wgrad_pending* pending, void* stream);  /* n2 > 0: rows [n2, N) -> dW2 / db2 (as chain2) */
 
+/* A 256 x 256 weight gradient from PRODUCER-SPLIT operands (round 6): A16 / Alo16 and B16 / Blo16 are the (hi, lo) fp16 planes of the
+ * f16x3 field kernels' tiles, row-major [M][256], value = (hi + lo) * 2^-exp[m / 64] (upnerf_field_fwd_args.h16 / h_lo16 / hexp,
+ * upnerf_field_bwd_args.gz16 / gz_lo16 / gzexp) -- the 4 bytes per element of the fp32 rows, which ARE hi + lo, already split.  The
+ * kernel stages them by LDS-DMA (no conversion pass, no staging registers, three 16-row chunks in flight) and contracts as
+ * upnerf_wgrad_f16x3 does (three MFMAs per block); dW / db / slabs / pending as upnerf_wgrad_f16x3_chain.  M % 64 == 0
+ * (UPNERF_EUNSUP otherwise: the caller keeps the fp32 rows for such shapes). */
+int upnerf_wgrad_planes_chain(int M, const uint16_t* A16, const uint16_t* Alo16, const int32_t* aexp, const uint16_t* B16,
+                              const uint16_t* Blo16, const int32_t* bexp, float* dW, int ldo, float* db, float* slabs, int nsplit,
+                              const int* expo_a, const int* expo_b, upnerf_wgrad_pending* pending, void* stream);
 /* "24-bit" operands (f16x3 mode): A16 / Alo8 [M][lda] and, with b_is_f16 = 1, B16 / Blo8 [M][ldb] hold hi + lo8 as the f16x3 field
  * kernels write them (h16 + h_lo8, gz16 + gz_lo8; exponents per 64 rows); with b_is_f16 = 0 B is fp32 rows, split into hi + lo
  * on load.  Three MFMAs per block as upnerf_wgrad_f16x3: the operands are exact to 2^-20 of their tile's maximum.  256 x 256

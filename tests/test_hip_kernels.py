@@ -223,6 +223,52 @@ def test_coarse_depths_with_the_jitter_generated_in_the_kernel(hip, disp):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("M", [64 * 37, 64 * 512])
+def test_weight_gradient_from_producer_split_planes_staged_by_lds_dma(hip, M):
+    """upnerf_wgrad_planes_chain (round 6; measured, not wired into the step: DESIGN.md 4.9): both operands as the (hi, lo) fp16 planes
+    + per-64-row exponents the f16x3 field kernels hold in LDS, staged by LDS-DMA.  Against fp64 on the values the planes decode to,
+    and against upnerf_wgrad_f16x3_chain on the fp32 rows (= hi + lo exactly): the same products, so 1e-6 of the maximum."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_wgrad_planes import split_planes, tensor_exp
+    L, ops = hip["lib"], hip["ops"]
+    lib, ptr, st = L.lib, L.ptr, L.stream
+    dev = "cuda"
+    g = torch.Generator().manual_seed(M)
+    A = (torch.randn(M, 256, generator=g) * torch.rand(M, 1, generator=g) ** 3 * (torch.rand(M, 256, generator=g) > 0.5)).to(dev)
+    B = torch.relu(torch.randn(M, 256, generator=g)).to(dev)
+    A[64:128] *= 1e-6  # a tile far below the tensor's maximum: its exponent gap exceeds what fp16 holds after the rescale
+    Ah, Al, aexp, Ad = split_planes(A, False)
+    Bh, Bl, bexp, Bd = split_planes(B, True)
+    ea = torch.tensor([tensor_exp(Ad)], dtype=torch.int32, device=dev)
+    eb = torch.tensor([tensor_exp(Bd)], dtype=torch.int32, device=dev)
+    ns = ops.nsplit_for(M)
+    res = []
+    for planes in (True, False):
+        dW, db = torch.full((256, 260), 7.0, device=dev), torch.full((256,), 7.0, device=dev)
+        ws = torch.empty(ns * (256 * 256 + 256 + 260), device=dev)
+        pend = L.WgradPending()
+        if planes:
+            rc = lib.upnerf_wgrad_planes_chain(M, ptr(Ah), ptr(Al), ptr(aexp), ptr(Bh), ptr(Bl), ptr(bexp), ptr(dW), 260, ptr(db), ptr(ws), ns, ptr(ea),
+                                               ptr(eb), C.byref(pend), st())
+        else:
+            rc = lib.upnerf_wgrad_f16x3_chain(M, ptr(Ad), 256, 256, ptr(Bd), 256, 256, ptr(dW), 260, ptr(db), ptr(ws), ns, ptr(ea), ptr(eb), 2,
+                                              C.byref(pend), st())
+        L.check(rc, "wgrad")
+        L.check(lib.upnerf_wgrad_finish(C.byref(pend), st()), "finish")
+        torch.cuda.synchronize()
+        assert float(dW[:, 256:].min()) == 7.0 and float(dW[:, 256:].max()) == 7.0  # the padding columns of the destination stay untouched
+        res.append((dW[:, :256].clone(), db.clone()))
+    ref, refb = Ad.double().t() @ Bd.double(), Ad.double().sum(0)
+    for dW, db in res:
+        assert float((dW.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+        assert float((db.double() - refb).abs().max() / refb.abs().max()) < 2e-6
+    assert float((res[0][0] - res[1][0]).abs().max() / res[1][0].abs().max()) < 1e-6
+    # not a multiple of 64 rows: refused, the caller keeps the fp32 rows
+    assert lib.upnerf_wgrad_planes_chain(M + 16, ptr(Ah), ptr(Al), ptr(aexp), ptr(Bh), ptr(Bl), ptr(bexp), ptr(dW), 260, ptr(db), ptr(ws), ns, ptr(ea),
+                                         ptr(eb), C.byref(L.WgradPending()), st()) == -2  # UPNERF_EUNSUP
+
+
 def test_fanout_sums_the_gradients_of_all_pairs_in_one_launch(hip):
     """ops.fanout: two aliases per tensor; the backward adds every pair with ONE upnerf_add_pairs launch -- the bits of autograd's own
     a + b -- and passes a lone gradient through."""

@@ -206,6 +206,8 @@ _SIGNATURES = {
     "upnerf_wgrad_f16p_chain": [_i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p,
                                 C.POINTER(WgradPending), _p],
     "upnerf_wgrad_f24p_chain": [_i, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p, C.POINTER(WgradPending), _p],
+    # (M, A16, Alo16, aexp, B16, Blo16, bexp, dW, ldo, db, slabs, nsplit, expo_a, expo_b, pending, stream)
+    "upnerf_wgrad_planes_chain": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _p, C.POINTER(WgradPending), _p],
     "upnerf_wgrad_grouped_scratch": [C.POINTER(WgradGroup), _i, _i],
     "upnerf_wgrad_grouped": [C.POINTER(WgradGroup), _i, _p, _i, _p],
     "upnerf_vec_wgrad": [_i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p],

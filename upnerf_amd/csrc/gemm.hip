@@ -963,6 +963,32 @@ extern "C" int upnerf_wgrad_f16p_chain_v(int M, const uint16_t* A16, const int32
   return 0;
 }
 
+extern "C" int upnerf_wgrad_planes_partial(int M, const uint16_t* Ah, const uint16_t* Al, const int* aexp, const uint16_t* Bh,
+                                           const uint16_t* Bl, const int* bexp, const int* expo_a, const int* expo_b, float* slabs,
+                                           float* bslabs, int nsplit, int rows, const upnerf_wgrad_pending* prev, void* stream);  // csrc/wgrad_f16x3.hip
+
+// dW[256][ldo] = sum_m A[m][:]^T B[m][:] from producer-split operands (include/upnerf_hip.h): a link of a chained run
+extern "C" int upnerf_wgrad_planes_chain(int M, const uint16_t* A16, const uint16_t* Alo16, const int32_t* aexp, const uint16_t* B16,
+                                         const uint16_t* Blo16, const int32_t* bexp, float* dW, int ldo, float* db, float* slabs, int nsplit,
+                                         const int* expo_a, const int* expo_b, upnerf_wgrad_pending* pending, void* stream) {
+  if (M <= 0 || !A16 || !Alo16 || !aexp || !B16 || !Blo16 || !bexp || !dW || !slabs || nsplit <= 0 || !expo_a || !expo_b || !pending || (ldo & 3))
+    return UPNERF_EINVAL;
+  if (M & 63) return UPNERF_EUNSUP;  // whole 64-row tiles (one exponent each) only
+  if (pending->nsplit > 0 && pending->slabs == slabs) return UPNERF_EINVAL;
+  const int TN = 256, TK = 256;
+  const int rows = (((M + nsplit - 1) / nsplit) + 63) / 64 * 64;
+  float* bslabs = slabs + (size_t)nsplit * TN * TK;
+  if (pending->nsplit > 0 && pending->rblocks > nsplit) {
+    int rc = upnerf_wgrad_finish(pending, stream);
+    if (rc) return rc;
+  }
+  int rc = upnerf_wgrad_planes_partial(M, A16, Alo16, aexp, B16, Blo16, bexp, expo_a, expo_b, slabs, bslabs, nsplit, rows,
+                                       pending->nsplit > 0 ? pending : nullptr, stream);
+  if (rc) return rc;
+  *pending = reduce_desc(256, 256, TN, TK, nsplit, slabs, bslabs, dW, ldo, db);
+  return 0;
+}
+
 extern "C" int upnerf_vec_wgrad_frag16(int M, const float* v, int ldv, int nvec, const uint16_t* X16, const int32_t* xexp, int K,
                                        float* dw, float* dbv, float* scratch, int nsplit, void* stream) {
   if (M <= 0 || !v || !X16 || !xexp || !dw || !scratch || nsplit <= 0 || ldv < nvec) return UPNERF_EINVAL;

@@ -808,6 +808,182 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   }
 }
 
+
+// ---- 256 x 256 block from PRODUCER-SPLIT operands, staged by LDS-DMA (round 6) -----------------------------------------------------
+// Both operands arrive as the (hi, lo) fp16 planes the f16x3 field kernels hold in LDS -- value = (hi + lo) * 2^-e, one exponent per
+// 64-row tile (upnerf_field_fwd_args.h16 / h_lo16 / hexp, upnerf_field_bwd_args.gz16 / gz_lo16 / gzexp): the SAME 4 bytes per element
+// as the fp32 rows (which are exactly hi + lo), but already split.  So this kernel has no conversion pass and no staging registers:
+// every wave copies its pieces of a 16-row chunk straight into the swizzled LDS image with global_load_lds_dwordx4 -- the XOR of the
+// image (himg) is applied on the SOURCE side, through the per-lane global address -- four chunks in a ring, three in flight (96 KB
+// per CU requested ahead of the matrix work, against 64 KB in registers in wgrad_f16x3_kernel), ONE counted s_waitcnt vmcnt + ONE
+// s_barrier per chunk.  The tile exponents are folded into the B fragments after the transposed read (v_pk_mul_f16 by a power of
+// two: exact unless the product sinks below fp16's range, i.e. is 2^-38 of the tensor's maximum), so the MFMA inputs are the ones
+// wgrad_f16x3_kernel builds from the fp32 rows: (hi + lo) 2^k splits into hi 2^k and lo 2^k.  Column sums of A (the bias gradient)
+// come from the A fragments: each of the four waves that share an n-range sums one of its four n-tiles.  M-range of a split: whole
+// 16-row chunks, whole 64-row tiles of exponents (the caller guarantees M % 64 == 0 and rows_per_split % 64 == 0).
+#define WP_CH 16
+#define WP_SLOTS 5   // the CU's whole 160 KB: four chunks in flight (the stream is LATENCY-bound: period = (latency + re-issue delay) / chunks in flight)
+#define WP_SLOT (4 * 8192)  // [A hi | A lo | B hi | B lo], each [2 panels][16 rows][256 bytes]
+__global__ __launch_bounds__(FX_THREADS, 1) void wgrad_planes_kernel(int M, const uint16_t* __restrict__ Ah, const uint16_t* __restrict__ Al,
+                                                                   const int* __restrict__ aexp, const uint16_t* __restrict__ Bh,
+                                                                   const uint16_t* __restrict__ Bl, const int* __restrict__ bexp,
+                                                                   const int* __restrict__ expo_a, const int* __restrict__ expo_b,
+                                                                   float* __restrict__ slabs, float* __restrict__ bslabs,
+                                                                   int rows_per_split, upnerf_wgrad_pending prev) {
+  constexpr int TN = 256, TK = 256, MT = 4, NT = 2, SZ = 8192;
+  __shared__ __attribute__((aligned(16))) char lds[WP_SLOTS * WP_SLOT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hh = lane >> 5;
+  const int wn = wave >> 2, wk = wave & 3;
+  const int n0 = wn * 32 * MT, k0 = wk * 32 * NT;
+  const int split = blockIdx.x;
+  const int mbeg = split * rows_per_split;
+  const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  if (prev.nsplit > 0) {
+    if ((int)blockIdx.x < prev.rblocks) {
+      wgrad_reduce_body(blockIdx.x, tid, prev, (f32x4(*)[64])lds);
+      __syncthreads();
+    }
+  }
+  const int ea = expo_a[0], eb = expo_b[0];
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  float bacc = 0.0f;  // column sum of A over this split, column n0 + 32 wk + li (both lane halves hold a part)
+  const int nchunk = mend > mbeg ? (mend - mbeg) / WP_CH : 0;
+  // this wave's pieces of a chunk: plane p = wave / 2 (A hi, A lo, B hi, B lo), panel = wave % 2, four 1 KiB pieces of four rows.
+  // Piece rg, lane l: image row 4 rg + l / 16, position l % 16 of the row's sixteen 16-byte chunks, which holds logical chunk
+  // position ^ (((row & 3) << 2) | (row >> 2))  (himg).
+  const int p = wave >> 1, panel = wave & 1;
+  const char* __restrict__ src = (const char*)(p == 0 ? Ah : (p == 1 ? Al : (p == 2 ? Bh : Bl)));
+  int soff[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int row = 4 * rg + (lane >> 4), pos = lane & 15;
+    soff[rg] = row * 512 + panel * 256 + ((pos ^ (((row & 3) << 2) | (row >> 2))) << 4);
+  }
+  auto dma_piece = [&](int c, int rg) {  // piece rg of chunk c (see dma)
+    const int cc = c < nchunk ? c : nchunk - 1;
+    const char* a = src + (size_t)(mbeg + cc * WP_CH) * 512 + soff[rg];
+    const unsigned d = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds) + (c % WP_SLOTS) * WP_SLOT + p * SZ + panel * 4096;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(d + rg * 1024), "v"(a) : "memory", "m0");
+  };
+  auto dma = [&](int c) {  // chunk c of this split into slot c % 4 (past the end: the last chunk again -- the waits count instructions)
+    const int cc = c < nchunk ? c : nchunk - 1;
+    const char* g = src + (size_t)(mbeg + cc * WP_CH) * 512;
+    // Issued as inline asm ON PURPOSE: behind the builtin hipcc's wait-count pass knows that LDS is being written by a vector-memory
+    // operation and -- having no alias information for the transposing reads below -- puts `s_waitcnt vmcnt(0)` in front of them:
+    // every chunk then waits for all three in flight (seen in the ISA of the first build).  The counted wait at the top of the
+    // loop + the barrier are the synchronisation; M0 = LDS byte address of the piece (lane l lands at M0 + 16 l).
+    const unsigned d = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds) + (c % WP_SLOTS) * WP_SLOT + p * SZ + panel * 4096;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const char* a = g + soff[rg];
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(d + rg * 1024), "v"(a) : "memory", "m0");
+    }
+  };
+  const int g4 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int trow = 8 * (g4 >> 1) + tq, tcol = 16 * (g4 & 1) + 4 * tp;
+  if (nchunk > 0) {
+    __syncthreads();  // (the reduction prologue is done with the LDS)
+    dma(0);
+    dma(1);
+    dma(2);
+    dma(3);
+    int nxa = aexp[mbeg >> 6], nxb = bexp[mbeg >> 6];  // tile exponents of the next chunk: requested one chunk ahead (scalar loads)
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+      const int xa = nxa, xb = nxb;
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // this wave's four pieces of chunk c have landed (chunks c + 1 .. c + 3 may fly)
+      __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): its reads of chunk c - 1 are done
+      __builtin_amdgcn_s_barrier();                      // everybody's pieces have landed; slot (c - 1) % 5 is free
+      asm volatile("" ::: "memory");
+      dma(c + 4);                                        // at once: what the stream waits for is the request, not the matrix work
+      {
+        const int mn = mbeg + (c + 1 < nchunk ? c + 1 : c) * WP_CH;
+        nxa = aexp[mn >> 6];
+        nxb = bexp[mn >> 6];
+      }
+#ifdef WP_EXP_NOREAD  // timing experiment (wrong results): the DMA stream and the per-chunk synchronisation alone
+      continue;
+#endif
+      const char* base = lds + (c % WP_SLOTS) * WP_SLOT;
+      // 2^((ea - xa) + (eb - xb)) as fp16: both tile exponents folded into the B fragments
+      int fe = (ea - xa) + (eb - xb);
+      fe = fe > 15 ? 15 : (fe < -24 ? -24 : fe);
+      const _Float16 f = (_Float16)ldexpf(1.0f, fe);
+      h8 ah[MT], al[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int o0 = himg<WP_CH>(trow, n0 + 32 * mt + tcol), o1 = himg<WP_CH>(trow + 4, n0 + 32 * mt + tcol);
+        const h4 x0 = tr_read(base, o0), x1 = tr_read(base, o1);
+        ah[mt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const h4 y0 = tr_read(base + SZ, o0), y1 = tr_read(base + SZ, o1);
+        al[mt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      h8 bhv[NT], blv[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int o0 = himg<WP_CH>(trow, k0 + 32 * nt + tcol), o1 = himg<WP_CH>(trow + 4, k0 + 32 * nt + tcol);
+        const h4 x0 = tr_read(base + 2 * SZ, o0), x1 = tr_read(base + 2 * SZ, o1);
+        bhv[nt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const h4 y0 = tr_read(base + 3 * SZ, o0), y1 = tr_read(base + 3 * SZ, o1);
+        blv[nt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // bias: the wave sums n-tile wk of its range (the other three waves of the range hold the same fragments)
+      {
+        float s = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          if (mt == wk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)ah[mt][j] + (float)al[mt][j];
+          }
+        bacc = fmaf(s, ldexpf(1.0f, -xa), bacc);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        h8 bh = bhv[nt], bl = blv[nt];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bh[j] = bh[j] * f;
+          bl[j] = bl[j] * f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#ifndef WP_EXP_NOMMA  // timing experiment (wrong results): everything but the matrix work
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+#else
+          acc[mt][nt][0] += (float)ah[mt][0] * (float)bh[0] + (float)al[mt][1] * (float)bl[1];
+#ifdef WP_EXP_SLEEP  // ... and the wave idles for the time its three MFMAs would hold the pipe when it has it to itself (96 cycles)
+          __builtin_amdgcn_s_sleep(1);
+          asm volatile("s_nop 15\n\ts_nop 15");
+#endif
+#endif
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus pieces of the tail
+  }
+  const float unscale = ldexpf(1.0f, -(ea + eb));
+  float* slab = slabs + (size_t)split * TN * TK;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        slab[n * TK + k0 + 32 * nt + li] = acc[mt][nt][r] * unscale;
+      }
+  if (bslabs) {
+    bacc += __shfl_xor(bacc, 32);  // the two k halves of the fragment
+    if (lane < 32) bslabs[(size_t)split * TN + n0 + 32 * wk + li] = bacc;
+  }
+}
+
 template <int MTW, int NTW, int PKB, int FRAG, int NP = 1>
 int launch_p(int M, int N, int K, const uint16_t* A, int lda, const int* aexp, const void* B, int ldb, const int* bexp,
              const int* expo_a, const int* expo_b, float* slabs, float* bslabs, int nsplit, int rows, hipStream_t st,
@@ -871,6 +1047,17 @@ extern "C" int upnerf_wgrad_f16x3_partial(int M, const float* A, int lda, int N,
   if (TN == 64 && TK == 128) return launch<1, 2>(WG_ARGS);
   return launch<1, 1>(WG_ARGS);
 #undef WG_ARGS
+}
+
+// 256 x 256 block from (hi, lo) fp16 planes, staged by LDS-DMA (wgrad_planes_kernel; upnerf_wgrad_planes_chain, gemm.hip)
+extern "C" int upnerf_wgrad_planes_partial(int M, const uint16_t* Ah, const uint16_t* Al, const int* aexp, const uint16_t* Bh,
+                                           const uint16_t* Bl, const int* bexp, const int* expo_a, const int* expo_b, float* slabs,
+                                           float* bslabs, int nsplit, int rows, const upnerf_wgrad_pending* prevp, void* stream) {
+  upnerf_wgrad_pending prev = {};
+  if (prevp) prev = *prevp;
+  hipLaunchKernelGGL(wgrad_planes_kernel, dim3(nsplit, 1, 1), dim3(FX_THREADS), 0, (hipStream_t)stream, M, Ah, Al, aexp, Bh, Bl, bexp, expo_a,
+                     expo_b, slabs, bslabs, rows, prev);
+  return (int)hipGetLastError();
 }
 
 // the same for the fragment-ordered fp16 operands of the register-resident field kernels (upnerf_wgrad_f16p_chain_v, gemm.hip)
