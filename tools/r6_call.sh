@@ -1,6 +1,4 @@
 #!/bin/bash
-out=gpurun_out/r6w; mkdir -p $out
-for v in _wpsleep; do
-echo "== lib$v"; UPNERF_LIB=$PWD/upnerf_amd/libupnerf_hip$v.so python tools/bench_wgrad_planes.py 786432 2>&1 | grep "us per launch"
-UPNERF_LIB=$PWD/upnerf_amd/libupnerf_hip$v.so python tools/bench_wgrad_planes.py 262144 2>&1 | grep "us per launch"
-done | tee $out/planes_eliminate.txt
+out=gpurun_out/r6j; mkdir -p $out
+timeout 1500 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py tests/test_hip_midsize.py tests/test_hip_fullsize.py -q -x -m gpu > $out/pytest.log 2>&1; tail -3 $out/pytest.log
+bash tools/r3_ab_libs.sh "_nojoin -" "64" 3 2>&1 | tee $out/ab_join.txt

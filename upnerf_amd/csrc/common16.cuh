@@ -258,6 +258,52 @@ __device__ __forceinline__ void mma16_lds(f32x16 (&acc)[MT][NT], const char* Ph,
   }
 }
 
+// Two contractions that read the SAME plane columns in one K loop (round 6): acc[mt][0] += planes . WfA[n0 ..)^T, acc[mt][1] +=
+// planes . WfB[n0 ..)^T -- the first layers of the colour and the candidate head both contract the 256 columns of e, each 128 wide
+// (one n-tile per wave): run one after the other, each loop has six MFMAs per k-block to cover its weight fragments' L2 latency
+// with (a trunk layer's loop has twelve) and reads the activation fragments again.  Joined, the k-block is a trunk layer's: four
+// weight fragments, two activation fragments, twelve MFMAs.  Per accumulator the products and their order are those of mma16_lds
+// with NT = 1 (bitwise the same sums).  T k-blocks, ring of AHEAD + 1 fragment sets, fully unrolled (as mma16_lds's unrolled form).
+template <int NP, int W, int T, int AHEAD, int MT>
+__device__ __forceinline__ void mma16_lds_pair(f32x16 (&acc)[MT][2], const char* Ph, const char* Pl, int row0, int kA0,
+                                               const char* __restrict__ WfA, int Kp16A, const char* __restrict__ WfB, int Kp16B, int n0,
+                                               int lane) {
+  constexpr int SETS = (AHEAD + 1 > T) ? T : AHEAD + 1;
+  constexpr int AH = SETS - 1;
+  int li = lane & 31, lh = lane >> 5;
+  asm volatile("" : "+v"(li), "+v"(lh));
+  const char* bpu[2];
+  bpu[0] = WfA + ((size_t)(n0 >> 5) * Kp16A) * 2048 + (li + 32 * lh) * 16;
+  bpu[1] = WfB + ((size_t)(n0 >> 5) * Kp16B) * 2048 + (li + 32 * lh) * 16;
+  h8 uwh[SETS][2], uwl[SETS][2], uxh[2][MT], uxl[2][MT];
+  auto ldw = [&](int t) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      uwh[t % SETS][nt] = W_LOAD(bpu[nt], t);
+      if constexpr (NP == 2) uwl[t % SETS][nt] = W_LOAD_LO(bpu[nt], t);
+    }
+  };
+  auto ldx = [&](int t) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int o = poff<W>(row0 + 32 * mt + li, kA0 + 16 * t + 8 * lh);
+      uxh[t & 1][mt] = *(const h8*)(Ph + o);
+      if constexpr (NP == 2) uxl[t & 1][mt] = *(const h8*)(Pl + o);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < AH; ++t) ldw(t);
+  ldx(0);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t + AH < T) ldw(t + AH);
+    if (t + 1 < T) ldx(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16_step<NP>(acc, uxh[t & 1], uxl[t & 1], uwh[t % SETS], uwl[t % SETS]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Same with the activation operand converted on the fly from fp32 rows in global memory (short side inputs: encoding for
 // the skip connection, per-ray embedding rows): xrow_ptr[mt] points at this lane's row at column 8*(lane>>5); `e` is the
 // exponent of the LDS planes the same accumulators are fed from.  K % 16 == 0.

@@ -53,6 +53,9 @@
 // burst behind the loop costs and the epilogue still waits for its barriers.  0 = behind the loop (shipped); 1 = the experiment.
 #define F16_STORE_IN_LOOP 0
 #endif
+#ifndef F16_JOIN_HEADS
+#define F16_JOIN_HEADS 1  // the first layers of the colour and the candidate head in one K loop when both run (0: one after the other, for A/B runs)
+#endif
 #ifndef F16_AHEAD_F16
 #define F16_AHEAD_F16 5  // (with non-temporal stores: 19.63 ms per Trevi step against 19.78 at three ahead; round 3)
 #endif
@@ -674,11 +677,27 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     rayrow[mt] = m / S;
   }
   float mr = 0.0f, mc = 0.0f;
+  // both heads on (the schedule's middle phase): their first layers contract the same 256 columns of e -- ONE K loop (common16.cuh:
+  // mma16_lds_pair; per accumulator bitwise the two loops it replaces)
+  const bool pair = F16_JOIN_HEADS && a.use_rgb && a.use_cand && TH::NT == 1;
+  if (pair) {
+    f32x16 acc2[TH::MT][2];
+    acc_zero(acc2);
+    mma16_lds_pair<NP, W, W / 16, AH>(acc2, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, P16 + 4 * (size_t)L.wc1,
+                                      (W + UPNERF_CK) / 16, hn0, lane);
+#pragma unroll
+    for (int mt = 0; mt < TH::MT; ++mt) {
+      accr[mt][0] = acc2[mt][0];
+      accc[mt][0] = acc2[mt][1];
+    }
+  }
   if (a.use_rgb) {
-    acc_zero(accr);
     f32x4 br[TH::NT][4];
     load_cols(br, P + L.br1, hn0, hh);
-    mma16_lds<NP, W, W / 16, AH>(accr, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, 0, lane);
+    if (!pair) {
+      acc_zero(accr);
+      mma16_lds<NP, W, W / 16, AH>(accr, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wr1, (W + UPNERF_AUXK) / 16, hn0, 0, lane);
+    }
     store_e();
     HSTAMP(0);  // colour: 256-deep K loop + the store of e
     const float* ap[TH::MT];
@@ -690,10 +709,12 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     HSTAMP(1);  // colour: side-input contraction (rows from global) + bias / relu / max
   }
   if (a.use_cand) {
-    acc_zero(accc);
     f32x4 bc[TH::NT][4];
     load_cols(bc, P + L.bc1, hn0, hh);
-    mma16_lds<NP, W, W / 16, AH>(accc, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, 0, lane);
+    if (!pair) {
+      acc_zero(accc);
+      mma16_lds<NP, W, W / 16, AH>(accc, Ph, Pl, hrow0, 0, P16 + 4 * (size_t)L.wc1, (W + UPNERF_CK) / 16, hn0, 0, lane);
+    }
     store_e();
     HSTAMP(2);  // candidate: 256-deep K loop
     const float* ap[TH::MT];
