@@ -1,10 +1,4 @@
 #!/bin/bash
-# round 6: full GPU suite on the final sources, then everything under profiles/r06_* (tools/final_profile.sh)
-out=gpurun_out/r6final; mkdir -p $out
-timeout 1500 python -m pytest tests -q -m gpu -rA > $out/pytest.log 2>&1; tail -4 $out/pytest.log
-grep -h "^\[masks\]" $out/pytest.log | sort | uniq > $out/masks.txt
-bash tools/final_profile.sh gpurun_out/final_r06 r06 > $out/final_profile.log 2>&1; tail -3 $out/final_profile.log
-python tools/bytes_table.py gpurun_out/final_r06/pmc.json > gpurun_out/final_r06/bytes_table.md 2>&1
-make -C upnerf_amd/csrc stamps > /dev/null 2>&1
-python tools/stamps_field16.py > gpurun_out/final_r06/stamps_field16.txt 2>/dev/null
-python tools/show_bench.py gpurun_out/final_r06/bench.json 2>/dev/null | head -6
+out=gpurun_out/r6s; mkdir -p $out
+bash tools/r3_ab_libs.sh "- _stl1 _stl2" "64" 3 2>&1 | tee $out/ab_stl.txt
+UPNERF_LIB=$PWD/upnerf_amd/libupnerf_hip_stl2.so timeout 900 python -m pytest tests/test_hip_kernels.py -q -x -m gpu -k "stage_by_stage or ragged or golden" 2>&1 | tail -3

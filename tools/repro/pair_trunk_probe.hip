@@ -44,6 +44,35 @@ struct LoopStore {
   int htid;
   __device__ __forceinline__ void operator()(int it) const { store_piece(Ph, Pl, dst, un, htid, it); }
 };
+// the same with the LDS words of piece t read one k-block ahead of their conversion and store (mode 12): the store's LDS round trip
+// passes under the previous k-block's MFMAs instead of standing in front of this one's
+struct LoopStorePipe {
+  const char *Ph, *Pl;
+  float* dst;
+  float un;
+  int htid;
+  u32x2_t h, l;
+  __device__ __forceinline__ void read(int it) {
+    int t = htid;
+    asm volatile("" : "+v"(t));
+    const int idx = t + it * 256, row = idx >> 6, g = idx & 63;
+    const int o = poff<W>(row, 4 * g);
+    h = *(const u32x2_t*)(Ph + o);
+    l = *(const u32x2_t*)(Pl + o);
+  }
+  __device__ __forceinline__ void flush(int it) const {
+    int t = htid;
+    asm volatile("" : "+v"(t));
+    const int idx = t + it * 256, row = idx >> 6, g = idx & 63;
+    const f32x4 v = {mix16<0>(h[0], un, mix16<0>(l[0], un, 0.f)), mix16<1>(h[0], un, mix16<1>(l[0], un, 0.f)),
+                     mix16<0>(h[1], un, mix16<0>(l[1], un, 0.f)), mix16<1>(h[1], un, mix16<1>(l[1], un, 0.f))};
+    __builtin_nontemporal_store(v, (f32x4*)&dst[(size_t)row * W + 4 * g]);
+  }
+  __device__ __forceinline__ void operator()(int it) {
+    if (it > 0) flush(it - 1);
+    read(it);
+  }
+};
 
 // the shipped epilogue of a trunk layer for one 64-row half (4 waves): returns the new exponent; planes rewritten
 template <int NBAR>
@@ -84,7 +113,7 @@ __device__ __forceinline__ void fill_planes(char* Ph, char* Pl, int htid, int se
 }
 
 // ---- modes 0 / 1: the shipped structure ------------------------------------------------------------------------------------------
-template <bool INLOOP>
+template <bool INLOOP, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void trunk_single(const char* __restrict__ P16, const float* __restrict__ bias, const int* __restrict__ wexp,
                                                        float* __restrict__ h, unsigned long long* __restrict__ hmask, int M, int L) {
   __shared__ __attribute__((aligned(16))) char planes[2 * HALF * W * 2];
@@ -105,7 +134,11 @@ __global__ __launch_bounds__(256, 2) void trunk_single(const char* __restrict__ 
     const int wel = __builtin_amdgcn_readfirstlane(wexp[l & 7]);
     const char* Wl = P16 + (size_t)(l & 7) * (W * W * 4);
     float* dst = h + ((size_t)((l + L - 1) % L) * M + m0) * W;  // h_{l-1} (layer 0 stores the filled planes as "h_{L-1}")
-    if (INLOOP) {
+    if (INLOOP && PIPE) {
+      LoopStorePipe ps{Ph, Pl, dst, ldexpf(1.0f, -ecur), tid};
+      mma16_lds<2, W, W / 16, 2>(acc, Ph, Pl, 0, 0, Wl, W / 16, 64 * wave, 0, lane, ps);
+      ps.flush(15);
+    } else if (INLOOP) {
       LoopStore ps{Ph, Pl, dst, ldexpf(1.0f, -ecur), tid};
       mma16_lds<2, W, W / 16, 2>(acc, Ph, Pl, 0, 0, Wl, W / 16, 64 * wave, 0, lane, ps);
     } else {
@@ -261,8 +294,9 @@ int main(int argc, char** argv) {
                          "pair, stores behind; NO barrier at odd units", "pair, stores inside; NO barrier at odd units",
                          "pair, stores behind; NO DMA                 ", "pair, stores inside; NO DMA                 ",
                          "pair, stores behind; NO unit barriers       ", "pair, stores inside; NO unit barriers       ",
-                         "pair, stores behind; MFMAs at raised priority", "pair, stores inside; MFMAs at raised priority"};
-  const int NMODE = 12;
+                         "pair, stores behind; MFMAs at raised priority", "pair, stores inside; MFMAs at raised priority",
+                         "shipped structure, stores inside the K loop, LDS words one k-block ahead"};
+  const int NMODE = 13;
   printf("trunk probe: %d samples, %d layers of 256 x 256 (f16x3), fp32 activation stores of every layer\n", M, L);
   for (int rep = 0; rep < 2; ++rep)
     for (int mode = 0; mode < NMODE; ++mode) {
@@ -283,6 +317,7 @@ int main(int argc, char** argv) {
       if (mode == 8) hipLaunchKernelGGL((trunk_pair<false, 4>), dim3(M / 128), dim3(512), 0, 0, P16, bias, wexp, h, hm, M, L);
       if (mode == 9) hipLaunchKernelGGL((trunk_pair<true, 4>), dim3(M / 128), dim3(512), 0, 0, P16, bias, wexp, h, hm, M, L);
       if (mode == 10) hipLaunchKernelGGL((trunk_pair<false, 8>), dim3(M / 128), dim3(512), 0, 0, P16, bias, wexp, h, hm, M, L);
+      if (mode == 12) hipLaunchKernelGGL((trunk_single<true, true>), dim3(M / 64), dim3(256), 0, 0, P16, bias, wexp, h, hm, M, L);
       if (mode == 11) hipLaunchKernelGGL((trunk_pair<true, 8>), dim3(M / 128), dim3(512), 0, 0, P16, bias, wexp, h, hm, M, L);
       (void)hipEventRecord(e1, 0);
       (void)hipDeviceSynchronize();
@@ -291,7 +326,7 @@ int main(int argc, char** argv) {
       (void)hipEventElapsedTime(&ms, e0, e1);
       unsigned long long a[8];
       (void)hipMemcpyFromSymbol(a, HIP_SYMBOL(probe_acc), sizeof(a));
-      const double waves = (mode < 2 ? 4.0 * (M / 64 / 16) : 8.0 * (M / 128 / 8)) * (double)L;  // reporting waves x layers
+      const double waves = ((mode < 2 || mode == 12) ? 4.0 * (M / 64 / 16) : 8.0 * (M / 128 / 8)) * (double)L;  // reporting waves x layers
       if (rep == 1)
         printf("mode %2d  %s: %.3f ms%s  per wave and layer (ticks of s_memtime): top %.0f  K loop %.0f  epilogue+stores %.0f  barrier %.0f  plane write %.0f  barrier %.0f  sum %.0f\n",
                mode, names[mode], ms, err == hipSuccess ? "" : " [LAUNCH ERROR]", a[0] / waves, a[1] / waves, a[2] / waves, a[3] / waves, a[4] / waves, a[5] / waves,

@@ -50,7 +50,11 @@
 // Activation stores as one 1 KiB piece per k-block INSIDE the next layer's K loop (PlaneStore).  Built, parity-green,
 // measured slower (round 5, alternating runs on one box: forward launch 2.61 / 2.58 ms against 2.52 / 2.54 behind the loop): the K loop
 // already keeps the CU's vector-memory path at the rate it sustains under this mix, a store per k-block lengthens it by what the
-// burst behind the loop costs and the epilogue still waits for its barriers.  0 = behind the loop (shipped); 1 = the experiment.
+// burst behind the loop costs and the epilogue still waits for its barriers.  0 = behind the loop (shipped); 1 = the experiment;
+// 2 (round 6) = the experiment with the piece's LDS words read one k-block ahead of their store.  In the trunk probe -- whose
+// workgroups are exact copies of each other and stay in phase -- 2 beats the burst (2.465 against 2.585 ms); in this kernel, whose
+// two workgroups per CU drift apart through their encoding and head stages and so already overlap one's burst with the other's K
+// loop, it does not: forward launch 2.431 (2) / 2.449 (1) against 2.374 ms, alternating on one box (profiles/r06_ab_stores_in_loop.txt).
 #define F16_STORE_IN_LOOP 0
 #endif
 #ifndef F16_JOIN_HEADS
@@ -219,6 +223,28 @@ struct PlaneStore {
     // loop, spilled them and reloaded them inside the K loop -- scratch loads, i.e. vmcnt waits behind the stores)
     asm volatile("" : "+v"(tid));
   }
+#if F16_STORE_IN_LOOP == 2
+  // Round 6: the piece's LDS words are read ONE K-BLOCK AHEAD of their conversion and store (operator()(t) stores piece t - 1 and reads
+  // piece t; flush(ITER - 1) behind the loop): the store's LDS round trip passes under the previous k-block's MFMAs instead of standing
+  // in front of this one's.  In the trunk probe (tools/repro/pair_trunk_probe.hip, mode 12) that turns the in-loop stores from a loss
+  // (2.70 against 2.585 ms) into a gain (2.465).
+  __device__ __forceinline__ void flush(int it) const {
+    const int idx = tid + it * THREADS, row = idx / GPR, g = idx % GPR;
+    const float un = row < TILE / 2 ? un0 : un1;
+    f32x4 v;
+    if constexpr (NP == 2)
+      v = f32x4{mix16<0>(ch[0], un, mix16<0>(cl[0], un, 0.f)), mix16<1>(ch[0], un, mix16<1>(cl[0], un, 0.f)),
+                mix16<0>(ch[1], un, mix16<0>(cl[1], un, 0.f)), mix16<1>(ch[1], un, mix16<1>(cl[1], un, 0.f))};
+    else
+      v = f32x4{mix16<0>(ch[0], un, 0.f), mix16<1>(ch[0], un, 0.f), mix16<0>(ch[1], un, 0.f), mix16<1>(ch[1], un, 0.f)};
+    ACT_STORE((f32x4*)&dst[(size_t)row * W + 4 * g], v);
+  }
+  __device__ __forceinline__ void operator()(int it) {
+    if (it > 0) flush(it - 1);
+    read(it, ch, cl);
+  }
+#else
+  __device__ __forceinline__ void flush(int) const {}
   __device__ __forceinline__ void operator()(int it) {
     // (read, convert and store in one go: carrying the next piece's LDS words across the MFMAs cost the forward kernel, which
     // sits at 256 registers, 47 spilled registers)
@@ -233,6 +259,7 @@ struct PlaneStore {
       v = f32x4{mix16<0>(ch[0], un, 0.f), mix16<1>(ch[0], un, 0.f), mix16<0>(ch[1], un, 0.f), mix16<1>(ch[1], un, 0.f)};
     ACT_STORE((f32x4*)&dst[(size_t)row * W + 4 * g], v);
   }
+#endif
 };
 
 // tile_store16 for a half-width tensor that also adds every stored row to the accumulator of the row's ray slot (sums[slot],
@@ -572,6 +599,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
       PlaneStore<NP, W, TILE, THREADS> ps(Ph, Pl, a.h + ((size_t)(l - 1) * M + m0) * W, pow2f(-ehalf[0]), pow2f(-ehalf[1]), tid);
       static_assert(PlaneStore<NP, W, TILE, THREADS>::ITER == W / 16, "one store piece per k-block");
       mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, W / 16, n0, 0, lane, ps);
+      ps.flush(W / 16 - 1);
     } else {
       mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)wl, W / 16, n0, 0, lane);
     }
@@ -637,6 +665,7 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_fwd_kernel(
     if (h_in_loop) {
       PlaneStore<NP, W, TILE, THREADS> ps(Ph, Pl, a.h + ((size_t)(D - 1) * M + m0) * W, pow2f(-ehalf[0]), pow2f(-ehalf[1]), tid);
       mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, lane, ps);
+      ps.flush(W / 16 - 1);
     } else {
       mma16_lds<NP, W, W / 16, AH>(acc, Ph, Pl, row0, 0, P16 + 4 * (size_t)L.we, W / 16, n0, 0, lane);
       asm volatile("" ::: "memory");  // the bias loads above stay above the stores below
