@@ -100,6 +100,34 @@ __device__ __forceinline__ float wave_max_rr(float m) {
   return __builtin_bit_cast(float, max(max(a, b), max(c, d)));
 }
 
+// One LDS-DMA instruction (1 KiB: lane l's 16 bytes from `g` land at LDS byte address lds + 16 l), issued as INLINE ASM on purpose
+// (round 6).  Behind __builtin_amdgcn_global_load_lds hipcc's wait-count pass knows that a vector-memory operation is writing LDS and,
+// having no alias information, puts `s_waitcnt vmcnt(0)` in front of every later LDS read it cannot tell apart from the destination --
+// in these kernels the read of the slab table inside every request (twice per slab pair) and the transposer's reads: each one a wait
+// for ALL of the wave's outstanding stores and requests, which is what the counted waits below exist to avoid (found in the ISA of
+// round 5's build: two `vmcnt(0)` per trip of the slab loop).  The kernels synchronise their DMA by hand -- counted vmcnt + barrier
+// before any read of a slot -- so nothing is lost with the compiler's view of it.
+// ASM: per kernel.  Measured (alternating runs on one box, 8192 rays, `profiles/r06_ab_rr_dma.txt`): the BACKWARD kernel gains 4.4 %
+// (2.304 -> 2.202 ms; slab loop 300k -> 277k cycles per wave), the FORWARD kernel loses 1.7 % (1.989 -> 2.023 ms: its contraction gets
+// faster, 1081 -> 892 cycles per slab, and its barrier waits longer) -- so the forward kernel keeps the builtin.
+// RR_EXP_DMA_BUILTIN / RR_EXP_DMA_ASM force one form in both kernels (A/B builds).
+template <bool ASM>
+__device__ __forceinline__ void lds_dma16(const void* g, const void* lds) {
+#if defined(RR_EXP_DMA_BUILTIN)
+  constexpr bool use_asm = false;
+#elif defined(RR_EXP_DMA_ASM)
+  constexpr bool use_asm = true;
+#else
+  constexpr bool use_asm = ASM;
+#endif
+  if constexpr (!use_asm) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+  } else {
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(g) : "memory", "m0");
+  }
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform RUN-TIME n (the instruction takes an immediate): a computed jump into a table of 32
 // {s_waitcnt vmcnt(k); s_branch end} pairs.  n above 31 waits for 31 -- a stronger wait, always safe.  expcnt / lgkmcnt untouched
 // (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]).  A switch statement here compiled into a chain of
@@ -183,7 +211,7 @@ __device__ __forceinline__ int build_slab_table(int2* slab_s, const int* st_off,
 // RUN-TIME loops (the unrolled form of round 4's first build was 60 KB of code per trunk layer against a 64 KB instruction
 // cache shared by two CUs: every phase of it ran at a third of its speed), so the slot index is a run-time scalar: four
 // scalars and selects, never an indexed array (hipcc would put it in scratch).
-template <int NW>
+template <int NW, bool ASM_DMA = false>
 struct Ring {
   const char* src;     // fragment buffer (P16 or PT16)
   const int2* slab_s;  // LDS table of the pass's slabs in consumption order: {byte offset of the tile's first k-block, k-blocks}
@@ -206,8 +234,11 @@ struct Ring {
     // vector-memory path takes it (~60 cycles each when eight waves issue together), and a blocked wave issues no MFMA.  The
     // lagging waves start a tile with the previous tile's epilogue anyway; their SIMD partners go straight to the matrix
     // work.  A leading wave waits for nothing of its own: the barrier behind the lagging waves' counted wait covers it.
-    if (nreq < nslab && wave >= NW / 2) {
-      constexpr int ND = NW / 2;
+#ifndef RR_DMA_ALL
+#define RR_DMA_ALL 0  // 1 (experiment): all eight waves request (two pieces each per 16 KB slab) instead of the lagging four (four each)
+#endif
+    if (nreq < nslab && (RR_DMA_ALL || wave >= NW / 2)) {
+      constexpr int ND = RR_DMA_ALL ? NW : NW / 2;
       const int2 e = slab_s[nreq];
       const int off = __builtin_amdgcn_readfirstlane(e.x), kb = __builtin_amdgcn_readfirstlane(e.y);
       const int per = (kb + ND - 1) / ND;
@@ -217,14 +248,13 @@ struct Ring {
 #ifndef RR_EXP_NODMA
 #pragma unroll 1
       for (int q = 0; q < per; ++q) {
-        int ch = (wave - ND) + ND * q;
+        int ch = (RR_DMA_ALL ? wave : wave - ND) + ND * q;
         ch = ch < kb ? ch : kb - 1;  // surplus waves repeat the last chunk (same bytes to the same place)
 #ifdef RR_EXP_PLAINLOAD  // timing experiment (wrong results): the same bytes by ordinary loads whose results are dropped
         const f32x4 v = *(const volatile f32x4*)(g + (size_t)ch * 2048);
         asm volatile("" ::"v"(v));
 #else
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)ch * 2048),
-                                         (__attribute__((address_space(3))) void*)(d + ch * 1024), 16, 0, 0);
+        lds_dma16<ASM_DMA>(g + (size_t)ch * 2048, d + ch * 1024);
 #endif
       }
       vmc += per;
@@ -516,8 +546,8 @@ struct TileOut {
   float* part = nullptr;  // per-ray column sums of the rows (stg_flush), or nullptr
   int rb = 32;            // first row of the wave's second ray
 };
-template <int NW, int BLK0, int JP, int NB>
-__device__ __forceinline__ void tile_out(Ring<NW>& rg, const TileOut& o, const u32x4_t (&blk)[2], h8 (&nx)[NB], char* stg, size_t t32, int lane) {
+template <int NW, int BLK0, int JP, int NB, class RG>
+__device__ __forceinline__ void tile_out(RG& rg, const TileOut& o, const u32x4_t (&blk)[2], h8 (&nx)[NB], char* stg, size_t t32, int lane) {
   nx[BLK0 + 2 * JP] = __builtin_bit_cast(h8, blk[0]);
   nx[BLK0 + 2 * JP + 1] = __builtin_bit_cast(h8, blk[1]);
   if (o.frag) {
@@ -548,8 +578,8 @@ __device__ __forceinline__ unsigned int mask_tile(const u32x4_t& words) {
 // half runs the epilogue of tile j - 1 and then contracts tile j -- one wave's vector work beside the other's matrix work on
 // every SIMD, one accumulator per wave (MI355X_MICROARCH.md, "try a stagger").  mma(p): the contraction of the slab at LDS
 // address p; epi(J): epilogue + outputs of tile J.
-template <int NW, int NT, class MMA, class EPI>
-__device__ __forceinline__ void run_tiles(Ring<NW>& rg, char* lds, bool lag, MMA mma, EPI epi) {
+template <int NW, int NT, class MMA, class EPI, class RG>
+__device__ __forceinline__ void run_tiles(RG& rg, char* lds, bool lag, MMA mma, EPI epi) {
   static_for<0, NT>([&](auto J) {
     constexpr int j = decltype(J)::value, slot = j & 3;
     rg.begin(lds, slot);
@@ -1265,7 +1295,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
   gGmax = __uint_as_float(mx_s[15]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ordinary load / store of the prologue has retired: the counter starts at 0
 
-  Ring<NW> rg;
+  Ring<NW, true> rg;  // (requests as inline asm: lds_dma16)
   rg.src = (const char*)a.PT16;
   rg.slab_s = slab_s;
   rg.nslab = nslab;
@@ -1284,9 +1314,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr16_bwd_kernel(upnerf_layout
   auto mask_request = [&](int slot) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);  // the reads of the buffer's previous content have returned
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)((const char*)a.hmask + (((size_t)slot * nt32 + t32) * 64 + lane) * 16),
-        (__attribute__((address_space(3))) void*)(msk + (slot & 1) * 1024), 16, 0, 0);
+    lds_dma16<true>((const char*)a.hmask + (((size_t)slot * nt32 + t32) * 64 + lane) * 16, msk + (slot & 1) * 1024);
     asm volatile("" ::: "memory");
     rg.count_dma(1);
     if (slot & 1) mmark1 = rg.vmc;
