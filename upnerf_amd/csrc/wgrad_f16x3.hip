@@ -48,6 +48,25 @@ __device__ __forceinline__ h4 tr_read(const char* base, int byteoff) {
 #define FX_THREADS 512
 #define WG_LOAD(p) NT_LOAD(p)  // operand rows: read once per step (common.cuh: streaming accesses)
 #define WG_OPLOAD(dst, p) dst = WG_LOAD((const f32x4*)(p))
+// Round 6: the loads of a register set stay where the source puts them -- right behind the barrier, in front of the contraction.  Left
+// to itself hipcc SINKS them (they have no consumer until the next staging) to the END of the contraction: the ISA of round 5's build
+// had the requests of set 0 behind the staging of set 1 and `s_waitcnt vmcnt(0)` in front of that staging -- one register set in flight
+// instead of two, 32 KB per CU instead of 64.  WG_NO_PIN: the old placement, for A/B builds.
+// Measured (alternating runs on one box, profiles/r06_ab_wgrad_pin.txt): the fp16-operand kernels (wgrad_f16p_kernel, configs[3]) gain
+// 0.9 % on the Trevi step with two resp. four sets really in flight; the f16x3 kernel (three MFMAs per product) LOSES 0.6 % on the
+// headline step -- its stream is held by the clock the part keeps under matrix work + memory traffic (profiles/r06_wgrad_planes.txt),
+// not by the bytes in flight, and the sunk requests interleave better with its MFMAs.  So: pinned in wgrad_f16p_kernel
+// (WG_PIN_LOADS_P), not in wgrad_f16x3_kernel (WG_PIN_LOADS: -DWG_PIN_X3 turns it on, -DWG_NO_PIN turns both off).
+#if defined(WG_PIN_X3) && !defined(WG_NO_PIN)
+#define WG_PIN_LOADS __builtin_amdgcn_sched_barrier(0)
+#else
+#define WG_PIN_LOADS
+#endif
+#ifdef WG_NO_PIN
+#define WG_PIN_LOADS_P
+#else
+#define WG_PIN_LOADS_P __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifdef UPNERF_EXP_HALFROW
 #define HALFROW_OK(T, c4) (!((T) == 256 && (c4) >= UPNERF_EXP_HALFROW))
 #else
@@ -218,7 +237,9 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
     // 47 spills; (d) the loop of (b) with the operand loads hidden in inline asm and hand-counted waits: hipcc re-used the loads'
     // destination registers for the contraction's operand reads while the loads were in flight (seen in the ISA; never run).
     gload(ra0, rb0, rv0, mbeg);
+    WG_PIN_LOADS;  // (set 0 is requested BEFORE set 1: the wait in front of the first staging then counts four younger loads)
     gload(ra1, rb1, rv1, mbeg + FX_CHUNK);
+    WG_PIN_LOADS;
 #pragma unroll 1
     for (int mc = mbeg; mc < mend; mc += 2 * FX_CHUNK) {
 #ifndef WG_EXP_NOSTAGE
@@ -227,6 +248,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       __syncthreads();
 #ifndef WG_EXP_NOLOAD
       gload(ra0, rb0, rv0, mc + 2 * FX_CHUNK);
+      WG_PIN_LOADS;
 #endif
 #ifndef WG_EXP_NOMMA
       contract(0);
@@ -237,6 +259,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16x3_kernel(int M, int N
       __syncthreads();
 #ifndef WG_EXP_NOLOAD
       gload(ra1, rb1, rv1, mc + 3 * FX_CHUNK);
+      WG_PIN_LOADS;
 #endif
 #ifndef WG_EXP_NOMMA
       contract(1);
@@ -739,7 +762,10 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
   // two register sets: the loads of chunk c+2 are in flight while chunk c is contracted (rows beyond mend load as zeros)
   // NS register sets: the loads of chunk c + NS are in flight while chunk c is contracted (rows beyond mend are staged as zeros)
 #pragma unroll
-  for (int u = 0; u < NS; ++u) gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], rvv[u], mbeg + u * FX_CHUNK);
+  for (int u = 0; u < NS; ++u) {
+    gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], rvv[u], mbeg + u * FX_CHUNK);
+    WG_PIN_LOADS_P;  // (the sets are requested in order, and stay where the source puts them: see WG_PIN_LOADS)
+  }
 #pragma unroll 1
   for (int mc = mbeg; mc < mend; mc += NS * FX_CHUNK) {
 #pragma unroll
@@ -747,6 +773,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void wgrad_f16p_kernel(int M, int N,
       lstore(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], rvv[u], u & 1, mc + u * FX_CHUNK);
       __syncthreads();
       gload(ra[u], xa[u], rbp[u], xb[u], rbf[u], la[u], lb[u], rvv[u], mc + (NS + u) * FX_CHUNK);
+      WG_PIN_LOADS_P;
       contract(u & 1);
     }
   }
