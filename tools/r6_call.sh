@@ -1,8 +1,14 @@
 #!/bin/bash
-out=gpurun_out/r6p; mkdir -p $out
-timeout 900 python -m pytest tests/test_hip_kernels.py -q -x -m gpu -k "wgrad or weight_grad or chained or slab or joined_head" 2>&1 | tail -2
-bash tools/r3_ab_libs.sh "_nopin -" "64" 3 2>&1 | tee $out/ab_pin.txt
-for r in 1 2 3; do for lib in _nopin ""; do
-UPNERF_LIB=$PWD/upnerf_amd/libupnerf_hip$lib.so timeout 300 python bench.py --config trevi --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('trevi lib[$lib]', round(d['value']), round(d['ms_per_step'],2))"
-done; done | tee $out/ab_pin_trevi.txt
+# round 6: full GPU suite on the final sources, then everything under profiles/r06_* (tools/final_profile.sh)
+out=gpurun_out/r6final; mkdir -p $out
+timeout 1500 python -m pytest tests -q -m gpu -rA > $out/pytest.log 2>&1; tail -4 $out/pytest.log
+grep -h "^\[masks\]" $out/pytest.log | sort | uniq > $out/masks.txt
+python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log
+python tools/rr_check.py --bwd > $out/rr_check.txt 2>&1; tail -1 $out/rr_check.txt
+python tools/rr_sweep.py > $out/rr_sweep.txt 2>&1; tail -1 $out/rr_sweep.txt
+bash tools/final_profile.sh gpurun_out/final_r06 r06 > $out/final_profile.log 2>&1; tail -3 $out/final_profile.log
+python tools/bytes_table.py gpurun_out/final_r06/pmc.json > gpurun_out/final_r06/bytes_table.md 2>&1
+make -C upnerf_amd/csrc stamps > /dev/null 2>&1
+python tools/stamps_field16.py > gpurun_out/final_r06/stamps_field16.txt 2>/dev/null
+python tools/stamps_rr16.py > gpurun_out/final_r06/stamps_rr16.txt 2>/dev/null
+python tools/show_bench.py gpurun_out/final_r06/bench.json 2>/dev/null | head -6
