@@ -1,14 +1,13 @@
 #!/bin/bash
-# round 6: full GPU suite on the final sources, then everything under profiles/r06_* (tools/final_profile.sh)
-out=gpurun_out/r6final; mkdir -p $out
-timeout 1500 python -m pytest tests -q -m gpu -rA > $out/pytest.log 2>&1; tail -4 $out/pytest.log
-grep -h "^\[masks\]" $out/pytest.log | sort | uniq > $out/masks.txt
-python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log
-python tools/rr_check.py --bwd > $out/rr_check.txt 2>&1; tail -1 $out/rr_check.txt
-python tools/rr_sweep.py > $out/rr_sweep.txt 2>&1; tail -1 $out/rr_sweep.txt
-bash tools/final_profile.sh gpurun_out/final_r06 r06 > $out/final_profile.log 2>&1; tail -3 $out/final_profile.log
-python tools/bytes_table.py gpurun_out/final_r06/pmc.json > gpurun_out/final_r06/bytes_table.md 2>&1
-make -C upnerf_amd/csrc stamps > /dev/null 2>&1
-python tools/stamps_field16.py > gpurun_out/final_r06/stamps_field16.txt 2>/dev/null
-python tools/stamps_rr16.py > gpurun_out/final_r06/stamps_rr16.txt 2>/dev/null
-python tools/show_bench.py gpurun_out/final_r06/bench.json 2>/dev/null | head -6
+# round-6 GPU driver (rewritten per call; the last content is the final profile run)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/lin
+timeout 1500 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py tests/test_trainer.py -m gpu -x -q 2>&1 | tail -5 > gpurun_out/lin/tests.txt
+bash tools/r3_ab_libs.sh "- _oldlin" "64" 3 > gpurun_out/lin/ab.txt 2>&1
+for lib in "" _oldlin; do
+  export UPNERF_LIB=$PWD/upnerf_amd/libupnerf_hip$lib.so
+  rocprofv3 --kernel-trace --stats -d gpurun_out/lin/prof$lib -o p -- python3 bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline > gpurun_out/lin/bench$lib.log 2>&1
+  f=$(find gpurun_out/lin/prof$lib -name '*kernel_stats.csv' | head -1)
+  grep -E "linear_kernel|matvec|Name" $f | cut -c1-220 > gpurun_out/lin/stats$lib.txt
+done
+cat gpurun_out/lin/tests.txt gpurun_out/lin/ab.txt gpurun_out/lin/stats.txt gpurun_out/lin/stats_oldlin.txt

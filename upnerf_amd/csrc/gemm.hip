@@ -376,6 +376,7 @@ __global__ __launch_bounds__(64 * KB) void vec_wgrad_frag16_kernel(int M, const 
 // act bit 0: ReLU;  act bit 1: B is given transposed, [K][N] with row stride ldb (no host-side transpose copy).
 #define LIN_T 64
 #define LIN_KC 64
+template <bool SLOWB>
 __global__ __launch_bounds__(NTHREADS, 4) void linear_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                              const float* __restrict__ B, int ldb,
                                                              const float* __restrict__ bias, float* __restrict__ C,
@@ -390,42 +391,60 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_kernel(int M, int N, int K
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  // this lane's bias value, requested now (unconditionally: a pointer select and a clamped column), consumed behind the K loop
+  float bv;
+  {
+    const int c = nb + wc + li;
+    bv = (bias ? bias : A)[bias ? (c < N ? c : N - 1) : 0];
+    if (!bias) bv = 0.0f;
+  }
   // Register-staged software pipeline: the global loads of chunk c+1 are in flight while chunk c is contracted out of
   // LDS (each chunk used to wait out its own HBM / L2 round trip between two barriers).
   constexpr int LPT = LIN_T * (LIN_KC / 4) / NTHREADS;  // 16-byte loads per thread and operand: 4
   f32x4 ra[LPT], rb[LPT];
+  // Round 6: every load of a chunk is UNCONDITIONAL (clamped row / column / k indices, a pointer select between the two layouts of B,
+  // masks applied to the loaded values).  The first form branched around each load (`if (!transb)`, `if (k < kk)`, `if (col + 3 < N)`):
+  // hipcc put `s_waitcnt vmcnt(0)` behind every such branch -- the ISA had the eight loads of a chunk as eight L2 / HBM round trips in
+  // a row (cdna_hip_programming.md, 'Three .s-level traps' (c)), which is what made a 0.8 GFLOP product a 23-38 us launch.  A B^T
+  // operand whose rows cannot be read in 16-byte pieces (ldb or N not a multiple of 4) takes the old element-wise path (`slowb`).
+  constexpr bool slowb = SLOWB;  // (chosen by the launcher: transb && (ldb % 4 || N % 4))
   auto gload = [&](int kc) {
     const int kk = (K - kc) < LIN_KC ? (K - kc) : LIN_KC;  // multiple of 8
 #pragma unroll
     for (int q = 0; q < LPT; ++q) {
       const int idx = tid + q * NTHREADS;
-      {
-        const int row = idx >> 4, g = idx & 15;
-        const bool kin = 4 * g < kk;
-        int ma = m0 + row, nbr = nb + row;
-        const bool ina = kin && ma < M, inb = kin && !transb && nbr < N;
-        ma = ma < M ? ma : M - 1;
-        nbr = nbr < N ? nbr : N - 1;
-        const int kg = kin ? kc + 4 * g : 0;
-        ra[q] = *(const f32x4*)&A[(size_t)ma * lda + kg];
-        if (!ina) ra[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!transb) {
-          rb[q] = *(const f32x4*)&B[(size_t)nbr * ldb + kg];
-          if (!inb) rb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+      const int row = idx >> 4, g = idx & 15;
+      const bool kin = 4 * g < kk;
+      int ma = m0 + row, nbr = nb + row;
+      const bool ina = kin && ma < M;
+      ma = ma < M ? ma : M - 1;
+      nbr = nbr < N ? nbr : N - 1;
+      const int kg = kin ? kc + 4 * g : 0;
+      ra[q] = *(const f32x4*)&A[(size_t)ma * lda + kg];
+      if (!ina) ra[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (!slowb) {
+        // B as [N][K] rows (row = n, 16 bytes of k), or B^T as [K][N] rows (row = k of the chunk, 16 bytes of n)
+        const int kt = row < kk ? kc + row : kc;          // transb: k of this piece, clamped into the chunk
+        int nt4 = nb + 4 * g;
+        const bool inbt = row < kk && nt4 + 3 < N;
+        nt4 = nt4 + 3 < N ? nt4 : 0;
+        const float* __restrict__ bp = transb ? &B[(size_t)kt * ldb + nt4] : &B[(size_t)nbr * ldb + kg];
+        const bool inb = transb ? inbt : (kin && nb + row < N);
+        rb[q] = *(const f32x4*)bp;
+        if (!inb) rb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (transb) {  // B^T tile: rows are k, 64 consecutive n per row
+    }
+    if constexpr (slowb) {
+#pragma unroll
+      for (int q = 0; q < LPT; ++q) {
+        const int idx = tid + q * NTHREADS;
         const int k = idx >> 4, g = idx & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (k < kk) {
           const float* src = &B[(size_t)(kc + k) * ldb + nb + 4 * g];
-          if (nb + 4 * g + 3 < N && (ldb & 3) == 0) {
-            v = *(const f32x4*)src;
-          } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (nb + 4 * g + j < N) v[j] = src[j];
-          }
+          for (int j = 0; j < 4; ++j)
+            if (nb + 4 * g + j < N) v[j] = src[j];
         }
         rb[q] = v;
       }
@@ -451,7 +470,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_kernel(int M, int N, int K
     __syncthreads();  // everyone is done reading the previous chunk
     lstore();
     __syncthreads();
-    if (kc + LIN_KC < K) gload(kc + LIN_KC);
+    gload(kc + LIN_KC < K ? kc + LIN_KC : kc);  // (unconditional: past the end the last chunk is requested again and never staged)
     for (int t = 0; t < (kk >> 3); ++t) {
       const f32x4 a = *(const f32x4*)&As[swz4(wr + li, 8 * t + 4 * hh, LIN_KC)];
       const f32x4 b = *(const f32x4*)&Bs[swz4(wc + li, 8 * t + 4 * hh, LIN_KC)];
@@ -459,17 +478,20 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_kernel(int M, int N, int K
       for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
     }
   }
+  // bias and activation on all sixteen values BEFORE the guarded stores (the bias was requested at kernel start): with the load
+  // behind `bias ? ... : 0` inside the guard, hipcc waited `vmcnt(0)` in front of every one of the sixteen store blocks -- for the
+  // bias the first time and for the PREVIOUS STORE every time after: sixteen store round trips in a row (round 6, seen in the ISA)
   const int col = nb + wc + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = acc[r] + bv;
+    acc[r] = (act & 1) ? fmaxf(v, 0.f) : v;
+  }
   if (col < N) {
-    const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (row < M) {
-        float v = acc[r] + bv;
-        if (act & 1) v = fmaxf(v, 0.f);
-        C[(size_t)row * ldc + col] = v;
-      }
+      if (row < M) C[(size_t)row * ldc + col] = acc[r];
     }
   }
 }
@@ -1278,8 +1300,10 @@ extern "C" int upnerf_linear(int M, int N, int K, const float* A, int lda, const
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 3) || (!(act & 2) && (ldb & 3)) || !A || !B || !C || (act & ~3))
     return UPNERF_EINVAL;
   dim3 grid((M + LIN_T - 1) / LIN_T, (N + LIN_T - 1) / LIN_T);
-  hipLaunchKernelGGL(linear_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, M, N, K, A, lda, B, ldb, bias, C, ldc,
-                     act);
+  if ((act & 2) && (((ldb & 3) != 0) || ((N & 3) != 0)))
+    hipLaunchKernelGGL(linear_kernel<true>, grid, dim3(NTHREADS), 0, (hipStream_t)stream, M, N, K, A, lda, B, ldb, bias, C, ldc, act);
+  else
+    hipLaunchKernelGGL(linear_kernel<false>, grid, dim3(NTHREADS), 0, (hipStream_t)stream, M, N, K, A, lda, B, ldb, bias, C, ldc, act);
   return (int)hipGetLastError();
 }
 
