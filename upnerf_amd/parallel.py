@@ -64,7 +64,7 @@ class GradSync:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.early]
         self.stats = {"early_launches": 0, "late_only": 0}
         # communication attribution (bench.py `comm`): with `timing` on, every all-reduce is bracketed -- by HIP events on the
-        # stream it is enqueued on (no host synchronisation: the pairs are read back in comm_summary()), by the host clock for a
+        # compute stream (no host synchronisation: the pairs are read back in comm_summary()), by the host clock for a
         # CPU group -- and the floats it moved are counted
         self.timing = False
         self._pairs, self._host_s, self._floats, self._reduces = [], 0.0, 0, 0
@@ -99,9 +99,10 @@ class GradSync:
             self._stream.wait_stream(torch.cuda.current_stream(dev))  # the gradients are complete on the compute stream
             with torch.cuda.stream(self._stream):
                 torch._foreach_copy_(views, [p.grad for p in live])
-                ev = self._mark(dev)
                 self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._mark_end(ev, dev, n)
+                # counted here, timed in _finish_early: an asynchronous collective runs on the backend's own stream, events
+                # around its enqueue would bracket nothing -- what the step pays for it is the wait at the end of backward
+                self._mark_end(None, dev, n)
         else:
             torch._foreach_copy_(views, [p.grad for p in live])
             self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -114,12 +115,18 @@ class GradSync:
         if self._work is None:
             return set()
         t0 = time.perf_counter()
+        dev = self._early_flat.device
+        ev = self._mark(dev) if dev.type == "cuda" else None
         self._work.wait()
-        if self.timing and not self._early_flat.is_cuda:
+        if self.timing and dev.type != "cuda":
             self._host_s += time.perf_counter() - t0
         flat = self._early_flat[:sum(v.numel() for v in self._early_views)]
         if flat.is_cuda:
-            torch.cuda.current_stream(flat.device).wait_stream(self._stream)
+            torch.cuda.current_stream(dev).wait_stream(self._stream)
+            if ev is not None:  # the EXPOSED part of the early all-reduce: how long the compute stream stood waiting for it
+                end = torch.cuda.Event(enable_timing=True)
+                end.record(torch.cuda.current_stream(dev))
+                self._pairs.append((ev, end))
         flat.mul_(1.0 / self.world)
         torch._foreach_copy_([p.grad for p in self._early_live], self._early_views)
         self._work = None
@@ -205,7 +212,7 @@ class GradSync:
         steps = max(steps, 1)
         return {"allreduce_ms": ms / steps, "bytes": 4 * self._floats / steps, "allreduces_per_step": self._reduces / steps,
                 "early_launches": self.stats["early_launches"], "late_only": self.stats["late_only"], "world": self.world,
-                "clock": "HIP events around each all-reduce on the stream it is enqueued on" if self._pairs else "host clock around each all-reduce (CPU group)"}
+                "clock": "HIP events on the compute stream around each blocking all-reduce and around the wait for the early one (its exposed part)" if self._pairs else "host clock around each all-reduce (CPU group)"}
 
     def unpack(self) -> None:
         """Averaged gradients back into the parameters' .grad tensors."""
