@@ -13,6 +13,17 @@
 #include "common.cuh"
 #pragma clang fp contract(off)
 
+// fp32 rows of e / g2 a wave (= a ray) requests before it uses the first, in the kernels that read them as rows (f16x3 / fp32
+// field modes).  Backward: each row ends in a wave-wide sum, and with one row in flight the launch sat at 4.9 TB/s; four rows:
+// 177 -> 157 us per launch (round 6, same box; eight: 204 us).  Forward: 145 us at 5.8 TB/s with one row, unchanged with four
+// or eight -- left at one.  Summation order per sample is the same for every value: bitwise-identical results.
+#ifndef COMPOSITE_ROWS_FWD
+#define COMPOSITE_ROWS_FWD 1
+#endif
+#ifndef COMPOSITE_ROWS_BWD
+#define COMPOSITE_ROWS_BWD 4
+#endif
+
 namespace {
 
 __device__ __forceinline__ float excl_prod_scan(float x, int lane, float& total) {
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS) void composite_fwd_kernel(upnerf_composit
       const bool g_rows = joint && !(EFRAG && a.g2_16);  // g2 as fp32 rows: the per-sample loop below
       // four samples' rows are requested before the first is used (the compiler keeps ONE load in flight otherwise, and a wave
       // per ray then waits out a full memory latency per sample); same summation order as a plain loop
-      constexpr int B = EFRAG ? 4 : 1;
+      constexpr int B = EFRAG ? 4 : COMPOSITE_ROWS_FWD;
       if (!EFRAG || g_rows)
       for (int j0 = 0; j0 < nv; j0 += B) {
         f32x4 ev[B], gv[B];
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(NTHREADS) void composite_bwd_kernel(upnerf_composit
     float dotE = 0.f, dotG = 0.f;
     if (need_dots) {
       const int nv = (S - c0) < 64 ? (S - c0) : 64;
-      constexpr int B = EFRAG ? 4 : 1;  // (rows of four samples in flight, see the forward kernel)
+      constexpr int B = EFRAG ? 4 : COMPOSITE_ROWS_BWD;  // (rows in flight: see COMPOSITE_ROWS_* above)
       const bool g_rows = joint && a.g_G_c && !g_frag;
       if (!EFRAG || g_rows)
       for (int j0 = 0; j0 < nv; j0 += B) {
