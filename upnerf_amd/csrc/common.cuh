@@ -374,7 +374,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // an experiment (`make variant` passes -DUPNERF_EXPERIMENT); a stray -D in the product build is a compile error, not a silently
 // wrong library.
 #if (defined(UPNERF_EXP_HALFROW) || defined(UPNERF_EXP_NOSTORE) || defined(UPNERF_EXP_SAMEB) || defined(RR_EXP_NOSTORE) || \
-     defined(RR_EXP_NODMA) || defined(RR_EXP_NOEPI) || defined(RR_EXP_NOMMA) || defined(RR_EXP_NOBARRIER) || defined(RR_EXP_NOLDS) || defined(RR_EXP_PLAINLOAD) || defined(WG_EXP_NOLOAD) || defined(WG_EXP_NOSTAGE) || defined(WG_EXP_NOMMA) || defined(WP_EXP_NOREAD) || defined(WP_EXP_NOMMA)) && !defined(UPNERF_EXPERIMENT)
+     defined(RR_EXP_NODMA) || defined(RR_EXP_NOEPI) || defined(RR_EXP_NOMMA) || defined(RR_EXP_NOBARRIER) || defined(RR_EXP_NOLDS) || defined(RR_EXP_PLAINLOAD) || defined(WG_EXP_NOLOAD) || defined(WG_EXP_NOSTAGE) || defined(WG_EXP_NOMMA) || defined(WP_EXP_NOREAD) || defined(WP_EXP_NOMMA) || defined(TR_EXP_NOLOAD) || defined(TR_EXP_NOMMA) || defined(TR_EXP_NOSTORE)) && !defined(UPNERF_EXPERIMENT)
 #error "UPNERF_EXP_* / RR_EXP_* switches produce wrong results: build them with -DUPNERF_EXPERIMENT (make variant), never into libupnerf_hip.so"
 #endif
 #ifdef UPNERF_NO_NT

@@ -446,7 +446,21 @@ __global__ void ray_aux_kernel(int R, const float* __restrict__ rays_d, const fl
       o[3 + 8 * n + 4 + k] = cv * wk[k];
     }
   }
-  for (int j = 0; j < 48; ++j) o[27 + j] = a_rows ? a_rows[(size_t)r * 48 + j] : 0.f;
+  // the 48 appearance-row floats: twelve 16-byte loads requested together, then the stores (the element-wise copy was compiled to
+  // load / wait / store forty-eight times over: one memory round trip per element, round 6); rows that do not start on 16 bytes
+  // (a table slice at an odd offset) keep the element-wise copy
+  if (a_rows && ((size_t)a_rows & 15) == 0) {
+    f32x4 av[12];
+    const f32x4* ap = (const f32x4*)(a_rows + (size_t)r * 48);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) av[j] = ap[j];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      o[27 + 4 * j] = av[j].x; o[28 + 4 * j] = av[j].y; o[29 + 4 * j] = av[j].z; o[30 + 4 * j] = av[j].w;
+    }
+  } else {
+    for (int j = 0; j < 48; ++j) o[27 + j] = a_rows ? a_rows[(size_t)r * 48 + j] : 0.f;
+  }
   for (int j = 75; j < UPNERF_AUXK; ++j) o[j] = 0.f;
 }
 
@@ -548,8 +562,8 @@ __global__ __launch_bounds__(NTHREADS) void embed_bwd_grouped_kernel(int R, int 
 #pragma unroll
     for (int u = 0; u < EMB_CHUNK / NTHREADS; ++u) {
       const int r = c0 + u * NTHREADS + (int)threadIdx.x;
-      const long long v = r < R ? idx[r] : -1;
-      idx_s[u * NTHREADS + threadIdx.x] = (v >= 0 && v < N) ? (int)v : -1;
+      const long long v = idx[r < R ? r : R - 1];  // (branch-free: sixteen guarded loads were sixteen memory round trips in a row)
+      idx_s[u * NTHREADS + threadIdx.x] = (r < R && v >= 0 && v < N) ? (int)v : -1;
     }
     __syncthreads();
     const int cnt = (R - c0) < EMB_CHUNK ? (R - c0) : EMB_CHUNK;

@@ -29,6 +29,33 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// Warm this XCD's L2 with the weights: one dword per 128-byte line, the lines of a tensor dealt over the threads of the XCD's
+// workgroups (consecutive workgroup ids go round the eight XCDs, so workgroup b is number b / 8 on its XCD), all requests in
+// flight at once.  Why (round 6): the weights are cold in every XCD's L2 when the kernel starts (Adam rewrote them), all 32
+// workgroups of an XCD walk the same lines in lockstep, and every K-loop group then waits out a full miss whatever the depth of
+// the register ring -- `wait_any` 0.59 of the wave cycles at `mfma_busy` 0.30, unchanged by a three-deep ring.  The values are
+// summed into a number nobody reads (kept alive by an empty asm at the end of the kernel).  A different workgroup -> XCD mapping
+// only lowers the coverage: nothing depends on it.
+#ifndef TR_WARM
+#define TR_WARM 1
+#endif
+__device__ __forceinline__ float warm_lines(const float* __restrict__ w, int nfloats, int lane_id, int nlanes) {
+  if (!TR_WARM) return 0.f;
+  const int lines = nfloats >> 5;
+  float s = w[(size_t)(lane_id < lines ? lane_id : lines - 1) << 5];  // unconditional: no branch, no wait (see the kernels' last line)
+  for (int l = lane_id + nlanes; l < lines; l += nlanes) s += w[(size_t)l << 5];  // (launches of fewer than 96 workgroups only)
+  return s;
+}
+struct WarmLanes {
+  int lane_id, nlanes;
+};
+__device__ __forceinline__ WarmLanes warm_lanes(int tid) {
+  const int per_xcd = ((int)gridDim.x + 7) >> 3, slices = per_xcd < 32 ? per_xcd : 32;
+  return WarmLanes{(((int)blockIdx.x >> 3) % slices) * NTHREADS + tid, slices * NTHREADS};
+}
+// the warmed values are never used: this only keeps their loads (and holds their registers until the loads have long landed)
+#define TR_WARM_KEEP(k) asm volatile("" ::"v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]))
+
 // y = act(x W^T + b) for the 16 rows of the workgroup.  Xs: LDS [16][TR_LD] (K columns used); W [N][ldw]; the wave owns N / 4
 // consecutive output columns starting at wave * N / 4, the lane NT = N / 64 consecutive ones of them.  Results go to Ys (LDS,
 // column offset ycol0) and, when gout is given, to gout[row][col] (row stride ldg) for rows < R.
@@ -46,35 +73,47 @@ __device__ __forceinline__ void layer_fwd(const float* Xs, const float* __restri
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = W + (size_t)(col0 + t) * ldw + 4 * q;
   const float* xp = Xs + c * TR_LD + 4 * q;
-  f32x4 b0[NT], b1[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) b0[t] = *(const f32x4*)(wp[t]);
-#pragma unroll 1
-  for (int g = 0; g < K / 16; g += 2) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) b1[t] = *(const f32x4*)(wp[t] + 16 * (g + 1));
-    {
-      const f32x4 a = *(const f32x4*)(xp + 16 * g);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t] = mfma4(a[j], b0[t][j], acc[t]);
-    }
-    if (g + 2 < K / 16) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) b0[t] = *(const f32x4*)(wp[t] + 16 * (g + 2));
-    }
-    {
-      const f32x4 a = *(const f32x4*)(xp + 16 * (g + 1));
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t] = mfma4(a[j], b1[t][j], acc[t]);
-    }
-  }
-  float bv[NT];
+  float bv[NT];  // (requested in front of the K loop, used behind it)
 #pragma unroll
   for (int t = 0; t < NT; ++t) bv[t] = bias[col0 + t];
+  // Weight fragments through a four-slot register ring, three groups requested ahead, no branch around a request (round 6: the
+  // loop had ONE group ahead behind `if (g + 2 < K / 16)`, and a counted wait cannot span the join -- hipcc waited vmcnt(0) in
+  // front of every second group; ~1400 cycles per group of 16 MFMAs that take 512).  Past the end the request is clamped to the
+  // last group (valid memory, value unused).  Same accumulation order as before: bitwise-identical results.
+  constexpr int G = K / 16;
+  static_assert(G % 4 == 0, "K is a multiple of 64");
+  f32x4 b[4][NT];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[s][t] = *(const f32x4*)(wp[t] + 16 * s);
+#pragma unroll 1
+  for (int g = 0; g < G; g += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int gn = g + u + 3 < G ? g + u + 3 : G - 1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#ifdef TR_EXP_NOLOAD
+        b[(u + 3) & 3][t] = f32x4{1.f, 2.f, 3.f, (float)gn};
+#else
+        b[(u + 3) & 3][t] = *(const f32x4*)(wp[t] + 16 * gn);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 a = *(const f32x4*)(xp + 16 * (g + u));
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#ifdef TR_EXP_NOMMA
+          acc[t][j] += a[j] * b[u][t][j];
+#else
+          acc[t] = mfma4(a[j], b[u][t][j], acc[t]);
+#endif
+        }
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 4 * q + r;
@@ -87,11 +126,15 @@ __device__ __forceinline__ void layer_fwd(const float* Xs, const float* __restri
     if constexpr (NT == 4) {
       const f32x4 o = {v[0], v[1], v[2], v[3]};
       *(f32x4*)&Ys[row * TR_LD + col0] = o;
+#ifndef TR_EXP_NOSTORE
       if (gout && m0 + row < R) *(f32x4*)&gout[(size_t)(m0 + row) * ldg + col0] = o;
+#endif
     } else {
       const f32x2 o = {v[0], v[1]};
       *(f32x2*)&Ys[row * TR_LD + col0] = o;
+#ifndef TR_EXP_NOSTORE
       if (gout && m0 + row < R) *(f32x2*)&gout[(size_t)(m0 + row) * ldg + col0] = o;
+#endif
     }
   }
 }
@@ -105,30 +148,27 @@ __device__ __forceinline__ void block_bwd(f32x4 (&acc)[4], const float* Gs, cons
   for (int x = 0; x < 4; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* wp = W + (size_t)(4 * q) * ldw + 64 * kb + 4 * c;
   const float* gp = Gs + c * TR_LD + 4 * q;
-  f32x4 b0[4], b1[4];
+  // (four-slot register ring, three groups ahead, branch-free: see layer_fwd)
+  constexpr int G = N / 16;
+  static_assert(G % 4 == 0, "N is a multiple of 64");
+  f32x4 b[4][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) b0[j] = *(const f32x4*)(wp + (size_t)j * ldw);
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[s][j] = *(const f32x4*)(wp + (size_t)(16 * s + j) * ldw);
 #pragma unroll 1
-  for (int g = 0; g < N / 16; g += 2) {
+  for (int g = 0; g < G; g += 4) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b1[j] = *(const f32x4*)(wp + (size_t)(16 * (g + 1) + j) * ldw);
-    {
-      const f32x4 a = *(const f32x4*)(gp + 16 * g);
+    for (int u = 0; u < 4; ++u) {
+      const int gn = g + u + 3 < G ? g + u + 3 : G - 1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) acc[x] = mfma4(a[j], b0[j][x], acc[x]);
-    }
-    if (g + 2 < N / 16) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b0[j] = *(const f32x4*)(wp + (size_t)(16 * (g + 2) + j) * ldw);
-    }
-    {
-      const f32x4 a = *(const f32x4*)(gp + 16 * (g + 1));
+      for (int j = 0; j < 4; ++j) b[(u + 3) & 3][j] = *(const f32x4*)(wp + (size_t)(16 * gn + j) * ldw);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 a = *(const f32x4*)(gp + 16 * (g + u));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int x = 0; x < 4; ++x) acc[x] = mfma4(a[j], b1[j][x], acc[x]);
+        for (int x = 0; x < 4; ++x) acc[x] = mfma4(a[j], b[u][j][x], acc[x]);
     }
   }
 }
@@ -174,6 +214,10 @@ __global__ __launch_bounds__(NTHREADS) void transient_fwd_kernel(upnerf_transien
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * TR_ROWS, R = a.R;
   const size_t RH = (size_t)R * TR_H;
+  const WarmLanes wl = warm_lanes(tid);
+  const float wk[6] = {warm_lines(a.w0, TR_H * TR_F, wl.lane_id, wl.nlanes), warm_lines(a.w1, TR_H * TR_H, wl.lane_id, wl.nlanes),
+                       warm_lines(a.w2, TR_H * TR_H, wl.lane_id, wl.nlanes), warm_lines(a.w3, TR_H * TR_H, wl.lane_id, wl.nlanes),
+                       warm_lines(a.wf, TR_H * TR_H, wl.lane_id, wl.nlanes), warm_lines(a.wt, TR_T * TR_F, wl.lane_id, wl.nlanes)};
   tile_load(bufA, 0, a.feat, TR_F, m0, R, tid);
   __syncthreads();
   layer_fwd<TR_H, TR_F, true>(bufA, a.w0, TR_F, a.b0, bufB, a.h, TR_H, m0, R, wave, lane);
@@ -205,26 +249,44 @@ __global__ __launch_bounds__(NTHREADS) void transient_fwd_kernel(upnerf_transien
     a.spre[m] = sp;
     a.beta[m] = softplusf(sp) * alpha + a.beta_min;
   }
+  TR_WARM_KEEP(wk);
+}
+
+// The stored activations that mask one output block of a backward layer (this lane's four rows), requested BEFORE the block's K
+// loop and branch-free (rows past R read the last row; their mask is forced to zero in emit_bwd): inside emit_bwd, as
+// `if (in) h = act[...]` per row, each of the four loads was a branch with `s_waitcnt vmcnt(0)` behind it -- four memory round
+// trips in a row per layer (round 6, seen in the ISA).
+struct ActRows {
+  f32x4 h[4];
+  f32x4 wv;
+};
+__device__ __forceinline__ ActRows act_rows(const float* __restrict__ act, int ldg, const float* __restrict__ r1w, int kb, int m0,
+                                            int R, int lane) {
+  const int c = lane & 15, q = lane >> 4, col = 64 * kb + 4 * c;
+  ActRows A;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + 4 * q + r < R ? m0 + 4 * q + r : R - 1;
+    A.h[r] = *(const f32x4*)&act[(size_t)m * ldg + col];
+  }
+  A.wv = r1w ? *(const f32x4*)&r1w[col] : f32x4{0.f, 0.f, 0.f, 0.f};
+  return A;
 }
 
 // One output block of a backward layer: += extra (a rank-1 term), masked by the stored activation, to LDS and to global.
+template <bool MASK>
 __device__ __forceinline__ void emit_bwd(const f32x4 (&acc)[4], int kb, float* Ys, float* __restrict__ gout, int ldg,
-                                         const float* __restrict__ act, const float* r1s, const float* __restrict__ r1w, int m0, int R,
-                                         int lane) {
+                                         const ActRows& A, const float* r1s, int m0, int R, int lane) {
   const int c = lane & 15, q = lane >> 4, col = 64 * kb + 4 * c;
-  f32x4 wv = {0.f, 0.f, 0.f, 0.f};
-  if (r1w) wv = *(const f32x4*)&r1w[col];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 4 * q + r;
     f32x4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-    if (r1w) o += wv * r1s[row];
+    if (r1s) o += A.wv * r1s[row];
     const bool in = m0 + row < R;
-    if (act) {
-      f32x4 h = {0.f, 0.f, 0.f, 0.f};
-      if (in) h = *(const f32x4*)&act[(size_t)(m0 + row) * ldg + col];
+    if constexpr (MASK) {
 #pragma unroll
-      for (int x = 0; x < 4; ++x) o[x] = h[x] > 0.f ? o[x] : 0.f;
+      for (int x = 0; x < 4; ++x) o[x] = (in && A.h[r][x] > 0.f) ? o[x] : 0.f;
     }
     if (Ys) *(f32x4*)&Ys[row * TR_LD + col] = o;
     if (gout && in) *(f32x4*)&gout[(size_t)(m0 + row) * ldg + col] = o;
@@ -238,6 +300,10 @@ __global__ __launch_bounds__(NTHREADS) void transient_bwd_kernel(upnerf_transien
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * TR_ROWS, R = a.R;
   const size_t RH = (size_t)R * TR_H;
+  const WarmLanes wl = warm_lanes(tid);  // (the order the layers are walked in: t-encoder, final, 3, 2, 1, 0)
+  const float wk[6] = {warm_lines(a.wt, TR_T * TR_F, wl.lane_id, wl.nlanes), warm_lines(a.wf, TR_H * TR_H, wl.lane_id, wl.nlanes),
+                       warm_lines(a.w3, TR_H * TR_H, wl.lane_id, wl.nlanes), warm_lines(a.w2, TR_H * TR_H, wl.lane_id, wl.nlanes),
+                       warm_lines(a.w1, TR_H * TR_H, wl.lane_id, wl.nlanes), warm_lines(a.w0, TR_H * TR_F, wl.lane_id, wl.nlanes)};
   // head pre-activation gradients (transient_net.py:33-37): beta = softplus(s) alpha + beta_min
   if (tid < TR_ROWS) {
     const int m = m0 + tid;
@@ -266,10 +332,9 @@ __global__ __launch_bounds__(NTHREADS) void transient_bwd_kernel(upnerf_transien
     f32x4 o = *(const f32x4*)&a.wb[4 * c4] * dz_s[row][1];
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc) o += *(const f32x4*)&a.wr[cc * TR_T + 4 * c4] * dz_s[row][2 + cc];
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    if (in) t = *(const f32x4*)&a.t[(size_t)(m0 + row) * TR_T + 4 * c4];
+    const f32x4 t = *(const f32x4*)&a.t[(size_t)(in ? m0 + row : R - 1) * TR_T + 4 * c4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) o[x] = t[x] > 0.f ? o[x] : 0.f;
+    for (int x = 0; x < 4; ++x) o[x] = (in && t[x] > 0.f) ? o[x] : 0.f;
     *(f32x4*)&bufA[row * TR_LD + 4 * c4] = o;
     if (in) *(f32x4*)&g.gz_t[(size_t)(m0 + row) * TR_T + 4 * c4] = o;
   }
@@ -279,7 +344,7 @@ __global__ __launch_bounds__(NTHREADS) void transient_bwd_kernel(upnerf_transien
   for (int kb = wave; kb < TR_F / 64; kb += 4) {
     block_bwd<TR_T>(acc, bufA, a.wt, TR_F, kb, lane);
     if (kb < TR_H / 64) {
-      emit_bwd(acc, kb, bufB, g.gz_e, TR_H, nullptr, nullptr, nullptr, m0, R, lane);
+      emit_bwd<false>(acc, kb, bufB, g.gz_e, TR_H, ActRows{}, nullptr, m0, R, lane);
     } else {  // the embedding's gradient rows: global only
       const int c = lane & 15, q = lane >> 4, col = 64 * kb + 4 * c - TR_H;
 #pragma unroll
@@ -294,24 +359,29 @@ __global__ __launch_bounds__(NTHREADS) void transient_bwd_kernel(upnerf_transien
   __shared__ float dza_s[TR_ROWS];
   if (tid < TR_ROWS) dza_s[tid] = dz_s[tid][0];
   __syncthreads();
+  ActRows A = act_rows(a.h + 3 * RH, TR_H, a.wa, wave, m0, R, lane);
   block_bwd<TR_H>(acc, bufB, a.wf, TR_H, wave, lane);
-  emit_bwd(acc, wave, bufA, g.gz_h + 3 * RH, TR_H, a.h + 3 * RH, dza_s, a.wa, m0, R, lane);
+  emit_bwd<true>(acc, wave, bufA, g.gz_h + 3 * RH, TR_H, A, dza_s, m0, R, lane);
   __syncthreads();
+  A = act_rows(a.h + 2 * RH, TR_H, nullptr, wave, m0, R, lane);
   block_bwd<TR_H>(acc, bufA, a.w3, TR_H, wave, lane);
-  emit_bwd(acc, wave, bufB, g.gz_h + 2 * RH, TR_H, a.h + 2 * RH, nullptr, nullptr, m0, R, lane);
+  emit_bwd<true>(acc, wave, bufB, g.gz_h + 2 * RH, TR_H, A, nullptr, m0, R, lane);
   __syncthreads();
+  A = act_rows(a.h + RH, TR_H, nullptr, wave, m0, R, lane);
   block_bwd<TR_H>(acc, bufB, a.w2, TR_H, wave, lane);
-  emit_bwd(acc, wave, bufA, g.gz_h + RH, TR_H, a.h + RH, nullptr, nullptr, m0, R, lane);
+  emit_bwd<true>(acc, wave, bufA, g.gz_h + RH, TR_H, A, nullptr, m0, R, lane);
   __syncthreads();
+  A = act_rows(a.h, TR_H, nullptr, wave, m0, R, lane);
   block_bwd<TR_H>(acc, bufA, a.w1, TR_H, wave, lane);
-  emit_bwd(acc, wave, bufB, g.gz_h, TR_H, a.h, nullptr, nullptr, m0, R, lane);
+  emit_bwd<true>(acc, wave, bufB, g.gz_h, TR_H, A, nullptr, m0, R, lane);
   __syncthreads();
   if (g.g_feat) {
     for (int kb = wave; kb < TR_F / 64; kb += 4) {
       block_bwd<TR_H>(acc, bufB, a.w0, TR_F, kb, lane);
-      emit_bwd(acc, kb, nullptr, g.g_feat, TR_F, nullptr, nullptr, nullptr, m0, R, lane);
+      emit_bwd<false>(acc, kb, nullptr, g.g_feat, TR_F, ActRows{}, nullptr, m0, R, lane);
     }
   }
+  TR_WARM_KEEP(wk);
 }
 
 }  // namespace
