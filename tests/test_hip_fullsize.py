@@ -369,8 +369,14 @@ def test_full_size_parameter_gradients_match_the_oracle():
     + the 301-ray oracle comparison).  The oracle (pinned restatement of models/rendering.py:53-314, losses.py:21-64) is run over
     the batch in eight shards of 512 rays at the GPU's fine depths -- every loss term is a mean over rays, so the batch gradient
     is the ray-count-weighted mean of the shard gradients (the property test_gradient_of_the_batch_is_the_mean_... holds the HIP
-    path to) -- in fp32, and in fp64 too for its own noise only if a gradient misses the flat 1e-3.  Gate: that of the golden and
-    mid-size tests, max(1e-3, min(4 x noise, 3e-2)); widenings are reported under "full:phase1" and the needed ones are pinned."""
+    path to; checked on the oracle itself in fp64 to 6e-14) -- in fp32.  Gate: that of the golden and mid-size tests,
+    max(1e-3, min(4 x noise, 3e-2)), noise = the oracle's own fp32-vs-fp64 difference on that tensor.  The fp64 pass costs ~130 s
+    of host time, so the noise of the two parameters known to need it is DATA (tests/golden/parity_widened_pinned.json,
+    "full_noise", measured by this test with UPNERF_FULL_NOISE=1) and the fp64 oracle runs only when asked for or when another
+    parameter misses the flat 1e-3 -- which then fails against the pinned list like any new widening.  Widenings are reported
+    under "full:phase1"."""
+    import json
+    import os
     from test_hip_midsize import SynthCase, hip_step, oracle_at
     from test_hip_parity import TOL_GRAD, grad_gate
     from golden_util import named_grads, rel_err
@@ -388,7 +394,7 @@ def test_full_size_parameter_gradients_match_the_oracle():
             total = sum(losses.values())
             total.backward()
             w = len(idx) / rays
-            loss_sum += float(total) * w
+            loss_sum += float(total.detach()) * w
             for n, g in named_grads(st).items():
                 if g is not None:
                     tot[n] = g.double() * w if tot.get(n) is None else tot[n] + g.double() * w
@@ -398,14 +404,19 @@ def test_full_size_parameter_gradients_match_the_oracle():
 
     g32, l32 = oracle_grads(torch.float32)
     assert abs(float(loss) - l32) <= 1e-4 * max(abs(l32), 1e-2), (float(loss), l32)
-    noise = {}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_widened_pinned.json")
+    pinned_noise = json.load(open(path)).get("full_noise", {})
+    measured = {}
 
-    def reference_noise():
-        if not noise:
+    def reference_noise(n):
+        if os.environ.get("UPNERF_FULL_NOISE") != "1" and n in pinned_noise:
+            return pinned_noise[n]
+        if not measured:
             g64, _ = oracle_grads(torch.float64)
-            noise.update({k: float((a - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-30)) for k, a in g32.items()
-                          if a is not None and g64[k] is not None})
-        return noise
+            measured.update({k: float((a - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-30)) for k, a in g32.items()
+                             if a is not None and g64[k] is not None})
+            print("[full_noise] " + json.dumps({k: v for k, v in measured.items() if k in pinned_noise or v > 2.5e-4}))
+        return measured.get(n, 0.0)
     got = dict(sysm.named_parameters())
     bad, compared = {}, 0
     for n, r in g32.items():
@@ -418,7 +429,9 @@ def test_full_size_parameter_gradients_match_the_oracle():
             continue
         compared += 1
         e = rel_err(g.detach().cpu().double().numpy(), r.numpy())
-        if not e < TOL_GRAD and not e < grad_gate(reference_noise().get(n, 0.0), "full:phase1", n, e):
-            bad[n] = (e, noise.get(n, 0.0))
+        if not e < TOL_GRAD:
+            nz = reference_noise(n)
+            if not e < grad_gate(nz, "full:phase1", n, e):
+                bad[n] = (e, nz)
     assert compared >= 60, compared
     assert not bad, bad
