@@ -1099,6 +1099,37 @@ def test_tile_partial_sums_match_the_separate_launches(hip, R, S, mode, use_cand
     assert not bad, bad
 
 
+@pytest.mark.parametrize("R", [1, 301, 4096])
+def test_ray_aux_with_aligned_misaligned_and_absent_appearance_rows(hip, R):
+    """upnerf_ray_aux (the per-ray direction encoding | appearance row | zero padding block of models/nerf.py:96-109's colour
+    head input): round 6 copies the 48 appearance floats as twelve 16-byte loads when the rows start on 16 bytes and element by
+    element otherwise -- the same bytes either way, and the kernel-space restatement's values."""
+    import ctypes as C
+    lib, ptr, check, stream = hip["lib"].lib, hip["lib"].ptr, hip["lib"].check, hip["lib"].stream
+    d = torch.nn.functional.normalize(gen((R, 3), 5), dim=1)
+    a = gen((R, 48), 6)
+    wk = [1.0, 0.75, 0.25, 0.0]
+    ref = ks.ray_aux(d, a, wk)
+    ref0 = ks.ray_aux(d, None, wk)
+    dg = d.cuda()
+    store = torch.zeros(R * 48 + 8, device="cuda")
+    outs = []
+    for off in (0, 4, 1, 3):  # floats: 0 and 4 start on 16 bytes, 1 and 3 do not
+        rows = store[off:off + R * 48].view(R, 48)
+        rows.copy_(a)
+        assert (rows.data_ptr() % 16 == 0) == (off % 4 == 0)
+        aux = torch.full((R, ks.AUXK), float("nan"), device="cuda")
+        check(lib.upnerf_ray_aux(R, ptr(dg), ptr(rows), (C.c_float * 4)(*wk), None, ptr(aux), stream()), "upnerf_ray_aux")
+        outs.append(cpu(aux))
+    aux = torch.full((R, ks.AUXK), float("nan"), device="cuda")
+    check(lib.upnerf_ray_aux(R, ptr(dg), None, (C.c_float * 4)(*wk), None, ptr(aux), stream()), "upnerf_ray_aux")
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert torch.equal(outs[0][:, 27:75], a)  # a copy: bit for bit
+    assert float((outs[0] - ref).abs().max()) < 2e-6
+    assert float((cpu(aux) - ref0).abs().max()) < 2e-6 and float(cpu(aux)[:, 27:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("R", [37, 1024])
 def test_fused_transient_net_matches_torch(hip, R):
     """csrc/transient.hip (the whole TransientNet as one forward and one backward launch + one grouped weight-gradient launch)
