@@ -15,11 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def part_a():
     import torch
     import torch.distributed as dist
     from upnerf_amd import parallel
-    os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port())
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", 0)
@@ -65,7 +72,7 @@ def part_c():
     import bench
     from upnerf_amd import parallel, rendering
     from upnerf_amd.graph_step import GraphedTrainingStep
-    os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port())
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", 0)
@@ -120,7 +127,7 @@ if __name__ == "__main__":
         part_b_rank()
     elif "--two" in sys.argv:
         import subprocess
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29532", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank"], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
                  for r in range(2)]
         for p in procs:

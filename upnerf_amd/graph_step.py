@@ -25,7 +25,11 @@ import warnings
 from collections import OrderedDict
 from typing import Dict, Optional
 
+import os
+import time
+
 import torch
+import torch.distributed  # noqa: F401 (is_initialized / get_backend below)
 
 from .rendering import band_weights
 from .step_scalars import StepScalars
@@ -156,9 +160,20 @@ class GraphedTrainingStep:
         if any(m.host_progress is None for m in s.models.values() if hasattr(m, "host_progress")):
             raise RuntimeError("graph capture needs the host mirror of NeRF.progress (use NeRFSystem.set_progress)")
         sync = s.grad_sync if (s.grad_sync is not None and s.grad_sync.world > 1) else None
-        # with a process group alive its watchdog thread polls events while this thread captures: only THIS thread's calls
-        # are held to the capture rules then (the work of the autograd thread lands in the capture through the stream)
-        mode = "thread_local" if sync is not None else "global"
+        # With a process group alive its watchdog thread polls the events of every collective it still tracks.  Two things follow
+        # (the second found on hardware in round 6, tools/rccl_probe.py --step: the N > 1 path had only ever run on gloo):
+        #  - only THIS thread's calls may be held to the capture rules ("thread_local"; the work of the autograd thread lands
+        #    in the capture through the stream);
+        #  - on HIP that is not enough: a hipEventQuery by the watchdog while this thread captures comes back as
+        #    hipErrorCapturedEvent ("operation not permitted on an event last recorded in a capturing stream") and the
+        #    watchdog takes the process down -- every time when the capture follows an eager step's all-reduce within the
+        #    watchdog's 100 ms period, which is exactly what a training run does.  So the device is drained and the watchdog
+        #    given three of its periods to retire what it tracks before the capture begins (once per captured graph).
+        pg_alive = torch.distributed.is_available() and torch.distributed.is_initialized()
+        mode = "thread_local" if (sync is not None or pg_alive) else "global"
+        if pg_alive and torch.distributed.get_backend() == "nccl":
+            torch.cuda.synchronize(self.device)
+            time.sleep(float(os.environ.get("UPNERF_CAPTURE_DRAIN_S", "0.3")))
         e = _Entry()
         e.scalars = StepScalars(self.device, self._providers())
         e.g1, e.g2, e.replays = torch.cuda.CUDAGraph(), None, 0

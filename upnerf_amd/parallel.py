@@ -39,6 +39,36 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, local, world
 
 
+def _gather(flat: torch.Tensor, views, tensors, scatter: bool = False) -> None:
+    """views[i] <- tensors[i] (scatter: tensors[i] <- views[i]); `views` tile the start of `flat` in order.  On the GPU through
+    upnerf_pack, 48 tensors per launch (three launches of ~8 us for the step's ~130 gradients): torch._foreach_copy_ spends two
+    33 us multi-tensor launches on the same 9 MB, and pack + unpack were 0.14 of the 0.36 ms the exchange costs a replayed step
+    on one device (tools/rccl_probe.py).  CPU tensors (gloo tests) and anything that is not contiguous
+    fp32 keep the torch path."""
+    ok = os.environ.get("UPNERF_GATHER", "1") != "0" and flat.is_cuda and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() < 2 ** 31 for t in tensors)
+    if ok:
+        try:
+            from ._lib import PackDesc, check, lib, ptr, stream
+        except Exception:  # noqa: BLE001 -- the exchange does not depend on the extension
+            ok = False
+    if not ok:
+        if scatter:
+            torch._foreach_copy_(list(tensors), list(views))
+        else:
+            torch._foreach_copy_(list(views), list(tensors))
+        return
+    base = flat.data_ptr()
+    descs = []
+    for v, t in zip(views, tensors):
+        n = t.numel()
+        if n:
+            descs.append(PackDesc(ptr=t.data_ptr(), rows=1, cols=n, src_ld=n, dst_off=(v.data_ptr() - base) // 4, dst_ld=n, accumulate=0))
+    for i in range(0, len(descs), 48):
+        chunk = descs[i:i + 48]
+        arr = (PackDesc * len(chunk))(*chunk)
+        check(lib.upnerf_pack(ptr(flat), arr, len(chunk), 1 if scatter else 0, stream()), "upnerf_pack")
+
+
 class GradSync:
     """Average the gradients of `params` across ranks with one flat all-reduce -- or, with `early` given, two: the
     parameters in `early` (the fine field: autograd produces its gradients first) are reduced on a side stream
@@ -98,13 +128,13 @@ class GradSync:
                 self._stream = torch.cuda.Stream(dev)
             self._stream.wait_stream(torch.cuda.current_stream(dev))  # the gradients are complete on the compute stream
             with torch.cuda.stream(self._stream):
-                torch._foreach_copy_(views, [p.grad for p in live])
+                _gather(flat, views, [p.grad for p in live])
                 self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 # counted here, timed in _finish_early: an asynchronous collective runs on the backend's own stream, events
                 # around its enqueue would bracket nothing -- what the step pays for it is the wait at the end of backward
                 self._mark_end(None, dev, n)
         else:
-            torch._foreach_copy_(views, [p.grad for p in live])
+            _gather(flat, views, [p.grad for p in live])
             self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._mark_end(None, dev, n)  # (asynchronous on a CPU group: its wait is timed in _finish_early)
         self._early_live, self._early_views = live, views
@@ -128,7 +158,7 @@ class GradSync:
                 end.record(torch.cuda.current_stream(dev))
                 self._pairs.append((ev, end))
         flat.mul_(1.0 / self.world)
-        torch._foreach_copy_([p.grad for p in self._early_live], self._early_views)
+        _gather(flat, self._early_views, [p.grad for p in self._early_live], scatter=True)
         self._work = None
         return {id(p) for p in self._early_live}
 
@@ -155,7 +185,7 @@ class GradSync:
             k = p.grad.numel()
             self._views.append(flat[off:off + k].view_as(p.grad))
             off += k
-        torch._foreach_copy_(self._views, [p.grad for p in self._live])
+        _gather(flat, self._views, [p.grad for p in self._live])
         return n
 
     def reduce(self, n: Optional[int] = None) -> None:
@@ -218,7 +248,7 @@ class GradSync:
         """Averaged gradients back into the parameters' .grad tensors."""
         if self._n == 0 or self.world == 1:
             return
-        torch._foreach_copy_([p.grad for p in self._live], self._views)
+        _gather(self._flat, self._views, [p.grad for p in self._live], scatter=True)
 
     def __call__(self) -> int:
         """All-reduce (mean) every gradient that exists; returns the number of floats exchanged (at the end of backward)."""
