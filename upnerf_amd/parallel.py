@@ -24,6 +24,10 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        # the host driver of the pool only supports dmabuf IPC: without this RCCL's buffer exchange fails with
+        # `hipIpcGetMemHandle: invalid argument`.  Read when the HSA runtime starts, i.e. at this process's first HIP call --
+        # which has not happened yet in a rank that comes here first (bench.py, the Trainer); exported already where the launcher did
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # UPNERF_DIST_BACKEND: diagnostic override (e.g. "gloo" to exercise the multi-rank path of bench.py on a
