@@ -168,12 +168,12 @@ class GraphedTrainingStep:
         #    hipErrorCapturedEvent ("operation not permitted on an event last recorded in a capturing stream") and the
         #    watchdog takes the process down -- every time when the capture follows an eager step's all-reduce within the
         #    watchdog's 100 ms period, which is exactly what a training run does.  So the device is drained and the watchdog
-        #    given three of its periods to retire what it tracks before the capture begins (once per captured graph).
+        #    given five of its periods to retire what it tracks before the capture begins (once per captured graph).
         pg_alive = torch.distributed.is_available() and torch.distributed.is_initialized()
         mode = "thread_local" if (sync is not None or pg_alive) else "global"
         if pg_alive and torch.distributed.get_backend() == "nccl":
             torch.cuda.synchronize(self.device)
-            time.sleep(float(os.environ.get("UPNERF_CAPTURE_DRAIN_S", "0.3")))
+            time.sleep(float(os.environ.get("UPNERF_CAPTURE_DRAIN_S", "0.5")))
         e = _Entry()
         e.scalars = StepScalars(self.device, self._providers())
         e.g1, e.g2, e.replays = torch.cuda.CUDAGraph(), None, 0
