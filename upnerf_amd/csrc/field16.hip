@@ -57,6 +57,11 @@
 // loop, it does not: forward launch 2.431 (2) / 2.449 (1) against 2.374 ms, alternating on one box (profiles/r06_ab_stores_in_loop.txt).
 #define F16_STORE_IN_LOOP 0
 #endif
+// the backward head stage's sums of the per-row scalars: 1 = one wave, a row per lane, butterfly (round 6); 0 = four threads walking
+// the tile's 64 rows while the other 252 wait at the barrier behind them
+#ifndef F16_BH_SCALAR_SUMS_WAVE
+#define F16_BH_SCALAR_SUMS_WAVE 1
+#endif
 #ifndef F16_JOIN_HEADS
 #define F16_JOIN_HEADS 1  // the first layers of the colour and the candidate head in one K loop when both run (0: one after the other, for A/B runs)
 #endif
@@ -1071,13 +1076,28 @@ __global__ __launch_bounds__(64 * NW, F16_EU(NP, TILE)) void field16_bwd_kernel(
       }
       __syncthreads();
       if (k < 4) *(f32x4*)&part[(k == 0 ? 0 : W2 * k) + 4 * g] = readout(k);
-      if (tid >= THREADS - 4) {  // sums of the per-row scalars: d b_csig, d b_r2
+#if F16_BH_SCALAR_SUMS_WAVE
+      if (wave == NW - 1) {  // sums of the per-row scalars (d b_csig, d b_r2): one row per lane, a butterfly over the wave (fixed order)
+        static_assert(TILE == 64 || TPW == 1, "one row per lane");
+        float v[4] = {dpc_s[lane], dprgb_s[lane][0], dprgb_s[lane][1], dprgb_s[lane][2]};
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += __shfl_xor(v[c], d);
+        if (lane < 4) {
+          part[4 * W2 + lane] = lane == 0 ? v[0] : (lane == 1 ? v[1] : (lane == 2 ? v[2] : v[3]));
+          part[4 * W2 + 4 + lane] = 0.0f;  // pad
+        }
+      }
+#else
+      if (tid >= THREADS - 4) {  // sums of the per-row scalars: d b_csig, d b_r2 (four threads walking the 64 rows)
         const int c = tid - (THREADS - 4);
         float sacc = 0.0f;
         for (int r = 0; r < TILE; ++r) sacc += c == 0 ? dpc_s[r] : dprgb_s[r][c - 1];
         part[4 * W2 + c] = sacc;
         part[4 * W2 + 4 + c] = 0.0f;  // pad
       }
+#endif
       __syncthreads();
 #pragma unroll
       for (int c = 0; c < MAXRAYS; ++c) {
